@@ -1,0 +1,132 @@
+"""CPU checker for the per-sample triplane head and the render loops -- TEST INFRASTRUCTURE ONLY.
+
+Restates, on numpy float32 arrays and the C checker kernels (oracle.py):
+  * NeRFNetwork.encode_x / density / forward        /root/reference/nerf_triplane/network.py:215-223, 252-311
+  * MLP (bias-free Linear + ReLU)                    network.py:73-94
+  * get_rays (full-image branch)                     nerf_triplane/utils.py:226-312
+  * NeRFRenderer.run_cuda_for_inference hot loop     nerf_triplane/renderer.py:476-561
+  * NeRFRenderer.run_cuda training branch            renderer.py:279-304
+
+Summation order of every Linear is explicit (`korder`, see encoders_oracle.c): the order below is the
+one documented in DESIGN.md ("head arithmetic contract").  Any order is an equally valid restatement
+of torch's `x @ W.T`; tests/test_golden.py pins this one against the reference's own torch modules.
+"""
+import numpy as np
+
+from . import oracle as O
+
+F32 = np.float32
+
+
+# ---------------------------------------------------------------------------------------------
+# summation orders
+# ---------------------------------------------------------------------------------------------
+def korder_natural(K, base=0):
+    k = list(range(base, base + K))
+    while len(k) % 4:
+        k.append(-1)
+    return k
+
+
+def korder_chained(K, base=0):
+    """Order in which a 16x16x4 f32 MFMA consumes a previous layer's accumulator tile without any
+    data movement: within each block of 16 features, step r takes features 4q + r for q = 0..3."""
+    Kp = (K + 15) // 16 * 16
+    k = []
+    for t in range(Kp // 16):
+        for r in range(4):
+            for q in range(4):
+                f = 16 * t + 4 * q + r
+                k.append(base + f if f < K else -1)
+    return k
+
+
+# ---------------------------------------------------------------------------------------------
+# triplane hyper-parameters (network.py:129-133)
+# ---------------------------------------------------------------------------------------------
+class TriplaneSpec:
+    def __init__(self, bound=1.0):
+        self.bound = float(bound)
+        self.input_dim, self.num_levels, self.level_dim = 2, 12, 1
+        self.base_resolution, self.log2_hashmap_size = 64, 14
+        desired = 512 * bound
+        # GridEncoder.__init__, grid.py:95-96
+        self.per_level_scale = np.exp2(np.log2(desired / self.base_resolution) / (self.num_levels - 1))
+        self.offsets = O.grid_offsets(2, 12, self.per_level_scale, 64, 14)
+        self.n_params = int(self.offsets[-1])
+
+
+def encode_plane(spec, uv, emb):
+    """GridEncoder.forward, grid.py:139-154: map [-bound, bound] -> [0, 1], then grid_encode."""
+    x = (uv.astype(F32) + F32(spec.bound)) / F32(2 * spec.bound)
+    out, _ = O.grid_encode_forward(x, emb, spec.offsets, spec.per_level_scale, spec.base_resolution)
+    return out
+
+
+def encode_x(spec, xyz, P):
+    """network.py:208-223: xy = x[:, :2], yz = x[:, 1:], xz = x[:, [0, 2]]"""
+    xyz = np.ascontiguousarray(xyz, dtype=F32)
+    fxy = encode_plane(spec, xyz[:, [0, 1]], P["encoder_xy.embeddings"])
+    fyz = encode_plane(spec, xyz[:, [1, 2]], P["encoder_yz.embeddings"])
+    fxz = encode_plane(spec, xyz[:, [0, 2]], P["encoder_xz.embeddings"])
+    return np.concatenate([fxy, fyz, fxz], axis=1)
+
+
+def density(spec, P, enc_x, enc_a, eye):
+    """network.py:283-311 (enc_x precomputed).  enc_a [1,32] or [32]; eye [1,1] / scalar / None."""
+    enc_a = np.asarray(enc_a, dtype=F32).reshape(1, -1)
+    a1 = O.linear(enc_x, P["aud_ch_att_net.net.0.weight"], korder_natural(36), relu=True)
+    att = O.linear(a1, P["aud_ch_att_net.net.1.weight"], korder_chained(64))
+    enc_w = enc_a * att
+    parts = [enc_x, enc_w]
+    order = korder_natural(36) + korder_chained(32, base=36)
+    eye_att = None
+    if eye is not None:
+        e1 = O.linear(enc_x, P["eye_att_net.net.0.weight"], korder_natural(36), relu=True)
+        e2 = O.linear(e1, P["eye_att_net.net.1.weight"], korder_chained(16))
+        eye_att = O.unary("sigmoid", e2)
+        parts.append(np.asarray(eye, dtype=F32).reshape(1, 1) * eye_att)
+        order = order + [68, -1, -1, -1]
+    h = np.ascontiguousarray(np.concatenate(parts, axis=1))
+    s1 = O.linear(h, P["sigma_net.net.0.weight"], order, relu=True)
+    s2 = O.linear(s1, P["sigma_net.net.1.weight"], korder_chained(64), relu=True)
+    s3 = O.linear(s2, P["sigma_net.net.2.weight"], korder_chained(64))
+    sigma = O.unary("exp", np.ascontiguousarray(s3[:, 0]))
+    geo = np.ascontiguousarray(s3[:, 1:])
+    sumsq = O.linear(att * att, np.ones((1, 32), dtype=F32), korder_chained(32))
+    amb_aud = np.sqrt(sumsq).astype(F32)
+    return dict(sigma=sigma, geo_feat=geo, ambient_aud=amb_aud, ambient_eye=eye_att, enc_x=enc_x)
+
+
+def head_forward(spec, P, xyz, dirs, enc_a, ind_code, eye, testing=True, unc_loss=True):
+    """NeRFNetwork.forward, network.py:252-280.  Returns sigma [M], rgb [M,3], amb_aud [M,1], amb_eye [M,1]|None,
+    unc [M,1] (the reference returns an over-sized [M,36,1] constant tensor in test mode, SURVEY 8a' note 16)."""
+    enc_x = encode_x(spec, xyz, P)
+    dres = density(spec, P, enc_x, enc_a, eye)
+    enc_d, _ = O.sh_encode_forward(dirs, 4)
+    parts = [enc_d, dres["geo_feat"]]
+    order = korder_natural(16) + korder_chained(64, base=16)
+    if ind_code is not None:
+        c = np.asarray(ind_code, dtype=F32).reshape(1, -1)
+        parts.append(np.repeat(c, enc_x.shape[0], axis=0))
+        order = order + korder_natural(c.shape[1], base=80)
+    h = np.ascontiguousarray(np.concatenate(parts, axis=1))
+    c1 = O.linear(h, P["color_net.net.0.weight"], order, relu=True)
+    c2 = O.linear(c1, P["color_net.net.1.weight"], korder_chained(64))
+    rgb = O.unary("sigmoid", c2) * F32(1 + 2 * 0.001) - F32(0.001)
+    M = enc_x.shape[0]
+    if testing or not unc_loss:
+        unc = np.full((M, 1), O.unary("softplus", np.zeros(1, F32))[0], dtype=F32)
+    else:
+        u1 = O.linear(enc_x, P["unc_net.net.0.weight"], korder_natural(36), relu=True)
+        u2 = O.linear(u1, P["unc_net.net.1.weight"], korder_chained(32))
+        unc = O.unary("softplus", u2)
+    return dres["sigma"], rgb.astype(F32), dres["ambient_aud"], dres["ambient_eye"], unc
+
+
+# ---------------------------------------------------------------------------------------------
+# rays
+# ---------------------------------------------------------------------------------------------
+def get_rays(pose, intrinsics, H, W):
+    """utils.py:226-312, N = -1 branch, one pose [4,4] -> rays_o, rays_d [H*W, 3] (C checker lzo_get_rays)."""
+    return O.get_rays(pose, intrinsics, H, W)
