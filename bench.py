@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512x512 triplane-head inference render at max_steps = 192 on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" renders one full synthetic frame per rank through the whole hot path (near/far -> [march -> fused
+head -> composite -> compaction] until every ray is done -> blend), inputs resident in HBM, no host sync inside
+the frame.  Workload: camera at (0,0,-3.35) looking down +z, fovy 21.24 deg, bound 1, aabb
+[-1,-.5,-1,1,.5,1], dt_gamma 1/256, T_thresh 1e-4, all-ones occupancy grid (dense: nothing is skipped), triplane
+tables U(-1,1), MLP weights = the reference's torch init under seed 0 (tests/golden fixture), enc_a ~ N(0,1),
+eye 0.25.  Data is synthetic.
+
+N > 1 (weak scaling): the global batch is N frames of one camera orbit, ray-sharded contiguously, i.e. rank r
+renders frame r; every step ends with ONE RCCL all-gather of the rendered RGB tiles so that every rank holds the
+whole batch.
+
+Prints one JSON line on rank 0.  `value` = marched samples (delta != 0) per second over all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_PER_SAMPLE = 46368          # 23 184 MAC per sample, inference head
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+HBM_PEAK_GBS = 8000.0
+
+
+def orbit_pose(k, n):
+    th = 0.15 * (k - (n - 1) / 2)
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], dtype=np.float32)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = R
+    pose[:3, 3] = R @ np.array([0, 0, -3.35], dtype=np.float32)
+    return pose
+
+
+def grid_roofline(device):
+    """stand-alone grid encoder: algorithmic bytes / event-timed launch duration"""
+    from lzzx_nerf_amd.gridencoder import GridEncoder, grid_encode
+    res = {}
+    g = torch.Generator(device=device).manual_seed(0)
+    for tag, kw, bytes_per_sample, B in (
+            ("triplane_plane_D2_L12_C1_f32", dict(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
+                                                  desired_resolution=512), 8 + 12 * 4 * 4 + 48, 1 << 24),
+            ("hashgrid_D3_L16_C2_f32", dict(), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23)):
+        enc = GridEncoder(**kw).to(device)
+        enc.embeddings.data.uniform_(-1, 1, generator=g)
+        x = torch.rand(B, enc.input_dim, device=device, generator=g)
+        f = lambda: grid_encode(x, enc.embeddings.data, enc.offsets, enc.per_level_scale, enc.base_resolution, False, 0, False)
+        for _ in range(3):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 10
+        e0.record()
+        for _ in range(n):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        gbs = bytes_per_sample * B / (ms * 1e-3) / 1e9
+        res[tag] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                        traffic=None, samples=B, ms=round(ms, 4), bytes_per_sample=bytes_per_sample)
+        del enc, x
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--max-steps", type=int, default=192)
+    ap.add_argument("--scene", default="ones", choices=["ones", "ellipsoid"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grid-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from lzzx_nerf_amd import _lib, dist as D
+    rank, world = D.init_from_env()
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if world == 1:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+    assert _lib.load().lz_device_ok() == 1, "bench needs a gfx950 device; there is no fallback path"
+
+    from conftest import ellipsoid_bitfield, make_params, synthetic_camera
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer, get_rays
+
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "reference_python.npz"))
+    P = make_params(golden)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in P.items()}, bound=1.0, device=device)
+    bits = np.full(128 ** 3 // 8, 255, np.uint8) if args.scene == "ones" else ellipsoid_bitfield()[0]
+    renderer = TriplaneRenderer(head, dev(bits), bound=1.0)
+    H = W = args.size
+    _, intr = synthetic_camera(H, W)
+    pose = orbit_pose(rank, world)
+    rays_o, rays_d = get_rays(dev(pose), intr, H, W)   # this rank's shard of the global ray batch = frame `rank`
+    enc_a, ind, eye = dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"])
+    N = H * W
+
+    def step():
+        out = renderer.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4)
+        tiles = D.gather_tiles(out["image"]) if world > 1 else out["image"]
+        return out, tiles
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    renderer._head_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, tiles = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    events = renderer._head_events
+    renderer._head_events = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    state = out["state"].cpu().numpy()
+    samples_per_frame = int(state[5])
+    iters_per_frame = int(state[6])
+    total_samples = torch.tensor([samples_per_frame], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(total_samples)
+    total_samples = float(total_samples.item())  # one frame per rank per step
+    value = total_samples * args.steps / dt
+    rays_per_s = N * world * args.steps / dt
+
+    if rank != 0:
+        return
+    # ---- roofline of the dominant kernel (fused head, MFMA-bound): live HIP events from the timed steps ----
+    head_ms = [a.elapsed_time(b) for a, b in events]
+    live = [m for m in head_ms if m > 0]
+    head_total_ms = float(np.sum(head_ms))
+    n_launch = len(head_ms)
+    launches_with_work = iters_per_frame * args.steps
+    achieved_tflops = FLOP_PER_SAMPLE * samples_per_frame * args.steps / (head_total_ms * 1e-3) / 1e12
+    roofline = dict(bound="mfma", achieved=round(achieved_tflops, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), traffic=None, kernel="lz_k_triplane_head<false>",
+                    avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5), launches=n_launch,
+                    launches_with_work=launches_with_work, flop_per_sample=FLOP_PER_SAMPLE,
+                    head_time_share=round(head_total_ms * 1e-3 / dt, 4))
+    result = {
+        "metric": "rendered samples/s (512x512 triplane head, max_steps 192)", "value": round(value, 1), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{H}x{W} inference frame per GPU, max_steps {args.max_steps}, triplane head (3x D2/L12/C1 hash grid + "
+                               f"audio/eye cond + SH4), occupancy={args.scene}, bound 1, dt_gamma 1/256, T_thresh 1e-4",
+                   "rays_per_gpu": N, "samples_per_frame": samples_per_frame, "iterations_per_frame": iters_per_frame,
+                   "nominal_samples_per_frame": N * args.max_steps, "parallelism": f"ray-sharded x{world}, 1 all-gather/step"},
+        "rays_per_s": round(rays_per_s, 1),
+        "samples_per_ray_mean": round(samples_per_frame / N, 2),
+        "roofline": roofline,
+    }
+    if not args.no_grid_roofline:
+        result["roofline_gridencoder"] = grid_roofline(device)
+    # ---- CPU baseline: the checker arranged like the reference loop, on a bounded sub-frame of the SAME rays ----
+    if not args.no_cpu_baseline:
+        from oracle.head import TriplaneSpec
+        from oracle.render import render_inference
+        stride = max(1, H // 64)
+        sel = (np.arange(0, H, stride)[:, None] * W + np.arange(0, W, stride)[None, :]).reshape(-1)
+        ro_c, rd_c = rays_o.cpu().numpy()[sel], rays_d.cpu().numpy()[sel]
+        st = {}
+        render_inference(TriplaneSpec(1.0), P, ro_c[:256], rd_c[:256], bits, golden["net_enc_a"], golden["net_ind"], golden["net_eye"],
+                         max_steps=args.max_steps)  # warm-up (page in, OpenMP team)
+        tc = time.perf_counter()
+        ref = render_inference(TriplaneSpec(1.0), P, ro_c, rd_c, bits, golden["net_enc_a"], golden["net_ind"], golden["net_eye"],
+                               max_steps=args.max_steps, stats=st)
+        tc = time.perf_counter() - tc
+        cpu_samples = int(st["samples_per_ray"].sum())
+        gpu_img = out["image"].cpu().numpy()[sel]
+        mse = float(((gpu_img.astype(np.float64) - ref["image"]) ** 2).mean())
+        psnr = float("inf") if mse == 0 else -10 * np.log10(mse)
+        result["cpu_baseline"] = dict(value=round(cpu_samples / tc, 1), unit="samples/s", cores=os.cpu_count(), kind="port",
+                                      sample=f"{len(sel)} rays (every {stride}th pixel of the same frame), {cpu_samples} samples, "
+                                             f"{tc:.1f} s; checker arranged like run_cuda_for_inference (renderer.py:495-548), OpenMP")
+        result["psnr_vs_checker_db"] = psnr if np.isfinite(psnr) else "inf"
+        result["max_abs_diff_vs_checker"] = float(np.abs(gpu_img - ref["image"]).max())
+        cnt = renderer.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4,
+                              count_samples=True)["ray_counts"].cpu().numpy()[sel]
+        result["sample_counts_equal"] = bool(np.array_equal(cnt.astype(np.int64), st["samples_per_ray"]))
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

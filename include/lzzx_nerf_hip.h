@@ -1,0 +1,212 @@
+/*
+ * lzzx_nerf_hip.h -- C ABI of liblzzx_nerf_hip.so, the gfx950 (MI355X) implementation of the
+ * nerf_triplane volumetric-rendering hot path.
+ *
+ * Drop-in boundary.  Every `lz_*` entry point in sections 1-4 replaces one function of the
+ * reference's pybind11 back-ends (file:line cited per entry).  The reference's bindings take
+ * at::Tensor; here every tensor is a raw DEVICE pointer to contiguous memory, dimensions are uint32_t,
+ * scalars are float, and the last argument is the hipStream_t to launch on (NULL = default stream).
+ * Ownership follows the reference: the caller allocates every output; kernels never allocate, free
+ * or synchronise.  Return value: 0 on success, otherwise a hipError_t (positive) or LZ_ERR_* (negative);
+ * lz_last_error() returns a thread-local message.  Unsupported (D, C) combinations return
+ * LZ_ERR_UNSUPPORTED where the reference throws std::runtime_error (gridencoder.cu:354,372).
+ *
+ * Section 5 holds entry points the reference does not have: the fused per-sample triplane head
+ * (the torch-level arithmetic of nerf_triplane/network.py:252-311 as one MFMA kernel) and the
+ * device-resident render loop (renderer.py:495-548 without host synchronisation).
+ */
+#ifndef LZZX_NERF_HIP_H
+#define LZZX_NERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lz_stream_t; /* hipStream_t */
+
+#define LZ_OK 0
+#define LZ_ERR_UNSUPPORTED (-1)
+#define LZ_ERR_BAD_ARGUMENT (-2)
+
+const char* lz_last_error(void);
+/* ABI version of this header; bumped on any signature change */
+int lz_abi_version(void);
+/* 1 when a gfx950 device is present and usable */
+int lz_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. gridencoder        (reference: gridencoder/src/gridencoder.h:12-13, gridencoder.cu:424-479)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* inputs [B,D] f32 in [0,1]; embeddings [sO,C] f32 or f16 (emb_f16); offsets [L+1] i32 (device);
+ * outputs: out_layout 0 = [L,B,C] (the reference's level-major layout, gridencoder.cu:95),
+ *          out_layout 1 = [B,L*C] (what grid.py:52 produces after its permute; saves that copy);
+ * dy_dx [B,L,D,C] or NULL.  S = log2(per_level_scale) as float, H = base resolution. */
+int lz_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                           uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                           uint32_t gridtype, int align_corners, int emb_f16, int out_layout, lz_stream_t stream);
+
+/* grad: grad_layout 0 = [L,B,C] (grid.py:70), 1 = [B,L*C]; grad_embeddings [sO,C] pre-zeroed by the caller
+ * (grid.py:72), accumulated with f32 atomics (f16: packed half2 atomics when C is even, gridencoder.cu:298-304);
+ * dy_dx / grad_inputs [B,D] optional (both or neither). */
+int lz_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                            void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                            const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, int emb_f16,
+                            int grad_layout, lz_stream_t stream);
+
+/* test hook: flat table index of every corner, [L,B,2^D] i32 (-1 = out of range); exposes get_grid_index
+ * (gridencoder.cu:54-72) so index parity can be asserted bit for bit */
+int lz_grid_corner_indices(const float* inputs, const int32_t* offsets, int32_t* corner_idx, uint32_t B, uint32_t D,
+                           uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                           lz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. shencoder          (reference: shencoder/src/shencoder.h:9-10, shencoder.cu:400-438)
+ * ------------------------------------------------------------------------------------------------ */
+/* inputs [B,3] f32; outputs [B,degree^2]; dy_dx [B,3,degree^2] or NULL; 1 <= degree <= 8 */
+int lz_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t degree, float* dy_dx,
+                         lz_stream_t stream);
+/* grad_inputs [B,3] accumulated into (pre-zeroed by the caller, sphere_harmonics.py:49) */
+int lz_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t degree,
+                          const float* dy_dx, float* grad_inputs, lz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3. freqencoder        (reference: freqencoder/src/freqencoder.h:7-10, freqencoder.cu:97-128)
+ * ------------------------------------------------------------------------------------------------ */
+int lz_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs,
+                           lz_stream_t stream);
+int lz_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                            float* grad_inputs, lz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 4. raymarching        (reference: raymarching/src/raymarching.h:7-37)
+ * ------------------------------------------------------------------------------------------------ */
+int lz_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
+                          float* nears, float* fars, lz_stream_t stream);                      /* raymarching.h:7  */
+int lz_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                    lz_stream_t stream);                                                       /* raymarching.h:8  */
+int lz_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, lz_stream_t stream);      /* raymarching.h:9  */
+int lz_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, lz_stream_t stream); /* raymarching.h:10 */
+int lz_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, lz_stream_t stream); /* :11 */
+int lz_morton3D_dilation(const float* grid, uint32_t C, uint32_t H, float* grid_dilation, lz_stream_t stream); /* :12 */
+
+/* raymarching.h:14.  counter [2] i32 = (points, rays), accumulated from its current contents like the
+ * reference's atomicAdd; ray rows are emitted in ray-id order (deterministic; one admissible outcome of the
+ * reference's unordered atomics, raymarching.cu:446-454).  workspace: >= (N + 2) * 4 bytes of device scratch. */
+int lz_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                        const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                        const float* noises, void* workspace, lz_stream_t stream);
+int lz_march_rays_train_backward(const float* grad_xyzs, const float* grad_dirs, const int32_t* rays, const float* deltas,
+                                 uint32_t N, uint32_t M, float* grad_rays_o, float* grad_rays_d,
+                                 lz_stream_t stream);                                          /* raymarching.h:15 */
+
+/* raymarching.h:19.  xyzs/dirs/deltas pre-zeroed by the caller (raymarching.py:384-386) */
+int lz_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                  const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                  const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                  const float* noises, lz_stream_t stream);
+
+/* Compositing.  One entry per direction; the reference's five channel variants
+ *   plain (raymarching.h:16-17,20)  ambient (:21)  sigma (:24-27)  uncertainty (:31-33)  triplane (:36-38)
+ * are selected by (n_amb, amb_weighted, has_unc) = plain (0,0,0) [inference only], ambient (1,0,0),
+ * sigma (1,1,0), uncertainty (1,0,1), triplane (2,0,1).  Unused channel pointers may be NULL. */
+int lz_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* amb0, const float* amb1,
+                                    const float* unc, const float* deltas, const int32_t* rays, uint32_t M, uint32_t N,
+                                    float T_thresh, int n_amb, int amb_weighted, int has_unc, float* weights_sum,
+                                    float* amb0_sum, float* amb1_sum, float* unc_sum, float* depth, float* image,
+                                    lz_stream_t stream);
+/* grad_* outputs pre-zeroed by the caller (raymarching.py:332-334, 649-653) */
+int lz_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_amb0_sum, const float* grad_amb1_sum,
+                                     const float* grad_unc_sum, const float* grad_image, const float* sigmas,
+                                     const float* rgbs, const float* amb0, const float* amb1, const float* unc,
+                                     const float* deltas, const int32_t* rays, const float* weights_sum,
+                                     const float* amb0_sum, const float* unc_sum, const float* image, uint32_t M,
+                                     uint32_t N, float T_thresh, int n_amb, int amb_weighted, int has_unc,
+                                     float* grad_sigmas, float* grad_rgbs, float* grad_amb0, float* grad_amb1,
+                                     float* grad_unc, lz_stream_t stream);
+/* in place on rays_alive, rays_t and the per-ray accumulators */
+int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                      const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,
+                      const float* unc, int n_amb, int amb_weighted, int has_unc, float* weights_sum, float* depth,
+                      float* image, float* amb0_sum, float* amb1_sum, float* unc_sum, lz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 5. extensions (no reference counterpart at the FFI level)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* full-image ray generation, nerf_triplane/utils.py:226-312 (N = -1 branch); pose: device [4,4] row-major c2w */
+int lz_get_rays(const float* pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, float* rays_o,
+                float* rays_d, lz_stream_t stream);
+
+/* Fused triplane head: xyz -> 3 x hash-grid (D=2, L=12, C=1) -> aud/eye attention -> sigma net -> SH(4) -> colour net.
+ * Weights are consumed in the packed "A-fragment" layout produced by lz_head_pack_weights; all arithmetic is f32
+ * (v_mfma_f32_16x16x4_f32), summation order documented in DESIGN.md.  See network.py:252-311. */
+#define LZ_HEAD_PACKED_FLOATS 27584 /* 431 A-fragments x 64 lanes */
+typedef struct {
+    const float* emb_xy;      /* [163584] tables of the three planes (device) */
+    const float* emb_yz;
+    const float* emb_xz;
+    const int32_t* offsets;   /* [13] device */
+    const float* packed;      /* packed MLP weights (device), from lz_head_pack_weights */
+    const float* enc_a;       /* [32] device */
+    const float* ind_code;    /* [4] device or NULL */
+    const float* eye;         /* [1] device or NULL (exp_eye off) */
+    float bound;
+    float S;                  /* log2(per_level_scale) */
+    uint32_t H;               /* base resolution (64) */
+    int testing;              /* 1: uncertainty = softplus(0) constant (network.py:243-249) */
+} lz_head_params;
+
+/* host-side helper: number of floats lz_head_pack_weights writes */
+uint32_t lz_head_packed_size(void);
+/* pack the nine bias-free Linear weights (row-major [out,in], DEVICE pointers; unc_* may be NULL) */
+int lz_head_pack_weights(const float* aud0, const float* aud1, const float* eye0, const float* eye1, const float* sig0,
+                         const float* sig1, const float* sig2, const float* col0, const float* col1, const float* unc0,
+                         const float* unc1, int has_eye, int has_ind, float* packed, lz_stream_t stream);
+/* xyzs/dirs [M,3] -> sigmas [M], rgbs [M,3], amb_aud [M], amb_eye [M], unc [M].  `count` (device i32, may be NULL)
+ * limits the work to min(M, *count) rows. */
+int lz_triplane_head_forward(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M,
+                             const int32_t* count, float* sigmas, float* rgbs, float* amb_aud, float* amb_eye,
+                             float* unc, lz_stream_t stream);
+
+/* Device-resident inference loop state (renderer.py:495-548): no host synchronisation inside the frame. */
+typedef struct {
+    int32_t n_alive;      /* rays alive at the start of the current iteration */
+    int32_t n_step;       /* max(min(N / n_alive, 8), 1), renderer.py:513 */
+    int32_t step;         /* sum of n_step so far */
+    int32_t done;         /* 1 once n_alive == 0 or step >= max_steps */
+    int32_t n_samples;    /* n_alive * n_step of the current iteration */
+    int32_t total_samples;/* marched samples so far (delta != 0) */
+    int32_t iterations;
+    int32_t pad;
+} lz_loop_state;
+
+/* rays_alive <- 0..N-1, rays_t <- nears, accumulators <- 0, state <- (N, n_step(N), 0, ...) */
+int lz_loop_begin(uint32_t N, uint32_t max_steps, const float* nears, int32_t* rays_alive, float* rays_t,
+                  float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum, float* unc_sum,
+                  lz_loop_state* state, lz_stream_t stream);
+/* march driven by *state (n_alive, n_step read on device); writes zero rows for exhausted rays; adds the marched
+ * sample count to state->total_samples and, when ray_counts != NULL, per ray to ray_counts[ray id] */
+int lz_loop_march(lz_loop_state* state, uint32_t N, const int32_t* rays_alive, const float* rays_t,
+                  const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                  uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs,
+                  float* deltas, int32_t* ray_counts, lz_stream_t stream);
+int lz_loop_composite(const lz_loop_state* state, uint32_t N, float T_thresh, int32_t* rays_alive, float* rays_t,
+                      const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,
+                      const float* unc, float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum,
+                      float* unc_sum, lz_stream_t stream);
+/* order-preserving stream compaction of rays_alive (drops -1 entries, renderer.py:542) into rays_alive_out and
+ * advance of the loop state (n_alive, n_step, step, done).  workspace: >= 4096 * 4 bytes. */
+int lz_loop_compact(lz_loop_state* state, uint32_t N, uint32_t max_steps, const int32_t* rays_alive_in,
+                    int32_t* rays_alive_out, void* workspace, lz_stream_t stream);
+/* image = clamp(image + (1 - weights_sum) * bg, 0, 1) (renderer.py:559-561); bg: device [N,3] or NULL -> bg_scalar */
+int lz_final_blend(const float* image, const float* weights_sum, const float* bg, float bg_scalar, uint32_t N,
+                   float* out, lz_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZZX_NERF_HIP_H */

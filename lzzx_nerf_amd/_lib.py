@@ -1,0 +1,93 @@
+"""ctypes binding of liblzzx_nerf_hip.so -- the only way product code reaches the kernels.
+
+Fails loudly: a missing library or a missing symbol raises at import/first use; there is no CPU or
+PyTorch fallback anywhere in this package (the CPU checker lives in /oracle and is never imported here).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "liblzzx_nerf_hip.so")
+
+vp, u32, f32, i32 = C.c_void_p, C.c_uint32, C.c_float, C.c_int
+
+
+class HeadParams(C.Structure):
+    """mirror of lz_head_params (include/lzzx_nerf_hip.h)"""
+    _fields_ = [("emb_xy", vp), ("emb_yz", vp), ("emb_xz", vp), ("offsets", vp), ("packed", vp), ("enc_a", vp),
+                ("ind_code", vp), ("eye", vp), ("bound", f32), ("S", f32), ("H", u32), ("testing", i32)]
+
+
+# name -> argtypes, in the order of include/lzzx_nerf_hip.h
+SIGNATURES = {
+    "lz_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, i32, i32, vp],
+    "lz_grid_encode_backward": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, i32, i32, vp],
+    "lz_grid_corner_indices": [vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, vp],
+    "lz_sh_encode_forward": [vp, vp, u32, u32, u32, vp, vp],
+    "lz_sh_encode_backward": [vp, vp, u32, u32, u32, vp, vp, vp],
+    "lz_freq_encode_forward": [vp, u32, u32, u32, u32, vp, vp],
+    "lz_freq_encode_backward": [vp, vp, u32, u32, u32, u32, vp, vp],
+    "lz_near_far_from_aabb": [vp, vp, vp, u32, f32, vp, vp, vp],
+    "lz_sph_from_ray": [vp, vp, f32, u32, vp, vp],
+    "lz_morton3D": [vp, u32, vp, vp],
+    "lz_morton3D_invert": [vp, u32, vp, vp],
+    "lz_packbits": [vp, u32, f32, vp, vp],
+    "lz_morton3D_dilation": [vp, u32, u32, vp, vp],
+    "lz_march_rays_train": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_march_rays_train_backward": [vp, vp, vp, vp, u32, u32, vp, vp, vp],
+    "lz_march_rays": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_composite_rays_train_forward": [vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "lz_composite_rays_train_backward": [vp] * 16 + [u32, u32, f32, i32, i32, i32] + [vp] * 6,
+    "lz_composite_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "lz_get_rays": [vp, f32, f32, f32, f32, u32, u32, vp, vp, vp],
+    "lz_head_pack_weights": [vp] * 11 + [i32, i32, vp, vp],
+    "lz_triplane_head_forward": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, vp, vp],
+    "lz_loop_begin": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_loop_march": [vp, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_loop_composite": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_loop_compact": [vp, u32, u32, vp, vp, vp, vp],
+    "lz_final_blend": [vp, vp, vp, f32, u32, vp, vp],
+}
+PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),
+         "lz_head_packed_size": ([], u32)}
+
+ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
+
+_lib = None
+
+
+class LzError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every symbol of the header; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise LzError(
+            "liblzzx_nerf_hip.so not found at %s -- build it with `python -m lzzx_nerf_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = i32
+    for name, (argtypes, restype) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().lz_last_error()
+        raise LzError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,487 @@
+// lz_head.hip -- fused per-sample triplane head for gfx950: three hash-grid planes -> audio/eye attention ->
+// sigma net -> SH(4) -> colour net (+ uncertainty net in training), one kernel, f32 end to end.
+//
+// Replaces, for the inference/training hot loop, the torch-level graph of NeRFNetwork.forward
+// (nerf_triplane/network.py:252-311): 3 grid_encode launches + permutes + cat, ~10 bias-free Linear GEMMs with
+// K in {36,69,84,64,16,32}, repeat/cat copies materialising [M,69] and [M,84], SH launch, exp/sigmoid kernels
+// -- 52 % of the reference's loop time.  Here activations never leave registers.
+//
+// MI355X design
+//   * GEMMs run on the matrix cores with v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: bit-for-bit a
+//     k-ordered fma chain, so the CPU checker reproduces every value exactly).  Orientation: A = weights
+//     (16 output features x 4 k), B = activations (4 k x 16 samples), D = 16 features x 16 samples with
+//     feature = 4*(lane>>4) + reg, sample = lane & 15.
+//   * Layer chaining without data movement: lane (s, q) of a D tile holds features 16t+4q+r (r = reg) of
+//     sample s, which is exactly the B operand of k-step (t, r) of the next layer if that layer's weights
+//     are consumed in the permuted k order  f(t, r, q) = 16t + 4q + r.  The packed weight buffer
+//     (lz_head_pack_weights) stores every A fragment pre-permuted, lane-linear: one conflict-free
+//     ds_read_b32 per fragment, shared by the wave's 4 sample tiles.
+//   * First-layer operands come straight from the gathers: the 4 lanes that share a sample split its 36
+//     (plane, level) features (feature f = 4i + q), so the bilinear lookups are spread over all 64 lanes
+//     and land directly in B-operand position.
+//   * One 512-thread workgroup per CU (8 waves = 2 per SIMD: one can gather while the other feeds the
+//     matrix pipe), persistent over 512-sample tiles; all packed weights (431 fragments = 110 KB) stay in
+//     LDS for the life of the workgroup.
+//   * `count` (device) bounds the work, so the render loop needs no host round trip.
+#include "lz_common.h"
+#include "lzzx_detmath.h"
+#include "lzzx_sh_eval.h"
+
+typedef float lz_f4 __attribute__((ext_vector_type(4)));
+
+// ---- packed layout: layer table (fragment offsets) ----
+enum {
+    LZ_L_A1 = 0, LZ_L_A2, LZ_L_E1, LZ_L_E2, LZ_L_NRM, LZ_L_S1, LZ_L_S2, LZ_L_S3, LZ_L_C1, LZ_L_C2, LZ_L_U1, LZ_L_U2, LZ_L_COUNT
+};
+//                                    A1  A2  E1 E2 NRM S1  S2  S3  C1  C2  U1 U2
+constexpr int LZ_KS[LZ_L_COUNT] = {   9, 16,  9, 4,  8, 18, 16, 16, 21, 16,  9, 8 };
+constexpr int LZ_NT[LZ_L_COUNT] = {   4,  2,  1, 1,  1,  4,  4,  5,  4,  1,  2, 1 };
+constexpr int lz_frag_base(int layer) {
+    int b = 0;
+    for (int i = 0; i < layer; i++) b += LZ_KS[i] * LZ_NT[i];
+    return b;
+}
+constexpr int LZ_FRAGS_INFER = lz_frag_base(LZ_L_U1);   // 405
+constexpr int LZ_FRAGS_ALL = lz_frag_base(LZ_L_COUNT);  // 431
+static_assert(LZ_FRAGS_ALL * 64 == LZ_HEAD_PACKED_FLOATS, "packed size mismatch with the header");
+
+extern "C" uint32_t lz_head_packed_size(void) { return (uint32_t)LZ_FRAGS_ALL * 64u; }
+
+// ---- weight packing -------------------------------------------------------------------------------
+__device__ __forceinline__ int lz_chained(int slot, int K) {  // slot -> feature in the chained order
+    const int t = slot >> 4, r = (slot & 15) >> 2, q = slot & 3;
+    const int f = 16 * t + 4 * q + r;
+    return f < K ? f : -1;
+}
+
+struct LzPackArgs {
+    const float* w[LZ_L_COUNT];  // source weight [nout, ld] per layer (NRM: unused)
+    int nout[LZ_L_COUNT];
+    int ld[LZ_L_COUNT];
+    int has_eye, has_ind;
+};
+
+__global__ void __launch_bounds__(256) lz_k_head_pack(LzPackArgs a, float* __restrict__ packed) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= LZ_FRAGS_ALL * 64) return;
+    const int frag = gid >> 6, lane = gid & 63;
+    int layer = 0, fb = 0;
+    for (int i = 0; i < LZ_L_COUNT; i++) {
+        const int n = LZ_KS[i] * LZ_NT[i];
+        if (frag < fb + n) { layer = i; break; }
+        fb += n;
+    }
+    const int local = frag - fb;
+    const int ks = local / LZ_NT[layer], ft = local - ks * LZ_NT[layer];
+    const int row = 16 * ft + (lane & 15), slot = 4 * ks + (lane >> 4);
+    int kf;  // input feature of this k slot, -1 = padding
+    switch (layer) {
+        case LZ_L_A1: case LZ_L_E1: case LZ_L_U1: kf = slot < 36 ? slot : -1; break;
+        case LZ_L_A2: case LZ_L_S2: case LZ_L_S3: case LZ_L_C2: kf = lz_chained(slot, 64); break;
+        case LZ_L_E2: kf = lz_chained(slot, 16); break;
+        case LZ_L_NRM: case LZ_L_U2: kf = lz_chained(slot, 32); break;
+        case LZ_L_S1:
+            if (slot < 36) kf = slot;
+            else if (slot < 68) kf = 36 + lz_chained(slot - 36, 32);
+            else kf = (slot == 68 && a.has_eye) ? 68 : -1;
+            break;
+        default:  // LZ_L_C1
+            if (slot < 16) kf = slot;
+            else if (slot < 80) kf = 16 + lz_chained(slot - 16, 64);
+            else kf = (slot < 84 && a.has_ind) ? slot : -1;
+            break;
+    }
+    int srow;  // source row of the weight matrix, -1 = padding row
+    if (layer == LZ_L_S3) srow = row < 64 ? row + 1 : (row == 64 ? 0 : -1);  // geo rows first, sigma row in tile 4
+    else srow = row < a.nout[layer] ? row : -1;
+    float v = 0.0f;
+    if (kf >= 0 && srow >= 0) {
+        if (layer == LZ_L_NRM) v = 1.0f;
+        else if (a.w[layer]) v = a.w[layer][(size_t)srow * a.ld[layer] + kf];
+    }
+    packed[gid] = v;
+}
+
+extern "C" int lz_head_pack_weights(const float* aud0, const float* aud1, const float* eye0, const float* eye1, const float* sig0,
+                                    const float* sig1, const float* sig2, const float* col0, const float* col1, const float* unc0,
+                                    const float* unc1, int has_eye, int has_ind, float* packed, lz_stream_t stream) {
+    LZ_REQUIRE(aud0 && aud1 && sig0 && sig1 && sig2 && col0 && col1 && packed, LZ_ERR_BAD_ARGUMENT, "head_pack_weights: null weight");
+    LZ_REQUIRE(!has_eye || (eye0 && eye1), LZ_ERR_BAD_ARGUMENT, "head_pack_weights: eye weights required when has_eye");
+    LzPackArgs a;
+    const float* w[LZ_L_COUNT] = {aud0, aud1, eye0, eye1, nullptr, sig0, sig1, sig2, col0, col1, unc0, unc1};
+    const int nout[LZ_L_COUNT] = {64, 32, 16, 1, 1, 64, 64, 65, 64, 3, 32, 1};
+    const int ld[LZ_L_COUNT] = {36, 64, 36, 16, 32, 68 + (has_eye ? 1 : 0), 64, 64, 80 + (has_ind ? 4 : 0), 64, 36, 32};
+    for (int i = 0; i < LZ_L_COUNT; i++) { a.w[i] = w[i]; a.nout[i] = nout[i]; a.ld[i] = ld[i]; }
+    a.has_eye = has_eye; a.has_ind = has_ind;
+    hipLaunchKernelGGL(lz_k_head_pack, dim3(lz_div_up((uint64_t)LZ_FRAGS_ALL * 64, 256)), dim3(256), 0, lz_st(stream), a, packed);
+    LZ_CHECK_LAUNCH("head_pack_weights");
+    return LZ_OK;
+}
+
+// ---- the fused head ---------------------------------------------------------------------------------
+#define LZ_T 4             // sample tiles (of 16) per wave pass
+#define LZ_WG 512          // threads per workgroup
+#define LZ_WG_SAMPLES (LZ_WG / 64 * LZ_T * 16)
+
+struct LzHeadArgs {
+    const float* emb[3];
+    const int* offsets;
+    const float* packed;
+    const float* enc_a;
+    const float* ind_code;
+    const float* eye;
+    float bound;
+    float scale[12];
+    uint32_t res[12];
+    int testing;
+};
+
+template <int LAYER, int T>
+__device__ __forceinline__ void lz_layer(const float* __restrict__ wl, int lane, const float (&b)[T][LZ_KS[LAYER]],
+                                         lz_f4 (&acc)[LZ_NT[LAYER]][T]) {
+    constexpr int KS = LZ_KS[LAYER], NT = LZ_NT[LAYER];
+    const float* frag = wl + lz_frag_base(LAYER) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        float a[NT];
+#pragma unroll
+        for (int ft = 0; ft < NT; ft++) a[ft] = frag[(ks * NT + ft) * 64];
+#pragma unroll
+        for (int ft = 0; ft < NT; ft++)
+#pragma unroll
+            for (int j = 0; j < T; j++) acc[ft][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ft], b[j][ks], acc[ft][j], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float lz_relu(float v) { return v > 0.0f ? v : 0.0f; }
+
+template <bool TRAIN_UNC>
+__global__ void __launch_bounds__(LZ_WG, 2)
+lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
+                   const int* __restrict__ count, float* __restrict__ sigmas, float* __restrict__ rgbs,
+                   float* __restrict__ amb_aud, float* __restrict__ amb_eye, float* __restrict__ unc_out) {
+    constexpr int NFRAG = TRAIN_UNC ? LZ_FRAGS_ALL : LZ_FRAGS_INFER;
+    __shared__ float wl[NFRAG * 64 + 64];  // packed A fragments, then the 13 level offsets
+    uint32_t Meff = M;
+    if (count) {
+        const int c = *count;
+        Meff = c < 0 ? 0u : ((uint32_t)c < M ? (uint32_t)c : M);
+    }
+    const uint32_t n_wg_tiles = (Meff + LZ_WG_SAMPLES - 1) / LZ_WG_SAMPLES;
+    if (blockIdx.x >= n_wg_tiles) return;
+
+    // stage weights into LDS (16 B per lane per step, coalesced)
+    {
+        const float4* src = reinterpret_cast<const float4*>(P.packed);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = threadIdx.x; i < NFRAG * 16; i += LZ_WG) dst[i] = src[i];
+        // per-level table (indexed per lane in the gather): [0,13) offsets, [16,28) scale, [32,44) resolution
+        int* tab = reinterpret_cast<int*>(wl + NFRAG * 64);
+        if (threadIdx.x < 13) tab[threadIdx.x] = P.offsets[threadIdx.x];
+        if (threadIdx.x < 12) {
+            wl[NFRAG * 64 + 16 + threadIdx.x] = P.scale[threadIdx.x];
+            tab[32 + threadIdx.x] = (int)P.res[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    const int* offs = reinterpret_cast<const int*>(wl + NFRAG * 64);
+    const float* lscale = wl + NFRAG * 64 + 16;
+    const int* lres = offs + 32;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    const float two_bound = 2.0f * P.bound;
+    const bool has_eye = P.eye != nullptr;
+    const float eye_v = has_eye ? P.eye[0] : 0.0f;
+    // per-lane constants: enc_a for the features this lane holds in a chained tile (16t + 4q + r), ind_code[q]
+    float enca[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) enca[t][r] = P.enc_a[16 * t + 4 * q + r];
+    const float indq = P.ind_code ? P.ind_code[q] : 0.0f;
+
+    for (uint32_t wg_tile = blockIdx.x; wg_tile < n_wg_tiles; wg_tile += gridDim.x) {
+        const uint32_t base = wg_tile * LZ_WG_SAMPLES + wave * (LZ_T * 16);
+        if (base >= Meff) continue;  // wave-uniform
+
+        // ---------------- gather: enc_x features f = 4i + q of sample (j, s) -> B operands ----------------
+        float encx[LZ_T][9];
+        float shq[LZ_T][4];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++) {
+            uint32_t m = base + j * 16 + s;
+            if (m >= Meff) m = Meff - 1;  // clamp: computed, never stored
+            const float px = xyzs[(size_t)m * 3], py = xyzs[(size_t)m * 3 + 1], pz = xyzs[(size_t)m * 3 + 2];
+            const float x01 = (px + P.bound) / two_bound, y01 = (py + P.bound) / two_bound, z01 = (pz + P.bound) / two_bound;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int f = 4 * i + q;             // 0..35
+                const int plane = f / 12, level = f - plane * 12;
+                const float u = plane == 1 ? y01 : x01;          // xy: (x,y)  yz: (y,z)  xz: (x,z)   network.py:211
+                const float v = plane == 0 ? y01 : z01;
+                const float* g = plane == 0 ? P.emb[0] : (plane == 1 ? P.emb[1] : P.emb[2]);
+                float val = 0.0f;
+                if (!(u < 0 || u > 1 || v < 0 || v > 1)) {
+                    const uint32_t off0 = (uint32_t)offs[level];
+                    const uint32_t hs = (uint32_t)offs[level + 1] - off0;
+                    const float scale = lscale[level];
+                    const uint32_t resolution = (uint32_t)lres[level];
+                    float p0 = lz_fmaf(u, scale, 0.5f), p1 = lz_fmaf(v, scale, 0.5f);
+                    const uint32_t g0 = (uint32_t)floorf(p0), g1 = (uint32_t)floorf(p1);
+                    p0 -= (float)g0; p1 -= (float)g1;
+                    // gridencoder.cu:54-72 for D = 2 (stride 1 <= hashmap_size always holds)
+                    const uint32_t stride1 = resolution + 1;
+                    const bool dense = stride1 <= hs && stride1 * stride1 <= hs;
+                    const float* gl = g + off0;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t c0 = g0 + (c & 1), c1 = g1 + (c >> 1);
+                        // dense while (res+1)^2 fits the level's table, else fast_hash (primes 1, 2654435761)
+                        uint32_t index = dense ? c0 + c1 * stride1 : (c0 ^ (c1 * 2654435761u));
+                        index %= hs;
+                        const float w = ((c & 1) ? p0 : 1 - p0) * ((c >> 1) ? p1 : 1 - p1);
+                        acc = lz_fmaf(w, gl[index], acc);
+                    }
+                    val = acc;
+                }
+                encx[j][i] = val;
+            }
+            // SH(4) of the view direction: this lane keeps components 4i + q
+            float o[16];
+            lz_sh_eval(dirs[(size_t)m * 3], dirs[(size_t)m * 3 + 1], dirs[(size_t)m * 3 + 2], 4, o, nullptr, nullptr, nullptr);
+#pragma unroll
+            for (int i = 0; i < 4; i++) shq[j][i] = q == 0 ? o[4 * i] : (q == 1 ? o[4 * i + 1] : (q == 2 ? o[4 * i + 2] : o[4 * i + 3]));
+        }
+
+        // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
+        float att[LZ_T][8];   // chained layout: [t*4 + r] = feature 16t + 4q + r
+        {
+            lz_f4 acc1[4][LZ_T];
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int j = 0; j < LZ_T; j++) acc1[ft][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_A1, LZ_T>(wl, lane, encx, acc1);
+            float b2[LZ_T][16];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
+            lz_f4 acc2[2][LZ_T];
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+                for (int j = 0; j < LZ_T; j++) acc2[ft][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_A2, LZ_T>(wl, lane, b2, acc2);
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+                for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) att[j][4 * ft + r] = acc2[ft][j][r];
+        }
+        // ambient_aud = || att ||_2 : sum of squares as a ones-row MFMA in the chained order, sqrt on lanes q == 0
+        float ambaud[LZ_T];
+        {
+            float sq[LZ_T][8];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) sq[j][k] = att[j][k] * att[j][k];
+            lz_f4 accn[1][LZ_T];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) accn[0][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_NRM, LZ_T>(wl, lane, sq, accn);
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) ambaud[j] = sqrtf(accn[0][j][0]);
+        }
+        // ---------------- eye attention: 36 -> 16 -> 1, sigmoid ----------------
+        float eyeatt[LZ_T];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++) eyeatt[j] = 0.0f;
+        if (has_eye) {
+            lz_f4 acce[1][LZ_T];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) acce[0][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_E1, LZ_T>(wl, lane, encx, acce);
+            float be[LZ_T][4];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) be[j][r] = lz_relu(acce[0][j][r]);
+            lz_f4 acce2[1][LZ_T];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) acce2[0][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_E2, LZ_T>(wl, lane, be, acce2);
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) eyeatt[j] = lz_sigmoidf(acce2[0][j][0]);  // valid on lanes q == 0
+        }
+        // ---------------- uncertainty ----------------
+        float uncv[LZ_T];
+        if constexpr (TRAIN_UNC) {
+            lz_f4 accu[2][LZ_T];
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+                for (int j = 0; j < LZ_T; j++) accu[ft][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_U1, LZ_T>(wl, lane, encx, accu);
+            float bu[LZ_T][8];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+                for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bu[j][4 * ft + r] = lz_relu(accu[ft][j][r]);
+            lz_f4 accu2[1][LZ_T];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) accu2[0][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_U2, LZ_T>(wl, lane, bu, accu2);
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) uncv[j] = lz_softplusf(accu2[0][j][0]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) uncv[j] = lz_softplusf(0.0f);   // network.py:243-249, 278
+        }
+        // ---------------- sigma net: [enc_x 36 | enc_a * att 32 | eye * eye_att 1] -> 64 -> 64 -> 65 ----------------
+        float geo[LZ_T][16];
+        float sigma[LZ_T];
+        {
+            float b1[LZ_T][18];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) b1[j][i] = encx[j][i];
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) b1[j][9 + 4 * t + r] = enca[t][r] * att[j][4 * t + r];
+                b1[j][17] = (has_eye && q == 0) ? eye_v * eyeatt[j] : 0.0f;
+            }
+            lz_f4 acc1[4][LZ_T];
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int j = 0; j < LZ_T; j++) acc1[ft][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_S1, LZ_T>(wl, lane, b1, acc1);
+            float b2[LZ_T][16];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
+            lz_f4 acc2[4][LZ_T];
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int j = 0; j < LZ_T; j++) acc2[ft][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_S2, LZ_T>(wl, lane, b2, acc2);
+            float b3[LZ_T][16];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) b3[j][4 * ft + r] = lz_relu(acc2[ft][j][r]);
+            lz_f4 acc3[5][LZ_T];
+#pragma unroll
+            for (int ft = 0; ft < 5; ft++)
+#pragma unroll
+                for (int j = 0; j < LZ_T; j++) acc3[ft][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_S3, LZ_T>(wl, lane, b3, acc3);
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) {
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) geo[j][4 * ft + r] = acc3[ft][j][r];   // geo_feat, no activation (network.py:304)
+                sigma[j] = lz_expf(acc3[4][j][0]);                                     // lanes q == 0
+            }
+        }
+        // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
+        float rgb[LZ_T][3];
+        {
+            float b1[LZ_T][21];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) b1[j][i] = shq[j][i];
+#pragma unroll
+                for (int k = 0; k < 16; k++) b1[j][4 + k] = geo[j][k];
+                b1[j][20] = indq;
+            }
+            lz_f4 acc1[4][LZ_T];
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int j = 0; j < LZ_T; j++) acc1[ft][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_C1, LZ_T>(wl, lane, b1, acc1);
+            float b2[LZ_T][16];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
+            lz_f4 acc2[1][LZ_T];
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) acc2[0][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_C2, LZ_T>(wl, lane, b2, acc2);
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) rgb[j][c] = lz_sigmoidf(acc2[0][j][c]) * 1.002f - 0.001f;   // network.py:275
+        }
+        // ---------------- store (lanes q == 0 own sample (j, s)) ----------------
+        if (q == 0) {
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) {
+                const uint32_t m = base + j * 16 + s;
+                if (m < Meff) {
+                    sigmas[m] = sigma[j];
+                    rgbs[(size_t)m * 3] = rgb[j][0]; rgbs[(size_t)m * 3 + 1] = rgb[j][1]; rgbs[(size_t)m * 3 + 2] = rgb[j][2];
+                    amb_aud[m] = ambaud[j];
+                    if (amb_eye) amb_eye[m] = eyeatt[j];
+                    unc_out[m] = uncv[j];
+                }
+            }
+        }
+    }
+}
+
+extern "C" int lz_triplane_head_forward(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M,
+                                        const int32_t* count, float* sigmas, float* rgbs, float* amb_aud, float* amb_eye,
+                                        float* unc, lz_stream_t stream) {
+    LZ_REQUIRE(p && xyzs && dirs && sigmas && rgbs && amb_aud && unc, LZ_ERR_BAD_ARGUMENT, "triplane_head_forward: null tensor");
+    LZ_REQUIRE(p->emb_xy && p->emb_yz && p->emb_xz && p->offsets && p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT,
+               "triplane_head_forward: incomplete lz_head_params");
+    if (M == 0) return LZ_OK;
+    LzHeadArgs a;
+    a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
+    a.offsets = p->offsets; a.packed = p->packed; a.enc_a = p->enc_a; a.ind_code = p->ind_code; a.eye = p->eye;
+    a.bound = p->bound; a.testing = p->testing;
+    for (int l = 0; l < 12; l++) {  // gridencoder.cu:125-126 on the host, same libm call as the CPU checker
+        const float sc = exp2f((float)l * p->S) * (float)p->H - 1.0f;
+        a.scale[l] = sc;
+        a.res[l] = (uint32_t)ceilf(sc) + 1u;
+    }
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const uint32_t tiles = lz_div_up(M, LZ_WG_SAMPLES);
+    const uint32_t grid = tiles < (uint32_t)n_cu ? tiles : (uint32_t)n_cu;
+    if (p->testing)
+        hipLaunchKernelGGL((lz_k_triplane_head<false>), dim3(grid), dim3(LZ_WG), 0, lz_st(stream), a, xyzs, dirs, M, count, sigmas, rgbs, amb_aud, amb_eye, unc);
+    else
+        hipLaunchKernelGGL((lz_k_triplane_head<true>), dim3(grid), dim3(LZ_WG), 0, lz_st(stream), a, xyzs, dirs, M, count, sigmas, rgbs, amb_aud, amb_eye, unc);
+    LZ_CHECK_LAUNCH("triplane_head_forward");
+    return LZ_OK;
+}

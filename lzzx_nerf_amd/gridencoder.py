@@ -1,0 +1,136 @@
+"""Multi-resolution hash / tiled grid encoder -- operator API of the reference's `gridencoder` package
+(/root/reference/gridencoder/grid.py:19-154) on top of the gfx950 kernels (csrc/lz_grid.hip).
+
+Same names, arguments, defaults, state-dict keys (`embeddings`, `offsets`) and error behaviour.  Differences
+that are invisible to callers: the kernel writes [B, L*C] directly (no permute/reshape copy, grid.py:52) and
+reads the gradient in that layout (no permute copy, grid.py:70); kernels run on torch's current stream.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from ._util import call, ptr, require_cuda, stream
+
+_gridtype_to_id = {"hash": 0, "tiled": 1}
+
+
+def _check_dc(D, C):
+    # the reference throws std::runtime_error from the dispatch switch (gridencoder.cu:354,372)
+    if C not in (1, 2, 4, 8):
+        raise RuntimeError("GridEncoding: C must be 1, 2, 4, or 8.")
+    if D not in (1, 2, 3, 4, 5):
+        raise RuntimeError("GridEncoding: D must be 1, 2, 3, 4, or 5")
+
+
+class _grid_encode(Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
+                align_corners=False):
+        # inputs: [B, D] float in [0, 1]; embeddings: [sO, C]; offsets: [L + 1] int32; returns [B, L * C]
+        inputs = inputs.float().contiguous()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.float32(np.log2(per_level_scale)))  # narrowed to float at the FFI, gridencoder.h:12
+        H = int(base_resolution)
+        _check_dc(D, C)
+
+        # half tables only under autocast and only when C is even (grid.py:38-39)
+        if torch.is_autocast_enabled() and C % 2 == 0:
+            embeddings = embeddings.to(torch.half)
+        embeddings = embeddings.contiguous()
+        if embeddings.dtype not in (torch.float32, torch.float16):
+            raise RuntimeError("embeddings must be a float32 or float16 tensor")
+        if offsets.dtype != torch.int32:
+            raise RuntimeError("offsets must be an int tensor")
+        require_cuda(inputs=inputs, embeddings=embeddings, offsets=offsets)
+
+        outputs = torch.empty(B, L * C, device=inputs.device, dtype=embeddings.dtype)
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
+        call("lz_grid_encode_forward", ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, S, H, ptr(dy_dx),
+             int(gridtype), int(bool(align_corners)), int(embeddings.dtype == torch.float16), 1, stream())
+
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = [B, D, C, L, S, H, gridtype]
+        ctx.align_corners = align_corners
+        return outputs
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype = ctx.dims
+        grad = grad.contiguous()  # [B, L * C], consumed in place of the reference's [L, B, C] copy
+        if grad.dtype != embeddings.dtype:
+            grad = grad.to(embeddings.dtype)
+        grad_embeddings = torch.zeros_like(embeddings)
+        grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
+        call("lz_grid_encode_backward", ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L,
+             S, H, ptr(dy_dx), ptr(grad_inputs), int(gridtype), int(bool(ctx.align_corners)),
+             int(embeddings.dtype == torch.float16), 1, stream())
+        if dy_dx is not None:
+            grad_inputs = grad_inputs.to(inputs.dtype)
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None
+
+
+grid_encode = _grid_encode.apply
+
+
+def grid_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners=False):
+    """table layout of GridEncoder.__init__ (grid.py:108-121): float64 resolution, cap, round up to 8"""
+    offsets, offset = [], 0
+    max_params = 2 ** log2_hashmap_size
+    for i in range(num_levels):
+        resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+        params_in_level = min(max_params, (resolution if align_corners else resolution + 1) ** input_dim)
+        params_in_level = int(np.ceil(params_in_level / 8) * 8)
+        offsets.append(offset)
+        offset += params_in_level
+    offsets.append(offset)
+    return offsets
+
+
+class GridEncoder(nn.Module):
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                 desired_resolution=None, gridtype="hash", align_corners=False):
+        super().__init__()
+        if desired_resolution is not None:  # overrides per_level_scale (grid.py:95-96)
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype = gridtype
+        self.gridtype_id = _gridtype_to_id[gridtype]
+        self.align_corners = align_corners
+        self.max_params = 2 ** log2_hashmap_size
+
+        offsets = grid_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
+        self.register_buffer("offsets", torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        self.n_params = offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(offsets[-1], level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        std = 1e-4
+        self.embeddings.data.uniform_(-std, std)
+
+    def __repr__(self):
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
+                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
+                f"align_corners={self.align_corners}")
+
+    def forward(self, inputs, bound=1):
+        # inputs: [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]
+        inputs = (inputs + bound) / (2 * bound)
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                              inputs.requires_grad, self.gridtype_id, self.align_corners)
+        return outputs.view(prefix_shape + [self.output_dim])

@@ -1,0 +1,93 @@
+"""Fused triplane head: the per-sample arithmetic of NeRFNetwork.forward / density
+(/root/reference/nerf_triplane/network.py:252-311) as ONE gfx950 kernel (csrc/lz_head.hip):
+3 hash-grid planes -> audio-channel / eye attention -> sigma net -> SH(4) -> colour net (-> uncertainty net).
+
+It consumes the reference's state_dict unchanged (keys `encoder_{xy,yz,xz}.embeddings`, `*.offsets`,
+`{aud_ch_att,eye_att,sigma,color,unc}_net.net.N.weight`, `individual_codes`), so a trained
+checkpoint renders without conversion.  The drop-in operator path (encoding.get_encoder + torch Linear)
+stays available for the reference's own NeRFNetwork; this module is the fast path used by
+lzzx_nerf_amd.renderer and bench.py.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._util import call, ptr, stream
+
+_W_KEYS = ["aud_ch_att_net.net.0.weight", "aud_ch_att_net.net.1.weight", "eye_att_net.net.0.weight", "eye_att_net.net.1.weight",
+           "sigma_net.net.0.weight", "sigma_net.net.1.weight", "sigma_net.net.2.weight", "color_net.net.0.weight",
+           "color_net.net.1.weight", "unc_net.net.0.weight", "unc_net.net.1.weight"]
+
+
+class FusedTriplaneHead:
+    """Inference/forward-only fused head (autograd for training goes through the operator path)."""
+
+    def __init__(self, state_dict, bound=1.0, exp_eye=True, device="cuda"):
+        self.device = torch.device(device)
+        self.bound = float(bound)
+        sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
+              if k in _W_KEYS or k.startswith("encoder_") and k.endswith(".embeddings") or k == "individual_codes"}
+        self.emb = [sd["encoder_%s.embeddings" % p] for p in ("xy", "yz", "xz")]
+        self.offsets = state_dict["encoder_xy.offsets"].to(self.device, torch.int32).contiguous()
+        if self.offsets.numel() != 13 or self.emb[0].shape[1] != 1:
+            raise RuntimeError("FusedTriplaneHead expects the triplane configuration (D=2, L=12, C=1, network.py:129-133)")
+        self.w = [sd.get(k) for k in _W_KEYS]
+        self.has_eye = bool(exp_eye)
+        self.individual_codes = sd.get("individual_codes")
+        self.has_ind = self.individual_codes is not None and self.w[7].shape[1] == 84
+        exp_sig = 68 + (1 if self.has_eye else 0)
+        if self.w[4].shape[1] != exp_sig:
+            raise RuntimeError("sigma_net input width %d does not match exp_eye=%s" % (self.w[4].shape[1], self.has_eye))
+        # GridEncoder hyper-parameters of the triplane (network.py:131-133, grid.py:95-96)
+        self.H = 64
+        self.per_level_scale = np.exp2(np.log2(512 * self.bound / 64) / 11)
+        self.S = float(np.float32(np.log2(self.per_level_scale)))
+        self.packed = torch.empty(_lib.load().lz_head_packed_size(), dtype=torch.float32, device=self.device)
+        self.repack()
+
+    @classmethod
+    def from_network(cls, net, **kw):
+        """net: a nerf_triplane.network.NeRFNetwork (reference class, unmodified)"""
+        return cls(net.state_dict(), bound=net.bound, exp_eye=bool(getattr(net, "exp_eye", True)), **kw)
+
+    def repack(self):
+        """(re)build the MFMA A-fragment buffer; call after the weights change"""
+        w = self.w
+        call("lz_head_pack_weights", *[ptr(t) for t in w], int(self.has_eye), int(self.has_ind), ptr(self.packed), stream())
+
+    def _params(self, enc_a, ind_code, eye, testing):
+        p = _lib.HeadParams()
+        p.emb_xy, p.emb_yz, p.emb_xz = self.emb[0].data_ptr(), self.emb[1].data_ptr(), self.emb[2].data_ptr()
+        p.offsets, p.packed, p.enc_a = self.offsets.data_ptr(), self.packed.data_ptr(), enc_a.data_ptr()
+        p.ind_code = ind_code.data_ptr() if (ind_code is not None and self.has_ind) else None
+        p.eye = eye.data_ptr() if (eye is not None and self.has_eye) else None
+        p.bound, p.S, p.H, p.testing = self.bound, self.S, self.H, int(bool(testing))
+        return p
+
+    def forward(self, xyzs, dirs, enc_a, ind_code=None, eye=None, testing=True, count_ptr=None, out=None):
+        """xyzs, dirs: [M, 3] f32 cuda.  Returns sigma [M], rgb [M,3], amb_aud [M,1], amb_eye [M,1], unc [M,1]
+        (same tuple as NeRFNetwork.forward, network.py:280).  `count_ptr`: device address of an int32 that bounds
+        the rows actually processed (the render loop's n_samples)."""
+        M = xyzs.shape[0]
+        enc_a = enc_a.reshape(-1).float().contiguous()
+        if enc_a.numel() != 32:
+            raise RuntimeError("enc_a must hold 32 audio features")
+        ind_code = None if ind_code is None else ind_code.reshape(-1).float().contiguous()
+        eye = None if eye is None else eye.reshape(-1).float().contiguous()
+        if not testing and self.w[9] is None:
+            raise RuntimeError("training-mode uncertainty needs unc_net weights")
+        if out is None:
+            kw = dict(dtype=torch.float32, device=xyzs.device)
+            out = (torch.empty(M, **kw), torch.empty(M, 3, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw),
+                   torch.empty(M, 1, **kw))
+        sig, rgb, aa, ae, un = out
+        p = self._params(enc_a, ind_code, eye, testing)
+        # keep the small tensors alive until the launch is enqueued (same stream -> ordering is enough)
+        call("lz_triplane_head_forward", C.byref(p), ptr(xyzs), ptr(dirs), M, C.c_void_p(count_ptr) if count_ptr else None,
+             ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un), stream())
+        self._keep = (enc_a, ind_code, eye)
+        return sig, rgb, aa, ae, un
+
+    __call__ = forward

@@ -1,0 +1,150 @@
+"""Device-resident triplane renderer: the thin counterpart of NeRFRenderer.run_cuda_for_inference
+(/root/reference/nerf_triplane/renderer.py:406-570) used by bench.py and the parity tests.
+
+Same algorithm and iteration schedule as the reference loop -- per iteration: march n_step samples for every
+alive ray, evaluate the head, composite, drop dead rays, n_step = max(min(N // n_alive, 8), 1), stop at
+max_steps -- but (n_alive, n_step, step) live in device memory (lz_loop_state), compaction is an
+order-preserving device scan, and the host never synchronises inside a frame: it enqueues iterations in chunks
+and peeks at a pinned copy of the state between chunks to stop early.  The reference's own renderer keeps
+working unmodified through the drop-in operators; this class is what removes its per-iteration host sync
+(38 % of its loop time) and ~20 launches per iteration.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._util import call, ptr, stream
+from .head import FusedTriplaneHead
+
+_STATE_INTS = 8          # sizeof(lz_loop_state) / 4
+_N_SAMPLES_OFF = 16      # offsetof(lz_loop_state, n_samples)
+
+
+def get_rays(pose, intrinsics, H, W):
+    """Full-image rays (nerf_triplane/utils.py:226-312, N = -1 branch) for one cam2world pose [4,4] (cuda).
+    Returns rays_o, rays_d [H*W, 3]."""
+    pose = pose.reshape(4, 4).float().contiguous()
+    fx, fy, cx, cy = [float(v) for v in intrinsics]
+    rays_o = torch.empty(H * W, 3, dtype=torch.float32, device=pose.device)
+    rays_d = torch.empty(H * W, 3, dtype=torch.float32, device=pose.device)
+    call("lz_get_rays", ptr(pose), fx, fy, cx, cy, int(H), int(W), ptr(rays_o), ptr(rays_d), stream())
+    return rays_o, rays_d
+
+
+class _Buffers:
+    def __init__(self, N, device):
+        f = dict(dtype=torch.float32, device=device)
+        i = dict(dtype=torch.int32, device=device)
+        self.N = N
+        self.nears, self.fars = torch.empty(N, **f), torch.empty(N, **f)
+        self.rays_alive = [torch.empty(N, **i), torch.empty(N, **i)]
+        self.rays_t = torch.empty(N, **f)
+        self.weights_sum, self.depth = torch.empty(N, **f), torch.empty(N, **f)
+        self.image, self.out = torch.empty(N, 3, **f), torch.empty(N, 3, **f)
+        self.amb_aud_sum, self.amb_eye_sum, self.unc_sum = torch.empty(N, **f), torch.empty(N, **f), torch.empty(N, **f)
+        # n_alive * n_step <= N always (renderer.py:513), so N sample rows suffice
+        self.xyzs, self.dirs, self.deltas = torch.empty(N, 3, **f), torch.empty(N, 3, **f), torch.empty(N, 2, **f)
+        self.sigmas, self.rgbs = torch.empty(N, **f), torch.empty(N, 3, **f)
+        self.amb_aud, self.amb_eye, self.unc = torch.empty(N, 1, **f), torch.empty(N, 1, **f), torch.empty(N, 1, **f)
+        self.state = torch.zeros(_STATE_INTS, **i)
+        self.workspace = torch.empty(4096, **i)
+        self.ray_counts = torch.zeros(N, **i)
+        self.state_host = torch.zeros(_STATE_INTS, dtype=torch.int32).pin_memory()
+
+
+class TriplaneRenderer:
+    """Inference renderer for one head / one occupancy grid.
+
+    head:             FusedTriplaneHead
+    density_bitfield: uint8 [cascade * grid_size^3 / 8] (cuda), as produced by raymarching.packbits
+    """
+
+    def __init__(self, head: FusedTriplaneHead, density_bitfield, bound=1.0, cascade=None, grid_size=128, aabb=None,
+                 min_near=0.05, density_scale=1):
+        import math
+        self.head = head
+        self.bound = float(bound)
+        self.cascade = cascade if cascade is not None else 1 + math.ceil(math.log2(bound))  # renderer.py:93
+        self.grid_size = grid_size
+        self.bitfield = density_bitfield.contiguous()
+        dev = self.bitfield.device
+        if aabb is None:  # renderer.py:110 -- y extent halved
+            aabb = torch.tensor([-bound, -bound / 2, -bound, bound, bound / 2, bound], dtype=torch.float32, device=dev)
+        self.aabb = aabb.to(dev, torch.float32).contiguous()
+        self.min_near = float(min_near)
+        if density_scale != 1:
+            raise NotImplementedError("density_scale != 1 (the reference hard-codes 1, renderer.py:95)")
+        self._buf = None
+        self._head_events = None  # set to a list to collect (start, end) HIP events around every head launch (bench.py)
+        self.chunk = 16  # iterations enqueued between two non-blocking peeks at the loop state
+
+    def _buffers(self, N, device):
+        if self._buf is None or self._buf.N != N:
+            self._buf = _Buffers(N, device)
+        return self._buf
+
+    def _iteration(self, b, cur, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples):
+        st = ptr(b.state)
+        call("lz_loop_march", st, N, ptr(b.rays_alive[cur]), ptr(b.rays_t), ptr(self._rays_o), ptr(self._rays_d), self.bound,
+             float(dt_gamma), int(max_steps), int(self.cascade), int(self.grid_size), ptr(self.bitfield), ptr(b.nears), ptr(b.fars),
+             ptr(b.xyzs), ptr(b.dirs), ptr(b.deltas), ptr(b.ray_counts) if count_samples else None, stream())
+        ev = self._head_events
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.head.forward(b.xyzs, b.dirs, enc_a, ind_code, eye, testing=True, count_ptr=b.state.data_ptr() + _N_SAMPLES_OFF,
+                          out=(b.sigmas, b.rgbs, b.amb_aud, b.amb_eye, b.unc))
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
+        call("lz_loop_composite", st, N, float(T_thresh), ptr(b.rays_alive[cur]), ptr(b.rays_t), ptr(b.sigmas), ptr(b.rgbs),
+             ptr(b.deltas), ptr(b.amb_aud), ptr(b.amb_eye), ptr(b.unc), ptr(b.weights_sum), ptr(b.depth), ptr(b.image),
+             ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), stream())
+        call("lz_loop_compact", st, N, int(max_steps), ptr(b.rays_alive[cur]), ptr(b.rays_alive[1 - cur]), ptr(b.workspace), stream())
+
+    @torch.no_grad()
+    def render(self, rays_o, rays_d, enc_a, ind_code=None, eye=None, dt_gamma=1.0 / 256, max_steps=16, T_thresh=1e-4,
+               bg_color=1.0, count_samples=False, sync_free=True):
+        """rays_o, rays_d: [N,3] (or [1,N,3]) f32 cuda.  Returns dict(image [N,3] blended+clamped, weights_sum, depth,
+        amb_aud_sum, amb_eye_sum, uncertainty_sum, state (device int32[8]), ray_counts if requested).
+        Nothing in here blocks the host when sync_free (the returned tensors are ready in stream order)."""
+        rays_o = rays_o.reshape(-1, 3).float().contiguous()
+        rays_d = rays_d.reshape(-1, 3).float().contiguous()
+        N = rays_o.shape[0]
+        b = self._buffers(N, rays_o.device)
+        self._rays_o, self._rays_d = rays_o, rays_d
+        call("lz_near_far_from_aabb", ptr(rays_o), ptr(rays_d), ptr(self.aabb), N, self.min_near, ptr(b.nears), ptr(b.fars), stream())
+        if count_samples:
+            b.ray_counts.zero_()
+        call("lz_loop_begin", N, int(max_steps), ptr(b.nears), ptr(b.rays_alive[0]), ptr(b.rays_t), ptr(b.weights_sum), ptr(b.depth),
+             ptr(b.image), ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ptr(b.state), stream())
+        cur, it = 0, 0
+        pending = None
+        while it < max_steps:  # n_step >= 1, so max_steps iterations always suffice (renderer.py:503,546)
+            n = min(self.chunk, max_steps - it)
+            for _ in range(n):
+                self._iteration(b, cur, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples)
+                cur = 1 - cur
+            it += n
+            if pending is not None and pending.query() and int(b.state_host[3]) == 1:
+                break  # a previous chunk already finished the frame; what was enqueued since is a no-op on the device
+            b.state_host.copy_(b.state, non_blocking=True)
+            pending = torch.cuda.Event()
+            pending.record()
+            if not sync_free:
+                pending.synchronize()
+                if int(b.state_host[3]) == 1:
+                    break
+        bg = None
+        bg_scalar = 1.0
+        if torch.is_tensor(bg_color):
+            bg = bg_color.to(rays_o.device, torch.float32).expand(N, 3).contiguous()
+        else:
+            bg_scalar = float(bg_color)
+        call("lz_final_blend", ptr(b.image), ptr(b.weights_sum), ptr(bg), bg_scalar, N, ptr(b.out), stream())
+        res = dict(image=b.out, image_raw=b.image, weights_sum=b.weights_sum, depth=b.depth, amb_aud_sum=b.amb_aud_sum,
+                   amb_eye_sum=b.amb_eye_sum, uncertainty_sum=b.unc_sum, state=b.state, nears=b.nears, fars=b.fars)
+        if count_samples:
+            res["ray_counts"] = b.ray_counts
+        return res
