@@ -103,6 +103,7 @@ static int lz_sh_dispatch(const float* in, float* out, uint32_t B, uint32_t degr
 extern "C" int lz_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t degree, float* dy_dx,
                                     lz_stream_t stream) {
     LZ_REQUIRE(D == 3, LZ_ERR_UNSUPPORTED, "SH encoder only support input dim == 3");
+    if (B == 0) return LZ_OK;
     LZ_REQUIRE(inputs && outputs, LZ_ERR_BAD_ARGUMENT, "sh_encode_forward: null tensor");
     if (B == 0) return LZ_OK;
     int rc = dy_dx ? lz_sh_dispatch<true>(inputs, outputs, B, degree, dy_dx, lz_st(stream))
@@ -116,6 +117,7 @@ extern "C" int lz_sh_encode_backward(const float* grad, const float* inputs, uin
                                      const float* dy_dx, float* grad_inputs, lz_stream_t stream) {
     (void)inputs;
     LZ_REQUIRE(D == 3 && degree >= 1 && degree <= 8, LZ_ERR_UNSUPPORTED, "sh_encode_backward: D must be 3, degree in [1, 8]");
+    if (B == 0) return LZ_OK;
     LZ_REQUIRE(grad && dy_dx && grad_inputs, LZ_ERR_BAD_ARGUMENT, "sh_encode_backward: null tensor");
     if (B == 0) return LZ_OK;
     hipLaunchKernelGGL(lz_k_sh_backward, dim3(lz_div_up((uint64_t)B * 3, 256)), dim3(256), 0, lz_st(stream), grad, B, degree * degree, dy_dx, grad_inputs);
@@ -164,6 +166,7 @@ lz_k_freq_backward(const float* __restrict__ grad, const float* __restrict__ out
 
 extern "C" int lz_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs,
                                       lz_stream_t stream) {
+    if (B == 0) return LZ_OK;
     LZ_REQUIRE(inputs && outputs, LZ_ERR_BAD_ARGUMENT, "freq_encode_forward: null tensor");
     LZ_REQUIRE(C == D + 2 * D * deg, LZ_ERR_BAD_ARGUMENT, "freq_encode_forward: C must equal D + 2*D*deg");
     if (B == 0) return LZ_OK;
@@ -174,6 +177,7 @@ extern "C" int lz_freq_encode_forward(const float* inputs, uint32_t B, uint32_t 
 
 extern "C" int lz_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
                                        float* grad_inputs, lz_stream_t stream) {
+    if (B == 0) return LZ_OK;
     LZ_REQUIRE(grad && outputs && grad_inputs, LZ_ERR_BAD_ARGUMENT, "freq_encode_backward: null tensor");
     LZ_REQUIRE(C == D + 2 * D * deg, LZ_ERR_BAD_ARGUMENT, "freq_encode_backward: C must equal D + 2*D*deg");
     if (B == 0) return LZ_OK;

@@ -348,6 +348,7 @@ static int lz_grid_fwd_d(const float* inputs, const T* emb, const int* offsets, 
 extern "C" int lz_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                                       uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
                                       uint32_t gridtype, int align_corners, int emb_f16, int out_layout, lz_stream_t stream) {
+    if (B == 0) return LZ_OK;
     LZ_REQUIRE(inputs && embeddings && offsets && outputs, LZ_ERR_BAD_ARGUMENT, "grid_encode_forward: null tensor");
     LzGridLevels lv;
     LZ_REQUIRE(lz_fill_levels(lv, L, S, H) == 0, LZ_ERR_UNSUPPORTED, "grid_encode_forward: at most %d levels", LZ_MAX_LEVELS);
@@ -427,6 +428,7 @@ extern "C" int lz_grid_encode_backward(const void* grad, const float* inputs, co
                                        const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, int emb_f16,
                                        int grad_layout, lz_stream_t stream) {
     (void)embeddings;
+    if (B == 0) return LZ_OK;
     LZ_REQUIRE(grad && inputs && offsets && grad_embeddings, LZ_ERR_BAD_ARGUMENT, "grid_encode_backward: null tensor");
     LzGridLevels lv;
     LZ_REQUIRE(lz_fill_levels(lv, L, S, H) == 0, LZ_ERR_UNSUPPORTED, "grid_encode_backward: at most %d levels", LZ_MAX_LEVELS);

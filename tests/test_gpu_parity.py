@@ -191,7 +191,9 @@ def test_get_rays_and_near_far_bit_exact():
     from lzzx_nerf_amd import raymarching as R
     from lzzx_nerf_amd.renderer import get_rays as gpu_get_rays
     for rot in (0.0, 0.4):
-        pose, intr, (ro, rd) = _camera_rays(96, 80, rot)
+        pose, intr, _ = _camera_rays(96, 80, rot)
+        intr = [intr[0] / 3, intr[1] / 3, intr[2], intr[3]]  # wide field of view: some rays miss the box
+        ro, rd = get_rays(pose, intr, 96, 80)
         ro_g, rd_g = gpu_get_rays(dev(pose), intr, 96, 80)
         assert np.array_equal(host(ro_g), ro) and np.array_equal(host(rd_g), rd)
         aabb = np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32)
@@ -251,8 +253,9 @@ def test_march_train_bit_exact(scene, bound, cascade):
     rt = torch.empty(N, 3, dtype=torch.int32, device="cuda")
     ctr.zero_()
     ws = torch.empty(N + 2, dtype=torch.int32, device="cuda")
-    call("lz_march_rays_train", ptr(dev(ro)), ptr(dev(rd)), ptr(dev(bits)), bound, 1 / 256, 48, N, cascade, 128, M, ptr(dev(nears)),
-         ptr(dev(fars)), ptr(xt), ptr(dt_), ptr(lt), ptr(rt), ptr(ctr), ptr(dev(noises)), ptr(ws), stream())
+    keep = [dev(a) for a in (ro, rd, bits, nears, fars, noises)]  # raw pointers: the tensors must outlive the launch
+    call("lz_march_rays_train", ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), bound, 1 / 256, 48, N, cascade, 128, M, ptr(keep[3]),
+         ptr(keep[4]), ptr(xt), ptr(dt_), ptr(lt), ptr(rt), ptr(ctr), ptr(keep[5]), ptr(ws), stream())
     assert np.array_equal(host(rt), ro_) and np.array_equal(host(xt), xo) and np.array_equal(host(lt), lo)
     assert host(ctr).tolist() == ctr_o.tolist()
 
@@ -459,7 +462,7 @@ def _scene(params, scale_sigma=0.0):
     return p
 
 
-@pytest.mark.parametrize("scene,max_steps,boost", [("ones", 32, 0.0), ("ellipsoid", 64, 0.0), ("ones", 64, 40.0)])
+@pytest.mark.parametrize("scene,max_steps,boost", [("ones", 32, 0.0), ("ellipsoid", 64, 0.0), ("ellipsoid", 64, 40.0)])
 def test_render_frame_matches_checker(params, golden, scene, max_steps, boost):
     """whole inference frame: same image, same per-ray sample counts, same iteration schedule as the reference loop"""
     from lzzx_nerf_amd.renderer import TriplaneRenderer
@@ -481,7 +484,7 @@ def test_render_frame_matches_checker(params, golden, scene, max_steps, boost):
     assert np.array_equal(host(out["weights_sum"]), ref["weights_sum"])
     assert np.array_equal(host(out["image"]), ref["image"]) and np.array_equal(host(out["depth"]), ref["depth"])
     assert np.array_equal(host(out["amb_aud_sum"]), ref["amb_aud_sum"]) and np.array_equal(host(out["uncertainty_sum"]), ref["uncertainty_sum"])
-    if boost:
+    if scene == "ellipsoid":
         assert len(set(s for _, s in st["schedule"])) > 1, "scene must exercise n_step > 1 (ray compaction)"
     mse = float(((host(out["image"]).astype(np.float64) - ref["image"]) ** 2).mean())
     assert mse == 0.0  # PSNR vs checker = inf
