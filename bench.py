@@ -51,7 +51,7 @@ def grid_roofline(device):
     for tag, kw, bytes_per_sample, B in (
             ("triplane_plane_D2_L12_C1_f32", dict(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
                                                   desired_resolution=512), 8 + 12 * 4 * 4 + 48, 1 << 24),
-            ("hashgrid_D3_L16_C2_f32", dict(), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23)):
+            ("hashgrid_D3_L16_C2_f32", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23)):
         enc = GridEncoder(**kw).to(device)
         enc.embeddings.data.uniform_(-1, 1, generator=g)
         x = torch.rand(B, enc.input_dim, device=device, generator=g)

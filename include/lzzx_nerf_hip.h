@@ -172,7 +172,10 @@ int lz_triplane_head_forward(const lz_head_params* p, const float* xyzs, const f
                              const int32_t* count, float* sigmas, float* rgbs, float* amb_aud, float* amb_eye,
                              float* unc, lz_stream_t stream);
 
-/* Device-resident inference loop state (renderer.py:495-548): no host synchronisation inside the frame. */
+/* Device-resident inference loop state (renderer.py:495-548): no host synchronisation inside the frame.
+ * The device buffer passed as `lz_loop_state*` must hold LZ_LOOP_STATE_INTS int32: the struct below followed by 64
+ * scratch words (per-workgroup sample-count slots, folded into total_samples by lz_loop_compact). */
+#define LZ_LOOP_STATE_INTS 72
 typedef struct {
     int32_t n_alive;      /* rays alive at the start of the current iteration */
     int32_t n_step;       /* max(min(N / n_alive, 8), 1), renderer.py:513 */

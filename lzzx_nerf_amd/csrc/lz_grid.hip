@@ -22,6 +22,7 @@
 #include "lzzx_detmath.h"
 #include <hip/hip_fp16.h>
 #include <math.h>
+#include <type_traits>
 
 #define LZ_MAX_LEVELS 32
 
@@ -177,6 +178,109 @@ lz_k_grid_forward(const float* __restrict__ inputs, const T* __restrict__ grid, 
     }
 }
 
+// Sample-major forward, the hot variant ([B, L*C] output, no dy_dx): 2-D workgroup (x = level, y = sample) so that
+// neither the lane -> (sample, level) map nor the output address needs an integer division, per-level constants
+// staged once per workgroup in LDS (each lane reads its own level's record), `% size` replaced by a mask / skipped
+// where that is exact: dense levels have index < size by construction, hashed levels have size = 2^T (grid.py:116).
+// A wave-uniform test falls back to the generic modulo when some level of the table does not satisfy this.
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256)
+lz_k_grid_forward_sm(const float* __restrict__ inputs, const T* __restrict__ grid, const int* __restrict__ offsets,
+                     T* __restrict__ outputs, uint32_t B, uint32_t L, LzGridLevels lv, uint32_t gridtype, bool align_corners) {
+    __shared__ float s_scale[LZ_MAX_LEVELS];
+    __shared__ uint32_t s_res[LZ_MAX_LEVELS], s_off[LZ_MAX_LEVELS], s_hs[LZ_MAX_LEVELS], s_mode[LZ_MAX_LEVELS];
+    const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (tid < L) {
+        const uint32_t off0 = (uint32_t)offsets[tid], hs = (uint32_t)offsets[tid + 1] - off0;
+        const uint32_t res = lv.res[tid];
+        // replay the stride loop of get_grid_index (gridencoder.cu:56-69) once per level
+        uint32_t stride = 1;
+        uint64_t stride_exact = 1;   // the same product without 32-bit wrap-around
+        for (uint32_t d = 0; d < D; d++)
+            if (stride <= hs) {
+                stride *= align_corners ? res : (res + 1);
+                stride_exact *= align_corners ? res : (res + 1);
+            }
+        const bool wrapped = stride_exact != (uint64_t)stride;   // very fine levels: the reference's uint32 stride wraps; keep
+                                                                  // its exact (index % size) behaviour via the generic path
+        const bool hashed = gridtype == 0 && stride > hs;
+        const bool dense = stride <= hs && !wrapped;          // every stride fitted: index < hs, modulo is the identity
+        const bool pow2 = (hs & (hs - 1u)) == 0u;
+        s_scale[tid] = lv.scale[tid];
+        s_res[tid] = res; s_off[tid] = off0; s_hs[tid] = hs;
+        // 0 none, 1 mask, 2 modulo; bit 2: hash
+        s_mode[tid] = dense ? 0u : ((pow2 && !wrapped) ? 1u : 2u) | (hashed ? 4u : 0u);
+    }
+    __syncthreads();
+    const uint32_t level = threadIdx.x;
+    const uint32_t b = blockIdx.x * blockDim.y + threadIdx.y;
+    if (b >= B) return;
+    T* out = outputs + ((size_t)b * L + level) * C;
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        if (x[d] < 0 || x[d] > 1) oob = true;
+    }
+    const uint32_t hashmap_size = s_hs[level], resolution = s_res[level], mode = s_mode[level];
+    const float scale = s_scale[level];
+    const T* g = grid + (size_t)s_off[level] * C;
+    float pos[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float xc = lz_fminf(lz_fmaxf(x[d], 0.0f), 1.0f);   // clamp for addressing only; result zeroed below
+        pos[d] = lz_fmaf(xc, scale, align_corners ? 0.0f : 0.5f);
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+    }
+    float res[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) res[ch] = 0.0f;
+    const bool slow = __any((mode & 3u) == 2u);
+    auto corners = [&](auto slow_tag) {
+        constexpr bool SLOW = decltype(slow_tag)::value;
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {
+            float w = 1.0f;
+            uint32_t pl[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+                else { w *= pos[d]; pl[d] = pg[d] + 1; }
+            }
+            uint32_t index;
+            if constexpr (SLOW) {
+                index = lz_grid_index<D>(C, gridtype, align_corners, hashmap_size, resolution, pl);
+            } else {
+                constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+                uint32_t lin = 0, h = 0, stride = 1;
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) {
+                    lin += pl[d] * stride;            // only used when every stride fitted (mode 0)
+                    stride *= align_corners ? resolution : (resolution + 1);
+                    h ^= pl[d] * primes[d];
+                }
+                // mode 0: dense.  mode 1|4: hashed, power-of-two table.  (mode 1 without hash = tiled wrap of a partial
+                // sum: routed to the generic path by `slow` below)
+                index = ((mode & 4u) ? (h & (hashmap_size - 1u)) : lin) * C;
+            }
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) res[ch] = LzElem<T>::acc(res[ch], w, LzElem<T>::ld(g + index + ch));
+        }
+    };
+    // generic path when some level needs a true modulo, or wraps a partial (tiled) sum
+    if (slow || __any(mode != 0u && (mode & 4u) == 0u)) corners(std::true_type{});
+    else corners(std::false_type{});
+    if constexpr (C == 2 && sizeof(T) == 4) {
+        *reinterpret_cast<float2*>(out) = oob ? make_float2(0.f, 0.f) : make_float2(res[0], res[1]);
+    } else {
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) out[ch] = LzElem<T>::st(oob ? 0.0f : res[ch]);
+    }
+}
+
 template <uint32_t D>
 __global__ void __launch_bounds__(256)
 lz_k_grid_corner_indices(const float* __restrict__ inputs, const int* __restrict__ offsets, int* __restrict__ out,
@@ -320,6 +424,18 @@ template <typename T, uint32_t D>
 static int lz_grid_fwd_c(const float* inputs, const T* emb, const int* offsets, T* out, uint32_t B, uint32_t C, uint32_t L,
                          const LzGridLevels& lv, T* dy_dx, uint32_t gridtype, bool ac, bool sm, hipStream_t st) {
     dim3 grid, block(256);
+    if (sm && !dy_dx) {  // hot path: 2-D workgroup (level, sample), see lz_k_grid_forward_sm
+        const uint32_t ny = 256 / L;
+        const dim3 b2(L, ny, 1), g2(lz_div_up(B, ny), 1, 1);
+        switch (C) {
+            case 1: hipLaunchKernelGGL((lz_k_grid_forward_sm<T, D, 1>), g2, b2, 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac); break;
+            case 2: hipLaunchKernelGGL((lz_k_grid_forward_sm<T, D, 2>), g2, b2, 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac); break;
+            case 4: hipLaunchKernelGGL((lz_k_grid_forward_sm<T, D, 4>), g2, b2, 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac); break;
+            case 8: hipLaunchKernelGGL((lz_k_grid_forward_sm<T, D, 8>), g2, b2, 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac); break;
+            default: lz_set_error("GridEncoding: C must be 1, 2, 4, or 8."); return LZ_ERR_UNSUPPORTED;
+        }
+        return LZ_OK;
+    }
     if (sm) grid = dim3(lz_div_up((uint64_t)B * L, 256), 1, 1);
     else grid = dim3(lz_div_up(B, 256), L, 1);
     switch (C) {

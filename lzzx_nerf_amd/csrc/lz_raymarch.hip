@@ -457,11 +457,20 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
             if (ray_counts) ray_counts[index] += (int)step;
         }
     }
-    if (STATE) {  // marched-sample statistics: one atomic per wave
+    if (STATE) {
+        // marched-sample statistics: wave shuffle -> LDS -> ONE atomic per workgroup, spread over the 64 slot words
+        // that follow the state struct (a single hot word saturates at ~88 atomics/us: 4096 waves on one address cost
+        // more than the march itself); lz_k_compact_scan folds the slots into state->total_samples.
+        __shared__ uint32_t wsum[4];
         uint32_t s = step;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&state->total_samples, (int)s);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (t) atomicAdd(reinterpret_cast<int*>(state + 1) + (blockIdx.x & 63), (int)t);
+        }
     }
 }
 
@@ -705,6 +714,7 @@ lz_k_loop_begin(uint32_t N, uint32_t max_steps, const float* __restrict__ nears,
         s.pad = 0;
         *state = s;
     }
+    if (n < 64) reinterpret_cast<int*>(state + 1)[n] = 0;  // sample-count slots (see lz_k_march_rays)
     if (n >= N) return;
     rays_alive[n] = (int)n;
     rays_t[n] = nears[n];
@@ -800,8 +810,18 @@ lz_k_compact_scan(lz_loop_state* __restrict__ state, uint32_t N, uint32_t max_st
         if (tid == 1023) carry_s = carry + wave_prefix + incl;
         __syncthreads();
     }
+    // fold the march kernel's 64 sample-count slots (stored right after the struct) into total_samples
+    int slot_sum = 0;
+    if (tid < 64) {
+        int* slots = reinterpret_cast<int*>(state + 1);
+        slot_sum = slots[tid];
+        slots[tid] = 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) slot_sum += __shfl_down(slot_sum, off, 64);
+    }
     if (tid == 0) {
         lz_loop_state s = *state;
+        s.total_samples += slot_sum;
         // the scatter kernel still needs the OLD n_alive; it is kept in `pad` until the next compaction
         s.pad = s.n_alive;
         if (!s.done) {

@@ -33,6 +33,13 @@ class FusedTriplaneHead:
         self.offsets = state_dict["encoder_xy.offsets"].to(self.device, torch.int32).contiguous()
         if self.offsets.numel() != 13 or self.emb[0].shape[1] != 1:
             raise RuntimeError("FusedTriplaneHead expects the triplane configuration (D=2, L=12, C=1, network.py:129-133)")
+        # the fused kernel masks instead of taking `% size` on hashed levels: sizes there are 2^14 by construction
+        # (grid.py:116); verify once on the host, at construction
+        off = self.offsets.cpu().numpy().astype(np.int64)
+        for l in range(12):
+            size, res1 = int(off[l + 1] - off[l]), int(np.ceil(np.float32(np.exp2(np.float32(l) * np.float32(np.log2(np.exp2(np.log2(512 * self.bound / 64) / 11)))) * 64 - 1))) + 2
+            if res1 * res1 > size and size & (size - 1):
+                raise RuntimeError("FusedTriplaneHead: hashed level %d has a non power-of-two table (%d entries)" % (l, size))
         self.w = [sd.get(k) for k in _W_KEYS]
         self.has_eye = bool(exp_eye)
         self.individual_codes = sd.get("individual_codes")

@@ -17,7 +17,7 @@ from . import _lib
 from ._util import call, ptr, stream
 from .head import FusedTriplaneHead
 
-_STATE_INTS = 8          # sizeof(lz_loop_state) / 4
+_STATE_INTS = 72         # LZ_LOOP_STATE_INTS: lz_loop_state (8 ints) + 64 sample-count slots
 _N_SAMPLES_OFF = 16      # offsetof(lz_loop_state, n_samples)
 
 
@@ -50,7 +50,7 @@ class _Buffers:
         self.state = torch.zeros(_STATE_INTS, **i)
         self.workspace = torch.empty(4096, **i)
         self.ray_counts = torch.zeros(N, **i)
-        self.state_host = torch.zeros(_STATE_INTS, dtype=torch.int32).pin_memory()
+        self.state_host = torch.zeros(8, dtype=torch.int32).pin_memory()
 
 
 class TriplaneRenderer:
@@ -129,7 +129,7 @@ class TriplaneRenderer:
             it += n
             if pending is not None and pending.query() and int(b.state_host[3]) == 1:
                 break  # a previous chunk already finished the frame; what was enqueued since is a no-op on the device
-            b.state_host.copy_(b.state, non_blocking=True)
+            b.state_host.copy_(b.state[:8], non_blocking=True)
             pending = torch.cuda.Event()
             pending.record()
             if not sync_free:

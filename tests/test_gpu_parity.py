@@ -46,6 +46,9 @@ GRID_CASES = [
     (3, 6, 8, 8, 12, 128, "tiled"),
     (4, 3, 2, 4, 12, 16, "hash"),
     (5, 2, 1, 4, 12, 8, "hash"),
+    (3, 16, 2, 16, 19, None, "hash"),    # GridEncoder() class defaults: per_level_scale 2 -> res up to 2^19, uint32 strides wrap
+    (2, 16, 1, 16, 19, None, "hash"),
+    (2, 16, 2, 16, 12, None, "tiled"),
 ]
 
 
@@ -70,6 +73,8 @@ def test_grid_forward_bit_exact(D, L, C, H, T, res, gt):
     xt = dev(x)
     out = grid_encode(xt, enc.embeddings, enc.offsets, enc.per_level_scale, H, True, gid, False)
     assert np.array_equal(host(out), out_o)
+    out_sm = grid_encode(xt, enc.embeddings, enc.offsets, enc.per_level_scale, H, False, gid, False)  # hot (sample-major) kernel
+    assert np.array_equal(host(out_sm), out_o)
     # indices, bit for bit
     from lzzx_nerf_amd._util import call, ptr, stream
     idx = torch.empty(L, B, 1 << D, dtype=torch.int32, device="cuda")
@@ -576,7 +581,7 @@ def test_full_size_grid_linearity_and_layouts():
     """B = 2^22 samples, cfg2 table (49 MB): f(a e1 + b e2) = a f(e1) + b f(e2) up to rounding; both output layouts agree"""
     from lzzx_nerf_amd._util import call, ptr, stream
     from lzzx_nerf_amd.gridencoder import GridEncoder, grid_encode
-    enc = GridEncoder().cuda()  # D=3, L=16, C=2, H=16, T=2^19, res 2048
+    enc = GridEncoder(desired_resolution=2048).cuda()  # get_encoder('hashgrid') defaults: D=3, L=16, C=2, H=16, T=2^19, res 2048
     B = 1 << 22
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.rand(B, 3, device="cuda", generator=g)
