@@ -119,8 +119,8 @@ extern "C" int lz_head_pack_weights(const float* aud0, const float* aud1, const 
 }
 
 // ---- the fused head ---------------------------------------------------------------------------------
-#define LZ_T 4             // sample tiles (of 16) per wave pass
-#define LZ_WG 512          // threads per workgroup
+#define LZ_T 1             // sample tiles (of 16) per wave pass
+#define LZ_WG 1024         // threads per workgroup (16 waves = 4 per SIMD)
 #define LZ_WG_SAMPLES (LZ_WG / 64 * LZ_T * 16)
 
 struct LzHeadArgs {
@@ -156,7 +156,7 @@ __device__ __forceinline__ void lz_layer(const float* __restrict__ wl, int lane,
 __device__ __forceinline__ float lz_relu(float v) { return v > 0.0f ? v : 0.0f; }
 
 template <bool TRAIN_UNC>
-__global__ void __launch_bounds__(LZ_WG, 2)
+__global__ void __launch_bounds__(LZ_WG, LZ_WG / 256)
 lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
                    const int* __restrict__ count, float* __restrict__ sigmas, float* __restrict__ rgbs,
                    float* __restrict__ amb_aud, float* __restrict__ amb_eye, float* __restrict__ unc_out) {
@@ -183,6 +183,7 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
             tab[32 + threadIdx.x] = (int)P.res[threadIdx.x];
         }
         if (threadIdx.x < 32) wl[NFRAG * 64 + 64 + threadIdx.x] = P.enc_a[threadIdx.x];
+        if (threadIdx.x == 0) tab[48] = 0;   // slice queue head (see the tile loop)
     }
     __syncthreads();
     const int* offs = reinterpret_cast<const int*>(wl + NFRAG * 64);
@@ -197,8 +198,20 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
     const float eye_v = has_eye ? P.eye[0] : 0.0f;
     const float indq = P.ind_code ? P.ind_code[q] : 0.0f;
 
-    for (uint32_t wg_tile = blockIdx.x; wg_tile < n_wg_tiles; wg_tile += gridDim.x) {
-        const uint32_t base = wg_tile * LZ_WG_SAMPLES + wave * (LZ_T * 16);
+    // Work distribution: the workgroup owns the 512-sample tiles blockIdx.x, +gridDim.x, ...; its 8 waves pull 64-sample
+    // slices of them from a queue in LDS (one ds_add_rtn per slice).  Together with a static priority for the second
+    // wave of every SIMD this de-synchronises the two waves that share a SIMD: one gathers (texture-address bound)
+    // while the other feeds the matrix pipe, instead of both gathering and then both multiplying in lockstep.
+    int* queue = reinterpret_cast<int*>(wl + NFRAG * 64) + 48;
+    constexpr uint32_t NW = LZ_WG / 64;
+    const uint32_t wg_tiles_mine = (n_wg_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    for (;;) {
+        int slice = 0;
+        if (lane == 0) slice = atomicAdd(queue, 1);
+        slice = __builtin_amdgcn_readfirstlane(slice);
+        if ((uint32_t)slice >= wg_tiles_mine * NW) break;
+        const uint32_t wg_tile = blockIdx.x + ((uint32_t)slice / NW) * gridDim.x;
+        const uint32_t base = wg_tile * LZ_WG_SAMPLES + ((uint32_t)slice % NW) * (LZ_T * 16);
         if (base >= Meff) continue;  // wave-uniform
 
         // ---------------- gather: enc_x features f = 4i + q of sample (j, s) -> B operands ----------------
