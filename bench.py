@@ -192,7 +192,7 @@ def main():
         gpu_img = out["image"].cpu().numpy()[sel]
         mse = float(((gpu_img.astype(np.float64) - ref["image"]) ** 2).mean())
         psnr = float("inf") if mse == 0 else -10 * np.log10(mse)
-        result["cpu_baseline"] = dict(value=round(cpu_samples / tc, 1), unit="samples/s", cores=os.cpu_count(), kind="port",
+        result["cpu_baseline"] = dict(value=round(cpu_samples / tc, 1), unit="samples/s", cores=len(os.sched_getaffinity(0)), kind="port",
                                       sample=f"{len(sel)} rays (every {stride}th pixel of the same frame), {cpu_samples} samples, "
                                              f"{tc:.1f} s; checker arranged like run_cuda_for_inference (renderer.py:495-548), OpenMP")
         result["psnr_vs_checker_db"] = psnr if np.isfinite(psnr) else "inf"

@@ -43,6 +43,8 @@ int lz_device_ok(void);
 /* inputs [B,D] f32 in [0,1]; embeddings [sO,C] f32 or f16 (emb_f16); offsets [L+1] i32 (device);
  * outputs: out_layout 0 = [L,B,C] (the reference's level-major layout, gridencoder.cu:95),
  *          out_layout 1 = [B,L*C] (what grid.py:52 produces after its permute; saves that copy);
+ *          out_layout 2 = [B,L*C] through the level-resident kernel: a hint that every level's table is <= 64 KB
+ *                         (levels that are larger still work, through global gathers, but slowly) -- use for large B;
  * dy_dx [B,L,D,C] or NULL.  S = log2(per_level_scale) as float, H = base resolution. */
 int lz_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,

@@ -419,11 +419,146 @@ lz_k_grid_input_backward(const T* __restrict__ grad, const T* __restrict__ dy_dx
     grad_inputs[t] = LzElem<T>::st(r);
 }
 
+// ---- level-resident forward: the level's whole table lives in LDS ------------------------------------------------
+// A random 4-byte gather costs the texture-address path ~1 lane/clk/CU (measured: 2^24 samples x 48 gathers in 1.8 ms),
+// which caps the sample-major kernel at ~2.3 TB/s of algorithmic traffic however well L2 hits.  The triplane tables are
+// tiny (<= 16384 entries = 64 KB per level), so here a workgroup owns ONE (level, sample chunk): it copies the level's
+// table into LDS once (coalesced 16 B/lane), then streams its chunk: x in (coalesced, re-used by the L workgroups of the
+// chunk through L2), 2^D corner reads from LDS (~8 lanes/clk even with bank conflicts), one strided store to [B, L*C].
+// blockIdx -> (chunk, level) puts the L workgroups of a chunk on ONE XCD (blocks b, b+8, b+16, ... share an XCD), next
+// to each other in dispatch order, so their partial-line stores merge in that XCD's L2 before write-back.
+// A level that does not fit LDS falls back to global gathers inside the same kernel (wave-uniform branch).
+#define LZ_GRID_LDS_BYTES 65536
+
+template <typename T, uint32_t D, uint32_t C, bool IN_LDS>
+__device__ __forceinline__ void lz_grid_level_stream(const float* __restrict__ inputs, const T* __restrict__ tab, T* __restrict__ outputs,
+                                                     uint32_t b0, uint32_t b1, uint32_t L, uint32_t level, float scale,
+                                                     uint32_t resolution, uint32_t hashmap_size, uint32_t mode, uint32_t gridtype,
+                                                     bool align_corners) {
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
+        float x[D];
+        bool oob = false;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            x[d] = inputs[(size_t)b * D + d];
+            if (x[d] < 0 || x[d] > 1) oob = true;
+        }
+        float pos[D];
+        uint32_t pg[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const float xc = lz_fminf(lz_fmaxf(x[d], 0.0f), 1.0f);
+            pos[d] = lz_fmaf(xc, scale, align_corners ? 0.0f : 0.5f);
+            pg[d] = (uint32_t)floorf(pos[d]);
+            pos[d] -= (float)pg[d];
+        }
+        float res[C];
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) res[ch] = 0.0f;
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {
+            float w = 1.0f;
+            uint32_t pl[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+                else { w *= pos[d]; pl[d] = pg[d] + 1; }
+            }
+            uint32_t index;
+            if (mode == 2u) {  // workgroup-uniform: true modulo / wrapped strides
+                index = lz_grid_index<D>(C, gridtype, align_corners, hashmap_size, resolution, pl);
+            } else {
+                constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+                uint32_t lin = 0, h = 0, stride = 1;
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) {
+                    lin += pl[d] * stride;
+                    stride *= align_corners ? resolution : (resolution + 1);
+                    h ^= pl[d] * primes[d];
+                }
+                index = (mode == 1u ? (h & (hashmap_size - 1u)) : lin) * C;
+            }
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) res[ch] = LzElem<T>::acc(res[ch], w, LzElem<T>::ld(tab + index + ch));
+        }
+        T* out = outputs + ((size_t)b * L + level) * C;
+        if constexpr (C == 2 && sizeof(T) == 4) {
+            *reinterpret_cast<float2*>(out) = oob ? make_float2(0.f, 0.f) : make_float2(res[0], res[1]);
+        } else {
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) out[ch] = LzElem<T>::st(oob ? 0.0f : res[ch]);
+        }
+    }
+}
+
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(512)
+lz_k_grid_forward_lds(const float* __restrict__ inputs, const T* __restrict__ grid, const int* __restrict__ offsets,
+                      T* __restrict__ outputs, uint32_t B, uint32_t L, LzGridLevels lv, uint32_t gridtype, bool align_corners,
+                      uint32_t chunk, uint32_t n_chunks) {
+    extern __shared__ __align__(16) unsigned char lz_grid_smem[];
+    T* tab = reinterpret_cast<T*>(lz_grid_smem);
+    const uint32_t r = blockIdx.x & 7u, t = blockIdx.x >> 3;
+    const uint32_t level = t % L, g = t / L;
+    const uint32_t c = 8u * g + r;
+    if (c >= n_chunks) return;
+    const uint32_t off0 = (uint32_t)offsets[level], hs = (uint32_t)offsets[level + 1] - off0;
+    const uint32_t res = lv.res[level];
+    const float scale = lv.scale[level];
+    // classify the level exactly like lz_k_grid_forward_sm: 0 dense (index < size), 1 hashed + power-of-two size (mask),
+    // 2 anything else (generic modulo path)
+    uint32_t stride = 1;
+    uint64_t stride_exact = 1;
+    for (uint32_t d = 0; d < D; d++)
+        if (stride <= hs) {
+            stride *= align_corners ? res : (res + 1);
+            stride_exact *= align_corners ? res : (res + 1);
+        }
+    const bool wrapped = stride_exact != (uint64_t)stride;
+    const bool hashed = gridtype == 0 && stride > hs;
+    const bool dense = stride <= hs && !wrapped;
+    const bool pow2 = (hs & (hs - 1u)) == 0u;
+    const uint32_t mode = dense ? 0u : ((hashed && pow2 && !wrapped) ? 1u : 2u);
+    const T* gsrc = grid + (size_t)off0 * C;
+    const size_t bytes = (size_t)hs * C * sizeof(T);
+    const uint32_t b0 = c * chunk, b1 = (b0 + chunk < B) ? b0 + chunk : B;
+    if (bytes <= LZ_GRID_LDS_BYTES) {
+        // (off0 * C * sizeof(T)) is a multiple of 16: level sizes are multiples of 8 entries (grid.py:117)
+        const uint4* s4 = reinterpret_cast<const uint4*>(gsrc);
+        uint4* d4 = reinterpret_cast<uint4*>(tab);
+        const uint32_t n16 = (reinterpret_cast<uintptr_t>(gsrc) & 15u) ? 0u : (uint32_t)(bytes >> 4);
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) d4[i] = s4[i];
+        for (uint32_t i = (n16 << 4) / sizeof(T) + threadIdx.x; i < hs * C; i += blockDim.x) tab[i] = gsrc[i];
+        __syncthreads();
+        lz_grid_level_stream<T, D, C, true>(inputs, tab, outputs, b0, b1, L, level, scale, res, hs, mode, gridtype, align_corners);
+    } else {
+        lz_grid_level_stream<T, D, C, false>(inputs, gsrc, outputs, b0, b1, L, level, scale, res, hs, mode, gridtype, align_corners);
+    }
+}
+
+template <typename T, uint32_t D, uint32_t C>
+static void lz_grid_lds_launch(const float* inputs, const T* emb, const int* offsets, T* out, uint32_t B, uint32_t L,
+                               const LzGridLevels& lv, uint32_t gridtype, bool ac, hipStream_t st) {
+    // chunk: large enough to amortise the table copy (<= 64 KB per chunk per level), small enough for >= ~2 waves of CUs
+    uint32_t chunk = 32768;
+    while (chunk > 2048 && (uint64_t)lz_div_up(B, chunk) * L < 1024) chunk >>= 1;
+    const uint32_t n_chunks = lz_div_up(B, chunk);
+    const uint32_t groups = lz_div_up(n_chunks, 8);
+    hipLaunchKernelGGL((lz_k_grid_forward_lds<T, D, C>), dim3(8u * groups * L), dim3(512), LZ_GRID_LDS_BYTES, st, inputs, emb, offsets, out, B, L,
+                       lv, gridtype, ac, chunk, n_chunks);
+}
+
 // ---- host dispatch ----
 template <typename T, uint32_t D>
 static int lz_grid_fwd_c(const float* inputs, const T* emb, const int* offsets, T* out, uint32_t B, uint32_t C, uint32_t L,
-                         const LzGridLevels& lv, T* dy_dx, uint32_t gridtype, bool ac, bool sm, hipStream_t st) {
+                         const LzGridLevels& lv, T* dy_dx, uint32_t gridtype, bool ac, bool sm, bool resident, hipStream_t st) {
     dim3 grid, block(256);
+    if (sm && !dy_dx && resident) {  // large batches: level-resident tables in LDS, see lz_k_grid_forward_lds
+        if constexpr (D <= 3) {
+            if (C == 1) { lz_grid_lds_launch<T, D, 1>(inputs, emb, offsets, out, B, L, lv, gridtype, ac, st); return LZ_OK; }
+            if (C == 2) { lz_grid_lds_launch<T, D, 2>(inputs, emb, offsets, out, B, L, lv, gridtype, ac, st); return LZ_OK; }
+        }
+    }
     if (sm && !dy_dx) {  // hot path: 2-D workgroup (level, sample), see lz_k_grid_forward_sm
         const uint32_t ny = 256 / L;
         const dim3 b2(L, ny, 1), g2(lz_div_up(B, ny), 1, 1);
@@ -450,13 +585,14 @@ static int lz_grid_fwd_c(const float* inputs, const T* emb, const int* offsets, 
 
 template <typename T>
 static int lz_grid_fwd_d(const float* inputs, const T* emb, const int* offsets, T* out, uint32_t B, uint32_t D, uint32_t C,
-                         uint32_t L, const LzGridLevels& lv, T* dy_dx, uint32_t gridtype, bool ac, bool sm, hipStream_t st) {
+                         uint32_t L, const LzGridLevels& lv, T* dy_dx, uint32_t gridtype, bool ac, bool sm, bool resident,
+                         hipStream_t st) {
     switch (D) {
-        case 1: return lz_grid_fwd_c<T, 1>(inputs, emb, offsets, out, B, C, L, lv, dy_dx, gridtype, ac, sm, st);
-        case 2: return lz_grid_fwd_c<T, 2>(inputs, emb, offsets, out, B, C, L, lv, dy_dx, gridtype, ac, sm, st);
-        case 3: return lz_grid_fwd_c<T, 3>(inputs, emb, offsets, out, B, C, L, lv, dy_dx, gridtype, ac, sm, st);
-        case 4: return lz_grid_fwd_c<T, 4>(inputs, emb, offsets, out, B, C, L, lv, dy_dx, gridtype, ac, sm, st);
-        case 5: return lz_grid_fwd_c<T, 5>(inputs, emb, offsets, out, B, C, L, lv, dy_dx, gridtype, ac, sm, st);
+        case 1: return lz_grid_fwd_c<T, 1>(inputs, emb, offsets, out, B, C, L, lv, dy_dx, gridtype, ac, sm, resident, st);
+        case 2: return lz_grid_fwd_c<T, 2>(inputs, emb, offsets, out, B, C, L, lv, dy_dx, gridtype, ac, sm, resident, st);
+        case 3: return lz_grid_fwd_c<T, 3>(inputs, emb, offsets, out, B, C, L, lv, dy_dx, gridtype, ac, sm, resident, st);
+        case 4: return lz_grid_fwd_c<T, 4>(inputs, emb, offsets, out, B, C, L, lv, dy_dx, gridtype, ac, sm, resident, st);
+        case 5: return lz_grid_fwd_c<T, 5>(inputs, emb, offsets, out, B, C, L, lv, dy_dx, gridtype, ac, sm, resident, st);
         default: lz_set_error("GridEncoding: D must be 1, 2, 3, 4, or 5"); return LZ_ERR_UNSUPPORTED;
     }
 }
@@ -470,12 +606,13 @@ extern "C" int lz_grid_encode_forward(const float* inputs, const void* embedding
     LZ_REQUIRE(lz_fill_levels(lv, L, S, H) == 0, LZ_ERR_UNSUPPORTED, "grid_encode_forward: at most %d levels", LZ_MAX_LEVELS);
     if (B == 0) return LZ_OK;
     int rc;
+    const bool sm = out_layout == 1 || out_layout == 2, resident = out_layout == 2;
     if (emb_f16)
         rc = lz_grid_fwd_d<__half>(inputs, (const __half*)embeddings, offsets, (__half*)outputs, B, D, C, L, lv, (__half*)dy_dx,
-                                   gridtype, align_corners != 0, out_layout == 1, lz_st(stream));
+                                   gridtype, align_corners != 0, sm, resident, lz_st(stream));
     else
         rc = lz_grid_fwd_d<float>(inputs, (const float*)embeddings, offsets, (float*)outputs, B, D, C, L, lv, (float*)dy_dx,
-                                  gridtype, align_corners != 0, out_layout == 1, lz_st(stream));
+                                  gridtype, align_corners != 0, sm, resident, lz_st(stream));
     if (rc != LZ_OK) return rc;
     LZ_CHECK_LAUNCH("grid_encode_forward");
     return LZ_OK;

@@ -23,6 +23,23 @@ def _check_dc(D, C):
         raise RuntimeError("GridEncoding: D must be 1, 2, 3, 4, or 5")
 
 
+_LEVEL_SIZE_CACHE = {}
+
+
+def _max_level_entries(offsets):
+    """largest per-level table (entries) of an `offsets` tensor; one tiny device->host copy the first time a given
+    offsets buffer is seen, cached afterwards (offsets are constants of a GridEncoder)"""
+    key = (offsets.data_ptr(), offsets._version, offsets.numel())
+    v = _LEVEL_SIZE_CACHE.get(key)
+    if v is None:
+        o = offsets.detach().cpu().numpy().astype(np.int64)
+        v = int(np.max(o[1:] - o[:-1])) if o.size > 1 else 0
+        if len(_LEVEL_SIZE_CACHE) > 256:
+            _LEVEL_SIZE_CACHE.clear()
+        _LEVEL_SIZE_CACHE[key] = v
+    return v
+
+
 class _grid_encode(Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
@@ -49,8 +66,13 @@ class _grid_encode(Function):
 
         outputs = torch.empty(B, L * C, device=inputs.device, dtype=embeddings.dtype)
         dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
+        # large batches over small tables (the triplane: <= 16384 entries per level): level-resident LDS kernel
+        layout = 1
+        if B >= 32768 and not calc_grad_inputs and D <= 3 and C <= 2 and \
+                _max_level_entries(offsets) * C * embeddings.element_size() <= 65536:
+            layout = 2
         call("lz_grid_encode_forward", ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, S, H, ptr(dy_dx),
-             int(gridtype), int(bool(align_corners)), int(embeddings.dtype == torch.float16), 1, stream())
+             int(gridtype), int(bool(align_corners)), int(embeddings.dtype == torch.float16), layout, stream())
 
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = [B, D, C, L, S, H, gridtype]

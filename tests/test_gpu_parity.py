@@ -90,6 +90,39 @@ def test_grid_forward_bit_exact(D, L, C, H, T, res, gt):
     assert np.array_equal(host(dd), dd_o)
 
 
+@pytest.mark.parametrize("D,L,C,H,T,res,gt,half", [
+    (2, 12, 1, 64, 14, 512, "hash", False),     # every level fits LDS (<= 64 KB)
+    (3, 16, 2, 16, 19, 2048, "hash", False),    # fine levels do not fit: in-kernel fallback to global gathers
+    (3, 16, 2, 16, 19, 2048, "hash", True),
+    (2, 16, 2, 16, 16, 2048, "tiled", False),   # tiled wrap: generic modulo path
+    (3, 16, 2, 16, 19, None, "hash", False),    # wrapped uint32 strides
+    (1, 6, 1, 8, 10, 256, "hash", False),
+])
+def test_grid_forward_level_resident_kernel_bit_exact(D, L, C, H, T, res, gt, half):
+    """B >= 32768 selects lz_k_grid_forward_lds (level table resident in LDS, XCD-grouped workgroups)"""
+    from lzzx_nerf_amd.gridencoder import GridEncoder, grid_encode
+    enc = GridEncoder(input_dim=D, num_levels=L, level_dim=C, base_resolution=H, log2_hashmap_size=T, desired_resolution=res,
+                      gridtype=gt).cuda()
+    rng = np.random.default_rng(77)
+    emb = rng.uniform(-1, 1, tuple(enc.embeddings.shape)).astype(np.float16 if half else np.float32)
+    B = 40000 + 123  # ragged last chunk
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[:3] = [[0.0] * D, [1.0] * D, [1.0000001] + [0.5] * (D - 1)]
+    gid = 0 if gt == "hash" else 1
+    out_o, _ = O.grid_encode_forward(x, emb, host(enc.offsets), enc.per_level_scale, H, False, gid)
+    from lzzx_nerf_amd._util import call, ptr, stream
+    xt, et = dev(x), dev(emb)
+    out = torch.empty(B, L * C, device="cuda", dtype=et.dtype)
+    call("lz_grid_encode_forward", ptr(xt), ptr(et), ptr(enc.offsets), ptr(out), B, D, C, L, float(np.float32(np.log2(enc.per_level_scale))),
+         H, None, gid, 0, int(half), 2, stream())   # out_layout 2: force the level-resident kernel, fitting or not
+    auto = grid_encode(xt, et, enc.offsets, enc.per_level_scale, H, False, gid, False)  # wrapper's own choice of kernel
+    assert torch.equal(auto, out)
+    if half:
+        assert np.array_equal(host(out).view(np.uint16), out_o.view(np.uint16))
+    else:
+        assert np.array_equal(host(out), out_o)
+
+
 def test_grid_forward_half_tables_bit_exact():
     from lzzx_nerf_amd.gridencoder import GridEncoder
     enc = GridEncoder(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=15, desired_resolution=512).cuda()
