@@ -146,6 +146,9 @@ def main():
     value = total_samples * args.steps / dt
     rays_per_s = N * world * args.steps / dt
 
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     # ---- roofline of the dominant kernel (fused head, MFMA-bound): live HIP events from the timed steps ----
@@ -172,10 +175,10 @@ def main():
         "samples_per_ray_mean": round(samples_per_frame / N, 2),
         "roofline": roofline,
     }
-    if not args.no_grid_roofline:
+    if not args.no_grid_roofline and world == 1:
         result["roofline_gridencoder"] = grid_roofline(device)
     # ---- CPU baseline: the checker arranged like the reference loop, on a bounded sub-frame of the SAME rays ----
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # rank 0, N = 1 only
         from oracle.head import TriplaneSpec
         from oracle.render import render_inference
         stride = max(1, H // 64)

@@ -189,24 +189,28 @@ typedef struct {
     int32_t pad;
 } lz_loop_state;
 
-/* rays_alive <- 0..N-1, rays_t <- nears, accumulators <- 0, state <- (N, n_step(N), 0, ...) */
+/* One iteration = lz_loop_march -> lz_triplane_head_forward(count = &state->n_samples) -> lz_loop_composite ->
+ * lz_loop_advance.  `workspace`: >= 4096 int32 of device scratch shared by the four calls (per-workgroup survivor
+ * counts / offsets); at most 4096 * 256 rays per frame.  The alive list ping-pongs between two [N] int32 buffers. */
+
+/* rays_alive <- 0..N-1, rays_t <- nears, accumulators <- 0, state <- (N, n_step(N), 0, ...), workspace <- identity offsets */
 int lz_loop_begin(uint32_t N, uint32_t max_steps, const float* nears, int32_t* rays_alive, float* rays_t,
                   float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum, float* unc_sum,
-                  lz_loop_state* state, lz_stream_t stream);
-/* march driven by *state (n_alive, n_step read on device); writes zero rows for exhausted rays; adds the marched
- * sample count to state->total_samples and, when ray_counts != NULL, per ray to ray_counts[ray id] */
-int lz_loop_march(lz_loop_state* state, uint32_t N, const int32_t* rays_alive, const float* rays_t,
-                  const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
-                  uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs,
-                  float* deltas, int32_t* ray_counts, lz_stream_t stream);
+                  lz_loop_state* state, void* workspace, lz_stream_t stream);
+/* order-preserving stream compaction of rays_alive_in (drops the -1 entries compositing left, renderer.py:542) into
+ * rays_alive_out, fused with the march of the survivors (n_step read on device); writes zero rows for exhausted rays;
+ * adds the marched sample count to state->total_samples and, when ray_counts != NULL, per ray to ray_counts[ray id] */
+int lz_loop_march(lz_loop_state* state, uint32_t N, const int32_t* rays_alive_in, int32_t* rays_alive_out,
+                  const void* workspace, const float* rays_t, const float* rays_o, const float* rays_d, float bound,
+                  float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
+                  const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* ray_counts, lz_stream_t stream);
+/* triplane compositing on the current list (in place), plus per-workgroup survivor counts into workspace */
 int lz_loop_composite(const lz_loop_state* state, uint32_t N, float T_thresh, int32_t* rays_alive, float* rays_t,
                       const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,
                       const float* unc, float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum,
-                      float* unc_sum, lz_stream_t stream);
-/* order-preserving stream compaction of rays_alive (drops -1 entries, renderer.py:542) into rays_alive_out and
- * advance of the loop state (n_alive, n_step, step, done).  workspace: >= 4096 * 4 bytes. */
-int lz_loop_compact(lz_loop_state* state, uint32_t N, uint32_t max_steps, const int32_t* rays_alive_in,
-                    int32_t* rays_alive_out, void* workspace, lz_stream_t stream);
+                      float* unc_sum, void* workspace, lz_stream_t stream);
+/* scan the survivor counts into offsets and advance the loop state (n_alive, n_step, step, done, n_samples) */
+int lz_loop_advance(lz_loop_state* state, uint32_t N, uint32_t max_steps, void* workspace, lz_stream_t stream);
 /* image = clamp(image + (1 - weights_sum) * bg, 0, 1) (renderer.py:559-561); bg: device [N,3] or NULL -> bg_scalar */
 int lz_final_blend(const float* image, const float* weights_sum, const float* bg, float bg_scalar, uint32_t N,
                    float* out, lz_stream_t stream);

@@ -42,10 +42,10 @@ SIGNATURES = {
     "lz_get_rays": [vp, f32, f32, f32, f32, u32, u32, vp, vp, vp],
     "lz_head_pack_weights": [vp] * 11 + [i32, i32, vp, vp],
     "lz_triplane_head_forward": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, vp, vp],
-    "lz_loop_begin": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "lz_loop_march": [vp, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
-    "lz_loop_composite": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "lz_loop_compact": [vp, u32, u32, vp, vp, vp, vp],
+    "lz_loop_begin": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_loop_march": [vp, u32, vp, vp, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_loop_composite": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_loop_advance": [vp, u32, u32, vp, vp],
     "lz_final_blend": [vp, vp, vp, f32, u32, vp, vp],
 }
 PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),

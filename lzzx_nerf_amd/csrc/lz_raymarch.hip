@@ -413,26 +413,47 @@ extern "C" int lz_march_rays_train_backward(const float* grad_xyzs, const float*
     return LZ_OK;
 }
 
-// inference march (raymarching.cu:827-929).  STATE: n_alive / n_step come from device memory and exhausted
-// rows are zero-filled here (the host wrapper of the API-compatible entry pre-zeroes instead).
+// inference march (raymarching.cu:827-929).
+// STATE = false: the reference's entry point (host scalars, caller pre-zeroed outputs).
+// STATE = true : device-resident loop.  The kernel ALSO performs the stream compaction of the alive list (the
+//   reference's `rays_alive[rays_alive >= 0]`, renderer.py:542): thread n owns entry n of the PREVIOUS iteration's list
+//   (entries killed by compositing are -1), ranks the survivors with a wave ballot + the per-workgroup offsets that
+//   lz_k_loop_scan produced, writes the compacted list, and marches its ray into sample rows [pos * n_step, ...).
+//   Order is preserved, so the list equals the reference's.  Exhausted rows are zero-filled here.
 template <bool STATE>
 __global__ void __launch_bounds__(256)
 lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict__ state, const int* __restrict__ rays_alive,
+                const int* __restrict__ block_offsets, int* __restrict__ rays_alive_out,
                 const float* __restrict__ rays_t, const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound,
                 float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
                 const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
                 const float* __restrict__ noises, int* __restrict__ ray_counts) {
-    const uint32_t n_alive = STATE ? (uint32_t)state->n_alive : n_alive_h;
+    __shared__ uint32_t wsum[4];
+    const uint32_t n_list = STATE ? (uint32_t)state->pad : n_alive_h;   // entries in the incoming list
     const uint32_t n_step = STATE ? (uint32_t)state->n_step : n_step_h;
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (STATE && blockIdx.x * blockDim.x >= n_list) return;            // whole workgroup past the list
+    int index = (n < n_list) ? rays_alive[n] : -1;
+    uint32_t row = n;                                                   // first sample row = row * n_step
+    if (STATE) {
+        const bool keep = index >= 0;
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
+        row = (uint32_t)block_offsets[blockIdx.x] + woff + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) rays_alive_out[row] = index;
+        __syncthreads();                                                // wsum is reused below
+    }
     uint32_t step = 0;
-    if (n < n_alive) {
-        const int index = rays_alive[n];
+    if (index >= 0) {
         LzMarch m;
         m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
-        float* px = xyzs + (size_t)n * n_step * 3;
-        float* pd = dirs + (size_t)n * n_step * 3;
-        float* pl = deltas + (size_t)n * n_step * 2;
+        float* px = xyzs + (size_t)row * n_step * 3;
+        float* pd = dirs + (size_t)row * n_step * 3;
+        float* pl = deltas + (size_t)row * n_step * 2;
         float t = rays_t[index];
         const float far = fars[index];
         const float noise = noises ? noises[n] : 0.0f;
@@ -460,8 +481,7 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
     if (STATE) {
         // marched-sample statistics: wave shuffle -> LDS -> ONE atomic per workgroup, spread over the 64 slot words
         // that follow the state struct (a single hot word saturates at ~88 atomics/us: 4096 waves on one address cost
-        // more than the march itself); lz_k_compact_scan folds the slots into state->total_samples.
-        __shared__ uint32_t wsum[4];
+        // more than the march itself); lz_k_loop_scan folds the slots into state->total_samples.
         uint32_t s = step;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -482,7 +502,7 @@ extern "C" int lz_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* r
     LZ_REQUIRE(C >= 1 && C <= 8 && H > 0, LZ_ERR_BAD_ARGUMENT, "march_rays: cascade must be in [1, 8]");
     if (n_alive == 0) return LZ_OK;
     hipLaunchKernelGGL((lz_k_march_rays<false>), dim3(lz_div_up(n_alive, 256)), dim3(256), 0, lz_st(stream), n_alive, n_step, (lz_loop_state*)nullptr,
-                       rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, (int*)nullptr);
+                       rays_alive, (const int*)nullptr, (int*)nullptr, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, (int*)nullptr);
     LZ_CHECK_LAUNCH("march_rays");
     return LZ_OK;
 }
@@ -589,43 +609,53 @@ lz_k_composite_rays(uint32_t n_alive_h, uint32_t n_step_h, const lz_loop_state* 
                     const float* __restrict__ rgbs, const float* __restrict__ deltas, const float* __restrict__ amb0,
                     const float* __restrict__ amb1, const float* __restrict__ unc, float* __restrict__ weights_sum,
                     float* __restrict__ depth, float* __restrict__ image, float* __restrict__ amb0_sum,
-                    float* __restrict__ amb1_sum, float* __restrict__ unc_sum) {
+                    float* __restrict__ amb1_sum, float* __restrict__ unc_sum, int* __restrict__ block_counts) {
     const uint32_t n_alive = STATE ? (uint32_t)state->n_alive : n_alive_h;
     const uint32_t n_step = STATE ? (uint32_t)state->n_step : n_step_h;
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_alive) return;
-    const int index = rays_alive[n];
-    float t = rays_t[index];
-    float weight_sum = weights_sum[index], d = depth[index];
-    float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
-    float a0 = NAMB > 0 ? amb0_sum[index] : 0.0f, a1 = NAMB > 1 ? amb1_sum[index] : 0.0f, u = UNC ? unc_sum[index] : 0.0f;
-    uint32_t step = 0;
-    while (step < n_step) {
-        const size_t i = (size_t)n * n_step + step;
-        const float2 dl = *reinterpret_cast<const float2*>(deltas + i * 2);
-        if (dl.x == 0) break;
-        const float alpha = 1.0f - lz_expf(-sigmas[i] * dl.x);
-        const float T = 1 - weight_sum;
-        const float weight = alpha * T;
-        weight_sum += weight;
-        t = dl.y;
-        d = lz_fmaf(weight, t, d);
-        r = lz_fmaf(weight, rgbs[i * 3], r);
-        g = lz_fmaf(weight, rgbs[i * 3 + 1], g);
-        b = lz_fmaf(weight, rgbs[i * 3 + 2], b);
-        if (NAMB > 0) a0 = AMBW ? lz_fmaf(weight, amb0[i], a0) : a0 + amb0[i];
-        if (NAMB > 1) a1 = AMBW ? lz_fmaf(weight, amb1[i], a1) : a1 + amb1[i];
-        if (UNC) u = lz_fmaf(weight, unc[i], u);
-        if (T < T_thresh) break;
-        step++;
+    bool survives = false;
+    if (n < n_alive) {
+        const int index = rays_alive[n];
+        float t = rays_t[index];
+        float weight_sum = weights_sum[index], d = depth[index];
+        float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
+        float a0 = NAMB > 0 ? amb0_sum[index] : 0.0f, a1 = NAMB > 1 ? amb1_sum[index] : 0.0f, u = UNC ? unc_sum[index] : 0.0f;
+        uint32_t step = 0;
+        while (step < n_step) {
+            const size_t i = (size_t)n * n_step + step;
+            const float2 dl = *reinterpret_cast<const float2*>(deltas + i * 2);
+            if (dl.x == 0) break;
+            const float alpha = 1.0f - lz_expf(-sigmas[i] * dl.x);
+            const float T = 1 - weight_sum;
+            const float weight = alpha * T;
+            weight_sum += weight;
+            t = dl.y;
+            d = lz_fmaf(weight, t, d);
+            r = lz_fmaf(weight, rgbs[i * 3], r);
+            g = lz_fmaf(weight, rgbs[i * 3 + 1], g);
+            b = lz_fmaf(weight, rgbs[i * 3 + 2], b);
+            if (NAMB > 0) a0 = AMBW ? lz_fmaf(weight, amb0[i], a0) : a0 + amb0[i];
+            if (NAMB > 1) a1 = AMBW ? lz_fmaf(weight, amb1[i], a1) : a1 + amb1[i];
+            if (UNC) u = lz_fmaf(weight, unc[i], u);
+            if (T < T_thresh) break;
+            step++;
+        }
+        survives = !(step < n_step);
+        if (survives) rays_t[index] = t; else rays_alive[n] = -1;
+        weights_sum[index] = weight_sum;
+        depth[index] = d;
+        image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+        if (NAMB > 0) amb0_sum[index] = a0;
+        if (NAMB > 1) amb1_sum[index] = a1;
+        if (UNC) unc_sum[index] = u;
     }
-    if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t;
-    weights_sum[index] = weight_sum;
-    depth[index] = d;
-    image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
-    if (NAMB > 0) amb0_sum[index] = a0;
-    if (NAMB > 1) amb1_sum[index] = a1;
-    if (UNC) unc_sum[index] = u;
+    if (STATE) {  // per-workgroup survivor count for the next iteration's compaction (consumed by lz_k_loop_scan)
+        __shared__ int wcnt[4];
+        const int c = __popcll(__ballot(survives));
+        if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) block_counts[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    }
 }
 
 // (n_amb, amb_weighted, has_unc) -> template instance
@@ -680,7 +710,7 @@ extern "C" int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thre
     if (n_alive == 0) return LZ_OK;
     dim3 grid(lz_div_up(n_alive, 256)), block(256);
     hipStream_t st = lz_st(stream);
-#define CALL(NA, AW, HU) hipLaunchKernelGGL((lz_k_composite_rays<NA, AW, HU, false>), grid, block, 0, st, n_alive, n_step, (const lz_loop_state*)nullptr, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, amb0, amb1, unc, weights_sum, depth, image, amb0_sum, amb1_sum, unc_sum)
+#define CALL(NA, AW, HU) hipLaunchKernelGGL((lz_k_composite_rays<NA, AW, HU, false>), grid, block, 0, st, n_alive, n_step, (const lz_loop_state*)nullptr, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, amb0, amb1, unc, weights_sum, depth, image, amb0_sum, amb1_sum, unc_sum, (int*)nullptr)
     LZ_VARIANT_SWITCH(n_amb, amb_weighted, has_unc, CALL);
 #undef CALL
     LZ_CHECK_LAUNCH("composite_rays");
@@ -688,7 +718,11 @@ extern "C" int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thre
 }
 
 // ------------------------------------------------------------------------------------------------
-// device-resident inference loop (renderer.py:495-548)
+// device-resident inference loop (renderer.py:495-548): 4 launches per iteration
+//   lz_loop_march      compaction of the previous list (ballot + offsets) fused with the march of the survivors
+//   lz_triplane_head_forward (lz_head.hip), bounded by state->n_samples
+//   lz_loop_composite  accumulate, kill rays, count survivors per workgroup
+//   lz_loop_advance    one workgroup: scan the counts -> offsets, advance (n_alive, n_step, step, done)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lz_n_step_rule(int N, int n_alive) {  // renderer.py:513
     int s = n_alive > 0 ? N / n_alive : 1;
@@ -699,7 +733,8 @@ __device__ __forceinline__ int lz_n_step_rule(int N, int n_alive) {  // renderer
 __global__ void __launch_bounds__(256)
 lz_k_loop_begin(uint32_t N, uint32_t max_steps, const float* __restrict__ nears, int* __restrict__ rays_alive, float* __restrict__ rays_t,
                 float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image, float* __restrict__ amb0_sum,
-                float* __restrict__ amb1_sum, float* __restrict__ unc_sum, lz_loop_state* __restrict__ state) {
+                float* __restrict__ amb1_sum, float* __restrict__ unc_sum, lz_loop_state* __restrict__ state,
+                int* __restrict__ block_offsets) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n == 0) {
         lz_loop_state s;
@@ -711,10 +746,11 @@ lz_k_loop_begin(uint32_t N, uint32_t max_steps, const float* __restrict__ nears,
         s.n_samples = s.n_alive * s.n_step;
         s.total_samples = 0;
         s.iterations = 0;
-        s.pad = 0;
+        s.pad = s.n_alive;   // entries of the list the first march will compact (the identity list)
         *state = s;
     }
     if (n < 64) reinterpret_cast<int*>(state + 1)[n] = 0;  // sample-count slots (see lz_k_march_rays)
+    if (threadIdx.x == 0) block_offsets[blockIdx.x] = (int)(blockIdx.x * blockDim.x);  // identity list: offset = first index
     if (n >= N) return;
     rays_alive[n] = (int)n;
     rays_t[n] = nears[n];
@@ -727,23 +763,26 @@ lz_k_loop_begin(uint32_t N, uint32_t max_steps, const float* __restrict__ nears,
 
 extern "C" int lz_loop_begin(uint32_t N, uint32_t max_steps, const float* nears, int32_t* rays_alive, float* rays_t, float* weights_sum,
                              float* depth, float* image, float* amb0_sum, float* amb1_sum, float* unc_sum, lz_loop_state* state,
-                             lz_stream_t stream) {
-    LZ_REQUIRE(state, LZ_ERR_BAD_ARGUMENT, "loop_begin: null state");
+                             void* workspace, lz_stream_t stream) {
+    LZ_REQUIRE(state && workspace, LZ_ERR_BAD_ARGUMENT, "loop_begin: null state / workspace");
+    LZ_REQUIRE(lz_div_up(N > 0 ? N : 1, 256) <= 4096, LZ_ERR_UNSUPPORTED, "loop: at most %u rays per call", 4096u * 256u);
     hipLaunchKernelGGL(lz_k_loop_begin, dim3(lz_div_up(N > 0 ? N : 1, 256)), dim3(256), 0, lz_st(stream), N, max_steps, nears, rays_alive, rays_t,
-                       weights_sum, depth, image, amb0_sum, amb1_sum, unc_sum, state);
+                       weights_sum, depth, image, amb0_sum, amb1_sum, unc_sum, state, reinterpret_cast<int*>(workspace));
     LZ_CHECK_LAUNCH("loop_begin");
     return LZ_OK;
 }
 
-extern "C" int lz_loop_march(lz_loop_state* state, uint32_t N, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
-                             const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
-                             const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
-                             int32_t* ray_counts, lz_stream_t stream) {
+extern "C" int lz_loop_march(lz_loop_state* state, uint32_t N, const int32_t* rays_alive_in, int32_t* rays_alive_out, const void* workspace,
+                             const float* rays_t, const float* rays_o, const float* rays_d, float bound, float dt_gamma,
+                             uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                             float* xyzs, float* dirs, float* deltas, int32_t* ray_counts, lz_stream_t stream) {
     (void)nears;
     LZ_REQUIRE(C >= 1 && C <= 8 && H > 0, LZ_ERR_BAD_ARGUMENT, "loop_march: cascade must be in [1, 8]");
+    LZ_REQUIRE(state && workspace && rays_alive_in && rays_alive_out, LZ_ERR_BAD_ARGUMENT, "loop_march: null argument");
     if (N == 0) return LZ_OK;
-    hipLaunchKernelGGL((lz_k_march_rays<true>), dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), 0u, 0u, state, rays_alive, rays_t, rays_o,
-                       rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, (const float*)nullptr, ray_counts);
+    hipLaunchKernelGGL((lz_k_march_rays<true>), dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), 0u, 0u, state, rays_alive_in,
+                       reinterpret_cast<const int*>(workspace), rays_alive_out, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid,
+                       fars, xyzs, dirs, deltas, (const float*)nullptr, ray_counts);
     LZ_CHECK_LAUNCH("loop_march");
     return LZ_OK;
 }
@@ -751,49 +790,29 @@ extern "C" int lz_loop_march(lz_loop_state* state, uint32_t N, const int32_t* ra
 extern "C" int lz_loop_composite(const lz_loop_state* state, uint32_t N, float T_thresh, int32_t* rays_alive, float* rays_t,
                                  const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,
                                  const float* unc, float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum,
-                                 float* unc_sum, lz_stream_t stream) {
+                                 float* unc_sum, void* workspace, lz_stream_t stream) {
+    LZ_REQUIRE(state && workspace, LZ_ERR_BAD_ARGUMENT, "loop_composite: null state / workspace");
     if (N == 0) return LZ_OK;
     hipLaunchKernelGGL((lz_k_composite_rays<2, false, true, true>), dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), 0u, 0u, state, T_thresh,
-                       rays_alive, rays_t, sigmas, rgbs, deltas, amb0, amb1, unc, weights_sum, depth, image, amb0_sum, amb1_sum, unc_sum);
+                       rays_alive, rays_t, sigmas, rgbs, deltas, amb0, amb1, unc, weights_sum, depth, image, amb0_sum, amb1_sum, unc_sum,
+                       reinterpret_cast<int*>(workspace));
     LZ_CHECK_LAUNCH("loop_composite");
     return LZ_OK;
 }
 
-// ---- order-preserving compaction: per-block survivor counts -> one-workgroup scan (+ state advance) -> scatter ----
-#define LZ_CMP_ITEMS 4
-#define LZ_CMP_TILE (256 * LZ_CMP_ITEMS)
-
-__global__ void __launch_bounds__(256)
-lz_k_compact_count(const lz_loop_state* __restrict__ state, const int* __restrict__ rays_alive, int* __restrict__ block_counts) {
-    __shared__ int wsum[4];
-    const uint32_t n_alive = (uint32_t)state->n_alive;
-    const uint32_t base = blockIdx.x * LZ_CMP_TILE;
-    if (base >= n_alive) {
-        if (threadIdx.x == 0) block_counts[blockIdx.x] = 0;
-        return;
-    }
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < LZ_CMP_ITEMS; k++) {
-        const uint32_t i = base + k * 256 + threadIdx.x;
-        const bool keep = (i < n_alive) && (rays_alive[i] >= 0);
-        c += __popcll(__ballot(keep));
-    }
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
+// one workgroup: exclusive scan of the per-workgroup survivor counts (in place -> offsets) + state advance
 __global__ void __launch_bounds__(1024)
-lz_k_compact_scan(lz_loop_state* __restrict__ state, uint32_t N, uint32_t max_steps, uint32_t n_blocks, int* __restrict__ block_counts) {
+lz_k_loop_scan(lz_loop_state* __restrict__ state, uint32_t N, uint32_t max_steps, uint32_t n_blocks, int* __restrict__ block_counts) {
     __shared__ int wave_sums[16];
     __shared__ int carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
+    // only the workgroups that covered the current list wrote a count; the others hold stale values: treat as 0
+    const uint32_t live_blocks = ((uint32_t)state->n_alive + 255u) / 256u;
     for (uint32_t start = 0; start < n_blocks; start += 1024) {
         const uint32_t i = start + tid;
-        const int v = (i < n_blocks) ? block_counts[i] : 0;
+        const int v = (i < live_blocks) ? block_counts[i] : 0;
         int incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -822,62 +841,28 @@ lz_k_compact_scan(lz_loop_state* __restrict__ state, uint32_t N, uint32_t max_st
     if (tid == 0) {
         lz_loop_state s = *state;
         s.total_samples += slot_sum;
-        // the scatter kernel still needs the OLD n_alive; it is kept in `pad` until the next compaction
-        s.pad = s.n_alive;
+        s.pad = s.n_alive;                  // length of the list the next march compacts
         if (!s.done) {
             s.step += s.n_step;             // renderer.py:546
             s.iterations += 1;
             s.n_alive = carry_s;            // renderer.py:542
             s.done = (s.n_alive <= 0 || s.step >= (int)max_steps) ? 1 : 0;
-            if (s.done) s.n_alive = 0;
+            if (s.done) { s.n_alive = 0; s.pad = 0; }
             s.n_step = lz_n_step_rule((int)N, s.n_alive);
             s.n_samples = s.n_alive * s.n_step;
+        } else {
+            s.pad = 0;
         }
         *state = s;
     }
 }
 
-__global__ void __launch_bounds__(256)
-lz_k_compact_scatter(const lz_loop_state* __restrict__ state, const int* __restrict__ rays_alive_in, const int* __restrict__ block_offsets,
-                     int* __restrict__ rays_alive_out) {
-    __shared__ int wbase[4];
-    const uint32_t n_alive_old = (uint32_t)state->pad;
-    const uint32_t base = blockIdx.x * LZ_CMP_TILE;
-    if (base >= n_alive_old) return;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int out_base = block_offsets[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < LZ_CMP_ITEMS; k++) {
-        const uint32_t i = base + k * 256 + threadIdx.x;
-        const int v = (i < n_alive_old) ? rays_alive_in[i] : -1;
-        const bool keep = v >= 0;
-        const unsigned long long mask = __ballot(keep);
-        const int wcount = __popcll(mask);
-        if (lane == 0) wbase[wave] = wcount;
-        __syncthreads();
-        int woff = 0;
-        for (uint32_t w = 0; w < wave; w++) woff += wbase[w];
-        const int total = wbase[0] + wbase[1] + wbase[2] + wbase[3];
-        if (keep) {
-            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-            rays_alive_out[out_base + woff + rank] = v;
-        }
-        out_base += total;
-        __syncthreads();
-    }
-}
-
-extern "C" int lz_loop_compact(lz_loop_state* state, uint32_t N, uint32_t max_steps, const int32_t* rays_alive_in,
-                               int32_t* rays_alive_out, void* workspace, lz_stream_t stream) {
-    LZ_REQUIRE(state && workspace, LZ_ERR_BAD_ARGUMENT, "loop_compact: null state / workspace");
-    const uint32_t n_blocks = lz_div_up(N > 0 ? N : 1, LZ_CMP_TILE);
-    LZ_REQUIRE(n_blocks <= 4096, LZ_ERR_UNSUPPORTED, "loop_compact: at most %u rays per call", 4096u * LZ_CMP_TILE);
-    int* block_counts = reinterpret_cast<int*>(workspace);
-    hipStream_t st = lz_st(stream);
-    hipLaunchKernelGGL(lz_k_compact_count, dim3(n_blocks), dim3(256), 0, st, state, rays_alive_in, block_counts);
-    hipLaunchKernelGGL(lz_k_compact_scan, dim3(1), dim3(1024), 0, st, state, N, max_steps, n_blocks, block_counts);
-    hipLaunchKernelGGL(lz_k_compact_scatter, dim3(n_blocks), dim3(256), 0, st, state, rays_alive_in, block_counts, rays_alive_out);
-    LZ_CHECK_LAUNCH("loop_compact");
+extern "C" int lz_loop_advance(lz_loop_state* state, uint32_t N, uint32_t max_steps, void* workspace, lz_stream_t stream) {
+    LZ_REQUIRE(state && workspace, LZ_ERR_BAD_ARGUMENT, "loop_advance: null state / workspace");
+    const uint32_t n_blocks = lz_div_up(N > 0 ? N : 1, 256);
+    LZ_REQUIRE(n_blocks <= 4096, LZ_ERR_UNSUPPORTED, "loop_advance: at most %u rays per call", 4096u * 256u);
+    hipLaunchKernelGGL(lz_k_loop_scan, dim3(1), dim3(1024), 0, lz_st(stream), state, N, max_steps, n_blocks, reinterpret_cast<int*>(workspace));
+    LZ_CHECK_LAUNCH("loop_advance");
     return LZ_OK;
 }
 

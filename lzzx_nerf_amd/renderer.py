@@ -77,7 +77,7 @@ class TriplaneRenderer:
             raise NotImplementedError("density_scale != 1 (the reference hard-codes 1, renderer.py:95)")
         self._buf = None
         self._head_events = None  # set to a list to collect (start, end) HIP events around every head launch (bench.py)
-        self.chunk = 16  # iterations enqueued between two non-blocking peeks at the loop state
+        self.chunk = 8   # iterations enqueued between two non-blocking peeks at the loop state
 
     def _buffers(self, N, device):
         if self._buf is None or self._buf.N != N:
@@ -85,10 +85,12 @@ class TriplaneRenderer:
         return self._buf
 
     def _iteration(self, b, cur, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples):
-        st = ptr(b.state)
-        call("lz_loop_march", st, N, ptr(b.rays_alive[cur]), ptr(b.rays_t), ptr(self._rays_o), ptr(self._rays_d), self.bound,
-             float(dt_gamma), int(max_steps), int(self.cascade), int(self.grid_size), ptr(self.bitfield), ptr(b.nears), ptr(b.fars),
-             ptr(b.xyzs), ptr(b.dirs), ptr(b.deltas), ptr(b.ray_counts) if count_samples else None, stream())
+        st, ws = ptr(b.state), ptr(b.workspace)
+        nxt = 1 - cur
+        # compaction of list[cur] -> list[nxt], fused with the march of the survivors
+        call("lz_loop_march", st, N, ptr(b.rays_alive[cur]), ptr(b.rays_alive[nxt]), ws, ptr(b.rays_t), ptr(self._rays_o),
+             ptr(self._rays_d), self.bound, float(dt_gamma), int(max_steps), int(self.cascade), int(self.grid_size), ptr(self.bitfield),
+             ptr(b.nears), ptr(b.fars), ptr(b.xyzs), ptr(b.dirs), ptr(b.deltas), ptr(b.ray_counts) if count_samples else None, stream())
         ev = self._head_events
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -98,10 +100,10 @@ class TriplaneRenderer:
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
-        call("lz_loop_composite", st, N, float(T_thresh), ptr(b.rays_alive[cur]), ptr(b.rays_t), ptr(b.sigmas), ptr(b.rgbs),
+        call("lz_loop_composite", st, N, float(T_thresh), ptr(b.rays_alive[nxt]), ptr(b.rays_t), ptr(b.sigmas), ptr(b.rgbs),
              ptr(b.deltas), ptr(b.amb_aud), ptr(b.amb_eye), ptr(b.unc), ptr(b.weights_sum), ptr(b.depth), ptr(b.image),
-             ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), stream())
-        call("lz_loop_compact", st, N, int(max_steps), ptr(b.rays_alive[cur]), ptr(b.rays_alive[1 - cur]), ptr(b.workspace), stream())
+             ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ws, stream())
+        call("lz_loop_advance", st, N, int(max_steps), ws, stream())
 
     @torch.no_grad()
     def render(self, rays_o, rays_d, enc_a, ind_code=None, eye=None, dt_gamma=1.0 / 256, max_steps=16, T_thresh=1e-4,
@@ -118,7 +120,7 @@ class TriplaneRenderer:
         if count_samples:
             b.ray_counts.zero_()
         call("lz_loop_begin", N, int(max_steps), ptr(b.nears), ptr(b.rays_alive[0]), ptr(b.rays_t), ptr(b.weights_sum), ptr(b.depth),
-             ptr(b.image), ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ptr(b.state), stream())
+             ptr(b.image), ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ptr(b.state), ptr(b.workspace), stream())
         cur, it = 0, 0
         pending = None
         while it < max_steps:  # n_step >= 1, so max_steps iterations always suffice (renderer.py:503,546)
