@@ -124,14 +124,13 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    renderer._head_events = []
+    renderer.timing_start(args.steps * args.max_steps + 16)   # HIP event pair around every head launch, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, tiles = step()
     barrier()
     dt = time.perf_counter() - t0
-    events = renderer._head_events
-    renderer._head_events = None
+    head_ms = renderer.timing_stop()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -152,8 +151,6 @@ def main():
     if rank != 0:
         return
     # ---- roofline of the dominant kernel (fused head, MFMA-bound): live HIP events from the timed steps ----
-    head_ms = [a.elapsed_time(b) for a, b in events]
-    live = [m for m in head_ms if m > 0]
     head_total_ms = float(np.sum(head_ms))
     n_launch = len(head_ms)
     launches_with_work = iters_per_frame * args.steps

@@ -211,6 +211,39 @@ int lz_loop_composite(const lz_loop_state* state, uint32_t N, float T_thresh, in
                       float* unc_sum, void* workspace, lz_stream_t stream);
 /* scan the survivor counts into offsets and advance the loop state (n_alive, n_step, step, done, n_samples) */
 int lz_loop_advance(lz_loop_state* state, uint32_t N, uint32_t max_steps, void* workspace, lz_stream_t stream);
+/* Everything one frame's loop touches (all device pointers; sample buffers hold N rows since n_alive * n_step <= N). */
+typedef struct {
+    lz_head_params head;
+    lz_loop_state* state;          /* LZ_LOOP_STATE_INTS int32 */
+    void* workspace;               /* >= 4096 int32 */
+    int32_t* rays_alive[2];        /* ping-pong alive lists, [N] each */
+    float* rays_t;                 /* [N] */
+    const float* rays_o;           /* [N,3] */
+    const float* rays_d;           /* [N,3] */
+    const float* nears;            /* [N] */
+    const float* fars;             /* [N] */
+    const uint8_t* grid;           /* density bitfield */
+    float* xyzs;  float* dirs;  float* deltas;                             /* [N,3] [N,3] [N,2] */
+    float* sigmas;  float* rgbs;  float* amb_aud;  float* amb_eye;  float* unc;   /* [N] [N,3] [N] [N] [N] */
+    float* weights_sum;  float* depth;  float* image;                     /* [N] [N] [N,3] */
+    float* amb_aud_sum;  float* amb_eye_sum;  float* unc_sum;             /* [N] each */
+    int32_t* ray_counts;           /* [N] or NULL */
+    uint32_t N, max_steps, C, H;
+    float bound, dt_gamma, T_thresh;
+} lz_frame;
+
+/* enqueue `n_iterations` iterations (march -> head -> composite -> advance) back to back; `parity` = index of the
+ * alive list that is current before the first of them (0 after lz_loop_begin, then the count of iterations run so far
+ * modulo 2).  Iterations past the end of the frame are no-ops on the device. */
+typedef struct lz_timing lz_timing;   /* opaque: pairs of HIP events */
+int lz_timing_create(uint32_t n_pairs, lz_timing** out);
+int lz_timing_destroy(lz_timing* t);
+int lz_timing_reset(lz_timing* t);
+/* elapsed ms of every recorded pair (host array); call after synchronising the stream */
+int lz_timing_elapsed_ms(lz_timing* t, float* out_ms, uint32_t capacity, uint32_t* n_pairs);
+/* `timing` (may be NULL): bracket every head launch with an event pair on the launch stream */
+int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterations, lz_timing* timing, lz_stream_t stream);
+
 /* image = clamp(image + (1 - weights_sum) * bg, 0, 1) (renderer.py:559-561); bg: device [N,3] or NULL -> bg_scalar */
 int lz_final_blend(const float* image, const float* weights_sum, const float* bg, float bg_scalar, uint32_t N,
                    float* out, lz_stream_t stream);

@@ -18,6 +18,15 @@ class HeadParams(C.Structure):
                 ("ind_code", vp), ("eye", vp), ("bound", f32), ("S", f32), ("H", u32), ("testing", i32)]
 
 
+class Frame(C.Structure):
+    """mirror of lz_frame (include/lzzx_nerf_hip.h)"""
+    _fields_ = [("head", HeadParams), ("state", vp), ("workspace", vp), ("rays_alive", vp * 2), ("rays_t", vp), ("rays_o", vp),
+                ("rays_d", vp), ("nears", vp), ("fars", vp), ("grid", vp), ("xyzs", vp), ("dirs", vp), ("deltas", vp), ("sigmas", vp),
+                ("rgbs", vp), ("amb_aud", vp), ("amb_eye", vp), ("unc", vp), ("weights_sum", vp), ("depth", vp), ("image", vp),
+                ("amb_aud_sum", vp), ("amb_eye_sum", vp), ("unc_sum", vp), ("ray_counts", vp), ("N", u32), ("max_steps", u32),
+                ("C", u32), ("H", u32), ("bound", f32), ("dt_gamma", f32), ("T_thresh", f32)]
+
+
 # name -> argtypes, in the order of include/lzzx_nerf_hip.h
 SIGNATURES = {
     "lz_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, i32, i32, vp],
@@ -46,6 +55,11 @@ SIGNATURES = {
     "lz_loop_march": [vp, u32, vp, vp, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_composite": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_advance": [vp, u32, u32, vp, vp],
+    "lz_loop_run": [C.POINTER(Frame), u32, u32, vp, vp],
+    "lz_timing_create": [u32, C.POINTER(vp)],
+    "lz_timing_destroy": [vp],
+    "lz_timing_reset": [vp],
+    "lz_timing_elapsed_ms": [vp, C.POINTER(f32), u32, C.POINTER(u32)],
     "lz_final_blend": [vp, vp, vp, f32, u32, vp, vp],
 }
 PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),

@@ -1,0 +1,92 @@
+// lz_render.hip -- native host-side driver of the device-resident inference loop.
+//
+// The reference drives its loop from Python (nerf_triplane/renderer.py:503-548): per iteration ~20 kernel launches
+// and one device->host synchronisation.  Here one C call enqueues `n_iterations` iterations of
+//     lz_loop_march -> lz_triplane_head_forward -> lz_loop_composite -> lz_loop_advance
+// back to back on the caller's stream (4 launches each, no host round trip, no Python between launches).  Iterations
+// enqueued after the frame finished are no-ops on the device (every kernel is bounded by the device-side state).
+//
+// Optional timing: an lz_timing object owns pairs of HIP events; when one is passed, every head launch is bracketed
+// by an event pair ON THE LAUNCH STREAM, so a benchmark gets the dominant kernel's per-launch duration from the very
+// launches it times end to end (no separate pass, no profiler attached).
+#include <vector>
+
+#include "lz_common.h"
+
+struct lz_timing {
+    std::vector<hipEvent_t> ev;  // 2 per pair
+    uint32_t used = 0;           // pairs recorded
+};
+
+extern "C" int lz_timing_create(uint32_t n_pairs, lz_timing** out) {
+    LZ_REQUIRE(out, LZ_ERR_BAD_ARGUMENT, "timing_create: null out");
+    lz_timing* t = new lz_timing();
+    t->ev.resize((size_t)n_pairs * 2);
+    for (auto& e : t->ev) {
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) {
+            lz_set_error("timing_create: hipEventCreate: %s", hipGetErrorString(rc));
+            delete t;
+            return (int)rc;
+        }
+    }
+    *out = t;
+    return LZ_OK;
+}
+
+extern "C" int lz_timing_destroy(lz_timing* t) {
+    if (!t) return LZ_OK;
+    for (auto& e : t->ev) (void)hipEventDestroy(e);
+    delete t;
+    return LZ_OK;
+}
+
+extern "C" int lz_timing_reset(lz_timing* t) {
+    LZ_REQUIRE(t, LZ_ERR_BAD_ARGUMENT, "timing_reset: null");
+    t->used = 0;
+    return LZ_OK;
+}
+
+// elapsed time of every recorded pair, in ms; call after the stream has been synchronised.  Returns the pair count.
+extern "C" int lz_timing_elapsed_ms(lz_timing* t, float* out_ms, uint32_t capacity, uint32_t* n_pairs) {
+    LZ_REQUIRE(t && out_ms && n_pairs, LZ_ERR_BAD_ARGUMENT, "timing_elapsed_ms: null argument");
+    const uint32_t n = t->used < capacity ? t->used : capacity;
+    for (uint32_t i = 0; i < n; i++) {
+        hipError_t rc = hipEventElapsedTime(&out_ms[i], t->ev[2 * i], t->ev[2 * i + 1]);
+        if (rc != hipSuccess) {
+            lz_set_error("timing_elapsed_ms: pair %u: %s", i, hipGetErrorString(rc));
+            return (int)rc;
+        }
+    }
+    *n_pairs = n;
+    return LZ_OK;
+}
+
+extern "C" int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterations, lz_timing* timing, lz_stream_t stream) {
+    LZ_REQUIRE(f && f->state && f->workspace && f->rays_alive[0] && f->rays_alive[1], LZ_ERR_BAD_ARGUMENT, "loop_run: incomplete lz_frame");
+    uint32_t cur = parity & 1u;
+    const int32_t* count = reinterpret_cast<const int32_t*>(f->state) + 4;  // &state->n_samples
+    for (uint32_t it = 0; it < n_iterations; it++) {
+        const uint32_t nxt = cur ^ 1u;
+        int rc = lz_loop_march(f->state, f->N, f->rays_alive[cur], f->rays_alive[nxt], f->workspace, f->rays_t, f->rays_o, f->rays_d,
+                               f->bound, f->dt_gamma, f->max_steps, f->C, f->H, f->grid, f->nears, f->fars, f->xyzs, f->dirs, f->deltas,
+                               f->ray_counts, stream);
+        if (rc != LZ_OK) return rc;
+        const bool timed = timing && (size_t)(timing->used + 1) * 2 <= timing->ev.size();
+        if (timed) (void)hipEventRecord(timing->ev[2 * timing->used], lz_st(stream));
+        rc = lz_triplane_head_forward(&f->head, f->xyzs, f->dirs, f->N, count, f->sigmas, f->rgbs, f->amb_aud, f->amb_eye, f->unc, stream);
+        if (rc != LZ_OK) return rc;
+        if (timed) {
+            (void)hipEventRecord(timing->ev[2 * timing->used + 1], lz_st(stream));
+            timing->used++;
+        }
+        rc = lz_loop_composite(f->state, f->N, f->T_thresh, f->rays_alive[nxt], f->rays_t, f->sigmas, f->rgbs, f->deltas, f->amb_aud,
+                               f->amb_eye, f->unc, f->weights_sum, f->depth, f->image, f->amb_aud_sum, f->amb_eye_sum, f->unc_sum,
+                               f->workspace, stream);
+        if (rc != LZ_OK) return rc;
+        rc = lz_loop_advance(f->state, f->N, f->max_steps, f->workspace, stream);
+        if (rc != LZ_OK) return rc;
+        cur = nxt;
+    }
+    return LZ_OK;
+}

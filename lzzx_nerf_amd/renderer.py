@@ -50,7 +50,7 @@ class _Buffers:
         self.state = torch.zeros(_STATE_INTS, **i)
         self.workspace = torch.empty(4096, **i)
         self.ray_counts = torch.zeros(N, **i)
-        self.state_host = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.state_ring = [torch.zeros(8, dtype=torch.int32).pin_memory() for _ in range(4)]
 
 
 class TriplaneRenderer:
@@ -76,8 +76,28 @@ class TriplaneRenderer:
         if density_scale != 1:
             raise NotImplementedError("density_scale != 1 (the reference hard-codes 1, renderer.py:95)")
         self._buf = None
-        self._head_events = None  # set to a list to collect (start, end) HIP events around every head launch (bench.py)
-        self.chunk = 8   # iterations enqueued between two non-blocking peeks at the loop state
+        self._head_events = None  # set to a list: Python-driven loop with torch events around every head launch (debug)
+        self._timing = None       # lz_timing handle: native loop records a HIP event pair around every head launch
+        self.chunk = 8       # iterations enqueued per C call
+        self.lookahead = 2   # chunks the host keeps queued ahead of the one whose result it inspects (ring holds lookahead + 2)
+
+    def timing_start(self, n_pairs):
+        """bracket every head launch of the following render() calls with HIP events (bench.py's roofline leg)"""
+        h = C.c_void_p()
+        call("lz_timing_create", int(n_pairs), C.byref(h))
+        self._timing = h
+
+    def timing_stop(self):
+        """-> list of head-launch durations in ms (synchronises the device)"""
+        torch.cuda.synchronize()
+        h, self._timing = self._timing, None
+        cap = 1 << 20
+        buf = (C.c_float * cap)()
+        n = C.c_uint32()
+        call("lz_timing_elapsed_ms", h, buf, cap, C.byref(n))
+        out = list(buf[: n.value])
+        call("lz_timing_destroy", h)
+        return out
 
     def _buffers(self, N, device):
         if self._buf is None or self._buf.N != N:
@@ -105,12 +125,35 @@ class TriplaneRenderer:
              ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ws, stream())
         call("lz_loop_advance", st, N, int(max_steps), ws, stream())
 
+    def _frame(self, b, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples):
+        """lz_frame for lz_loop_run; the small conditioning tensors are kept alive on self until the next frame"""
+        h = self.head
+        enc_a = enc_a.reshape(-1).float().contiguous()
+        ind_code = None if ind_code is None else ind_code.reshape(-1).float().contiguous()
+        eye = None if eye is None else eye.reshape(-1).float().contiguous()
+        self._cond = (enc_a, ind_code, eye)
+        f = _lib.Frame()
+        f.head = h._params(enc_a, ind_code, eye, True)
+        p = lambda t: t.data_ptr()
+        f.state, f.workspace = p(b.state), p(b.workspace)
+        f.rays_alive[0], f.rays_alive[1] = p(b.rays_alive[0]), p(b.rays_alive[1])
+        f.rays_t, f.rays_o, f.rays_d, f.nears, f.fars, f.grid = p(b.rays_t), p(self._rays_o), p(self._rays_d), p(b.nears), p(b.fars), p(self.bitfield)
+        f.xyzs, f.dirs, f.deltas = p(b.xyzs), p(b.dirs), p(b.deltas)
+        f.sigmas, f.rgbs, f.amb_aud, f.amb_eye, f.unc = p(b.sigmas), p(b.rgbs), p(b.amb_aud), p(b.amb_eye), p(b.unc)
+        f.weights_sum, f.depth, f.image = p(b.weights_sum), p(b.depth), p(b.image)
+        f.amb_aud_sum, f.amb_eye_sum, f.unc_sum = p(b.amb_aud_sum), p(b.amb_eye_sum), p(b.unc_sum)
+        f.ray_counts = p(b.ray_counts) if count_samples else None
+        f.N, f.max_steps, f.C, f.H = N, int(max_steps), int(self.cascade), int(self.grid_size)
+        f.bound, f.dt_gamma, f.T_thresh = self.bound, float(dt_gamma), float(T_thresh)
+        return f
+
     @torch.no_grad()
     def render(self, rays_o, rays_d, enc_a, ind_code=None, eye=None, dt_gamma=1.0 / 256, max_steps=16, T_thresh=1e-4,
                bg_color=1.0, count_samples=False, sync_free=True):
         """rays_o, rays_d: [N,3] (or [1,N,3]) f32 cuda.  Returns dict(image [N,3] blended+clamped, weights_sum, depth,
         amb_aud_sum, amb_eye_sum, uncertainty_sum, state (device int32[8]), ray_counts if requested).
-        Nothing in here blocks the host when sync_free (the returned tensors are ready in stream order)."""
+        sync_free: the host never waits for the newest work, only for the chunk `lookahead` chunks back (the GPU
+        queue never drains); the returned tensors are ready in stream order."""
         rays_o = rays_o.reshape(-1, 3).float().contiguous()
         rays_d = rays_d.reshape(-1, 3).float().contiguous()
         N = rays_o.shape[0]
@@ -122,21 +165,34 @@ class TriplaneRenderer:
         call("lz_loop_begin", N, int(max_steps), ptr(b.nears), ptr(b.rays_alive[0]), ptr(b.rays_t), ptr(b.weights_sum), ptr(b.depth),
              ptr(b.image), ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ptr(b.state), ptr(b.workspace), stream())
         cur, it = 0, 0
-        pending = None
+        pending_q = []
+        native = self._head_events is None   # the Python-driven loop is kept for debugging with torch events
+        if native:
+            frame = self._frame(b, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples)
         while it < max_steps:  # n_step >= 1, so max_steps iterations always suffice (renderer.py:503,546)
             n = min(self.chunk, max_steps - it)
-            for _ in range(n):
-                self._iteration(b, cur, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples)
-                cur = 1 - cur
+            if native:   # one C call enqueues n x (march, head, composite, advance)
+                call("lz_loop_run", C.byref(frame), cur, n, self._timing, stream())
+                cur = (cur + n) & 1
+            else:
+                for _ in range(n):
+                    self._iteration(b, cur, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples)
+                    cur = 1 - cur
             it += n
-            if pending is not None and pending.query() and int(b.state_host[3]) == 1:
-                break  # a previous chunk already finished the frame; what was enqueued since is a no-op on the device
-            b.state_host.copy_(b.state[:8], non_blocking=True)
-            pending = torch.cuda.Event()
-            pending.record()
-            if not sync_free:
-                pending.synchronize()
-                if int(b.state_host[3]) == 1:
+            # After every chunk the loop state is copied to a pinned slot (ring of `lookahead + 1`) behind an event.
+            # Before enqueuing more, the host looks at the chunk `lookahead` chunks back: the GPU always has that many
+            # chunks queued (no bubble), and at most that many no-op chunks are enqueued after the frame has finished.
+            k = len(pending_q)
+            slot = b.state_ring[k % len(b.state_ring)]
+            slot.copy_(b.state[:8], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending_q.append((ev, slot))
+            look = 0 if not sync_free else self.lookahead
+            if k >= look:
+                ev_old, slot_old = pending_q[k - look]
+                ev_old.synchronize()
+                if int(slot_old[3]) == 1:
                     break
         bg = None
         bg_scalar = 1.0
