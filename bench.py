@@ -17,6 +17,7 @@ whole batch.
 Prints one JSON line on rank 0.  `value` = marched samples (delta != 0) per second over all ranks.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -30,6 +31,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_SAMPLE = 46368          # 23 184 MAC per sample, inference head
+ISSUED_FLOP_PER_ROW = 405 * 2048 // 16   # the head issues 405 v_mfma_f32_16x16x4_f32 (2048 FLOP each) per 16-row slice
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
 
@@ -48,14 +50,25 @@ def grid_roofline(device):
     from lzzx_nerf_amd.gridencoder import GridEncoder, grid_encode
     res = {}
     g = torch.Generator(device=device).manual_seed(0)
-    for tag, kw, bytes_per_sample, B in (
-            ("triplane_plane_D2_L12_C1_f32", dict(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
-                                                  desired_resolution=512), 8 + 12 * 4 * 4 + 48, 1 << 24),
-            ("hashgrid_D3_L16_C2_f32", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23)):
+    tri = dict(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14, desired_resolution=512)
+    for tag, kw, bytes_per_sample, B, mode in (
+            ("triplane_plane_D2_L12_C1_f32", tri, 8 + 12 * 4 * 4 + 48, 1 << 24, "fwd"),
+            ("hashgrid_D3_L16_C2_f32", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23, "fwd"),
+            ("hashgrid_D3_L16_C2_f16", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 2 + 64, 1 << 23, "fwd16"),
+            ("triplane_plane_D2_L12_C1_f32_backward", tri, 8 + 48 + 12 * 4 * 4 * 2, 1 << 22, "bwd")):
         enc = GridEncoder(**kw).to(device)
         enc.embeddings.data.uniform_(-1, 1, generator=g)
         x = torch.rand(B, enc.input_dim, device=device, generator=g)
-        f = lambda: grid_encode(x, enc.embeddings.data, enc.offsets, enc.per_level_scale, enc.base_resolution, False, 0, False)
+        emb = enc.embeddings.data.half() if mode == "fwd16" else enc.embeddings.data
+        if mode == "bwd":
+            from lzzx_nerf_amd._util import call, ptr, stream
+            grad = torch.rand(B, enc.output_dim, device=device, generator=g)
+            gemb = torch.zeros_like(emb)
+            S = float(np.float32(np.log2(enc.per_level_scale)))
+            f = lambda: call("lz_grid_encode_backward", ptr(grad), ptr(x), ptr(emb), ptr(enc.offsets), ptr(gemb), B, enc.input_dim,
+                             enc.level_dim, enc.num_levels, S, enc.base_resolution, None, None, 0, 0, 0, 1, stream())
+        else:
+            f = lambda: grid_encode(x, emb, enc.offsets, enc.per_level_scale, enc.base_resolution, False, 0, False)
         for _ in range(3):
             f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -73,8 +86,102 @@ def grid_roofline(device):
     return res
 
 
+class TriplaneTrainNet(torch.nn.Module):
+    """caller-side graph of the reference's NeRFNetwork.forward in training mode (network.py:252-311) on the operator API:
+    3 GridEncoders + SHEncoder from get_encoder(), bias-free torch Linear stacks (rocBLAS), autograd"""
+
+    def __init__(self, P, device):
+        super().__init__()
+        from lzzx_nerf_amd.encoding import get_encoder
+        mk = lambda: get_encoder("hashgrid", input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
+                                 desired_resolution=512)[0]
+        self.encoder_xy, self.encoder_yz, self.encoder_xz = mk(), mk(), mk()
+        self.encoder_dir = get_encoder("spherical_harmonics")[0]
+        self.W = torch.nn.ParameterDict({k.replace(".", "_"): torch.nn.Parameter(torch.from_numpy(v).clone()) for k, v in P.items()
+                                         if k.endswith(".weight")})
+        self.to(device)
+        with torch.no_grad():
+            for n in ("xy", "yz", "xz"):
+                getattr(self, "encoder_" + n).embeddings.copy_(torch.from_numpy(P[f"encoder_{n}.embeddings"]))
+
+    def mlp(self, h, name, n):
+        for i in range(n):
+            h = torch.nn.functional.linear(h, self.W[f"{name}_net_{i}_weight"])
+            if i < n - 1:
+                h = torch.relu(h)
+        return h
+
+    def forward(self, x, d, enc_a, ind, eye):
+        enc_x = torch.cat([self.encoder_xy(x[:, :2], bound=1), self.encoder_yz(x[:, 1:], bound=1), self.encoder_xz(x[:, [0, 2]], bound=1)], -1)
+        att = self.mlp(enc_x, "aud_ch_att_net", 2)
+        eye_att = torch.sigmoid(self.mlp(enc_x, "eye_att_net", 2))
+        h = self.mlp(torch.cat([enc_x, enc_a * att, eye * eye_att], -1), "sigma_net", 3)
+        sigma = torch.exp(h[:, 0])
+        hc = torch.cat([self.encoder_dir(d), h[:, 1:], ind.expand(x.shape[0], -1)], -1)
+        rgb = torch.sigmoid(self.mlp(hc, "color_net", 2)) * 1.002 - 0.001
+        unc = torch.nn.functional.softplus(self.mlp(enc_x.detach(), "unc_net", 2))[:, 0]
+        return sigma, rgb, att.norm(dim=-1), eye_att.abs().sum(-1), unc
+
+
+def train_bench(args, device, P, golden, bits):
+    """BASELINE cfg3: one training step (fwd + bwd + Adam) on `--train-rays` random rays of the 512x512 frame through the
+    operator API as the reference's run_cuda arranges it (renderer.py:279-304).  The MLP GEMMs are torch/rocBLAS here;
+    everything else is this repo's HIP kernels.  Reported beside the headline line, never instead of it."""
+    from conftest import synthetic_camera
+    from lzzx_nerf_amd import raymarching as R
+    from lzzx_nerf_amd.renderer import get_rays
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    H = W = args.size
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(dev(pose), intr, H, W)
+    g = torch.Generator(device=device).manual_seed(0)
+    n_rays = min(args.train_rays, H * W)
+    sel = torch.randperm(H * W, device=device, generator=g)[:n_rays]
+    ro, rd = ro[sel].contiguous(), rd[sel].contiguous()
+    target = torch.rand(n_rays, 3, device=device, generator=g)
+    net = TriplaneTrainNet(P, device)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-15)
+    enc_a, ind, eye = dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"])
+    aabb = dev(np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32))
+    bitfield = dev(bits)
+    ctr = torch.zeros(2, dtype=torch.int32, device=device)
+    n_samples = [0]
+
+    def step():
+        nears, fars = R.near_far_from_aabb(ro, rd, aabb, 0.05)
+        ctr.zero_()
+        xyzs, dirs, deltas, rays = R.march_rays_train(ro, rd, 1.0, bitfield, 1, 128, nears, fars, ctr, -1, True, 128, True, 1 / 256,
+                                                      args.max_steps)
+        sigma, rgb, a0, a1, unc = net(xyzs, dirs, enc_a, ind, eye)
+        ws, a0s, a1s, us, dep, img = R.composite_rays_train_triplane(sigma, rgb, a0, a1, unc, deltas, rays)
+        loss = ((img + (1 - ws).unsqueeze(-1) - target) ** 2).mean() + 1e-4 * a0s.mean() + 1e-4 * a1s.mean() + 1e-3 * us.mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        n_samples[0] = xyzs.shape[0]
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    return dict(workload=f"cfg3: {n_rays} random rays of a {H}x{W} frame, max_steps {args.max_steps}, occupancy={args.scene}, "
+                         "march_rays_train -> 3 grid + SH encoders -> torch Linear heads -> composite_rays_train_triplane -> MSE -> "
+                         "backward (grid scatter-add) -> Adam", rays=n_rays, samples_per_step=int(n_samples[0]),
+                ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
+                loss=float(loss), dtype="f32", mlp="torch/rocBLAS")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--budget-factor", type=int, default=1, help="sample rows per iteration = factor x rays (reference: 1)")
+    ap.add_argument("--n-step-cap", type=int, default=8, help="max samples per ray per iteration (reference: 8)")
+    ap.add_argument("--train", action="store_true", help="also time a cfg3 training step (operator API) and add it as 'train_step'")
+    ap.add_argument("--train-rays", type=int, default=65536)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -83,6 +190,7 @@ def main():
     ap.add_argument("--scene", default="ones", choices=["ones", "ellipsoid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid-roofline", action="store_true")
+    ap.add_argument("--no-fat-schedule", action="store_true")
     args = ap.parse_args()
 
     from lzzx_nerf_amd import _lib, dist as D
@@ -103,7 +211,7 @@ def main():
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in P.items()}, bound=1.0, device=device)
     bits = np.full(128 ** 3 // 8, 255, np.uint8) if args.scene == "ones" else ellipsoid_bitfield()[0]
-    renderer = TriplaneRenderer(head, dev(bits), bound=1.0)
+    renderer = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=args.budget_factor, n_step_cap=args.n_step_cap)
     H = W = args.size
     _, intr = synthetic_camera(H, W)
     pose = orbit_pose(rank, world)
@@ -131,6 +239,15 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     head_ms = renderer.timing_stop()
+    # sustained shader clock under the head's load: 8 back-to-back 2M-row launches, counters of one wave of the last one
+    gp = torch.Generator(device=device).manual_seed(1)
+    xs = torch.rand(1 << 21, 3, device=device, generator=gp) * 2 - 1
+    ds = torch.nn.functional.normalize(torch.randn(1 << 21, 3, device=device, generator=gp), dim=-1)
+    for _ in range(8):
+        head.forward(xs, ds, enc_a, ind, eye)
+    probe = (C.c_uint64 * 2)()
+    _lib.call("lz_debug_head_clocks", probe)
+    del xs, ds
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -138,6 +255,7 @@ def main():
     state = out["state"].cpu().numpy()
     samples_per_frame = int(state[5])
     iters_per_frame = int(state[6])
+    rows_per_frame = int(state[72])   # LZ_LOOP_STAT_ROWS: rows the head evaluated (n_alive * n_step, exhausted rows included)
     total_samples = torch.tensor([samples_per_frame], dtype=torch.float64, device=device)
     if world > 1:
         torch.distributed.all_reduce(total_samples)
@@ -159,7 +277,9 @@ def main():
                     frac=round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), traffic=None, kernel="lz_k_triplane_head<false>",
                     avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5), launches=n_launch,
                     launches_with_work=launches_with_work, flop_per_sample=FLOP_PER_SAMPLE,
-                    head_time_share=round(head_total_ms * 1e-3 / dt, 4))
+                    head_time_share=round(head_total_ms * 1e-3 / dt, 4), rows_per_frame=rows_per_frame,
+                    shader_clock_mhz_under_load=round(probe[0] / max(probe[1], 1) * 100.0, 1),
+                    issued_frac=round(ISSUED_FLOP_PER_ROW * rows_per_frame * args.steps / (head_total_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
     result = {
         "metric": "rendered samples/s (512x512 triplane head, max_steps 192)", "value": round(value, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -167,13 +287,39 @@ def main():
         "config": {"workload": f"{H}x{W} inference frame per GPU, max_steps {args.max_steps}, triplane head (3x D2/L12/C1 hash grid + "
                                f"audio/eye cond + SH4), occupancy={args.scene}, bound 1, dt_gamma 1/256, T_thresh 1e-4",
                    "rays_per_gpu": N, "samples_per_frame": samples_per_frame, "iterations_per_frame": iters_per_frame,
-                   "nominal_samples_per_frame": N * args.max_steps, "parallelism": f"ray-sharded x{world}, 1 all-gather/step"},
+                   "nominal_samples_per_frame": N * args.max_steps, "parallelism": f"ray-sharded x{world}, 1 all-gather/step",
+                   "schedule": f"n_step = max(min({args.budget_factor} * N // n_alive, {args.n_step_cap}), 1)"
+                               + (" (the reference's, renderer.py:513)" if (args.budget_factor, args.n_step_cap) == (1, 8) else "")},
         "rays_per_s": round(rays_per_s, 1),
         "samples_per_ray_mean": round(samples_per_frame / N, 2),
         "roofline": roofline,
     }
+    if world == 1 and (args.budget_factor, args.n_step_cap) == (1, 8) and not args.no_fat_schedule:
+        # same frame with 8x the reference's per-iteration sample budget (fewer, fatter launches; pixels must not change)
+        fat = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=8, n_step_cap=8)
+        frender = lambda: fat.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4)
+        for _ in range(2):
+            frender()
+        torch.cuda.synchronize()
+        fat.timing_start(args.steps * args.max_steps + 16)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fo = frender()
+        torch.cuda.synchronize()
+        fdt = time.perf_counter() - t0
+        fms = float(np.sum(fat.timing_stop()))
+        fst = fo["state"].cpu().numpy()
+        result["fat_schedule"] = dict(
+            schedule="n_step = max(min(8 * N // n_alive, 8), 1)", value=round(int(fst[5]) * args.steps / fdt, 1), unit="samples/s",
+            ms_per_step=round(fdt / args.steps * 1e3, 4), iterations_per_frame=int(fst[6]), rows_per_frame=int(fst[72]),
+            image_equal_to_reference_schedule=bool(torch.equal(fo["image"], out["image"])),
+            head_frac=round(FLOP_PER_SAMPLE * int(fst[5]) * args.steps / (fms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            head_issued_frac=round(ISSUED_FLOP_PER_ROW * int(fst[72]) * args.steps / (fms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
+        del fat
     if not args.no_grid_roofline and world == 1:
         result["roofline_gridencoder"] = grid_roofline(device)
+    if args.train and world == 1:
+        result["train_step"] = train_bench(args, device, P, golden, bits)
     # ---- CPU baseline: the checker arranged like the reference loop, on a bounded sub-frame of the SAME rays ----
     if not args.no_cpu_baseline and world == 1:   # rank 0, N = 1 only
         from oracle.head import TriplaneSpec
@@ -186,7 +332,7 @@ def main():
                          max_steps=args.max_steps)  # warm-up (page in, OpenMP team)
         tc = time.perf_counter()
         ref = render_inference(TriplaneSpec(1.0), P, ro_c, rd_c, bits, golden["net_enc_a"], golden["net_ind"], golden["net_eye"],
-                               max_steps=args.max_steps, stats=st)
+                               max_steps=args.max_steps, stats=st, budget_factor=args.budget_factor, n_step_cap=args.n_step_cap)
         tc = time.perf_counter() - tc
         cpu_samples = int(st["samples_per_ray"].sum())
         gpu_img = out["image"].cpu().numpy()[sel]

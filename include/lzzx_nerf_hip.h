@@ -42,7 +42,8 @@ int lz_device_ok(void);
 
 /* inputs [B,D] f32 in [0,1]; embeddings [sO,C] f32 or f16 (emb_f16); offsets [L+1] i32 (device);
  * outputs: out_layout 0 = [L,B,C] (the reference's level-major layout, gridencoder.cu:95),
- *          out_layout 1 = [B,L*C] (what grid.py:52 produces after its permute; saves that copy);
+ *          out_layout 1 = [B,L*C] (what grid.py:52 produces after its permute; saves that copy); for B >= 65536 the
+ *                         buffer is first filled level by level in sample tiles, then untiled in place (same stream);
  *          out_layout 2 = [B,L*C] through the level-resident kernel: a hint that every level's table is <= 64 KB
  *                         (levels that are larger still work, through global gathers, but slowly) -- use for large B;
  * dy_dx [B,L,D,C] or NULL.  S = log2(per_level_scale) as float, H = base resolution. */
@@ -50,7 +51,9 @@ int lz_grid_encode_forward(const float* inputs, const void* embeddings, const in
                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
                            uint32_t gridtype, int align_corners, int emb_f16, int out_layout, lz_stream_t stream);
 
-/* grad: grad_layout 0 = [L,B,C] (grid.py:70), 1 = [B,L*C]; grad_embeddings [sO,C] pre-zeroed by the caller
+/* grad: grad_layout 0 = [L,B,C] (grid.py:70), 1 = [B,L*C]; 2 / 3 = [B,L*C] / [L,B,C] plus the hint that every level's
+ * table is <= 64 KB, which selects per-level accumulation in LDS (f32 tables, D <= 3, C <= 2; ignored otherwise; levels
+ * that are larger still work, through global atomics); grad_embeddings [sO,C] pre-zeroed by the caller
  * (grid.py:72), accumulated with f32 atomics (f16: packed half2 atomics when C is even, gridencoder.cu:298-304);
  * dy_dx / grad_inputs [B,D] optional (both or neither). */
 int lz_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
@@ -175,12 +178,14 @@ int lz_triplane_head_forward(const lz_head_params* p, const float* xyzs, const f
                              float* unc, lz_stream_t stream);
 
 /* Device-resident inference loop state (renderer.py:495-548): no host synchronisation inside the frame.
- * The device buffer passed as `lz_loop_state*` must hold LZ_LOOP_STATE_INTS int32: the struct below followed by 64
- * scratch words (per-workgroup sample-count slots, folded into total_samples by lz_loop_compact). */
-#define LZ_LOOP_STATE_INTS 72
+ * The device buffer passed as `lz_loop_state*` must hold LZ_LOOP_STATE_INTS int32: the struct below, 64 scratch words
+ * (per-workgroup sample-count slots, folded into total_samples by lz_loop_advance), then statistics:
+ * word 72 = sample rows handed to the head so far (sum of n_alive * n_step, exhausted rows included). */
+#define LZ_LOOP_STATE_INTS 80
+#define LZ_LOOP_STAT_ROWS 72
 typedef struct {
     int32_t n_alive;      /* rays alive at the start of the current iteration */
-    int32_t n_step;       /* max(min(N / n_alive, 8), 1), renderer.py:513 */
+    int32_t n_step;       /* max(min(sample_budget / n_alive, n_step_cap), 1); budget = N, cap = 8: renderer.py:513 */
     int32_t step;         /* sum of n_step so far */
     int32_t done;         /* 1 once n_alive == 0 or step >= max_steps */
     int32_t n_samples;    /* n_alive * n_step of the current iteration */
@@ -193,8 +198,15 @@ typedef struct {
  * lz_loop_advance.  `workspace`: >= 4096 int32 of device scratch shared by the four calls (per-workgroup survivor
  * counts / offsets); at most 4096 * 256 rays per frame.  The alive list ping-pongs between two [N] int32 buffers. */
 
+/* Iteration schedule: the reference marches n_step = max(min(N / n_alive, 8), 1) samples per alive ray per iteration
+ * (renderer.py:513), i.e. a budget of N sample rows per iteration and at most 8 steps.  `sample_budget` / `n_step_cap`
+ * generalise the two constants (0 = the reference's N / 8): a larger budget means fewer, fatter iterations.  Pixels do
+ * not depend on the schedule (rays are independent and compositing resumes exactly); per-ray marched-sample counts do
+ * only for rays that terminate early inside a chunk.  Sample buffers must hold max(sample_budget, N) rows. */
+
 /* rays_alive <- 0..N-1, rays_t <- nears, accumulators <- 0, state <- (N, n_step(N), 0, ...), workspace <- identity offsets */
-int lz_loop_begin(uint32_t N, uint32_t max_steps, const float* nears, int32_t* rays_alive, float* rays_t,
+int lz_loop_begin(uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap, const float* nears,
+                  int32_t* rays_alive, float* rays_t,
                   float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum, float* unc_sum,
                   lz_loop_state* state, void* workspace, lz_stream_t stream);
 /* order-preserving stream compaction of rays_alive_in (drops the -1 entries compositing left, renderer.py:542) into
@@ -210,8 +222,14 @@ int lz_loop_composite(const lz_loop_state* state, uint32_t N, float T_thresh, in
                       const float* unc, float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum,
                       float* unc_sum, void* workspace, lz_stream_t stream);
 /* scan the survivor counts into offsets and advance the loop state (n_alive, n_step, step, done, n_samples) */
-int lz_loop_advance(lz_loop_state* state, uint32_t N, uint32_t max_steps, void* workspace, lz_stream_t stream);
-/* Everything one frame's loop touches (all device pointers; sample buffers hold N rows since n_alive * n_step <= N). */
+int lz_loop_advance(lz_loop_state* state, uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap,
+                    void* workspace, lz_stream_t stream);
+/* diagnostic (synchronises the device): out2[0] = shader-clock cycles, out2[1] = 100 MHz wall-clock ticks that wave 0 of
+ * workgroup 0 spent inside the most recent lz_triplane_head_forward launch; ratio x 100 MHz = sustained shader clock */
+int lz_debug_head_clocks(uint64_t* out2);
+
+/* Everything one frame's loop touches (all device pointers; sample buffers hold max(sample_budget, N) rows since
+ * n_alive * n_step <= max(sample_budget, N)). */
 typedef struct {
     lz_head_params head;
     lz_loop_state* state;          /* LZ_LOOP_STATE_INTS int32 */
@@ -230,6 +248,7 @@ typedef struct {
     int32_t* ray_counts;           /* [N] or NULL */
     uint32_t N, max_steps, C, H;
     float bound, dt_gamma, T_thresh;
+    uint32_t sample_budget, n_step_cap;   /* 0 = the reference's schedule (N, 8) */
 } lz_frame;
 
 /* enqueue `n_iterations` iterations (march -> head -> composite -> advance) back to back; `parity` = index of the

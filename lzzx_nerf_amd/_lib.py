@@ -24,7 +24,8 @@ class Frame(C.Structure):
                 ("rays_d", vp), ("nears", vp), ("fars", vp), ("grid", vp), ("xyzs", vp), ("dirs", vp), ("deltas", vp), ("sigmas", vp),
                 ("rgbs", vp), ("amb_aud", vp), ("amb_eye", vp), ("unc", vp), ("weights_sum", vp), ("depth", vp), ("image", vp),
                 ("amb_aud_sum", vp), ("amb_eye_sum", vp), ("unc_sum", vp), ("ray_counts", vp), ("N", u32), ("max_steps", u32),
-                ("C", u32), ("H", u32), ("bound", f32), ("dt_gamma", f32), ("T_thresh", f32)]
+                ("C", u32), ("H", u32), ("bound", f32), ("dt_gamma", f32), ("T_thresh", f32),
+                ("sample_budget", u32), ("n_step_cap", u32)]
 
 
 # name -> argtypes, in the order of include/lzzx_nerf_hip.h
@@ -51,16 +52,17 @@ SIGNATURES = {
     "lz_get_rays": [vp, f32, f32, f32, f32, u32, u32, vp, vp, vp],
     "lz_head_pack_weights": [vp] * 11 + [i32, i32, vp, vp],
     "lz_triplane_head_forward": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, vp, vp],
-    "lz_loop_begin": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_loop_begin": [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_march": [vp, u32, vp, vp, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_composite": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "lz_loop_advance": [vp, u32, u32, vp, vp],
+    "lz_loop_advance": [vp, u32, u32, u32, u32, vp, vp],
     "lz_loop_run": [C.POINTER(Frame), u32, u32, vp, vp],
     "lz_timing_create": [u32, C.POINTER(vp)],
     "lz_timing_destroy": [vp],
     "lz_timing_reset": [vp],
     "lz_timing_elapsed_ms": [vp, C.POINTER(f32), u32, C.POINTER(u32)],
     "lz_final_blend": [vp, vp, vp, f32, u32, vp, vp],
+    "lz_debug_head_clocks": [C.POINTER(C.c_uint64)],
 }
 PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),
          "lz_head_packed_size": ([], u32)}

@@ -73,8 +73,11 @@ template <> struct LzElem<float> {
 template <> struct LzElem<__half> {
     static __device__ __forceinline__ float rh(float v) { return __half2float(__float2half_rn(v)); }
     static __device__ __forceinline__ float ld(const __half* p) { return __half2float(*p); }
-    static __device__ __forceinline__ float acc(float r, float w, float g) { return rh(r + rh(w * g)); }
-    static __device__ __forceinline__ float accd(float r, float w, float gr, float gl) { return rh(r + rh(w * rh(gr - gl))); }
+    // at::Half semantics: the f32 product is rounded to f32 FIRST, then to half.  The opaque asm keeps the compiler from
+    // selecting v_fma_mixlo_f16 for cvt(mul(cvt(g), w)), which rounds the exact product once and differs in ~2^-13 of cases.
+    static __device__ __forceinline__ float mul32(float a, float b) { float p = a * b; asm("" : "+v"(p)); return p; }
+    static __device__ __forceinline__ float acc(float r, float w, float g) { return rh(r + rh(mul32(w, g))); }
+    static __device__ __forceinline__ float accd(float r, float w, float gr, float gl) { return rh(r + rh(mul32(w, rh(gr - gl)))); }
     static __device__ __forceinline__ __half st(float v) { return __float2half_rn(v); }
 };
 
@@ -548,6 +551,249 @@ static void lz_grid_lds_launch(const float* inputs, const T* emb, const int* off
                        lv, gridtype, ac, chunk, n_chunks);
 }
 
+// ---- big tables (a level does not fit LDS): level-major pass over sample tiles + in-place untile --------------------
+// The sample-major kernel above makes every wave touch all L levels at once, so the L2 working set is the whole table
+// (49 MB for D3/L16/C2/T19) and most gathers miss to the Infinity Cache.  Here blockIdx.y = level is the SLOW launch
+// dimension: at any moment the whole chip gathers from one or two levels (<= 4 MB each, L2-resident), the level's mode
+// (dense / mask / modulo) is workgroup-uniform, and a corner is ONE vector load of C elements.  To keep stores whole
+// lines without a scratch buffer the pass writes the caller's [B, L*C] buffer in a TILED order
+//     [tile][level][sample in tile][C]          (tile = Tn samples; same bytes as the tile's final [sample][level][C])
+// and lz_k_grid_untile then transposes every tile in place through LDS (one workgroup owns one tile: load all, barrier,
+// store all).  The untile pass costs one read + one write of the output (~0.3 ms per GB), far less than it saves.
+template <uint32_t D>
+__device__ __forceinline__ uint32_t lz_grid_level_mode(uint32_t hs, uint32_t res, uint32_t gridtype, bool align_corners) {
+    uint32_t stride = 1;
+    uint64_t stride_exact = 1;
+    for (uint32_t d = 0; d < D; d++)
+        if (stride <= hs) {
+            stride *= align_corners ? res : (res + 1);
+            stride_exact *= align_corners ? res : (res + 1);
+        }
+    const bool wrapped = stride_exact != (uint64_t)stride;
+    const bool hashed = gridtype == 0 && stride > hs;
+    const bool dense = stride <= hs && !wrapped;
+    const bool pow2 = (hs & (hs - 1u)) == 0u;
+    return dense ? 0u : ((hashed && pow2 && !wrapped) ? 1u : 2u);   // 0 identity, 1 hash + mask, 2 generic modulo
+}
+
+template <typename T, uint32_t C> struct LzVec {
+    T v[C];
+};
+
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256)
+lz_k_grid_forward_lm(const float* __restrict__ inputs, const T* __restrict__ grid, const int* __restrict__ offsets,
+                     T* __restrict__ outputs, uint32_t B, uint32_t L, LzGridLevels lv, uint32_t gridtype, bool align_corners) {
+    const uint32_t Tn = blockDim.x, tile = blockIdx.x, level = blockIdx.y, t = threadIdx.x;
+    const uint32_t b0 = tile * Tn;
+    const uint32_t n = (B - b0 < Tn) ? B - b0 : Tn;
+    if (t >= n) return;
+    const uint32_t b = b0 + t;
+    const uint32_t off0 = (uint32_t)offsets[level], hs = (uint32_t)offsets[level + 1] - off0;
+    const uint32_t resolution = lv.res[level];
+    const float scale = lv.scale[level];
+    const uint32_t mode = lz_grid_level_mode<D>(hs, resolution, gridtype, align_corners);
+    const T* g = grid + (size_t)off0 * C;
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        if (x[d] < 0 || x[d] > 1) oob = true;
+    }
+    float pos[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float xc = lz_fminf(lz_fmaxf(x[d], 0.0f), 1.0f);   // clamp for addressing only; result zeroed below
+        pos[d] = lz_fmaf(xc, scale, align_corners ? 0.0f : 0.5f);
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+    }
+    uint32_t index[1u << D];
+    float w[1u << D];
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float wc = 1.0f;
+        uint32_t pl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { wc *= 1 - pos[d]; pl[d] = pg[d]; }
+            else { wc *= pos[d]; pl[d] = pg[d] + 1; }
+        }
+        w[idx] = wc;
+        if (mode == 2u) {  // workgroup-uniform
+            index[idx] = lz_grid_index<D>(C, gridtype, align_corners, hs, resolution, pl);
+        } else {
+            constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+            uint32_t lin = 0, h = 0, stride = 1;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                lin += pl[d] * stride;
+                stride *= align_corners ? resolution : (resolution + 1);
+                h ^= pl[d] * primes[d];
+            }
+            index[idx] = (mode == 1u ? (h & (hs - 1u)) : lin) * C;
+        }
+    }
+    // all 2^D corner reads in flight before the first use; (index * sizeof(T)) is a multiple of the vector size
+    LzVec<T, C> cv[1u << D];
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++)
+        __builtin_memcpy(&cv[idx], __builtin_assume_aligned(g + index[idx], sizeof(T) * C), sizeof(T) * C);
+    float res[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) res[ch] = 0.0f;
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++)
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) res[ch] = LzElem<T>::acc(res[ch], w[idx], LzElem<T>::ld(&cv[idx].v[ch]));
+    LzVec<T, C> o;
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) o.v[ch] = LzElem<T>::st(oob ? 0.0f : res[ch]);
+    T* out = outputs + ((size_t)b0 * L + (size_t)level * n + t) * C;
+    __builtin_memcpy(__builtin_assume_aligned(out, sizeof(T) * C), &o, sizeof(T) * C);
+}
+
+// one workgroup per tile; W = dwords per (sample, level) group = C * sizeof(T) / 4; the tile is [L][n][W] -> [n][L][W]
+__global__ void __launch_bounds__(256)
+lz_k_grid_untile(uint32_t* __restrict__ out, uint32_t B, uint32_t L, uint32_t W, uint32_t Tn, uint32_t pitch) {
+    extern __shared__ __align__(16) uint32_t lz_untile_smem[];
+    const uint32_t b0 = blockIdx.x * Tn;
+    const uint32_t n = (B - b0 < Tn) ? B - b0 : Tn;
+    const uint32_t LW = L * W, nW = n * W;
+    uint32_t* reg = out + (size_t)b0 * LW;
+    for (uint32_t l = 0; l < L; l++)
+        for (uint32_t i = threadIdx.x; i < nW; i += blockDim.x) lz_untile_smem[l * pitch + i] = reg[(size_t)l * nW + i];
+    __syncthreads();
+    const uint32_t rows = blockDim.x / LW;          // >= 1: LW <= 256
+    const uint32_t dt = threadIdx.x / LW, r = threadIdx.x - dt * LW;
+    if (dt >= rows) return;
+    const uint32_t l = r / W, wq = r - l * W;
+    const uint32_t* src = lz_untile_smem + l * pitch + wq;
+    for (uint32_t t = dt; t < n; t += rows) reg[(size_t)t * LW + r] = src[t * W];
+}
+
+template <typename T, uint32_t D, uint32_t C>
+static void lz_grid_lm_launch(const float* inputs, const T* emb, const int* offsets, T* out, uint32_t B, uint32_t L,
+                              const LzGridLevels& lv, uint32_t gridtype, bool ac, hipStream_t st) {
+    constexpr uint32_t W = C * sizeof(T) / 4;
+    const uint32_t LW = L * W;
+    const uint32_t Tn = LW <= 64 ? 256u : (LW <= 128 ? 128u : 64u);      // tile <= 64 KB
+    const uint32_t tiles = lz_div_up(B, Tn);
+    hipLaunchKernelGGL((lz_k_grid_forward_lm<T, D, C>), dim3(tiles, L), dim3(Tn), 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac);
+    // LDS row pitch: level l starts at bank (l * 64/L) so the 64 lanes of a store (64/LW samples x L levels x W) hit 64 banks
+    const uint32_t want = L < 64 ? 64u / L : 1u;
+    const uint32_t pitch = Tn * W + ((want + 64u - (Tn * W) % 64u) % 64u);
+    hipLaunchKernelGGL(lz_k_grid_untile, dim3(tiles), dim3(256), (size_t)L * pitch * 4, st, reinterpret_cast<uint32_t*>(out), B, L, W, Tn, pitch);
+}
+
+// ---- level-resident backward: the level's gradient table is accumulated in LDS -------------------------------------
+// Scattered global float atomics execute at the memory side at ~2e10 lane-adds/s chip-wide (64 lanes -> 64 lines), which
+// is what the plain scatter kernel above gets (a triplane plane: 0.37 Gsample/s).  When a level's table fits LDS a
+// workgroup owns ONE (level, sample chunk): it zeroes a private copy, accumulates its chunk with LDS atomics (ds_add_f32),
+// then flushes the non-zero entries with CONTIGUOUS global atomics (whole-line wave instructions: full atomic rate).
+// Summation order differs from the plain kernel (as it does between two runs of the reference); results agree to rounding.
+template <uint32_t D, uint32_t C, bool IN_LDS>
+__device__ __forceinline__ void lz_grid_level_scatter(const float* __restrict__ grad, const float* __restrict__ inputs, float* dst,
+                                                      uint32_t b0, uint32_t b1, uint32_t B, uint32_t L, uint32_t level, float scale,
+                                                      uint32_t resolution, uint32_t hs, uint32_t mode, uint32_t gridtype,
+                                                      bool align_corners, bool sample_major) {
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
+        float x[D];
+        bool oob = false;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            x[d] = inputs[(size_t)b * D + d];
+            if (x[d] < 0 || x[d] > 1) oob = true;
+        }
+        if (oob) continue;
+        const float* gsrc = grad + (sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C);
+        float gcur[C];
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) gcur[ch] = gsrc[ch];
+        float pos[D];
+        uint32_t pg[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            pos[d] = lz_fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+            pg[d] = (uint32_t)floorf(pos[d]);
+            pos[d] -= (float)pg[d];
+        }
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {
+            float w = 1.0f;
+            uint32_t pl[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+                else { w *= pos[d]; pl[d] = pg[d] + 1; }
+            }
+            uint32_t index;
+            if (mode == 2u) {
+                index = lz_grid_index<D>(C, gridtype, align_corners, hs, resolution, pl);
+            } else {
+                constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+                uint32_t lin = 0, h = 0, stride = 1;
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) {
+                    lin += pl[d] * stride;
+                    stride *= align_corners ? resolution : (resolution + 1);
+                    h ^= pl[d] * primes[d];
+                }
+                index = (mode == 1u ? (h & (hs - 1u)) : lin) * C;
+            }
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) {
+                if constexpr (IN_LDS) __hip_atomic_fetch_add(dst + index + ch, w * gcur[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else lz_atomic_add(dst + index + ch, w * gcur[ch]);
+            }
+        }
+    }
+}
+
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(1024)
+lz_k_grid_backward_lds(const float* __restrict__ grad, const float* __restrict__ inputs, const int* __restrict__ offsets,
+                       float* __restrict__ grad_grid, uint32_t B, uint32_t L, LzGridLevels lv, uint32_t gridtype, bool align_corners,
+                       bool sample_major, uint32_t chunk) {
+    extern __shared__ __align__(16) float lz_grid_acc[];
+    const uint32_t level = blockIdx.x % L, c = blockIdx.x / L;
+    const uint32_t off0 = (uint32_t)offsets[level], hs = (uint32_t)offsets[level + 1] - off0;
+    const uint32_t res = lv.res[level];
+    const float scale = lv.scale[level];
+    const uint32_t mode = lz_grid_level_mode<D>(hs, res, gridtype, align_corners);
+    const uint32_t b0 = c * chunk, b1 = (B - b0 < chunk) ? B : b0 + chunk;
+    float* gg = grad_grid + (size_t)off0 * C;
+    const uint32_t n = hs * C;
+    if ((size_t)n * 4 <= LZ_GRID_LDS_BYTES) {
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lz_grid_acc[i] = 0.0f;
+        __syncthreads();
+        lz_grid_level_scatter<D, C, true>(grad, inputs, lz_grid_acc, b0, b1, B, L, level, scale, res, hs, mode, gridtype, align_corners,
+                                          sample_major);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const float v = lz_grid_acc[i];
+            if (v != 0.0f) lz_atomic_add(gg + i, v);
+        }
+    } else {
+        lz_grid_level_scatter<D, C, false>(grad, inputs, gg, b0, b1, B, L, level, scale, res, hs, mode, gridtype, align_corners, sample_major);
+    }
+}
+
+template <uint32_t D, uint32_t C>
+static void lz_grid_bwd_lds_launch(const float* grad, const float* inputs, const int* offsets, float* gemb, uint32_t B, uint32_t L,
+                                   const LzGridLevels& lv, uint32_t gridtype, bool ac, bool sm, hipStream_t st) {
+    // ~1024 workgroups (2 per CU: 64 KB of LDS each), never less than 4096 samples per workgroup
+    uint32_t n_chunks = lz_div_up(B, 4096);
+    const uint32_t cap = 1024 / L > 0 ? 1024 / L : 1;
+    if (n_chunks > cap) n_chunks = cap;
+    const uint32_t chunk = lz_div_up(B, n_chunks);
+    n_chunks = lz_div_up(B, chunk);
+    hipLaunchKernelGGL((lz_k_grid_backward_lds<D, C>), dim3(n_chunks * L), dim3(1024), LZ_GRID_LDS_BYTES, st, grad, inputs, offsets, gemb,
+                       B, L, lv, gridtype, ac, sm, chunk);
+}
+
 // ---- host dispatch ----
 template <typename T, uint32_t D>
 static int lz_grid_fwd_c(const float* inputs, const T* emb, const int* offsets, T* out, uint32_t B, uint32_t C, uint32_t L,
@@ -559,7 +805,16 @@ static int lz_grid_fwd_c(const float* inputs, const T* emb, const int* offsets, 
             if (C == 2) { lz_grid_lds_launch<T, D, 2>(inputs, emb, offsets, out, B, L, lv, gridtype, ac, st); return LZ_OK; }
         }
     }
-    if (sm && !dy_dx) {  // hot path: 2-D workgroup (level, sample), see lz_k_grid_forward_sm
+    if (sm && !dy_dx && B >= 65536) {  // large batches over big tables: level-major tiles + in-place untile
+        if constexpr (D == 2 || D == 3) {
+            if constexpr (sizeof(T) == 4)
+                if (C == 1) { lz_grid_lm_launch<T, D, 1>(inputs, emb, offsets, out, B, L, lv, gridtype, ac, st); return LZ_OK; }
+            if (C == 2) { lz_grid_lm_launch<T, D, 2>(inputs, emb, offsets, out, B, L, lv, gridtype, ac, st); return LZ_OK; }
+            if (C == 4) { lz_grid_lm_launch<T, D, 4>(inputs, emb, offsets, out, B, L, lv, gridtype, ac, st); return LZ_OK; }
+            if (C == 8) { lz_grid_lm_launch<T, D, 8>(inputs, emb, offsets, out, B, L, lv, gridtype, ac, st); return LZ_OK; }
+        }
+    }
+    if (sm && !dy_dx) {  // 2-D workgroup (level, sample), see lz_k_grid_forward_sm
         const uint32_t ny = 256 / L;
         const dim3 b2(L, ny, 1), g2(lz_div_up(B, ny), 1, 1);
         switch (C) {
@@ -641,23 +896,33 @@ extern "C" int lz_grid_corner_indices(const float* inputs, const int32_t* offset
 
 template <typename T, uint32_t D, uint32_t C>
 static void lz_grid_bwd_launch(const T* grad, const float* inputs, const int* offsets, T* gemb, uint32_t B, uint32_t L,
-                               const LzGridLevels& lv, const T* dy_dx, T* ginp, uint32_t gridtype, bool ac, bool sm, hipStream_t st) {
+                               const LzGridLevels& lv, const T* dy_dx, T* ginp, uint32_t gridtype, bool ac, bool sm, bool resident,
+                               hipStream_t st) {
     dim3 grid, block(256);
-    if (sm) grid = dim3(lz_div_up((uint64_t)B * L, 256), 1, 1);
-    else grid = dim3(lz_div_up(B, 256), L, 1);
-    hipLaunchKernelGGL((lz_k_grid_backward<T, D, C>), grid, block, 0, st, grad, inputs, offsets, gemb, B, L, lv, gridtype, ac, sm);
+    bool done = false;
+    if constexpr (sizeof(T) == 4 && D <= 3 && C <= 2) {
+        if (resident) {  // level tables fit LDS: private accumulation, see lz_k_grid_backward_lds
+            lz_grid_bwd_lds_launch<D, C>(grad, inputs, offsets, gemb, B, L, lv, gridtype, ac, sm, st);
+            done = true;
+        }
+    }
+    if (!done) {
+        if (sm) grid = dim3(lz_div_up((uint64_t)B * L, 256), 1, 1);
+        else grid = dim3(lz_div_up(B, 256), L, 1);
+        hipLaunchKernelGGL((lz_k_grid_backward<T, D, C>), grid, block, 0, st, grad, inputs, offsets, gemb, B, L, lv, gridtype, ac, sm);
+    }
     if (dy_dx && ginp)
         hipLaunchKernelGGL((lz_k_grid_input_backward<T, D, C>), dim3(lz_div_up((uint64_t)B * D, 256)), block, 0, st, grad, dy_dx, ginp, B, L, sm);
 }
 
 template <typename T, uint32_t D>
 static int lz_grid_bwd_c(const T* grad, const float* inputs, const int* offsets, T* gemb, uint32_t B, uint32_t C, uint32_t L,
-                         const LzGridLevels& lv, const T* dy_dx, T* ginp, uint32_t gridtype, bool ac, bool sm, hipStream_t st) {
+                         const LzGridLevels& lv, const T* dy_dx, T* ginp, uint32_t gridtype, bool ac, bool sm, bool resident, hipStream_t st) {
     switch (C) {
-        case 1: lz_grid_bwd_launch<T, D, 1>(grad, inputs, offsets, gemb, B, L, lv, dy_dx, ginp, gridtype, ac, sm, st); break;
-        case 2: lz_grid_bwd_launch<T, D, 2>(grad, inputs, offsets, gemb, B, L, lv, dy_dx, ginp, gridtype, ac, sm, st); break;
-        case 4: lz_grid_bwd_launch<T, D, 4>(grad, inputs, offsets, gemb, B, L, lv, dy_dx, ginp, gridtype, ac, sm, st); break;
-        case 8: lz_grid_bwd_launch<T, D, 8>(grad, inputs, offsets, gemb, B, L, lv, dy_dx, ginp, gridtype, ac, sm, st); break;
+        case 1: lz_grid_bwd_launch<T, D, 1>(grad, inputs, offsets, gemb, B, L, lv, dy_dx, ginp, gridtype, ac, sm, resident, st); break;
+        case 2: lz_grid_bwd_launch<T, D, 2>(grad, inputs, offsets, gemb, B, L, lv, dy_dx, ginp, gridtype, ac, sm, resident, st); break;
+        case 4: lz_grid_bwd_launch<T, D, 4>(grad, inputs, offsets, gemb, B, L, lv, dy_dx, ginp, gridtype, ac, sm, resident, st); break;
+        case 8: lz_grid_bwd_launch<T, D, 8>(grad, inputs, offsets, gemb, B, L, lv, dy_dx, ginp, gridtype, ac, sm, resident, st); break;
         default: lz_set_error("GridEncoding: C must be 1, 2, 4, or 8."); return LZ_ERR_UNSUPPORTED;
     }
     return LZ_OK;
@@ -665,13 +930,14 @@ static int lz_grid_bwd_c(const T* grad, const float* inputs, const int* offsets,
 
 template <typename T>
 static int lz_grid_bwd_d(const T* grad, const float* inputs, const int* offsets, T* gemb, uint32_t B, uint32_t D, uint32_t C,
-                         uint32_t L, const LzGridLevels& lv, const T* dy_dx, T* ginp, uint32_t gridtype, bool ac, bool sm, hipStream_t st) {
+                         uint32_t L, const LzGridLevels& lv, const T* dy_dx, T* ginp, uint32_t gridtype, bool ac, bool sm, bool resident,
+                         hipStream_t st) {
     switch (D) {
-        case 1: return lz_grid_bwd_c<T, 1>(grad, inputs, offsets, gemb, B, C, L, lv, dy_dx, ginp, gridtype, ac, sm, st);
-        case 2: return lz_grid_bwd_c<T, 2>(grad, inputs, offsets, gemb, B, C, L, lv, dy_dx, ginp, gridtype, ac, sm, st);
-        case 3: return lz_grid_bwd_c<T, 3>(grad, inputs, offsets, gemb, B, C, L, lv, dy_dx, ginp, gridtype, ac, sm, st);
-        case 4: return lz_grid_bwd_c<T, 4>(grad, inputs, offsets, gemb, B, C, L, lv, dy_dx, ginp, gridtype, ac, sm, st);
-        case 5: return lz_grid_bwd_c<T, 5>(grad, inputs, offsets, gemb, B, C, L, lv, dy_dx, ginp, gridtype, ac, sm, st);
+        case 1: return lz_grid_bwd_c<T, 1>(grad, inputs, offsets, gemb, B, C, L, lv, dy_dx, ginp, gridtype, ac, sm, resident, st);
+        case 2: return lz_grid_bwd_c<T, 2>(grad, inputs, offsets, gemb, B, C, L, lv, dy_dx, ginp, gridtype, ac, sm, resident, st);
+        case 3: return lz_grid_bwd_c<T, 3>(grad, inputs, offsets, gemb, B, C, L, lv, dy_dx, ginp, gridtype, ac, sm, resident, st);
+        case 4: return lz_grid_bwd_c<T, 4>(grad, inputs, offsets, gemb, B, C, L, lv, dy_dx, ginp, gridtype, ac, sm, resident, st);
+        case 5: return lz_grid_bwd_c<T, 5>(grad, inputs, offsets, gemb, B, C, L, lv, dy_dx, ginp, gridtype, ac, sm, resident, st);
         default: lz_set_error("GridEncoding: D must be 1, 2, 3, 4, or 5"); return LZ_ERR_UNSUPPORTED;
     }
 }
@@ -687,12 +953,13 @@ extern "C" int lz_grid_encode_backward(const void* grad, const float* inputs, co
     LZ_REQUIRE(lz_fill_levels(lv, L, S, H) == 0, LZ_ERR_UNSUPPORTED, "grid_encode_backward: at most %d levels", LZ_MAX_LEVELS);
     if (B == 0) return LZ_OK;
     int rc;
+    const bool sm = grad_layout == 1 || grad_layout == 2, resident = grad_layout >= 2;
     if (emb_f16)
         rc = lz_grid_bwd_d<__half>((const __half*)grad, inputs, offsets, (__half*)grad_embeddings, B, D, C, L, lv, (const __half*)dy_dx,
-                                   (__half*)grad_inputs, gridtype, align_corners != 0, grad_layout == 1, lz_st(stream));
+                                   (__half*)grad_inputs, gridtype, align_corners != 0, sm, resident, lz_st(stream));
     else
         rc = lz_grid_bwd_d<float>((const float*)grad, inputs, offsets, (float*)grad_embeddings, B, D, C, L, lv, (const float*)dy_dx,
-                                  (float*)grad_inputs, gridtype, align_corners != 0, grad_layout == 1, lz_st(stream));
+                                  (float*)grad_inputs, gridtype, align_corners != 0, sm, resident, lz_st(stream));
     if (rc != LZ_OK) return rc;
     LZ_CHECK_LAUNCH("grid_encode_backward");
     return LZ_OK;

@@ -155,6 +155,10 @@ __device__ __forceinline__ void lz_layer(const float* __restrict__ wl, int lane,
 
 __device__ __forceinline__ float lz_relu(float v) { return v > 0.0f ? v : 0.0f; }
 
+// diagnostic: shader-clock cycles (s_memtime) and 100 MHz wall ticks (s_memrealtime) that wave 0 of workgroup 0 of the most
+// recent launch spent in the kernel -> the sustained shader clock under this kernel's load (lz_debug_head_clocks)
+__device__ unsigned long long lz_head_probe[2];
+
 template <bool TRAIN_UNC>
 __global__ void __launch_bounds__(LZ_WG, LZ_WG / 256)
 lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
@@ -167,8 +171,15 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
         const int c = *count;
         Meff = c < 0 ? 0u : ((uint32_t)c < M ? (uint32_t)c : M);
     }
-    const uint32_t n_wg_tiles = (Meff + LZ_WG_SAMPLES - 1) / LZ_WG_SAMPLES;
-    if (blockIdx.x >= n_wg_tiles) return;
+    // the workgroup owns a contiguous, near-equal share of the 16-sample slices (shares differ by at most one slice, so a
+    // launch whose row count is not a multiple of gridDim.x * LZ_WG_SAMPLES loses at most one slice time, not one tile time)
+    const uint32_t n_slices = (Meff + LZ_T * 16 - 1) / (LZ_T * 16);
+    const uint32_t slice_lo = (uint32_t)(((uint64_t)n_slices * blockIdx.x) / gridDim.x);
+    const uint32_t slice_hi = (uint32_t)(((uint64_t)n_slices * (blockIdx.x + 1)) / gridDim.x);
+    if (slice_lo >= slice_hi) return;
+    const bool probe = blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long probe_c = 0, probe_w = 0;
+    if (probe) { probe_c = clock64(); probe_w = wall_clock64(); }
 
     // stage weights into LDS (16 B per lane per step, coalesced)
     {
@@ -198,21 +209,19 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
     const float eye_v = has_eye ? P.eye[0] : 0.0f;
     const float indq = P.ind_code ? P.ind_code[q] : 0.0f;
 
-    // Work distribution: the workgroup owns the 512-sample tiles blockIdx.x, +gridDim.x, ...; its 8 waves pull 64-sample
-    // slices of them from a queue in LDS (one ds_add_rtn per slice).  Together with a static priority for the second
-    // wave of every SIMD this de-synchronises the two waves that share a SIMD: one gathers (texture-address bound)
-    // while the other feeds the matrix pipe, instead of both gathering and then both multiplying in lockstep.
+    // Work distribution: the workgroup owns slices [slice_lo, slice_hi); its 16 waves pull 16-sample slices from a queue
+    // in LDS (one ds_add_rtn per slice).  The waves that share a SIMD drift apart: some gather (texture-address bound)
+    // while another feeds the matrix pipe, instead of all gathering and then all multiplying in lockstep.
     int* queue = reinterpret_cast<int*>(wl + NFRAG * 64) + 48;
-    constexpr uint32_t NW = LZ_WG / 64;
-    const uint32_t wg_tiles_mine = (n_wg_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     for (;;) {
         int slice = 0;
         if (lane == 0) slice = atomicAdd(queue, 1);
         slice = __builtin_amdgcn_readfirstlane(slice);
-        if ((uint32_t)slice >= wg_tiles_mine * NW) break;
-        const uint32_t wg_tile = blockIdx.x + ((uint32_t)slice / NW) * gridDim.x;
-        const uint32_t base = wg_tile * LZ_WG_SAMPLES + ((uint32_t)slice % NW) * (LZ_T * 16);
-        if (base >= Meff) continue;  // wave-uniform
+        if (slice_lo + (uint32_t)slice >= slice_hi) {
+            if (probe) { lz_head_probe[0] = clock64() - probe_c; lz_head_probe[1] = wall_clock64() - probe_w; }
+            break;
+        }
+        const uint32_t base = (slice_lo + (uint32_t)slice) * (LZ_T * 16);
 
         // ---------------- gather: enc_x features f = 4i + q of sample (j, s) -> B operands ----------------
         // the three grid levels this lane touches (level = 4 m + q), gridencoder.cu:124-126; rebuilt per tile from LDS so
@@ -492,6 +501,15 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
             }
         }
     }
+}
+
+extern "C" int lz_debug_head_clocks(uint64_t* out2) {
+    LZ_REQUIRE(out2, LZ_ERR_BAD_ARGUMENT, "debug_head_clocks: null");
+    unsigned long long v[2] = {0, 0};
+    hipError_t rc = hipMemcpyFromSymbol(v, HIP_SYMBOL(lz_head_probe), sizeof(v));
+    if (rc != hipSuccess) { lz_set_error("debug_head_clocks: %s", hipGetErrorString(rc)); return (int)rc; }
+    out2[0] = v[0]; out2[1] = v[1];
+    return LZ_OK;
 }
 
 extern "C" int lz_triplane_head_forward(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M,

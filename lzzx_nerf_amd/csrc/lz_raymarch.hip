@@ -724,14 +724,16 @@ extern "C" int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thre
 //   lz_loop_composite  accumulate, kill rays, count survivors per workgroup
 //   lz_loop_advance    one workgroup: scan the counts -> offsets, advance (n_alive, n_step, step, done)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lz_n_step_rule(int N, int n_alive) {  // renderer.py:513
-    int s = n_alive > 0 ? N / n_alive : 1;
-    s = s < 8 ? s : 8;
+__device__ __forceinline__ int lz_n_step_rule(uint32_t N, uint32_t sample_budget, uint32_t n_step_cap, int n_alive) {
+    // renderer.py:513 is max(min(N // n_alive, 8), 1); budget / cap generalise N / 8 (0 = the reference's value)
+    const int budget = (int)(sample_budget ? sample_budget : N), cap = (int)(n_step_cap ? n_step_cap : 8u);
+    int s = n_alive > 0 ? budget / n_alive : 1;
+    s = s < cap ? s : cap;
     return s > 1 ? s : 1;
 }
 
 __global__ void __launch_bounds__(256)
-lz_k_loop_begin(uint32_t N, uint32_t max_steps, const float* __restrict__ nears, int* __restrict__ rays_alive, float* __restrict__ rays_t,
+lz_k_loop_begin(uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap, const float* __restrict__ nears, int* __restrict__ rays_alive, float* __restrict__ rays_t,
                 float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image, float* __restrict__ amb0_sum,
                 float* __restrict__ amb1_sum, float* __restrict__ unc_sum, lz_loop_state* __restrict__ state,
                 int* __restrict__ block_offsets) {
@@ -739,7 +741,7 @@ lz_k_loop_begin(uint32_t N, uint32_t max_steps, const float* __restrict__ nears,
     if (n == 0) {
         lz_loop_state s;
         s.n_alive = (int)N;
-        s.n_step = lz_n_step_rule((int)N, (int)N);
+        s.n_step = lz_n_step_rule(N, sample_budget, n_step_cap, (int)N);
         s.step = 0;
         s.done = (N == 0 || max_steps == 0) ? 1 : 0;
         if (s.done) s.n_alive = 0;
@@ -748,6 +750,7 @@ lz_k_loop_begin(uint32_t N, uint32_t max_steps, const float* __restrict__ nears,
         s.iterations = 0;
         s.pad = s.n_alive;   // entries of the list the first march will compact (the identity list)
         *state = s;
+        reinterpret_cast<int*>(state)[LZ_LOOP_STAT_ROWS] = 0;
     }
     if (n < 64) reinterpret_cast<int*>(state + 1)[n] = 0;  // sample-count slots (see lz_k_march_rays)
     if (threadIdx.x == 0) block_offsets[blockIdx.x] = (int)(blockIdx.x * blockDim.x);  // identity list: offset = first index
@@ -761,12 +764,13 @@ lz_k_loop_begin(uint32_t N, uint32_t max_steps, const float* __restrict__ nears,
     if (unc_sum) unc_sum[n] = 0;
 }
 
-extern "C" int lz_loop_begin(uint32_t N, uint32_t max_steps, const float* nears, int32_t* rays_alive, float* rays_t, float* weights_sum,
+extern "C" int lz_loop_begin(uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap, const float* nears,
+                             int32_t* rays_alive, float* rays_t, float* weights_sum,
                              float* depth, float* image, float* amb0_sum, float* amb1_sum, float* unc_sum, lz_loop_state* state,
                              void* workspace, lz_stream_t stream) {
     LZ_REQUIRE(state && workspace, LZ_ERR_BAD_ARGUMENT, "loop_begin: null state / workspace");
     LZ_REQUIRE(lz_div_up(N > 0 ? N : 1, 256) <= 4096, LZ_ERR_UNSUPPORTED, "loop: at most %u rays per call", 4096u * 256u);
-    hipLaunchKernelGGL(lz_k_loop_begin, dim3(lz_div_up(N > 0 ? N : 1, 256)), dim3(256), 0, lz_st(stream), N, max_steps, nears, rays_alive, rays_t,
+    hipLaunchKernelGGL(lz_k_loop_begin, dim3(lz_div_up(N > 0 ? N : 1, 256)), dim3(256), 0, lz_st(stream), N, max_steps, sample_budget, n_step_cap, nears, rays_alive, rays_t,
                        weights_sum, depth, image, amb0_sum, amb1_sum, unc_sum, state, reinterpret_cast<int*>(workspace));
     LZ_CHECK_LAUNCH("loop_begin");
     return LZ_OK;
@@ -802,7 +806,8 @@ extern "C" int lz_loop_composite(const lz_loop_state* state, uint32_t N, float T
 
 // one workgroup: exclusive scan of the per-workgroup survivor counts (in place -> offsets) + state advance
 __global__ void __launch_bounds__(1024)
-lz_k_loop_scan(lz_loop_state* __restrict__ state, uint32_t N, uint32_t max_steps, uint32_t n_blocks, int* __restrict__ block_counts) {
+lz_k_loop_scan(lz_loop_state* __restrict__ state, uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap,
+               uint32_t n_blocks, int* __restrict__ block_counts) {
     __shared__ int wave_sums[16];
     __shared__ int carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -841,6 +846,7 @@ lz_k_loop_scan(lz_loop_state* __restrict__ state, uint32_t N, uint32_t max_steps
     if (tid == 0) {
         lz_loop_state s = *state;
         s.total_samples += slot_sum;
+        if (!s.done) reinterpret_cast<int*>(state)[LZ_LOOP_STAT_ROWS] += s.n_samples;   // rows of the iteration just finished
         s.pad = s.n_alive;                  // length of the list the next march compacts
         if (!s.done) {
             s.step += s.n_step;             // renderer.py:546
@@ -848,7 +854,7 @@ lz_k_loop_scan(lz_loop_state* __restrict__ state, uint32_t N, uint32_t max_steps
             s.n_alive = carry_s;            // renderer.py:542
             s.done = (s.n_alive <= 0 || s.step >= (int)max_steps) ? 1 : 0;
             if (s.done) { s.n_alive = 0; s.pad = 0; }
-            s.n_step = lz_n_step_rule((int)N, s.n_alive);
+            s.n_step = lz_n_step_rule(N, sample_budget, n_step_cap, s.n_alive);
             s.n_samples = s.n_alive * s.n_step;
         } else {
             s.pad = 0;
@@ -857,11 +863,13 @@ lz_k_loop_scan(lz_loop_state* __restrict__ state, uint32_t N, uint32_t max_steps
     }
 }
 
-extern "C" int lz_loop_advance(lz_loop_state* state, uint32_t N, uint32_t max_steps, void* workspace, lz_stream_t stream) {
+extern "C" int lz_loop_advance(lz_loop_state* state, uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap,
+                               void* workspace, lz_stream_t stream) {
     LZ_REQUIRE(state && workspace, LZ_ERR_BAD_ARGUMENT, "loop_advance: null state / workspace");
     const uint32_t n_blocks = lz_div_up(N > 0 ? N : 1, 256);
     LZ_REQUIRE(n_blocks <= 4096, LZ_ERR_UNSUPPORTED, "loop_advance: at most %u rays per call", 4096u * 256u);
-    hipLaunchKernelGGL(lz_k_loop_scan, dim3(1), dim3(1024), 0, lz_st(stream), state, N, max_steps, n_blocks, reinterpret_cast<int*>(workspace));
+    hipLaunchKernelGGL(lz_k_loop_scan, dim3(1), dim3(1024), 0, lz_st(stream), state, N, max_steps, sample_budget, n_step_cap, n_blocks,
+                       reinterpret_cast<int*>(workspace));
     LZ_CHECK_LAUNCH("loop_advance");
     return LZ_OK;
 }

@@ -66,6 +66,7 @@ extern "C" int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterat
     LZ_REQUIRE(f && f->state && f->workspace && f->rays_alive[0] && f->rays_alive[1], LZ_ERR_BAD_ARGUMENT, "loop_run: incomplete lz_frame");
     uint32_t cur = parity & 1u;
     const int32_t* count = reinterpret_cast<const int32_t*>(f->state) + 4;  // &state->n_samples
+    const uint32_t rows = f->sample_budget > f->N ? f->sample_budget : f->N;  // capacity of the sample buffers
     for (uint32_t it = 0; it < n_iterations; it++) {
         const uint32_t nxt = cur ^ 1u;
         int rc = lz_loop_march(f->state, f->N, f->rays_alive[cur], f->rays_alive[nxt], f->workspace, f->rays_t, f->rays_o, f->rays_d,
@@ -74,7 +75,7 @@ extern "C" int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterat
         if (rc != LZ_OK) return rc;
         const bool timed = timing && (size_t)(timing->used + 1) * 2 <= timing->ev.size();
         if (timed) (void)hipEventRecord(timing->ev[2 * timing->used], lz_st(stream));
-        rc = lz_triplane_head_forward(&f->head, f->xyzs, f->dirs, f->N, count, f->sigmas, f->rgbs, f->amb_aud, f->amb_eye, f->unc, stream);
+        rc = lz_triplane_head_forward(&f->head, f->xyzs, f->dirs, rows, count, f->sigmas, f->rgbs, f->amb_aud, f->amb_eye, f->unc, stream);
         if (rc != LZ_OK) return rc;
         if (timed) {
             (void)hipEventRecord(timing->ev[2 * timing->used + 1], lz_st(stream));
@@ -84,7 +85,7 @@ extern "C" int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterat
                                f->amb_eye, f->unc, f->weights_sum, f->depth, f->image, f->amb_aud_sum, f->amb_eye_sum, f->unc_sum,
                                f->workspace, stream);
         if (rc != LZ_OK) return rc;
-        rc = lz_loop_advance(f->state, f->N, f->max_steps, f->workspace, stream);
+        rc = lz_loop_advance(f->state, f->N, f->max_steps, f->sample_budget, f->n_step_cap, f->workspace, stream);
         if (rc != LZ_OK) return rc;
         cur = nxt;
     }

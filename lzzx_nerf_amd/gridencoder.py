@@ -68,14 +68,15 @@ class _grid_encode(Function):
         dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
         # large batches over small tables (the triplane: <= 16384 entries per level): level-resident LDS kernel
         layout = 1
-        if B >= 32768 and not calc_grad_inputs and D <= 3 and C <= 2 and \
-                _max_level_entries(offsets) * C * embeddings.element_size() <= 65536:
+        small = D <= 3 and C <= 2 and _max_level_entries(offsets) * C * embeddings.element_size() <= 65536
+        if B >= 32768 and not calc_grad_inputs and small:
             layout = 2
         call("lz_grid_encode_forward", ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, S, H, ptr(dy_dx),
              int(gridtype), int(bool(align_corners)), int(embeddings.dtype == torch.float16), layout, stream())
 
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = [B, D, C, L, S, H, gridtype]
+        ctx.small_levels = small
         ctx.align_corners = align_corners
         return outputs
 
@@ -88,10 +89,12 @@ class _grid_encode(Function):
         if grad.dtype != embeddings.dtype:
             grad = grad.to(embeddings.dtype)
         grad_embeddings = torch.zeros_like(embeddings)
+        # small f32 tables + large batches: per-level accumulation in LDS instead of scattered global atomics
+        glayout = 2 if (ctx.small_levels and B >= 16384 and embeddings.dtype == torch.float32) else 1
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         call("lz_grid_encode_backward", ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L,
              S, H, ptr(dy_dx), ptr(grad_inputs), int(gridtype), int(bool(ctx.align_corners)),
-             int(embeddings.dtype == torch.float16), 1, stream())
+             int(embeddings.dtype == torch.float16), glayout, stream())
         if dy_dx is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
         return grad_inputs, grad_embeddings, None, None, None, None, None, None

@@ -17,7 +17,8 @@ from . import _lib
 from ._util import call, ptr, stream
 from .head import FusedTriplaneHead
 
-_STATE_INTS = 72         # LZ_LOOP_STATE_INTS: lz_loop_state (8 ints) + 64 sample-count slots
+_STATE_INTS = 80         # LZ_LOOP_STATE_INTS: lz_loop_state (8 ints) + 64 sample-count slots + statistics
+STAT_ROWS = 72           # LZ_LOOP_STAT_ROWS: sample rows handed to the head (exhausted rows included)
 _N_SAMPLES_OFF = 16      # offsetof(lz_loop_state, n_samples)
 
 
@@ -33,20 +34,21 @@ def get_rays(pose, intrinsics, H, W):
 
 
 class _Buffers:
-    def __init__(self, N, device):
+    def __init__(self, N, rows, device):
         f = dict(dtype=torch.float32, device=device)
         i = dict(dtype=torch.int32, device=device)
-        self.N = N
+        self.N, self.rows = N, rows
         self.nears, self.fars = torch.empty(N, **f), torch.empty(N, **f)
         self.rays_alive = [torch.empty(N, **i), torch.empty(N, **i)]
         self.rays_t = torch.empty(N, **f)
         self.weights_sum, self.depth = torch.empty(N, **f), torch.empty(N, **f)
         self.image, self.out = torch.empty(N, 3, **f), torch.empty(N, 3, **f)
         self.amb_aud_sum, self.amb_eye_sum, self.unc_sum = torch.empty(N, **f), torch.empty(N, **f), torch.empty(N, **f)
-        # n_alive * n_step <= N always (renderer.py:513), so N sample rows suffice
-        self.xyzs, self.dirs, self.deltas = torch.empty(N, 3, **f), torch.empty(N, 3, **f), torch.empty(N, 2, **f)
-        self.sigmas, self.rgbs = torch.empty(N, **f), torch.empty(N, 3, **f)
-        self.amb_aud, self.amb_eye, self.unc = torch.empty(N, 1, **f), torch.empty(N, 1, **f), torch.empty(N, 1, **f)
+        # n_alive * n_step <= rows = max(sample budget, N) always (renderer.py:513 with budget = N)
+        M = rows
+        self.xyzs, self.dirs, self.deltas = torch.empty(M, 3, **f), torch.empty(M, 3, **f), torch.empty(M, 2, **f)
+        self.sigmas, self.rgbs = torch.empty(M, **f), torch.empty(M, 3, **f)
+        self.amb_aud, self.amb_eye, self.unc = torch.empty(M, 1, **f), torch.empty(M, 1, **f), torch.empty(M, 1, **f)
         self.state = torch.zeros(_STATE_INTS, **i)
         self.workspace = torch.empty(4096, **i)
         self.ray_counts = torch.zeros(N, **i)
@@ -61,7 +63,7 @@ class TriplaneRenderer:
     """
 
     def __init__(self, head: FusedTriplaneHead, density_bitfield, bound=1.0, cascade=None, grid_size=128, aabb=None,
-                 min_near=0.05, density_scale=1):
+                 min_near=0.05, density_scale=1, budget_factor=1, n_step_cap=8):
         import math
         self.head = head
         self.bound = float(bound)
@@ -75,6 +77,9 @@ class TriplaneRenderer:
         self.min_near = float(min_near)
         if density_scale != 1:
             raise NotImplementedError("density_scale != 1 (the reference hard-codes 1, renderer.py:95)")
+        # iteration schedule n_step = max(min(budget_factor * N // n_alive, n_step_cap), 1); (1, 8) is the reference's
+        # (renderer.py:513).  A larger budget trades HBM (288 GB here) for fewer, fatter iterations; pixels are unchanged.
+        self.budget_factor, self.n_step_cap = int(budget_factor), int(n_step_cap)
         self._buf = None
         self._head_events = None  # set to a list: Python-driven loop with torch events around every head launch (debug)
         self._timing = None       # lz_timing handle: native loop records a HIP event pair around every head launch
@@ -100,8 +105,9 @@ class TriplaneRenderer:
         return out
 
     def _buffers(self, N, device):
-        if self._buf is None or self._buf.N != N:
-            self._buf = _Buffers(N, device)
+        rows = max(N * self.budget_factor, N)
+        if self._buf is None or self._buf.N != N or self._buf.rows != rows:
+            self._buf = _Buffers(N, rows, device)
         return self._buf
 
     def _iteration(self, b, cur, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples):
@@ -123,7 +129,7 @@ class TriplaneRenderer:
         call("lz_loop_composite", st, N, float(T_thresh), ptr(b.rays_alive[nxt]), ptr(b.rays_t), ptr(b.sigmas), ptr(b.rgbs),
              ptr(b.deltas), ptr(b.amb_aud), ptr(b.amb_eye), ptr(b.unc), ptr(b.weights_sum), ptr(b.depth), ptr(b.image),
              ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ws, stream())
-        call("lz_loop_advance", st, N, int(max_steps), ws, stream())
+        call("lz_loop_advance", st, N, int(max_steps), N * self.budget_factor, self.n_step_cap, ws, stream())
 
     def _frame(self, b, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples):
         """lz_frame for lz_loop_run; the small conditioning tensors are kept alive on self until the next frame"""
@@ -145,6 +151,7 @@ class TriplaneRenderer:
         f.ray_counts = p(b.ray_counts) if count_samples else None
         f.N, f.max_steps, f.C, f.H = N, int(max_steps), int(self.cascade), int(self.grid_size)
         f.bound, f.dt_gamma, f.T_thresh = self.bound, float(dt_gamma), float(T_thresh)
+        f.sample_budget, f.n_step_cap = N * self.budget_factor, self.n_step_cap
         return f
 
     @torch.no_grad()
@@ -162,7 +169,7 @@ class TriplaneRenderer:
         call("lz_near_far_from_aabb", ptr(rays_o), ptr(rays_d), ptr(self.aabb), N, self.min_near, ptr(b.nears), ptr(b.fars), stream())
         if count_samples:
             b.ray_counts.zero_()
-        call("lz_loop_begin", N, int(max_steps), ptr(b.nears), ptr(b.rays_alive[0]), ptr(b.rays_t), ptr(b.weights_sum), ptr(b.depth),
+        call("lz_loop_begin", N, int(max_steps), N * self.budget_factor, self.n_step_cap, ptr(b.nears), ptr(b.rays_alive[0]), ptr(b.rays_t), ptr(b.weights_sum), ptr(b.depth),
              ptr(b.image), ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ptr(b.state), ptr(b.workspace), stream())
         cur, it = 0, 0
         pending_q = []

@@ -123,6 +123,81 @@ def test_grid_forward_level_resident_kernel_bit_exact(D, L, C, H, T, res, gt, ha
         assert np.array_equal(host(out), out_o)
 
 
+@pytest.mark.parametrize("D,L,C,H,T,res,gt,half", [
+    (3, 16, 2, 16, 19, 2048, "hash", False),    # BASELINE cfg2: 4 MB levels, 256-sample tiles
+    (3, 16, 2, 16, 19, 2048, "hash", True),
+    (2, 12, 1, 64, 14, 512, "hash", False),     # C = 1: one dword per (sample, level)
+    (2, 16, 2, 16, 16, 2048, "tiled", False),   # tiled wrap: generic modulo path
+    (3, 16, 2, 16, 19, None, "hash", False),    # wrapped uint32 strides
+    (3, 6, 8, 8, 12, 128, "tiled", False),      # 8 dwords per group
+    (3, 16, 8, 16, 14, 512, "hash", False),     # L*W = 128 -> 128-sample tiles
+    (2, 32, 8, 4, 10, 256, "hash", False),      # L*W = 256 -> 64-sample tiles
+    (3, 16, 4, 16, 15, 512, "hash", True),
+])
+def test_grid_forward_tiled_level_major_bit_exact(D, L, C, H, T, res, gt, half):
+    """B >= 65536 with out_layout 1 selects lz_k_grid_forward_lm + lz_k_grid_untile (level-major tiles, untiled in place)"""
+    from lzzx_nerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=D, num_levels=L, level_dim=C, base_resolution=H, log2_hashmap_size=T, desired_resolution=res,
+                      gridtype=gt).cuda()
+    rng = np.random.default_rng(78)
+    emb = rng.uniform(-1, 1, tuple(enc.embeddings.shape)).astype(np.float16 if half else np.float32)
+    B = 65536 + 256 + 77  # ragged last tile for every tile size
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[:3] = [[0.0] * D, [1.0] * D, [1.0000001] + [0.5] * (D - 1)]
+    x[-1] = [-1e-7] + [0.25] * (D - 1)
+    gid = 0 if gt == "hash" else 1
+    out_o, _ = O.grid_encode_forward(x, emb, host(enc.offsets), enc.per_level_scale, H, False, gid)
+    from lzzx_nerf_amd._util import call, ptr, stream
+    xt, et = dev(x), dev(emb)
+    out = torch.full((B, L * C), 7.0, device="cuda", dtype=et.dtype)
+    call("lz_grid_encode_forward", ptr(xt), ptr(et), ptr(enc.offsets), ptr(out), B, D, C, L, float(np.float32(np.log2(enc.per_level_scale))),
+         H, None, gid, 0, int(half), 1, stream())
+    if half:
+        assert np.array_equal(host(out).view(np.uint16), out_o.view(np.uint16))
+    else:
+        assert np.array_equal(host(out), out_o)
+
+
+@pytest.mark.parametrize("D,L,C,H,T,res,gt", [
+    (2, 12, 1, 64, 14, 512, "hash"),     # one triplane plane: every level <= 64 KB
+    (3, 8, 2, 16, 13, 256, "hash"),      # 8192 x 2 floats = 64 KB exactly
+    (2, 16, 2, 16, 12, 2048, "tiled"),
+    (3, 8, 2, 16, 16, 256, "hash"),      # fine levels do not fit: in-kernel fallback to global atomics
+])
+def test_grid_backward_level_resident(D, L, C, H, T, res, gt):
+    """grad_layout 2 / 3: lz_k_grid_backward_lds (per-level accumulation in LDS, contiguous flush) vs the checker and vs the
+    plain scatter kernel; the summation order is free, so tolerance, not bits"""
+    from lzzx_nerf_amd.gridencoder import GridEncoder
+    from lzzx_nerf_amd._util import call, ptr, stream
+    enc = GridEncoder(input_dim=D, num_levels=L, level_dim=C, base_resolution=H, log2_hashmap_size=T, desired_resolution=res,
+                      gridtype=gt).cuda()
+    rng = np.random.default_rng(79)
+    B = 50000 + 17
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[:3] = [[0.0] * D, [1.0] * D, [1.0000001] + [0.5] * (D - 1)]
+    g = rng.normal(size=(B, L * C)).astype(np.float32)
+    gid = 0 if gt == "hash" else 1
+    off = host(enc.offsets)
+    ge, _ = O.grid_encode_backward(g, x, tuple(enc.embeddings.shape), off, enc.per_level_scale, H, None, gid)
+    xt, gt_ = dev(x), dev(g)
+    S = float(np.float32(np.log2(enc.per_level_scale)))
+    res_ = {}
+    for layout in (1, 2, 3):
+        gemb = torch.zeros_like(enc.embeddings.data)
+        gin = gt_ if layout != 3 else gt_.view(B, L, C).permute(1, 0, 2).contiguous()
+        call("lz_grid_encode_backward", ptr(gin), ptr(xt), ptr(enc.embeddings.data), ptr(enc.offsets), ptr(gemb), B, D, C, L, S, H,
+             None, None, gid, 0, 0, layout, stream())
+        res_[layout] = host(gemb)
+        scale = np.abs(ge).max()
+        assert np.max(np.abs(res_[layout] - ge)) < 1e-5 * scale * 10, layout
+    # autograd wrapper picks the level-resident kernel for large B over small tables
+    enc.embeddings.grad = None
+    out = enc(dev(x * 2 - 1), bound=1)
+    out.backward(gt_)
+    if T <= 14:
+        assert np.max(np.abs(host(enc.embeddings.grad) - ge)) < 1e-4 * np.abs(ge).max()
+
+
 def test_grid_forward_half_tables_bit_exact():
     from lzzx_nerf_amd.gridencoder import GridEncoder
     enc = GridEncoder(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=15, desired_resolution=512).cuda()
@@ -526,6 +601,32 @@ def test_render_frame_matches_checker(params, golden, scene, max_steps, boost):
         assert len(set(s for _, s in st["schedule"])) > 1, "scene must exercise n_step > 1 (ray compaction)"
     mse = float(((host(out["image"]).astype(np.float64) - ref["image"]) ** 2).mean())
     assert mse == 0.0  # PSNR vs checker = inf
+
+
+@pytest.mark.parametrize("scene,boost,factor,cap", [("ones", 0.0, 8, 8), ("ellipsoid", 40.0, 8, 8), ("ellipsoid", 40.0, 4, 16)])
+def test_render_frame_fat_schedule(params, golden, scene, boost, factor, cap):
+    """sample budget / n_step cap other than the reference's (N, 8): same schedule rule in the checker -> same sample
+    counts bit for bit; and the pixels equal those of the reference schedule (rays are independent)"""
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    p = _scene(params, boost)
+    H = W = 64
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    bits = np.full(128 ** 3 // 8, 255, np.uint8) if scene == "ones" else ellipsoid_bitfield()[0]
+    enc_a, eye, ind = golden["net_enc_a"], golden["net_eye"], golden["net_ind"]
+    st = {}
+    ref = render_inference(TriplaneSpec(1.0), p, ro, rd, bits, enc_a, ind, eye, max_steps=64, stats=st, budget_factor=factor, n_step_cap=cap)
+    head = _head(p)
+    r = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=factor, n_step_cap=cap)
+    out = r.render(dev(ro), dev(rd), dev(enc_a), dev(ind), dev(eye), max_steps=64, count_samples=True)
+    state = host(out["state"])
+    assert np.array_equal(host(out["ray_counts"]).astype(np.int64), st["samples_per_ray"])
+    assert state[5] == st["samples_per_ray"].sum() and state[6] == len(st["schedule"]) and state[3] == 1
+    assert max(s for _, s in st["schedule"]) > 1
+    assert np.array_equal(host(out["image"]), ref["image"]) and np.array_equal(host(out["depth"]), ref["depth"])
+    base = TriplaneRenderer(head, dev(bits), bound=1.0).render(dev(ro), dev(rd), dev(enc_a), dev(ind), dev(eye), max_steps=64)
+    assert torch.equal(base["image"], out["image"]) and torch.equal(base["weights_sum"], out["weights_sum"])
+    assert host(base["state"])[6] > state[6]   # fewer, fatter iterations
 
 
 def test_dropin_network_path_matches_checker(params, golden):
