@@ -66,7 +66,7 @@ def grid_roofline(device):
             gemb = torch.zeros_like(emb)
             S = float(np.float32(np.log2(enc.per_level_scale)))
             f = lambda: call("lz_grid_encode_backward", ptr(grad), ptr(x), ptr(emb), ptr(enc.offsets), ptr(gemb), B, enc.input_dim,
-                             enc.level_dim, enc.num_levels, S, enc.base_resolution, None, None, 0, 0, 0, 1, stream())
+                             enc.level_dim, enc.num_levels, S, enc.base_resolution, None, None, 0, 0, 0, 2, stream())
         else:
             f = lambda: grid_encode(x, emb, enc.offsets, enc.per_level_scale, enc.base_resolution, False, 0, False)
         for _ in range(3):
@@ -275,11 +275,25 @@ def main():
     achieved_tflops = FLOP_PER_SAMPLE * samples_per_frame * args.steps / (head_total_ms * 1e-3) / 1e12
     roofline = dict(bound="mfma", achieved=round(achieved_tflops, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), traffic=None, kernel="lz_k_triplane_head<false>",
-                    avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5), launches=n_launch,
+                    avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5),
+                    avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5), launches=n_launch,
                     launches_with_work=launches_with_work, flop_per_sample=FLOP_PER_SAMPLE,
                     head_time_share=round(head_total_ms * 1e-3 / dt, 4), rows_per_frame=rows_per_frame,
                     shader_clock_mhz_under_load=round(probe[0] / max(probe[1], 1) * 100.0, 1),
                     issued_frac=round(ISSUED_FLOP_PER_ROW * rows_per_frame * args.steps / (head_total_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
+    # HBM-side traffic of the head per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs, tools/profile_bench.sh): KiB per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    # for gfx950 (128-B requests tallied at 64 B).  bench.py cannot collect counters itself; null when the summary is absent.
+    pmc_path = os.path.join(ROOT, "profiles", "r1_final_pmc_summary.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            k = "lz_k_triplane_head<false>"
+            roofline["traffic"] = round((2 * pmc["FETCH_SIZE"][k]["avg_per_launch"] + pmc["WRITE_SIZE"][k]["avg_per_launch"]) * 1024)
+            roofline["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, averaged over all launches of profiles/r1_final_pmc_summary.json)"
+            roofline["algorithmic_bytes_per_launch"] = round(52 * rows_per_frame * args.steps / max(n_launch, 1))
+        except (KeyError, ValueError):
+            pass
     result = {
         "metric": "rendered samples/s (512x512 triplane head, max_steps 192)", "value": round(value, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
