@@ -180,6 +180,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--budget-factor", type=int, default=1, help="sample rows per iteration = factor x rays (reference: 1)")
     ap.add_argument("--n-step-cap", type=int, default=8, help="max samples per ray per iteration (reference: 8)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
+                    help="f16 = the reference's opt.fp16 / autocast arithmetic on the f16 matrix cores (not bit-exact vs the f32 checker)")
     ap.add_argument("--train", action="store_true", help="also time a cfg3 training step (operator API) and add it as 'train_step'")
     ap.add_argument("--train-rays", type=int, default=65536)
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +193,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid-roofline", action="store_true")
     ap.add_argument("--no-fat-schedule", action="store_true")
+    ap.add_argument("--no-fp16-leg", action="store_true")
     args = ap.parse_args()
 
     from lzzx_nerf_amd import _lib, dist as D
@@ -209,7 +212,7 @@ def main():
     golden = np.load(os.path.join(ROOT, "tests", "golden", "reference_python.npz"))
     P = make_params(golden)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in P.items()}, bound=1.0, device=device)
+    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in P.items()}, bound=1.0, device=device, precision=args.precision)
     bits = np.full(128 ** 3 // 8, 255, np.uint8) if args.scene == "ones" else ellipsoid_bitfield()[0]
     renderer = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=args.budget_factor, n_step_cap=args.n_step_cap)
     H = W = args.size
@@ -279,13 +282,17 @@ def main():
                     avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5), launches=n_launch,
                     launches_with_work=launches_with_work, flop_per_sample=FLOP_PER_SAMPLE,
                     head_time_share=round(head_total_ms * 1e-3 / dt, 4), rows_per_frame=rows_per_frame,
-                    shader_clock_mhz_under_load=round(probe[0] / max(probe[1], 1) * 100.0, 1),
+                    shader_clock_mhz_under_load=round(probe[0] / max(probe[1], 1) * 100.0, 1) if args.precision == "f32" else None,
                     issued_frac=round(ISSUED_FLOP_PER_ROW * rows_per_frame * args.steps / (head_total_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
+    if args.precision == "f16":   # 59 v_mfma_f32_16x16x32_f16 per slice: priced against the dense f16 peak; really gather-rate bound
+        roofline.update(peak=2500.0, frac=round(achieved_tflops / 2500.0, 5), kernel="lz_k_triplane_head_f16",
+                        issued_frac=round(59 * 16384 / 16 * rows_per_frame * args.steps / (head_total_ms * 1e-3) / 1e12 / 2500.0, 5),
+                        note="matrix work is 7% of the f32 kernel's; the kernel is bound by the 144 table gathers per sample")
     # HBM-side traffic of the head per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs, tools/profile_bench.sh): KiB per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     # for gfx950 (128-B requests tallied at 64 B).  bench.py cannot collect counters itself; null when the summary is absent.
     pmc_path = os.path.join(ROOT, "profiles", "r1_final_pmc_summary.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and args.precision == "f32":
         try:
             pmc = json.load(open(pmc_path))
             k = "lz_k_triplane_head<false>"
@@ -297,7 +304,7 @@ def main():
     result = {
         "metric": "rendered samples/s (512x512 triplane head, max_steps 192)", "value": round(value, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16 (f32 accumulate, torch-autocast rounding)", "data": "synthetic",
         "config": {"workload": f"{H}x{W} inference frame per GPU, max_steps {args.max_steps}, triplane head (3x D2/L12/C1 hash grid + "
                                f"audio/eye cond + SH4), occupancy={args.scene}, bound 1, dt_gamma 1/256, T_thresh 1e-4",
                    "rays_per_gpu": N, "samples_per_frame": samples_per_frame, "iterations_per_frame": iters_per_frame,
@@ -308,28 +315,48 @@ def main():
         "samples_per_ray_mean": round(samples_per_frame / N, 2),
         "roofline": roofline,
     }
-    if world == 1 and (args.budget_factor, args.n_step_cap) == (1, 8) and not args.no_fat_schedule:
-        # same frame with 8x the reference's per-iteration sample budget (fewer, fatter launches; pixels must not change)
-        fat = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=8, n_step_cap=8)
-        frender = lambda: fat.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4)
+    def side_leg(h, budget_factor):
+        """same frame, K timed steps after 2 warm-ups, with another head precision and / or iteration schedule"""
+        r2 = TriplaneRenderer(h, dev(bits), bound=1.0, budget_factor=budget_factor, n_step_cap=8)
+        rr = lambda: r2.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4)
         for _ in range(2):
-            frender()
+            rr()
         torch.cuda.synchronize()
-        fat.timing_start(args.steps * args.max_steps + 16)
+        r2.timing_start(args.steps * args.max_steps + 16)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            fo = frender()
+            o2 = rr()
         torch.cuda.synchronize()
-        fdt = time.perf_counter() - t0
-        fms = float(np.sum(fat.timing_stop()))
-        fst = fo["state"].cpu().numpy()
-        result["fat_schedule"] = dict(
-            schedule="n_step = max(min(8 * N // n_alive, 8), 1)", value=round(int(fst[5]) * args.steps / fdt, 1), unit="samples/s",
-            ms_per_step=round(fdt / args.steps * 1e3, 4), iterations_per_frame=int(fst[6]), rows_per_frame=int(fst[72]),
-            image_equal_to_reference_schedule=bool(torch.equal(fo["image"], out["image"])),
-            head_frac=round(FLOP_PER_SAMPLE * int(fst[5]) * args.steps / (fms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-            head_issued_frac=round(ISSUED_FLOP_PER_ROW * int(fst[72]) * args.steps / (fms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
-        del fat
+        d2 = time.perf_counter() - t0
+        hms = float(np.sum(r2.timing_stop()))
+        s2 = o2["state"].cpu().numpy()
+        img2 = o2["image"].clone()
+        return dict(schedule=f"n_step = max(min({budget_factor} * N // n_alive, 8), 1)", value=round(int(s2[5]) * args.steps / d2, 1),
+                    unit="samples/s", ms_per_step=round(d2 / args.steps * 1e3, 4), iterations_per_frame=int(s2[6]),
+                    rows_per_frame=int(s2[72]), head_ms_per_step=round(hms / args.steps, 4)), img2, hms, s2
+
+    if world == 1 and (args.budget_factor, args.n_step_cap) == (1, 8) and not args.no_fat_schedule:
+        # same frame with 8x the reference's per-iteration sample budget (fewer, fatter launches; pixels must not change)
+        leg, fimg, fms, fst = side_leg(head, 8)
+        leg["image_equal_to_reference_schedule"] = bool(torch.equal(fimg, out["image"]))
+        if args.precision == "f32":
+            leg["head_frac"] = round(FLOP_PER_SAMPLE * int(fst[5]) * args.steps / (fms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)
+            leg["head_issued_frac"] = round(ISSUED_FLOP_PER_ROW * int(fst[72]) * args.steps / (fms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)
+        result["fat_schedule"] = leg
+    if world == 1 and args.precision == "f32" and not args.no_fp16_leg:
+        # the reference's opt.fp16 arithmetic (torch autocast) on the f16 matrix cores: a different rounding sequence, so it is
+        # reported beside the bit-exact f32 headline, with its distance from the f32 image
+        h16 = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in P.items()}, bound=1.0, device=device, precision="f16")
+        leg, img16, _, _ = side_leg(h16, 1)
+        leg8, img16b, _, _ = side_leg(h16, 8)
+        diff = (img16 - out["image"]).double()
+        mse16 = float((diff ** 2).mean())
+        leg.update(dtype="f16 (f32 accumulate, torch-autocast rounding)", kernel="lz_k_triplane_head_f16",
+                   max_abs_diff_vs_f32_image=float(diff.abs().max()), psnr_vs_f32_image_db=round(-10 * np.log10(max(mse16, 1e-300)), 2),
+                   fat_schedule_value=leg8["value"], fat_schedule_ms_per_step=leg8["ms_per_step"],
+                   fat_schedule_image_equal=bool(torch.equal(img16, img16b)))
+        result["fp16_head"] = leg
+        del h16
     if not args.no_grid_roofline and world == 1:
         result["roofline_gridencoder"] = grid_roofline(device)
     if args.train and world == 1:

@@ -150,12 +150,13 @@ int lz_get_rays(const float* pose, float fx, float fy, float cx, float cy, uint3
  * Weights are consumed in the packed "A-fragment" layout produced by lz_head_pack_weights; all arithmetic is f32
  * (v_mfma_f32_16x16x4_f32), summation order documented in DESIGN.md.  See network.py:252-311. */
 #define LZ_HEAD_PACKED_FLOATS 27584 /* 431 A-fragments x 64 lanes */
+#define LZ_HEAD_PACKED_F16_BYTES 60416 /* f16 head: 59 A-fragments x 64 lanes x 8 halfs */
 typedef struct {
     const float* emb_xy;      /* [163584] tables of the three planes (device) */
     const float* emb_yz;
     const float* emb_xz;
     const int32_t* offsets;   /* [13] device */
-    const float* packed;      /* packed MLP weights (device), from lz_head_pack_weights */
+    const void* packed;       /* packed MLP weights (device), from lz_head_pack_weights (precision 0) or _f16 (precision 1) */
     const float* enc_a;       /* [32] device */
     const float* ind_code;    /* [4] device or NULL */
     const float* eye;         /* [1] device or NULL (exp_eye off) */
@@ -163,6 +164,8 @@ typedef struct {
     float S;                  /* log2(per_level_scale) */
     uint32_t H;               /* base resolution (64) */
     int testing;              /* 1: uncertainty = softplus(0) constant (network.py:243-249) */
+    int precision;            /* 0: f32 MFMA, bit-exact fma chains.  1: f16 MFMA with the rounding sequence of the reference
+                               * under torch autocast (opt.fp16): half Linear inputs/weights/outputs, f32 accumulate; inference only */
 } lz_head_params;
 
 /* host-side helper: number of floats lz_head_pack_weights writes */
@@ -171,6 +174,11 @@ uint32_t lz_head_packed_size(void);
 int lz_head_pack_weights(const float* aud0, const float* aud1, const float* eye0, const float* eye1, const float* sig0,
                          const float* sig1, const float* sig2, const float* col0, const float* col1, const float* unc0,
                          const float* unc1, int has_eye, int has_ind, float* packed, lz_stream_t stream);
+/* the same for the f16 head (no uncertainty net: inference only); `packed`: LZ_HEAD_PACKED_F16_BYTES bytes (device) */
+uint32_t lz_head_packed_size_f16(void);
+int lz_head_pack_weights_f16(const float* aud0, const float* aud1, const float* eye0, const float* eye1, const float* sig0,
+                             const float* sig1, const float* sig2, const float* col0, const float* col1, int has_eye,
+                             int has_ind, void* packed, lz_stream_t stream);
 /* xyzs/dirs [M,3] -> sigmas [M], rgbs [M,3], amb_aud [M], amb_eye [M], unc [M].  `count` (device i32, may be NULL)
  * limits the work to min(M, *count) rows. */
 int lz_triplane_head_forward(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M,

@@ -15,7 +15,7 @@ vp, u32, f32, i32 = C.c_void_p, C.c_uint32, C.c_float, C.c_int
 class HeadParams(C.Structure):
     """mirror of lz_head_params (include/lzzx_nerf_hip.h)"""
     _fields_ = [("emb_xy", vp), ("emb_yz", vp), ("emb_xz", vp), ("offsets", vp), ("packed", vp), ("enc_a", vp),
-                ("ind_code", vp), ("eye", vp), ("bound", f32), ("S", f32), ("H", u32), ("testing", i32)]
+                ("ind_code", vp), ("eye", vp), ("bound", f32), ("S", f32), ("H", u32), ("testing", i32), ("precision", i32)]
 
 
 class Frame(C.Structure):
@@ -63,9 +63,10 @@ SIGNATURES = {
     "lz_timing_elapsed_ms": [vp, C.POINTER(f32), u32, C.POINTER(u32)],
     "lz_final_blend": [vp, vp, vp, f32, u32, vp, vp],
     "lz_debug_head_clocks": [C.POINTER(C.c_uint64)],
+    "lz_head_pack_weights_f16": [vp] * 9 + [i32, i32, vp, vp],
 }
 PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),
-         "lz_head_packed_size": ([], u32)}
+         "lz_head_packed_size": ([], u32), "lz_head_packed_size_f16": ([], u32)}
 
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
 

@@ -503,6 +503,9 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
     }
 }
 
+int lz_head_forward_f16_impl(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M, const int32_t* count, float* sigmas,
+                             float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t st);   // lz_head_f16.hip
+
 extern "C" int lz_debug_head_clocks(uint64_t* out2) {
     LZ_REQUIRE(out2, LZ_ERR_BAD_ARGUMENT, "debug_head_clocks: null");
     unsigned long long v[2] = {0, 0};
@@ -519,9 +522,16 @@ extern "C" int lz_triplane_head_forward(const lz_head_params* p, const float* xy
     LZ_REQUIRE(p->emb_xy && p->emb_yz && p->emb_xz && p->offsets && p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT,
                "triplane_head_forward: incomplete lz_head_params");
     if (M == 0) return LZ_OK;
+    if (p->precision == 1) {
+        const int rc = lz_head_forward_f16_impl(p, xyzs, dirs, M, count, sigmas, rgbs, amb_aud, amb_eye, unc, lz_st(stream));
+        if (rc != LZ_OK) return rc;
+        LZ_CHECK_LAUNCH("triplane_head_forward(f16)");
+        return LZ_OK;
+    }
+    LZ_REQUIRE(p->precision == 0, LZ_ERR_BAD_ARGUMENT, "triplane_head_forward: precision must be 0 (f32) or 1 (f16)");
     LzHeadArgs a;
     a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
-    a.offsets = p->offsets; a.packed = p->packed; a.enc_a = p->enc_a; a.ind_code = p->ind_code; a.eye = p->eye;
+    a.offsets = p->offsets; a.packed = reinterpret_cast<const float*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code; a.eye = p->eye;
     a.bound = p->bound; a.testing = p->testing;
     for (int l = 0; l < 12; l++) {  // gridencoder.cu:125-126 on the host, same libm call as the CPU checker
         const float sc = exp2f((float)l * p->S) * (float)p->H - 1.0f;

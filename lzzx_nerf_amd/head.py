@@ -24,7 +24,12 @@ _W_KEYS = ["aud_ch_att_net.net.0.weight", "aud_ch_att_net.net.1.weight", "eye_at
 class FusedTriplaneHead:
     """Inference/forward-only fused head (autograd for training goes through the operator path)."""
 
-    def __init__(self, state_dict, bound=1.0, exp_eye=True, device="cuda"):
+    def __init__(self, state_dict, bound=1.0, exp_eye=True, device="cuda", precision="f32"):
+        """precision "f32": f32 MFMA, bit-exact against the checker.  "f16": the reference's opt.fp16 / autocast arithmetic
+        (half Linear inputs, weights and outputs, f32 accumulate) on the f16 matrix cores; inference only."""
+        if precision not in ("f32", "f16"):
+            raise ValueError("precision must be 'f32' or 'f16'")
+        self.precision = precision
         self.device = torch.device(device)
         self.bound = float(bound)
         sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
@@ -51,7 +56,10 @@ class FusedTriplaneHead:
         self.H = 64
         self.per_level_scale = np.exp2(np.log2(512 * self.bound / 64) / 11)
         self.S = float(np.float32(np.log2(self.per_level_scale)))
-        self.packed = torch.empty(_lib.load().lz_head_packed_size(), dtype=torch.float32, device=self.device)
+        if precision == "f16":
+            self.packed = torch.empty(_lib.load().lz_head_packed_size_f16(), dtype=torch.uint8, device=self.device)
+        else:
+            self.packed = torch.empty(_lib.load().lz_head_packed_size(), dtype=torch.float32, device=self.device)
         self.repack()
 
     @classmethod
@@ -62,7 +70,10 @@ class FusedTriplaneHead:
     def repack(self):
         """(re)build the MFMA A-fragment buffer; call after the weights change"""
         w = self.w
-        call("lz_head_pack_weights", *[ptr(t) for t in w], int(self.has_eye), int(self.has_ind), ptr(self.packed), stream())
+        if self.precision == "f16":
+            call("lz_head_pack_weights_f16", *[ptr(t) for t in w[:9]], int(self.has_eye), int(self.has_ind), ptr(self.packed), stream())
+        else:
+            call("lz_head_pack_weights", *[ptr(t) for t in w], int(self.has_eye), int(self.has_ind), ptr(self.packed), stream())
 
     def _params(self, enc_a, ind_code, eye, testing):
         p = _lib.HeadParams()
@@ -71,6 +82,7 @@ class FusedTriplaneHead:
         p.ind_code = ind_code.data_ptr() if (ind_code is not None and self.has_ind) else None
         p.eye = eye.data_ptr() if (eye is not None and self.has_eye) else None
         p.bound, p.S, p.H, p.testing = self.bound, self.S, self.H, int(bool(testing))
+        p.precision = 1 if self.precision == "f16" else 0
         return p
 
     def forward(self, xyzs, dirs, enc_a, ind_code=None, eye=None, testing=True, count_ptr=None, out=None):
@@ -85,6 +97,8 @@ class FusedTriplaneHead:
         eye = None if eye is None else eye.reshape(-1).float().contiguous()
         if not testing and self.w[9] is None:
             raise RuntimeError("training-mode uncertainty needs unc_net weights")
+        if not testing and self.precision == "f16":
+            raise RuntimeError("the f16 head is inference-only")
         if out is None:
             kw = dict(dtype=torch.float32, device=xyzs.device)
             out = (torch.empty(M, **kw), torch.empty(M, 3, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw),

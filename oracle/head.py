@@ -125,6 +125,53 @@ def head_forward(spec, P, xyz, dirs, enc_a, ind_code, eye, testing=True, unc_los
 
 
 # ---------------------------------------------------------------------------------------------
+# the same forward under torch autocast (opt.fp16): what the reference computes when it renders in half precision
+# ---------------------------------------------------------------------------------------------
+F16 = np.float16
+
+
+def _h(x):
+    return np.asarray(x, dtype=F32).astype(F16)
+
+
+def _lin16(x16, W):
+    """autocast nn.Linear (bias-free): input and weight cast to half, f32 accumulation, half output"""
+    return (x16.astype(F32) @ _h(W).astype(F32).T).astype(F16)
+
+
+def head_forward_fp16(spec, P, xyz, dirs, enc_a, ind_code, eye):
+    """NeRFNetwork.forward (network.py:252-311) in test mode with autocast enabled: the grid encoders stay f32 (C = 1,
+    grid.py:38), SH is f32 (custom_fwd cast_inputs), every Linear returns half, relu / sigmoid / products run in half
+    (f32 internally, rounded to half), trunc_exp and norm run in f32.  The summation order inside a half GEMM is the
+    library's (here numpy's), so this pins the GPU's f16 head to half rounding, not to the bit."""
+    relu = lambda a: np.maximum(a, F16(0))
+    enc_x = encode_x(spec, xyz, P)
+    M = enc_x.shape[0]
+    x16 = _h(enc_x)
+    att = _lin16(relu(_lin16(x16, P["aud_ch_att_net.net.0.weight"])), P["aud_ch_att_net.net.1.weight"])
+    enc_a16 = _h(enc_a).reshape(1, -1)
+    parts = [x16, (enc_a16.astype(F32) * att.astype(F32)).astype(F16)]
+    eye_att = None
+    if eye is not None:
+        e2 = _lin16(relu(_lin16(x16, P["eye_att_net.net.0.weight"])), P["eye_att_net.net.1.weight"])
+        eye_att = _h(O.unary("sigmoid", np.ascontiguousarray(e2.astype(F32))))
+        parts.append(_h(np.asarray(eye, dtype=F32).reshape(1, 1) * eye_att.astype(F32)))
+    h = np.concatenate(parts, axis=1)
+    s3 = _lin16(relu(_lin16(relu(_lin16(h, P["sigma_net.net.0.weight"])), P["sigma_net.net.1.weight"])), P["sigma_net.net.2.weight"])
+    sigma = O.unary("exp", np.ascontiguousarray(s3[:, 0].astype(F32)))
+    enc_d, _ = O.sh_encode_forward(dirs, 4)
+    parts = [_h(enc_d), s3[:, 1:]]
+    if ind_code is not None:
+        parts.append(np.repeat(_h(ind_code).reshape(1, -1), M, axis=0))
+    c2 = _lin16(relu(_lin16(np.concatenate(parts, axis=1), P["color_net.net.0.weight"])), P["color_net.net.1.weight"])
+    sg = _h(O.unary("sigmoid", np.ascontiguousarray(c2.astype(F32))))
+    rgb = _h(_h(sg.astype(F32) * F32(1 + 2 * 0.001)).astype(F32) - F32(0.001)).astype(F32)
+    amb_aud = np.sqrt((att.astype(F32) ** 2).sum(1, keepdims=True)).astype(F32)
+    unc = np.full((M, 1), O.unary("softplus", np.zeros(1, F32))[0], dtype=F32)
+    return sigma, rgb, amb_aud, None if eye_att is None else eye_att.astype(F32), unc
+
+
+# ---------------------------------------------------------------------------------------------
 # rays
 # ---------------------------------------------------------------------------------------------
 def get_rays(pose, intrinsics, H, W):

@@ -517,10 +517,10 @@ def test_composite_inference_bit_exact(variant):
 # ------------------------------------------------------------------------------------------------
 # fused head (MFMA) and the device-resident render loop
 # ------------------------------------------------------------------------------------------------
-def _head(params, exp_eye=True):
+def _head(params, exp_eye=True, precision="f32"):
     from lzzx_nerf_amd.head import FusedTriplaneHead
     sd = {k: torch.from_numpy(v) for k, v in params.items()}
-    return FusedTriplaneHead(sd, bound=1.0, exp_eye=exp_eye)
+    return FusedTriplaneHead(sd, bound=1.0, exp_eye=exp_eye, precision=precision)
 
 
 @pytest.mark.parametrize("testing", [True, False])
@@ -563,6 +563,60 @@ def test_fused_head_count_bound_and_no_eye(params, golden):
     so, ro, *_ = head_forward(spec, p2, xyz, d, golden["net_enc_a"], golden["net_ind"], None)
     sg, rg, *_ = h2.forward(dev(xyz), dev(d), dev(golden["net_enc_a"]), dev(golden["net_ind"]), None)
     assert np.array_equal(host(sg), so) and np.array_equal(host(rg), ro)
+
+
+@pytest.mark.parametrize("boost,use_eye", [(0.0, True), (40.0, True), (0.0, False)])
+def test_fused_head_f16_matches_autocast_checker(params, golden, boost, use_eye):
+    """precision="f16": the reference's autocast (opt.fp16) rounding sequence on v_mfma_f32_16x16x32_f16.  The order of
+    the f32 accumulation inside a half GEMM is the matrix core's (vs numpy's in the checker), so values agree to half
+    rounding: the bulk bit-equal, the rest within a few half ulps; sigma = exp(half) within 1 ulp of its half argument."""
+    from oracle.head import head_forward_fp16
+    p = _scene(params, boost)
+    if not use_eye:
+        p = dict(p)
+        p["sigma_net.net.0.weight"] = np.ascontiguousarray(p["sigma_net.net.0.weight"][:, :68])
+    head = _head(p, exp_eye=use_eye, precision="f16")
+    rng = np.random.default_rng(31)
+    M = 4000 + 7   # ragged last slice
+    xyz = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    xyz[:4] = [[1, 1, 1], [-1, -1, -1], [1.0000001, 0, 0], [0, 0, -1.0000001]]
+    d = rng.normal(size=(M, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    enc_a, ind, eye = golden["net_enc_a"], golden["net_ind"], golden["net_eye"] if use_eye else None
+    so, ro, ao, eo, uo = head_forward_fp16(TriplaneSpec(1.0), p, xyz, d, enc_a, ind, eye)
+    sg, rg, ag, eg, ug = head.forward(dev(xyz), dev(d), dev(enc_a), dev(ind), None if eye is None else dev(eye))
+    sg, rg, ag, ug = host(sg), host(rg), host(ag), host(ug)
+    assert np.array_equal(ug, uo)
+    assert np.allclose(rg, ro, atol=4e-3) and np.mean(rg == ro) > 0.85, (np.abs(rg - ro).max(), np.mean(rg == ro))
+    assert np.allclose(sg, so, rtol=2e-2) and np.mean(sg == so) > 0.85, (np.abs(sg / so - 1).max(), np.mean(sg == so))
+    assert np.allclose(ag, ao, rtol=5e-3, atol=1e-4)
+    if use_eye:
+        assert np.allclose(host(eg), eo, atol=2e-3)
+    # and it is the half-precision version of the f32 head: close to it, not equal to it
+    s32, r32, *_ = _head(p, exp_eye=use_eye).forward(dev(xyz), dev(d), dev(enc_a), dev(ind), None if eye is None else dev(eye))
+    assert np.allclose(rg, host(r32), atol=2e-2) and not np.array_equal(rg, host(r32))
+    with pytest.raises(RuntimeError, match="inference-only"):
+        head.forward(dev(xyz), dev(d), dev(enc_a), dev(ind), None if eye is None else dev(eye), testing=False)
+
+
+def test_render_frame_f16_head(params, golden):
+    """whole frame with the f16 head: PSNR against the f32 checker image, marching (independent of the head) unchanged"""
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    p = _scene(params, 40.0)
+    H = W = 64
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    bits = ellipsoid_bitfield()[0]
+    enc_a, eye, ind = golden["net_enc_a"], golden["net_eye"], golden["net_ind"]
+    st = {}
+    ref = render_inference(TriplaneSpec(1.0), p, ro, rd, bits, enc_a, ind, eye, max_steps=64, stats=st)
+    r = TriplaneRenderer(_head(p, precision="f16"), dev(bits), bound=1.0)
+    out = r.render(dev(ro), dev(rd), dev(enc_a), dev(ind), dev(eye), max_steps=64, count_samples=True)
+    img = host(out["image"])
+    mse = float(((img.astype(np.float64) - ref["image"]) ** 2).mean())
+    assert mse > 0 and -10 * np.log10(mse) > 50.0, -10 * np.log10(mse)
+    cnt = host(out["ray_counts"]).astype(np.int64)
+    assert np.mean(cnt == st["samples_per_ray"]) > 0.98 and abs(int(cnt.sum()) - int(st["samples_per_ray"].sum())) < 0.01 * cnt.sum()
 
 
 def _scene(params, scale_sigma=0.0):
