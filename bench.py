@@ -302,7 +302,7 @@ def main():
         except (KeyError, ValueError):
             pass
     result = {
-        "metric": "rendered samples/s (512x512 triplane head, max_steps 192)", "value": round(value, 1), "unit": "samples/s",
+        "metric": f"rendered samples/s ({H}x{W} triplane head, max_steps {args.max_steps})", "value": round(value, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16 (f32 accumulate, torch-autocast rounding)", "data": "synthetic",
         "config": {"workload": f"{H}x{W} inference frame per GPU, max_steps {args.max_steps}, triplane head (3x D2/L12/C1 hash grid + "
