@@ -599,6 +599,28 @@ def test_fused_head_f16_matches_autocast_checker(params, golden, boost, use_eye)
         head.forward(dev(xyz), dev(d), dev(enc_a), dev(ind), None if eye is None else dev(eye), testing=False)
 
 
+def test_render_loop_python_driven_equals_native(params, golden):
+    """the per-iteration entries called one by one from Python (debug path) and the native driver lz_loop_run enqueue the
+    same launches: same frame, same state, bit for bit"""
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    p = _scene(params, 40.0)
+    H = W = 96
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    bits = ellipsoid_bitfield()[0]
+    enc_a, eye, ind = dev(golden["net_enc_a"]), dev(golden["net_eye"]), dev(golden["net_ind"])
+    head = _head(p)
+    r1 = TriplaneRenderer(head, dev(bits), bound=1.0)
+    a = r1.render(dev(ro), dev(rd), enc_a, ind, eye, max_steps=64, count_samples=True)
+    a = {k: v.clone() for k, v in a.items()}
+    r2 = TriplaneRenderer(head, dev(bits), bound=1.0)
+    r2._head_events = []   # selects the Python-driven loop
+    b = r2.render(dev(ro), dev(rd), enc_a, ind, eye, max_steps=64, count_samples=True)
+    for k in ("image", "depth", "weights_sum", "ray_counts", "amb_aud_sum", "uncertainty_sum"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["state"][:8], b["state"][:8]) and int(a["state"][72]) == int(b["state"][72]) and len(r2._head_events) >= int(b["state"][6])
+
+
 def test_render_frame_f16_head(params, golden):
     """whole frame with the f16 head: PSNR against the f32 checker image, marching (independent of the head) unchanged"""
     from lzzx_nerf_amd.renderer import TriplaneRenderer
