@@ -90,9 +90,11 @@ class TriplaneTrainNet(torch.nn.Module):
     """caller-side graph of the reference's NeRFNetwork.forward in training mode (network.py:252-311) on the operator API:
     3 GridEncoders + SHEncoder from get_encoder(), bias-free torch Linear stacks (rocBLAS), autograd"""
 
-    def __init__(self, P, device):
+    def __init__(self, P, device, mlp="lz"):
         super().__init__()
         from lzzx_nerf_amd.encoding import get_encoder
+        from lzzx_nerf_amd.linear import lz_linear
+        self.use_lz, self.lz_linear = mlp == "lz", lz_linear
         mk = lambda: get_encoder("hashgrid", input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
                                  desired_resolution=512)[0]
         self.encoder_xy, self.encoder_yz, self.encoder_xz = mk(), mk(), mk()
@@ -106,9 +108,12 @@ class TriplaneTrainNet(torch.nn.Module):
 
     def mlp(self, h, name, n):
         for i in range(n):
-            h = torch.nn.functional.linear(h, self.W[f"{name}_net_{i}_weight"])
-            if i < n - 1:
-                h = torch.relu(h)
+            if self.use_lz:   # csrc/lz_linear.hip: one MFMA kernel per layer forward (ReLU fused), two backward
+                h = self.lz_linear(h, self.W[f"{name}_net_{i}_weight"], i < n - 1)
+            else:
+                h = torch.nn.functional.linear(h, self.W[f"{name}_net_{i}_weight"])
+                if i < n - 1:
+                    h = torch.relu(h)
         return h
 
     def forward(self, x, d, enc_a, ind, eye):
@@ -139,7 +144,7 @@ def train_bench(args, device, P, golden, bits):
     sel = torch.randperm(H * W, device=device, generator=g)[:n_rays]
     ro, rd = ro[sel].contiguous(), rd[sel].contiguous()
     target = torch.rand(n_rays, 3, device=device, generator=g)
-    net = TriplaneTrainNet(P, device)
+    net = TriplaneTrainNet(P, device, mlp=args.train_mlp)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-15)
     enc_a, ind, eye = dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"])
     aabb = dev(np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32))
@@ -173,7 +178,7 @@ def train_bench(args, device, P, golden, bits):
                          "march_rays_train -> 3 grid + SH encoders -> torch Linear heads -> composite_rays_train_triplane -> MSE -> "
                          "backward (grid scatter-add) -> Adam", rays=n_rays, samples_per_step=int(n_samples[0]),
                 ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
-                loss=float(loss), dtype="f32", mlp="torch/rocBLAS")
+                loss=float(loss.detach()), dtype="f32", mlp="csrc/lz_linear.hip (MFMA f32)" if args.train_mlp == "lz" else "torch/rocBLAS")
 
 
 def main():
@@ -184,6 +189,7 @@ def main():
                     help="f16 = the reference's opt.fp16 / autocast arithmetic on the f16 matrix cores (not bit-exact vs the f32 checker)")
     ap.add_argument("--train", action="store_true", help="also time a cfg3 training step (operator API) and add it as 'train_step'")
     ap.add_argument("--train-rays", type=int, default=65536)
+    ap.add_argument("--train-mlp", default="lz", choices=["lz", "torch"], help="Linear layers of the training step: lz_linear kernels or torch")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)

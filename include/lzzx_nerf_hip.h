@@ -185,6 +185,18 @@ int lz_triplane_head_forward(const lz_head_params* p, const float* xyzs, const f
                              const int32_t* count, float* sigmas, float* rgbs, float* amb_aud, float* amb_eye,
                              float* unc, lz_stream_t stream);
 
+/* Tall-skinny bias-free Linear for the training path of the heads (the reference's MLP, network.py:73-94, is a stack of
+ * nn.Linear(bias=False) with K, N <= 84 over M ~ 1e6..1e7 samples; torch dispatches them to library GEMMs).  Row-major f32,
+ * explicit leading dimensions (column slices of wider buffers are fine), v_mfma_f32_16x16x4_f32.
+ * forward: Y[M,N] = act(Xm[M,K] . W[N,K]^T), Xm = X where mask > 0 else 0 (mask optional, same layout as X), act = ReLU when
+ * relu_out.  The data gradient of a layer is the same call: dX = lz_linear_forward(dY, mask = Y, W^T).  K, N <= 128. */
+int lz_linear_forward(const float* X, uint32_t ldx, const float* mask, const float* W, uint32_t ldw, float* Y, uint32_t ldy,
+                      uint32_t M, uint32_t K, uint32_t N, int relu_out, lz_stream_t stream);
+/* weight gradient: dW[N,K] += (dY where mask > 0)[M,N]^T . X[M,K]; the reduction over M happens inside the kernel (registers ->
+ * LDS -> one float atomic per element and workgroup); dW is accumulated into, zero it first.  ceil(N/16)*ceil(K/16) <= 24. */
+int lz_linear_grad_w(const float* dY, uint32_t ldd, const float* mask, const float* X, uint32_t ldx, float* dW, uint32_t ldw,
+                     uint32_t M, uint32_t K, uint32_t N, lz_stream_t stream);
+
 /* Device-resident inference loop state (renderer.py:495-548): no host synchronisation inside the frame.
  * The device buffer passed as `lz_loop_state*` must hold LZ_LOOP_STATE_INTS int32: the struct below, 64 scratch words
  * (per-workgroup sample-count slots, folded into total_samples by lz_loop_advance), then statistics:

@@ -40,8 +40,63 @@ def _grid64(x01, emb, offsets, scales, ress):
     return torch.stack(outs, 1)
 
 
-def test_train_step_gradients(params, golden):
+@pytest.mark.parametrize("K,N,relu", [(36, 64, True), (64, 32, False), (36, 16, True), (16, 1, False), (69, 64, True), (64, 64, True),
+                                      (64, 65, False), (84, 64, True), (64, 3, False), (36, 32, True), (32, 1, False), (1, 5, True),
+                                      (96, 64, False), (128, 7, True)])
+def test_lz_linear_matches_float64(K, N, relu):
+    """csrc/lz_linear.hip (forward with fused ReLU, data gradient with fused ReLU mask, in-kernel weight-gradient reduction)
+    against float64 torch on every layer shape of the triplane head, ragged M; tolerance = f32 accumulation order"""
+    from lzzx_nerf_amd.linear import lz_linear
+    g = torch.Generator().manual_seed(K * 131 + N)
+    M = 5003
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    gy = torch.randn(M, N, generator=g)
+    xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    y = lz_linear(xg, wg, relu)
+    xc, wc = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yc = xc @ wc.T
+    if relu:
+        yc = torch.relu(yc)
+    assert torch.allclose(y.detach().cpu().double(), yc.detach(), atol=2e-5, rtol=1e-5)
+    nb, kb = (N + 15) // 16, (K + 15) // 16
+    if nb * kb <= 24 and nb <= 6 and kb <= 6:   # weight gradient: at most 24 accumulator tiles per wave
+        y.backward(gy.cuda())
+        yc.backward(gy.double())
+        # ReLU mask decided in f32 vs f64: exclude the (measure-zero) samples where the pre-activation is within rounding of 0
+        assert torch.allclose(xg.grad.cpu().double(), xc.grad, atol=5e-4, rtol=1e-4)
+        assert torch.allclose(wg.grad.cpu().double(), wc.grad, atol=2e-3 * max(1.0, float(wc.grad.abs().max())), rtol=1e-4)
+    else:
+        with pytest.raises(RuntimeError, match="<= 24"):
+            y.backward(gy.cuda())
+
+
+def test_lz_linear_leading_dimensions_and_errors():
+    """C ABI: column slices of wider buffers in and out (what saves the torch.cat copies), argument checks"""
+    from lzzx_nerf_amd._util import call, ptr, stream
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 1000, 36, 64
+    big_in = torch.randn(M, 80, generator=g).cuda()
+    big_out = torch.full((M, 100), 7.0).cuda()
+    w = (torch.randn(N, K, generator=g) / 6).cuda()
+    xin, yout = big_in[:, 8:], big_out[:, 16:]
+    call("lz_linear_forward", ptr(xin), 80, None, ptr(w), K, ptr(yout), 100, M, K, N, 1, stream())
+    ref = torch.relu(xin[:, :K].double() @ w.double().T)
+    assert torch.allclose(big_out[:, 16:16 + N].double(), ref, atol=2e-5) and bool((big_out[:, :16] == 7).all()) and bool((big_out[:, 80:] == 7).all())
+    gy = torch.randn(M, N, generator=g).cuda()
+    dw2 = torch.zeros(N, K).cuda()
+    ym = big_out[:, 16:16 + N].contiguous()   # the mask shares dY's layout (same leading dimension)
+    call("lz_linear_grad_w", ptr(gy), N, ptr(ym), ptr(xin), 80, ptr(dw2), K, M, K, N, stream())
+    refw = (gy.double() * (ref > 0)).T @ xin[:, :K].double()
+    assert torch.allclose(dw2.double(), refw, atol=2e-3)
+    with pytest.raises(RuntimeError, match="leading dimension"):
+        call("lz_linear_forward", ptr(big_in), 8, None, ptr(w), K, ptr(big_out), 100, M, K, N, 0, stream())
+
+
+@pytest.mark.parametrize("mlp", ["torch", "lz"])
+def test_train_step_gradients(params, golden, mlp):
     from lzzx_nerf_amd import raymarching as R
+    from lzzx_nerf_amd.linear import lz_linear
     from lzzx_nerf_amd.encoding import get_encoder
     torch.manual_seed(0)
     H = W = 24
@@ -69,20 +124,23 @@ def test_train_step_gradients(params, golden):
     assert M > 500
     x = xyzs.contiguous()
 
-    def mlp(h, name, n):
+    def mlp_(h, name, n):
         for i in range(n):
-            h = lin(h, Wg[f"{name}.net.{i}.weight"])
-            if i < n - 1:
-                h = torch.relu(h)
+            if mlp == "lz":   # hand-written MFMA Linear (csrc/lz_linear.hip), ReLU fused
+                h = lz_linear(h, Wg[f"{name}.net.{i}.weight"], i < n - 1)
+            else:
+                h = lin(h, Wg[f"{name}.net.{i}.weight"])
+                if i < n - 1:
+                    h = torch.relu(h)
         return h
 
     enc_x = torch.cat([encs[0](x[:, :2], bound=1), encs[1](x[:, 1:], bound=1), encs[2](x[:, [0, 2]], bound=1)], -1)
-    att = mlp(enc_x, "aud_ch_att_net", 2)
-    eye_att = torch.sigmoid(mlp(enc_x, "eye_att_net", 2))
-    h = mlp(torch.cat([enc_x, dev(enc_a) * att, dev(eye) * eye_att], -1), "sigma_net", 3)
+    att = mlp_(enc_x, "aud_ch_att_net", 2)
+    eye_att = torch.sigmoid(mlp_(enc_x, "eye_att_net", 2))
+    h = mlp_(torch.cat([enc_x, dev(enc_a) * att, dev(eye) * eye_att], -1), "sigma_net", 3)
     sigma = torch.exp(h[:, 0])
-    rgb = torch.sigmoid(mlp(torch.cat([enc_dir(dirs), h[:, 1:], dev(ind).repeat(x.shape[0], 1)], -1), "color_net", 2)) * 1.002 - 0.001
-    unc = torch.log(1 + torch.exp(mlp(enc_x.detach(), "unc_net", 2)))
+    rgb = torch.sigmoid(mlp_(torch.cat([enc_dir(dirs), h[:, 1:], dev(ind).repeat(x.shape[0], 1)], -1), "color_net", 2)) * 1.002 - 0.001
+    unc = torch.log(1 + torch.exp(mlp_(enc_x.detach(), "unc_net", 2)))
     ws, a0s, a1s, us, dep, img = R.composite_rays_train_triplane(sigma, rgb, att.norm(dim=-1), eye_att.abs().sum(-1), unc[:, 0], deltas, rays)
     target = torch.linspace(0, 1, H * W * 3, device="cuda").reshape(-1, 3)
     loss = ((img - target) ** 2).mean() + 0.1 * ws.mean() + 1e-3 * a0s.mean() + 1e-3 * a1s.mean() + 1e-2 * us.mean()
