@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--no-grid-roofline", action="store_true")
     ap.add_argument("--no-fat-schedule", action="store_true")
     ap.add_argument("--no-fp16-leg", action="store_true")
+    ap.add_argument("--no-occupancy", action="store_true")
     args = ap.parse_args()
 
     from lzzx_nerf_amd import _lib, dist as D
@@ -367,6 +368,22 @@ def main():
         result["roofline_gridencoder"] = grid_roofline(device)
     if args.train and world == 1:
         result["train_step"] = train_bench(args, device, P, golden, bits)
+    if world == 1 and not args.no_occupancy and args.precision == "f32":
+        # the occupancy-grid maintenance of update_extra_state (renderer.py:699-766) as 5 launches, no sync
+        from lzzx_nerf_amd.occupancy import update_density_grid
+        dg = torch.zeros(1, 128 ** 3, device=device)
+        bf = torch.zeros(128 ** 3 // 8, dtype=torch.uint8, device=device)
+        nz = torch.rand(1, 128 ** 3, 3, device=device, generator=torch.Generator(device=device).manual_seed(2))
+        for _ in range(2):
+            update_density_grid(head, dg, bf, enc_a, eye, bound=1.0, noise=nz)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            mean_d, _ = update_density_grid(head, dg, bf, enc_a, eye, bound=1.0, noise=nz)
+        torch.cuda.synchronize()
+        result["occupancy_grid_update"] = dict(ms=round((time.perf_counter() - t0) / 5 * 1e3, 3), cells=128 ** 3, cascade=1,
+                                               mean_density=float(mean_d), launches=5, host_syncs=0)
+        del dg, bf, nz
     # ---- CPU baseline: the checker arranged like the reference loop, on a bounded sub-frame of the SAME rays ----
     if not args.no_cpu_baseline and world == 1:   # rank 0, N = 1 only
         from oracle.head import TriplaneSpec

@@ -185,6 +185,19 @@ int lz_triplane_head_forward(const lz_head_params* p, const float* xyzs, const f
                              const int32_t* count, float* sigmas, float* rgbs, float* amb_aud, float* amb_eye,
                              float* unc, lz_stream_t stream);
 
+/* Occupancy-grid maintenance, head branch of update_extra_state (nerf_triplane/renderer.py:699-766).
+ * lz_density_grid_points: the query point of every cell of every cascade, in meshgrid order (x slowest, z fastest):
+ *   xyz = (2 c / (G-1) - 1) * (bound_c - bound_c/G) + (noise * 2 - 1) * bound_c/G, bound_c = min(2^cascade, bound);
+ *   noise [C, G^3, 3] in [0,1) is supplied by the caller (the reference draws torch.rand_like per cascade); xyzs [C*G^3, 3].
+ * lz_density_grid_update: sigmas [C*G^3] = density at those points (e.g. lz_triplane_head_forward) ->
+ *   tmp[cas, morton(cell)] = sigma * density_scale; 6-neighbour dilation (raymarching.cu:304-341); EMA
+ *   grid = max(grid * decay, tmp) where both >= 0; stats[0] = mean(clamp(grid, 0)), stats[1] = min(stats[0], density_thresh);
+ *   bitfield = packbits(grid, stats[1]).  density_grid [C, G^3] f32 Morton-ordered, in place; bitfield [C*G^3/8];
+ *   stats: 2 floats (device); workspace: >= ceil(C*G^3/256) floats (device).  No host synchronisation. */
+int lz_density_grid_points(const float* noise, uint32_t C, uint32_t G, float bound, float* xyzs, lz_stream_t stream);
+int lz_density_grid_update(const float* sigmas, float density_scale, float decay, float density_thresh, uint32_t C, uint32_t G,
+                           float* density_grid, uint8_t* bitfield, float* stats, void* workspace, lz_stream_t stream);
+
 /* Tall-skinny bias-free Linear for the training path of the heads (the reference's MLP, network.py:73-94, is a stack of
  * nn.Linear(bias=False) with K, N <= 84 over M ~ 1e6..1e7 samples; torch dispatches them to library GEMMs).  Row-major f32,
  * explicit leading dimensions (column slices of wider buffers are fine), v_mfma_f32_16x16x4_f32.

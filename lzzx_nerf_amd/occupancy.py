@@ -1,0 +1,42 @@
+"""Occupancy-grid maintenance on device: the head branch of `NeRFRenderer.update_extra_state`
+(/root/reference/nerf_triplane/renderer.py:699-766) without its Python cascade loop, boolean-mask EMA and `.item()` syncs.
+
+    mean, thresh = update_density_grid(head, density_grid, density_bitfield, enc_a, eye, bound=1.0)
+
+`density_grid` [cascade, G^3] (Morton order, -1 = untrained) and `density_bitfield` [cascade * G^3 / 8] are updated in place,
+exactly as the reference's attributes of the same names; `mean` / `thresh` are 0-d device tensors (the reference's
+`self.mean_density` and the threshold it packs with), ready in stream order.
+"""
+import math
+
+import torch
+
+from ._util import call, ptr, stream
+
+
+@torch.no_grad()
+def update_density_grid(head, density_grid, density_bitfield, enc_a, eye=None, bound=1.0, decay=0.95, density_thresh=0.01,
+                        density_scale=1.0, noise=None):
+    cascade, cells = density_grid.shape
+    G = round(cells ** (1 / 3))
+    if G ** 3 != cells or density_grid.dtype != torch.float32 or not density_grid.is_contiguous():
+        raise RuntimeError("density_grid must be a contiguous float32 [cascade, grid_size^3] tensor")
+    if cascade != 1 + math.ceil(math.log2(bound)):
+        raise RuntimeError("cascade does not match bound (renderer.py:93)")
+    dev = density_grid.device
+    n = cascade * cells
+    if noise is None:   # one torch.rand per cascade, in the order the reference draws them (S = grid_size: one block per cascade)
+        noise = torch.stack([torch.rand(cells, 3, dtype=torch.float32, device=dev) for _ in range(cascade)])
+    noise = noise.to(dev, torch.float32).contiguous()
+    if noise.numel() != n * 3:
+        raise RuntimeError("noise must hold cascade * grid_size^3 * 3 values")
+    xyzs = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    call("lz_density_grid_points", ptr(noise), cascade, G, float(bound), ptr(xyzs), stream())
+    dirs = torch.zeros(n, 3, dtype=torch.float32, device=dev)
+    dirs[:, 2] = 1.0   # the density does not depend on the view direction; the fused head still wants one
+    sigma = head.forward(xyzs, dirs, enc_a, None, eye, testing=True)[0]
+    stats = torch.empty(2, dtype=torch.float32, device=dev)
+    workspace = torch.empty((n + 255) // 256, dtype=torch.float32, device=dev)
+    call("lz_density_grid_update", ptr(sigma), float(density_scale), float(decay), float(density_thresh), cascade, G, ptr(density_grid),
+         ptr(density_bitfield), ptr(stats), ptr(workspace), stream())
+    return stats[0], stats[1]

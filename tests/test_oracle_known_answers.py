@@ -409,3 +409,38 @@ def test_march_train_overflow_drops_rays_like_reference():
     comp = O.composite_rays_train_forward("ambient", np.ones(1024, np.float32), np.ones((1024, 3), np.float32), dl, rays,
                                           amb0=np.ones(1024, np.float32))
     assert np.all(comp["weights_sum"][rays[dropped, 0]] == 0) and np.all(comp["weights_sum"][rays[~dropped & (rays[:, 2] > 0), 0]] > 0)
+
+
+def test_occupancy_update_restatement_small():
+    """oracle/occupancy.py on a 4^3 grid with a constant-density stand-in: EMA / untrained / dilation / threshold logic"""
+    from oracle import occupancy as OC
+    G = 4
+    grid = np.zeros((1, G ** 3), np.float32)
+    grid[0, 5] = -1.0
+    grid[0, 7] = 3.0
+    calls = {}
+    orig_density, orig_encode = OC.density, OC.encode_x
+    try:
+        OC.encode_x = lambda spec, x, P: x
+        def fake_density(spec, P, enc_x, enc_a, eye):
+            calls["xyz"] = enc_x
+            return dict(sigma=(enc_x[:, 0] > 0).astype(np.float32))   # density 1 on the +x half
+        OC.density = fake_density
+        noise = np.full((1, G ** 3, 3), 0.5, np.float32)               # zero offset
+        mean, thresh, bits = OC.update_density_grid(None, None, grid, None, None, 1.0, noise, decay=0.5, density_thresh=0.25)
+    finally:
+        OC.density, OC.encode_x = orig_density, orig_encode
+    xyz = calls["xyz"]
+    assert xyz.shape == (64, 3) and np.allclose(xyz.min(), -0.75) and np.allclose(xyz.max(), 0.75)   # (2c/3 - 1) * (1 - 1/4)
+    coords = np.stack(np.meshgrid(*[np.arange(G)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    m = O.morton3D(coords)
+    expect = np.where(coords[:, 0] >= 1, 1.0, 0.0)                     # x >= 2 has density 1; dilation reaches x = 1
+    for c, mi in zip(coords, m):
+        if mi == 5:
+            assert grid[0, mi] == -1.0                                  # untrained stays
+        elif mi == 7:
+            assert grid[0, mi] == max(3.0 * 0.5, expect[(coords == c).all(1)][0])
+        else:
+            assert grid[0, mi] == expect[(coords == c).all(1)][0]
+    assert thresh == 0.25 and mean == pytest.approx(np.clip(grid, 0, None).mean())
+    assert np.array_equal(np.unpackbits(bits, bitorder="little")[:64].astype(bool), grid[0] > 0.25)
