@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--no-fat-schedule", action="store_true")
     ap.add_argument("--no-fp16-leg", action="store_true")
     ap.add_argument("--no-occupancy", action="store_true")
+    ap.add_argument("--gather", default="f32", choices=["f32", "rgb24"],
+                    help="what the per-step all-gather moves: f32 RGB tiles, or the video pipe's RGB24 quantised on device (4x fewer bytes)")
     args = ap.parse_args()
 
     from lzzx_nerf_amd import _lib, dist as D
@@ -230,8 +232,10 @@ def main():
     N = H * W
 
     def step():
-        out = renderer.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4)
-        tiles = D.gather_tiles(out["image"]) if world > 1 else out["image"]
+        out = renderer.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4,
+                              rgb24=args.gather == "rgb24")
+        tile = out["image_rgb24"] if args.gather == "rgb24" else out["image"]
+        tiles = D.gather_tiles(tile) if world > 1 else tile
         return out, tiles
 
     def barrier():
@@ -315,7 +319,7 @@ def main():
         "config": {"workload": f"{H}x{W} inference frame per GPU, max_steps {args.max_steps}, triplane head (3x D2/L12/C1 hash grid + "
                                f"audio/eye cond + SH4), occupancy={args.scene}, bound 1, dt_gamma 1/256, T_thresh 1e-4",
                    "rays_per_gpu": N, "samples_per_frame": samples_per_frame, "iterations_per_frame": iters_per_frame,
-                   "nominal_samples_per_frame": N * args.max_steps, "parallelism": f"ray-sharded x{world}, 1 all-gather/step",
+                   "nominal_samples_per_frame": N * args.max_steps, "parallelism": f"ray-sharded x{world}, 1 all-gather/step ({args.gather} tiles)",
                    "schedule": f"n_step = max(min({args.budget_factor} * N // n_alive, {args.n_step_cap}), 1)"
                                + (" (the reference's, renderer.py:513)" if (args.budget_factor, args.n_step_cap) == (1, 8) else "")},
         "rays_per_s": round(rays_per_s, 1),

@@ -299,6 +299,10 @@ int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterations, lz_ti
 /* image = clamp(image + (1 - weights_sum) * bg, 0, 1) (renderer.py:559-561); bg: device [N,3] or NULL -> bg_scalar */
 int lz_final_blend(const float* image, const float* weights_sum, const float* bg, float bg_scalar, uint32_t N,
                    float* out, lz_stream_t stream);
+/* the same plus the hand-off format of the reference's video pipe, (pred * 255).astype(np.uint8) (TrainerUtil.py:550-555,
+ * 668): out_rgb24 [N,3] u8, truncating; `out` (f32) may be NULL */
+int lz_final_blend_rgb24(const float* image, const float* weights_sum, const float* bg, float bg_scalar, uint32_t N,
+                         float* out, uint8_t* out_rgb24, lz_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "lz_timing_reset": [vp],
     "lz_timing_elapsed_ms": [vp, C.POINTER(f32), u32, C.POINTER(u32)],
     "lz_final_blend": [vp, vp, vp, f32, u32, vp, vp],
+    "lz_final_blend_rgb24": [vp, vp, vp, f32, u32, vp, vp, vp],
     "lz_debug_head_clocks": [C.POINTER(C.c_uint64)],
     "lz_head_pack_weights_f16": [vp] * 9 + [i32, i32, vp, vp],
     "lz_density_grid_points": [vp, u32, u32, f32, vp, vp],

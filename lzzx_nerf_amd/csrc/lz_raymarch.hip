@@ -993,19 +993,32 @@ extern "C" int lz_loop_advance(lz_loop_state* state, uint32_t N, uint32_t max_st
 
 __global__ void __launch_bounds__(256)
 lz_k_final_blend(const float* __restrict__ image, const float* __restrict__ weights_sum, const float* __restrict__ bg, float bg_scalar,
-                 uint32_t N, float* __restrict__ out) {
+                 uint32_t N, float* __restrict__ out, uint8_t* __restrict__ out_rgb24) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N * 3) return;
     const uint32_t n = t / 3;
     const float b = bg ? bg[t] : bg_scalar;
     const float v = image[t] + (1.0f - weights_sum[n]) * b;   // two roundings, like the torch expression (renderer.py:559)
-    out[t] = lz_fminf(lz_fmaxf(v, 0.0f), 1.0f);
+    const float c = lz_fminf(lz_fmaxf(v, 0.0f), 1.0f);
+    if (out) out[t] = c;
+    if (out_rgb24) out_rgb24[t] = (uint8_t)(c * 255.0f);      // (pred * 255).astype(np.uint8): truncation (TrainerUtil.py:551)
 }
 
 extern "C" int lz_final_blend(const float* image, const float* weights_sum, const float* bg, float bg_scalar, uint32_t N, float* out,
                               lz_stream_t stream) {
     if (N == 0) return LZ_OK;
-    hipLaunchKernelGGL(lz_k_final_blend, dim3(lz_div_up((uint64_t)N * 3, 256)), dim3(256), 0, lz_st(stream), image, weights_sum, bg, bg_scalar, N, out);
+    hipLaunchKernelGGL(lz_k_final_blend, dim3(lz_div_up((uint64_t)N * 3, 256)), dim3(256), 0, lz_st(stream), image, weights_sum, bg, bg_scalar, N, out,
+                       (uint8_t*)nullptr);
     LZ_CHECK_LAUNCH("final_blend");
+    return LZ_OK;
+}
+
+extern "C" int lz_final_blend_rgb24(const float* image, const float* weights_sum, const float* bg, float bg_scalar, uint32_t N, float* out,
+                                    uint8_t* out_rgb24, lz_stream_t stream) {
+    if (N == 0) return LZ_OK;
+    LZ_REQUIRE(image && weights_sum && out_rgb24, LZ_ERR_BAD_ARGUMENT, "final_blend_rgb24: null tensor");
+    hipLaunchKernelGGL(lz_k_final_blend, dim3(lz_div_up((uint64_t)N * 3, 256)), dim3(256), 0, lz_st(stream), image, weights_sum, bg, bg_scalar, N, out,
+                       out_rgb24);
+    LZ_CHECK_LAUNCH("final_blend_rgb24");
     return LZ_OK;
 }

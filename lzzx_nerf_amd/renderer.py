@@ -156,7 +156,7 @@ class TriplaneRenderer:
 
     @torch.no_grad()
     def render(self, rays_o, rays_d, enc_a, ind_code=None, eye=None, dt_gamma=1.0 / 256, max_steps=16, T_thresh=1e-4,
-               bg_color=1.0, count_samples=False, sync_free=True):
+               bg_color=1.0, count_samples=False, sync_free=True, rgb24=False):
         """rays_o, rays_d: [N,3] (or [1,N,3]) f32 cuda.  Returns dict(image [N,3] blended+clamped, weights_sum, depth,
         amb_aud_sum, amb_eye_sum, uncertainty_sum, state (device int32[8]), ray_counts if requested).
         sync_free: the host never waits for the newest work, only for the chunk `lookahead` chunks back (the GPU
@@ -207,9 +207,16 @@ class TriplaneRenderer:
             bg = bg_color.to(rays_o.device, torch.float32).expand(N, 3).contiguous()
         else:
             bg_scalar = float(bg_color)
-        call("lz_final_blend", ptr(b.image), ptr(b.weights_sum), ptr(bg), bg_scalar, N, ptr(b.out), stream())
+        if rgb24:   # + the video pipe's hand-off format, quantised on device (TrainerUtil.py:550-555)
+            if getattr(b, "out_rgb24", None) is None:
+                b.out_rgb24 = torch.empty(N, 3, dtype=torch.uint8, device=rays_o.device)
+            call("lz_final_blend_rgb24", ptr(b.image), ptr(b.weights_sum), ptr(bg), bg_scalar, N, ptr(b.out), ptr(b.out_rgb24), stream())
+        else:
+            call("lz_final_blend", ptr(b.image), ptr(b.weights_sum), ptr(bg), bg_scalar, N, ptr(b.out), stream())
         res = dict(image=b.out, image_raw=b.image, weights_sum=b.weights_sum, depth=b.depth, amb_aud_sum=b.amb_aud_sum,
                    amb_eye_sum=b.amb_eye_sum, uncertainty_sum=b.unc_sum, state=b.state, nears=b.nears, fars=b.fars)
         if count_samples:
             res["ray_counts"] = b.ray_counts
+        if rgb24:
+            res["image_rgb24"] = b.out_rgb24
         return res

@@ -621,6 +621,18 @@ def test_render_loop_python_driven_equals_native(params, golden):
     assert torch.equal(a["state"][:8], b["state"][:8]) and int(a["state"][72]) == int(b["state"][72]) and len(r2._head_events) >= int(b["state"][6])
 
 
+def test_render_rgb24_handoff(params, golden):
+    """the frame quantised on device equals (pred * 255).astype(np.uint8) of the f32 frame"""
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    H = W = 48
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    r = TriplaneRenderer(_head(_scene(params, 40.0)), dev(ellipsoid_bitfield()[0]), bound=1.0)
+    out = r.render(dev(ro), dev(rd), dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]), max_steps=48, rgb24=True)
+    f32 = host(out["image"])
+    assert np.array_equal(host(out["image_rgb24"]), (f32 * 255).astype(np.uint8)) and len(np.unique(host(out["image_rgb24"]))) > 8
+
+
 def test_render_frame_f16_head(params, golden):
     """whole frame with the f16 head: PSNR against the f32 checker image, marching (independent of the head) unchanged"""
     from lzzx_nerf_amd.renderer import TriplaneRenderer
