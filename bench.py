@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_SAMPLE = 46368          # 23 184 MAC per sample, inference head
-ISSUED_FLOP_PER_ROW = 405 * 2048 // 16   # the head issues 405 v_mfma_f32_16x16x4_f32 (2048 FLOP each) per 16-row slice
+ISSUED_FLOP_PER_ROW = 361 * 2048 // 16   # the head issues 361 v_mfma_f32_16x16x4_f32 (2048 FLOP each) per 16-row slice
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
 

@@ -149,7 +149,7 @@ int lz_get_rays(const float* pose, float fx, float fy, float cx, float cy, uint3
 /* Fused triplane head: xyz -> 3 x hash-grid (D=2, L=12, C=1) -> aud/eye attention -> sigma net -> SH(4) -> colour net.
  * Weights are consumed in the packed "A-fragment" layout produced by lz_head_pack_weights; all arithmetic is f32
  * (v_mfma_f32_16x16x4_f32), summation order documented in DESIGN.md.  See network.py:252-311. */
-#define LZ_HEAD_PACKED_FLOATS 27584 /* 431 A-fragments x 64 lanes */
+#define LZ_HEAD_PACKED_FLOATS 24576 /* 379 A-fragments x 64 lanes + 320 floats of VALU-layer rows */
 #define LZ_HEAD_PACKED_F16_BYTES 60416 /* f16 head: 59 A-fragments x 64 lanes x 8 halfs */
 typedef struct {
     const float* emb_xy;      /* [163584] tables of the three planes (device) */

@@ -30,22 +30,25 @@
 typedef float lz_f4 __attribute__((ext_vector_type(4)));
 
 // ---- packed layout: layer table (fragment offsets) ----
-enum {
-    LZ_L_A1 = 0, LZ_L_A2, LZ_L_E1, LZ_L_E2, LZ_L_NRM, LZ_L_S1, LZ_L_S2, LZ_L_S3, LZ_L_C1, LZ_L_C2, LZ_L_U1, LZ_L_U2, LZ_L_COUNT
-};
-//                                    A1  A2  E1 E2 NRM S1  S2  S3  C1  C2  U1 U2
-constexpr int LZ_KS[LZ_L_COUNT] = {   9, 16,  9, 4,  8, 18, 16, 16, 21, 16,  9, 8 };
-constexpr int LZ_NT[LZ_L_COUNT] = {   4,  2,  1, 1,  1,  4,  4,  5,  4,  1,  2, 1 };
+// Layers on the matrix cores.  The skinny ones (eye_att 16 -> 1, sigma row of sigma_net.2, colour 64 -> 3, unc 32 -> 1, and
+// the sum of squares behind ||att||) would each burn whole 16-row MFMA tiles for 1-3 useful rows (44 of 405 MFMAs per slice);
+// they run on the VALU instead (lz_lane_dot), concurrently with the other waves' MFMAs.
+enum { LZ_L_A1 = 0, LZ_L_A2, LZ_L_E1, LZ_L_S1, LZ_L_S2, LZ_L_S3, LZ_L_C1, LZ_L_U1, LZ_L_COUNT };
+//                                    A1  A2  E1  S1  S2  S3  C1  U1
+constexpr int LZ_KS[LZ_L_COUNT] = {   9, 16,  9, 18, 16, 16, 21,  9 };
+constexpr int LZ_NT[LZ_L_COUNT] = {   4,  2,  1,  4,  4,  4,  4,  2 };
 constexpr int lz_frag_base(int layer) {
     int b = 0;
     for (int i = 0; i < layer; i++) b += LZ_KS[i] * LZ_NT[i];
     return b;
 }
-constexpr int LZ_FRAGS_INFER = lz_frag_base(LZ_L_U1);   // 405
-constexpr int LZ_FRAGS_ALL = lz_frag_base(LZ_L_COUNT);  // 431
-static_assert(LZ_FRAGS_ALL * 64 == LZ_HEAD_PACKED_FLOATS, "packed size mismatch with the header");
+constexpr int LZ_FRAGS_INFER = lz_frag_base(LZ_L_U1);   // 361
+constexpr int LZ_FRAGS_ALL = lz_frag_base(LZ_L_COUNT);  // 379
+// VALU-layer weights, plain rows indexed by input feature, after the fragments: colour.1 [3][64], sigma row [64], eye.1 [16], unc.1 [32]
+constexpr int LZ_WV_C2 = 0, LZ_WV_SIG = 192, LZ_WV_E2 = 256, LZ_WV_U2 = 272, LZ_WV_FLOATS = 320;
+static_assert(LZ_FRAGS_ALL * 64 + LZ_WV_FLOATS == LZ_HEAD_PACKED_FLOATS, "packed size mismatch with the header");
 
-extern "C" uint32_t lz_head_packed_size(void) { return (uint32_t)LZ_FRAGS_ALL * 64u; }
+extern "C" uint32_t lz_head_packed_size(void) { return (uint32_t)LZ_HEAD_PACKED_FLOATS; }
 
 // ---- weight packing -------------------------------------------------------------------------------
 __device__ __forceinline__ int lz_chained(int slot, int K) {  // slot -> feature in the chained order
@@ -55,15 +58,26 @@ __device__ __forceinline__ int lz_chained(int slot, int K) {  // slot -> feature
 }
 
 struct LzPackArgs {
-    const float* w[LZ_L_COUNT];  // source weight [nout, ld] per layer (NRM: unused)
+    const float* w[LZ_L_COUNT];  // source weight [nout, ld] per MFMA layer
     int nout[LZ_L_COUNT];
     int ld[LZ_L_COUNT];
+    const float *eye1, *col1, *unc1;   // VALU layers: [1,16], [3,64], [1,32]
     int has_eye, has_ind;
 };
 
 __global__ void __launch_bounds__(256) lz_k_head_pack(LzPackArgs a, float* __restrict__ packed) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= LZ_FRAGS_ALL * 64) return;
+    if (gid >= LZ_HEAD_PACKED_FLOATS) return;
+    if (gid >= LZ_FRAGS_ALL * 64) {   // VALU-layer rows
+        const int i = gid - LZ_FRAGS_ALL * 64;
+        float v = 0.0f;
+        if (i < LZ_WV_SIG) v = a.col1[i];                                                      // colour.1 [3][64]
+        else if (i < LZ_WV_E2) v = a.w[LZ_L_S3][i - LZ_WV_SIG];                                // row 0 of sigma_net.2
+        else if (i < LZ_WV_U2) v = (a.has_eye && a.eye1) ? a.eye1[i - LZ_WV_E2] : 0.0f;        // eye.1 [16]
+        else if (i < LZ_WV_U2 + 32) v = a.unc1 ? a.unc1[i - LZ_WV_U2] : 0.0f;                  // unc.1 [32]
+        packed[gid] = v;
+        return;
+    }
     const int frag = gid >> 6, lane = gid & 63;
     int layer = 0, fb = 0;
     for (int i = 0; i < LZ_L_COUNT; i++) {
@@ -77,9 +91,7 @@ __global__ void __launch_bounds__(256) lz_k_head_pack(LzPackArgs a, float* __res
     int kf;  // input feature of this k slot, -1 = padding
     switch (layer) {
         case LZ_L_A1: case LZ_L_E1: case LZ_L_U1: kf = slot < 36 ? slot : -1; break;
-        case LZ_L_A2: case LZ_L_S2: case LZ_L_S3: case LZ_L_C2: kf = lz_chained(slot, 64); break;
-        case LZ_L_E2: kf = lz_chained(slot, 16); break;
-        case LZ_L_NRM: case LZ_L_U2: kf = lz_chained(slot, 32); break;
+        case LZ_L_A2: case LZ_L_S2: case LZ_L_S3: kf = lz_chained(slot, 64); break;
         case LZ_L_S1:
             if (slot < 36) kf = slot;
             else if (slot < 68) kf = 36 + lz_chained(slot - 36, 32);
@@ -92,13 +104,10 @@ __global__ void __launch_bounds__(256) lz_k_head_pack(LzPackArgs a, float* __res
             break;
     }
     int srow;  // source row of the weight matrix, -1 = padding row
-    if (layer == LZ_L_S3) srow = row < 64 ? row + 1 : (row == 64 ? 0 : -1);  // geo rows first, sigma row in tile 4
+    if (layer == LZ_L_S3) srow = row < 64 ? row + 1 : -1;  // the 64 geo rows; the sigma row (0) is a VALU layer
     else srow = row < a.nout[layer] ? row : -1;
     float v = 0.0f;
-    if (kf >= 0 && srow >= 0) {
-        if (layer == LZ_L_NRM) v = 1.0f;
-        else if (a.w[layer]) v = a.w[layer][(size_t)srow * a.ld[layer] + kf];
-    }
+    if (kf >= 0 && srow >= 0 && a.w[layer]) v = a.w[layer][(size_t)srow * a.ld[layer] + kf];
     packed[gid] = v;
 }
 
@@ -108,12 +117,13 @@ extern "C" int lz_head_pack_weights(const float* aud0, const float* aud1, const 
     LZ_REQUIRE(aud0 && aud1 && sig0 && sig1 && sig2 && col0 && col1 && packed, LZ_ERR_BAD_ARGUMENT, "head_pack_weights: null weight");
     LZ_REQUIRE(!has_eye || (eye0 && eye1), LZ_ERR_BAD_ARGUMENT, "head_pack_weights: eye weights required when has_eye");
     LzPackArgs a;
-    const float* w[LZ_L_COUNT] = {aud0, aud1, eye0, eye1, nullptr, sig0, sig1, sig2, col0, col1, unc0, unc1};
-    const int nout[LZ_L_COUNT] = {64, 32, 16, 1, 1, 64, 64, 65, 64, 3, 32, 1};
-    const int ld[LZ_L_COUNT] = {36, 64, 36, 16, 32, 68 + (has_eye ? 1 : 0), 64, 64, 80 + (has_ind ? 4 : 0), 64, 36, 32};
+    const float* w[LZ_L_COUNT] = {aud0, aud1, eye0, sig0, sig1, sig2, col0, unc0};
+    const int nout[LZ_L_COUNT] = {64, 32, 16, 64, 64, 65, 64, 32};
+    const int ld[LZ_L_COUNT] = {36, 64, 36, 68 + (has_eye ? 1 : 0), 64, 64, 80 + (has_ind ? 4 : 0), 36};
     for (int i = 0; i < LZ_L_COUNT; i++) { a.w[i] = w[i]; a.nout[i] = nout[i]; a.ld[i] = ld[i]; }
+    a.eye1 = eye1; a.col1 = col1; a.unc1 = unc1;
     a.has_eye = has_eye; a.has_ind = has_ind;
-    hipLaunchKernelGGL(lz_k_head_pack, dim3(lz_div_up((uint64_t)LZ_FRAGS_ALL * 64, 256)), dim3(256), 0, lz_st(stream), a, packed);
+    hipLaunchKernelGGL(lz_k_head_pack, dim3(lz_div_up((uint64_t)LZ_HEAD_PACKED_FLOATS, 256)), dim3(256), 0, lz_st(stream), a, packed);
     LZ_CHECK_LAUNCH("head_pack_weights");
     return LZ_OK;
 }
@@ -155,6 +165,22 @@ __device__ __forceinline__ void lz_layer(const float* __restrict__ wl, int lane,
 
 __device__ __forceinline__ float lz_relu(float v) { return v > 0.0f ? v : 0.0f; }
 
+// VALU layer: dot product of a weight row with an activation vector held in the chained layout (lane q of a sample holds
+// x[4 t + r] = feature 16 t + 4 q + r, t < NTILE).  Each lane runs an fma chain over its features in (t, r) order, then the four
+// lanes of the sample are combined as (p0 + p1) + (p2 + p3) (two xor shuffles; f32 addition commutes, so every lane ends with the
+// same bits).  This order is what oracle/head.py restates (lzo_linear_lanes).
+template <int NTILE>
+__device__ __forceinline__ float lz_lane_dot(const float* __restrict__ wrow, int q, const float (&x)[4 * NTILE]) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NTILE; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc = lz_fmaf(wrow[16 * t + 4 * q + r], x[4 * t + r], acc);
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    return acc;
+}
+
 // diagnostic: shader-clock cycles (s_memtime) and 100 MHz wall ticks (s_memrealtime) that wave 0 of workgroup 0 of the most
 // recent launch spent in the kernel -> the sustained shader clock under this kernel's load (lz_debug_head_clocks)
 __device__ unsigned long long lz_head_probe[2];
@@ -165,7 +191,8 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
                    const int* __restrict__ count, float* __restrict__ sigmas, float* __restrict__ rgbs,
                    float* __restrict__ amb_aud, float* __restrict__ amb_eye, float* __restrict__ unc_out) {
     constexpr int NFRAG = TRAIN_UNC ? LZ_FRAGS_ALL : LZ_FRAGS_INFER;
-    __shared__ float wl[NFRAG * 64 + 96];  // packed A fragments, level table (64 words), enc_a (32)
+    constexpr int WV = NFRAG * 64, TAB = WV + LZ_WV_FLOATS;
+    __shared__ float wl[TAB + 96];  // packed A fragments, VALU-layer rows, level table (64 words), enc_a (32)
     uint32_t Meff = M;
     if (count) {
         const int c = *count;
@@ -186,21 +213,22 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
         const float4* src = reinterpret_cast<const float4*>(P.packed);
         float4* dst = reinterpret_cast<float4*>(wl);
         for (int i = threadIdx.x; i < NFRAG * 16; i += LZ_WG) dst[i] = src[i];
+        if (threadIdx.x < LZ_WV_FLOATS) wl[WV + threadIdx.x] = P.packed[LZ_FRAGS_ALL * 64 + threadIdx.x];
         // per-level table (indexed per lane in the gather): [0,13) offsets, [16,28) scale, [32,44) resolution
-        int* tab = reinterpret_cast<int*>(wl + NFRAG * 64);
+        int* tab = reinterpret_cast<int*>(wl + TAB);
         if (threadIdx.x < 13) tab[threadIdx.x] = P.offsets[threadIdx.x];
         if (threadIdx.x < 12) {
-            wl[NFRAG * 64 + 16 + threadIdx.x] = P.scale[threadIdx.x];
+            wl[TAB + 16 + threadIdx.x] = P.scale[threadIdx.x];
             tab[32 + threadIdx.x] = (int)P.res[threadIdx.x];
         }
-        if (threadIdx.x < 32) wl[NFRAG * 64 + 64 + threadIdx.x] = P.enc_a[threadIdx.x];
+        if (threadIdx.x < 32) wl[TAB + 64 + threadIdx.x] = P.enc_a[threadIdx.x];
         if (threadIdx.x == 0) tab[48] = 0;   // slice queue head (see the tile loop)
     }
     __syncthreads();
-    const int* offs = reinterpret_cast<const int*>(wl + NFRAG * 64);
-    const float* lscale = wl + NFRAG * 64 + 16;
+    const int* offs = reinterpret_cast<const int*>(wl + TAB);
+    const float* lscale = wl + TAB + 16;
     const int* lres = offs + 32;
-    const float* lenca = wl + NFRAG * 64 + 64;
+    const float* lenca = wl + TAB + 64;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
@@ -212,7 +240,7 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
     // Work distribution: the workgroup owns slices [slice_lo, slice_hi); its 16 waves pull 16-sample slices from a queue
     // in LDS (one ds_add_rtn per slice).  The waves that share a SIMD drift apart: some gather (texture-address bound)
     // while another feeds the matrix pipe, instead of all gathering and then all multiplying in lockstep.
-    int* queue = reinterpret_cast<int*>(wl + NFRAG * 64) + 48;
+    int* queue = reinterpret_cast<int*>(wl + TAB) + 48;
     for (;;) {
         int slice = 0;
         if (lane == 0) slice = atomicAdd(queue, 1);
@@ -328,20 +356,16 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
 #pragma unroll
                     for (int r = 0; r < 4; r++) att[j][4 * ft + r] = acc2[ft][j][r];
         }
-        // ambient_aud = || att ||_2 : sum of squares as a ones-row MFMA in the chained order, sqrt on lanes q == 0
+        // ambient_aud = || att ||_2 : sum of squares in the lane-partial order (att is its own weight row), then sqrt
         float ambaud[LZ_T];
-        {
-            float sq[LZ_T][8];
 #pragma unroll
-            for (int j = 0; j < LZ_T; j++)
+        for (int j = 0; j < LZ_T; j++) {
+            float acc = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 8; k++) sq[j][k] = att[j][k] * att[j][k];
-            lz_f4 accn[1][LZ_T];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) accn[0][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_NRM, LZ_T>(wl, lane, sq, accn);
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) ambaud[j] = sqrtf(accn[0][j][0]);
+            for (int k = 0; k < 8; k++) acc = lz_fmaf(att[j][k], att[j][k], acc);
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            ambaud[j] = sqrtf(acc);
         }
         // ---------------- eye attention: 36 -> 16 -> 1, sigmoid ----------------
         float eyeatt[LZ_T];
@@ -357,12 +381,8 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
             for (int j = 0; j < LZ_T; j++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) be[j][r] = lz_relu(acce[0][j][r]);
-            lz_f4 acce2[1][LZ_T];
 #pragma unroll
-            for (int j = 0; j < LZ_T; j++) acce2[0][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_E2, LZ_T>(wl, lane, be, acce2);
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) eyeatt[j] = lz_sigmoidf(acce2[0][j][0]);  // valid on lanes q == 0
+            for (int j = 0; j < LZ_T; j++) eyeatt[j] = lz_sigmoidf(lz_lane_dot<1>(wl + WV + LZ_WV_E2, q, be[j]));
         }
         // ---------------- uncertainty ----------------
         float uncv[LZ_T];
@@ -380,12 +400,8 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
                 for (int ft = 0; ft < 2; ft++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) bu[j][4 * ft + r] = lz_relu(accu[ft][j][r]);
-            lz_f4 accu2[1][LZ_T];
 #pragma unroll
-            for (int j = 0; j < LZ_T; j++) accu2[0][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_U2, LZ_T>(wl, lane, bu, accu2);
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) uncv[j] = lz_softplusf(accu2[0][j][0]);
+            for (int j = 0; j < LZ_T; j++) uncv[j] = lz_softplusf(lz_lane_dot<2>(wl + WV + LZ_WV_U2, q, bu[j]));
         } else {
 #pragma unroll
             for (int j = 0; j < LZ_T; j++) uncv[j] = lz_softplusf(0.0f);   // network.py:243-249, 278
@@ -431,9 +447,9 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
                 for (int ft = 0; ft < 4; ft++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) b3[j][4 * ft + r] = lz_relu(acc2[ft][j][r]);
-            lz_f4 acc3[5][LZ_T];
+            lz_f4 acc3[4][LZ_T];
 #pragma unroll
-            for (int ft = 0; ft < 5; ft++)
+            for (int ft = 0; ft < 4; ft++)
 #pragma unroll
                 for (int j = 0; j < LZ_T; j++) acc3[ft][j] = lz_f4{0, 0, 0, 0};
             lz_layer<LZ_L_S3, LZ_T>(wl, lane, b3, acc3);
@@ -443,7 +459,7 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
                 for (int ft = 0; ft < 4; ft++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) geo[j][4 * ft + r] = acc3[ft][j][r];   // geo_feat, no activation (network.py:304)
-                sigma[j] = lz_expf(acc3[4][j][0]);                                     // lanes q == 0
+                sigma[j] = lz_expf(lz_lane_dot<4>(wl + WV + LZ_WV_SIG, q, b3[j]));     // row 0 of sigma_net.2 on the VALU
             }
         }
         // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
@@ -477,14 +493,11 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
                 for (int ft = 0; ft < 4; ft++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
-            lz_f4 acc2[1][LZ_T];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) acc2[0][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_C2, LZ_T>(wl, lane, b2, acc2);
 #pragma unroll
             for (int j = 0; j < LZ_T; j++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) rgb[j][c] = lz_sigmoidf(acc2[0][j][c]) * 1.002f - 0.001f;   // network.py:275
+                for (int c = 0; c < 3; c++)   // colour_net.1 (64 -> 3) on the VALU; network.py:275
+                    rgb[j][c] = lz_sigmoidf(lz_lane_dot<4>(wl + WV + LZ_WV_C2 + 64 * c, q, b2[j])) * 1.002f - 0.001f;
         }
         // ---------------- store (lanes q == 0 own sample (j, s)) ----------------
         if (q == 0) {

@@ -106,6 +106,31 @@ void lzo_linear(const float* x, uint32_t ldx, const float* W, uint32_t ldw, cons
     }
 }
 
+/* "lane-partial" order of the VALU layers of the fused head (csrc/lz_head.hip, lz_lane_dot): the four lanes q that share a
+ * sample each run an fma chain, in the order t = 0.., r = 0..3, over the features f = 16 t + 4 q + r they hold; the partials
+ * are combined as (p0 + p1) + (p2 + p3).  W == NULL: the weight row is x itself (sum of squares behind ||att||). */
+void lzo_linear_lanes(const float* x, uint32_t ldx, const float* W, uint32_t ldw, uint32_t K, uint32_t B, uint32_t N, float* y,
+                      uint32_t ldy) {
+#pragma omp parallel for schedule(static)
+    for (uint32_t b = 0; b < B; b++) {
+        const float* xb = x + (size_t)b * ldx;
+        for (uint32_t n = 0; n < N; n++) {
+            const float* w = W ? W + (size_t)n * ldw : xb;
+            float p[4];
+            for (uint32_t q = 0; q < 4; q++) {
+                float acc = 0.0f;
+                for (uint32_t t = 0; 16 * t < K; t++)
+                    for (uint32_t r = 0; r < 4; r++) {
+                        const uint32_t f = 16 * t + 4 * q + r;
+                        if (f < K) acc = lz_fmaf(w[f], xb[f], acc);
+                    }
+                p[q] = acc;
+            }
+            y[(size_t)b * ldy + n] = (p[0] + p[1]) + (p[2] + p[3]);
+        }
+    }
+}
+
 /* elementwise deterministic transcendentals over a vector (op: 0 exp, 1 sigmoid, 2 softplus, 3 sin, 4 log) */
 void lzo_vec_unary(int op, const float* x, float* y, size_t n) {
 #pragma omp parallel for schedule(static)

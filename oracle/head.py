@@ -83,17 +83,17 @@ def density(spec, P, enc_x, enc_a, eye):
     eye_att = None
     if eye is not None:
         e1 = O.linear(enc_x, P["eye_att_net.net.0.weight"], korder_natural(36), relu=True)
-        e2 = O.linear(e1, P["eye_att_net.net.1.weight"], korder_chained(16))
+        e2 = O.linear_lanes(e1, P["eye_att_net.net.1.weight"])                 # VALU layer (csrc/lz_head.hip: lz_lane_dot)
         eye_att = O.unary("sigmoid", e2)
         parts.append(np.asarray(eye, dtype=F32).reshape(1, 1) * eye_att)
         order = order + [68, -1, -1, -1]
     h = np.ascontiguousarray(np.concatenate(parts, axis=1))
     s1 = O.linear(h, P["sigma_net.net.0.weight"], order, relu=True)
     s2 = O.linear(s1, P["sigma_net.net.1.weight"], korder_chained(64), relu=True)
-    s3 = O.linear(s2, P["sigma_net.net.2.weight"], korder_chained(64))
-    sigma = O.unary("exp", np.ascontiguousarray(s3[:, 0]))
-    geo = np.ascontiguousarray(s3[:, 1:])
-    sumsq = O.linear(att * att, np.ones((1, 32), dtype=F32), korder_chained(32))
+    W3 = P["sigma_net.net.2.weight"]
+    geo = O.linear(s2, np.ascontiguousarray(W3[1:]), korder_chained(64))       # 64 geo rows on the matrix cores
+    sigma = O.unary("exp", np.ascontiguousarray(O.linear_lanes(s2, np.ascontiguousarray(W3[:1]))[:, 0]))   # sigma row: VALU layer
+    sumsq = O.linear_lanes(att)                                                # sum of squares, lane-partial order
     amb_aud = np.sqrt(sumsq).astype(F32)
     return dict(sigma=sigma, geo_feat=geo, ambient_aud=amb_aud, ambient_eye=eye_att, enc_x=enc_x)
 
@@ -112,14 +112,14 @@ def head_forward(spec, P, xyz, dirs, enc_a, ind_code, eye, testing=True, unc_los
         order = order + korder_natural(c.shape[1], base=80)
     h = np.ascontiguousarray(np.concatenate(parts, axis=1))
     c1 = O.linear(h, P["color_net.net.0.weight"], order, relu=True)
-    c2 = O.linear(c1, P["color_net.net.1.weight"], korder_chained(64))
+    c2 = O.linear_lanes(c1, P["color_net.net.1.weight"])                       # VALU layer
     rgb = O.unary("sigmoid", c2) * F32(1 + 2 * 0.001) - F32(0.001)
     M = enc_x.shape[0]
     if testing or not unc_loss:
         unc = np.full((M, 1), O.unary("softplus", np.zeros(1, F32))[0], dtype=F32)
     else:
         u1 = O.linear(enc_x, P["unc_net.net.0.weight"], korder_natural(36), relu=True)
-        u2 = O.linear(u1, P["unc_net.net.1.weight"], korder_chained(32))
+        u2 = O.linear_lanes(u1, P["unc_net.net.1.weight"])                     # VALU layer
         unc = O.unary("softplus", u2)
     return dres["sigma"], rgb.astype(F32), dres["ambient_aud"], dres["ambient_eye"], unc
 

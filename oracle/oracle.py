@@ -156,6 +156,21 @@ def freq_encode_backward(grad, outputs, input_dim, degree):
 # ----------------------------------------------------------------------------------------------
 # linear / elementwise
 # ----------------------------------------------------------------------------------------------
+def linear_lanes(x, W=None):
+    """y = x @ W.T in the lane-partial order of the fused head's VALU layers (lzo_linear_lanes); W None: sum of squares of x"""
+    x = _f32(x)
+    B, K = x.shape
+    if W is None:
+        N, ldw, wp = 1, 0, None
+    else:
+        W = _f32(W)
+        N, ldw, wp = W.shape[0], K, W
+        assert W.shape[1] == K
+    y = np.empty((B, N), dtype=np.float32)
+    lib().lzo_linear_lanes(_p(x), u32(K), _p(wp), u32(ldw), u32(K), u32(B), u32(N), _p(y), u32(N))
+    return y
+
+
 def linear(x, W, korder=None, relu=False):
     """y = x @ W.T as an fma chain in the given order (network.py:73-94; bias-free)."""
     x = _f32(x)

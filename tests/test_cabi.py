@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.ALL_SYMBOLS) == _declared()
     bound = _lib.load()
     assert bound.lz_abi_version() == 2
-    assert bound.lz_head_packed_size() == 27584
+    assert bound.lz_head_packed_size() == 24576 and bound.lz_head_packed_size_f16() == 60416
 
 
 def test_missing_library_fails_loudly(monkeypatch):
