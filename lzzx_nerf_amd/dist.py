@@ -18,10 +18,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        if backend is None:   # LZ_DIST_BACKEND=gloo: rehearse the multi-process path on a box with fewer GPUs than ranks
+            backend = os.environ.get("LZ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" is RCCL on ROCm
+        if torch.cuda.is_available():
+            local = int(os.environ.get("LOCAL_RANK", rank))
+            torch.cuda.set_device(local % torch.cuda.device_count() if backend != "nccl" else local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
 
