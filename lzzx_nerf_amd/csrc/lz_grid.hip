@@ -655,6 +655,91 @@ lz_k_grid_forward_lm(const float* __restrict__ inputs, const T* __restrict__ gri
     __builtin_memcpy(__builtin_assume_aligned(out, sizeof(T) * C), &o, sizeof(T) * C);
 }
 
+// The same pass with TWO lanes per sample: lane pair (2t, 2t+1) splits the 2^D corners by their x bit.  The x and x+1 corners of
+// a cell sit in the same 128-byte line almost always (dense levels: adjacent entries; hashed levels: prime_x = 1, so the two
+// indices differ by x ^ (x+1), within 16 entries 94 % of the time), and the texture-address unit processes one line per clock:
+// putting both corners in ONE load instruction halves the lines per instruction (64 -> ~34).  The partner's values come back
+// through a DPP lane swap and the even lane runs the fma chain in the reference's corner order, so results stay bit-identical.
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(512)
+lz_k_grid_forward_lmp(const float* __restrict__ inputs, const T* __restrict__ grid, const int* __restrict__ offsets,
+                      T* __restrict__ outputs, uint32_t B, uint32_t L, LzGridLevels lv, uint32_t gridtype, bool align_corners) {
+    constexpr uint32_t NC = 1u << (D - 1), WORDS = sizeof(T) * C / 4;
+    static_assert(sizeof(T) * C % 4 == 0, "pair kernel moves whole dwords");
+    const uint32_t Tn = blockDim.x >> 1, tile = blockIdx.x, level = blockIdx.y, t = threadIdx.x >> 1, xb = threadIdx.x & 1u;
+    const uint32_t b0 = tile * Tn;
+    const uint32_t n = (B - b0 < Tn) ? B - b0 : Tn;
+    if (t >= n) return;   // pair-uniform
+    const uint32_t b = b0 + t;
+    const uint32_t off0 = (uint32_t)offsets[level], hs = (uint32_t)offsets[level + 1] - off0;
+    const uint32_t resolution = lv.res[level];
+    const float scale = lv.scale[level];
+    const uint32_t mode = lz_grid_level_mode<D>(hs, resolution, gridtype, align_corners);
+    const T* g = grid + (size_t)off0 * C;
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        if (x[d] < 0 || x[d] > 1) oob = true;
+    }
+    float pos[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float xc = lz_fminf(lz_fmaxf(x[d], 0.0f), 1.0f);
+        pos[d] = lz_fmaf(xc, scale, align_corners ? 0.0f : 0.5f);
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+    }
+    uint32_t own[NC][WORDS], oth[NC][WORDS];
+#pragma unroll
+    for (uint32_t h = 0; h < NC; h++) {
+        const uint32_t idx = (h << 1) | xb;
+        uint32_t pl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1u);
+        uint32_t index;
+        if (mode == 2u) {
+            index = lz_grid_index<D>(C, gridtype, align_corners, hs, resolution, pl);
+        } else {
+            constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+            uint32_t lin = 0, hh = 0, stride = 1;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                lin += pl[d] * stride;
+                stride *= align_corners ? resolution : (resolution + 1);
+                hh ^= pl[d] * primes[d];
+            }
+            index = (mode == 1u ? (hh & (hs - 1u)) : lin) * C;
+        }
+        __builtin_memcpy(own[h], __builtin_assume_aligned(g + index, sizeof(T) * C), sizeof(T) * C);
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < NC; h++)
+#pragma unroll
+        for (uint32_t k = 0; k < WORDS; k++) oth[h][k] = (uint32_t)__shfl_xor((int)own[h][k], 1, 64);
+    if (xb != 0) return;
+    float res[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) res[ch] = 0.0f;
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float wc = 1.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) wc *= ((idx & (1u << d)) == 0) ? 1 - pos[d] : pos[d];
+        LzVec<T, C> cvv;
+        __builtin_memcpy(&cvv, (idx & 1u) ? oth[idx >> 1] : own[idx >> 1], sizeof(T) * C);
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) res[ch] = LzElem<T>::acc(res[ch], wc, LzElem<T>::ld(&cvv.v[ch]));
+    }
+    LzVec<T, C> o;
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) o.v[ch] = LzElem<T>::st(oob ? 0.0f : res[ch]);
+    T* out = outputs + ((size_t)b0 * L + (size_t)level * n + t) * C;
+    __builtin_memcpy(__builtin_assume_aligned(out, sizeof(T) * C), &o, sizeof(T) * C);
+}
+
 // one workgroup per tile; W = dwords per (sample, level) group = C * sizeof(T) / 4; the tile is [L][n][W] -> [n][L][W]
 __global__ void __launch_bounds__(256)
 lz_k_grid_untile(uint32_t* __restrict__ out, uint32_t B, uint32_t L, uint32_t W, uint32_t Tn, uint32_t pitch) {
@@ -681,7 +766,11 @@ static void lz_grid_lm_launch(const float* inputs, const T* emb, const int* offs
     const uint32_t LW = L * W;
     const uint32_t Tn = LW <= 64 ? 256u : (LW <= 128 ? 128u : 64u);      // tile <= 64 KB
     const uint32_t tiles = lz_div_up(B, Tn);
-    hipLaunchKernelGGL((lz_k_grid_forward_lm<T, D, C>), dim3(tiles, L), dim3(Tn), 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac);
+    if constexpr (sizeof(T) * C % 4 == 0 && D >= 3)   // two lanes per sample (x corner pairs share a line); measured: D3/C2 f32
+                                                      // 3.62 -> 3.29 ms, f16 3.05 -> 2.36 ms per 2^23 samples; D2/C1 gets slower
+        hipLaunchKernelGGL((lz_k_grid_forward_lmp<T, D, C>), dim3(tiles, L), dim3(2 * Tn), 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac);
+    else
+        hipLaunchKernelGGL((lz_k_grid_forward_lm<T, D, C>), dim3(tiles, L), dim3(Tn), 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac);
     // LDS row pitch: level l starts at bank (l * 64/L) so the 64 lanes of a store (64/LW samples x L levels x W) hit 64 banks
     const uint32_t want = L < 64 ? 64u / L : 1u;
     const uint32_t pitch = Tn * W + ((want + 64u - (Tn * W) % 64u) % 64u);
