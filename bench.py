@@ -388,6 +388,33 @@ def main():
         result["occupancy_grid_update"] = dict(ms=round((time.perf_counter() - t0) / 5 * 1e3, 3), cells=128 ** 3, cascade=1,
                                                mean_density=float(mean_d), launches=5, host_syncs=0)
         del dg, bf, nz
+    if world == 1 and not args.no_occupancy:
+        # torso branch of the frame (run_torso + forward_torso) as one kernel, 512 x 512 pixels, random weights
+        from lzzx_nerf_amd.torso import FusedTorso
+        from oracle import oracle as O_   # table layout helper only (offsets of the reference's tiled grid)
+        rngt = np.random.default_rng(7)
+        offs = O_.grid_offsets(2, 16, np.exp2(np.log2(2048 / 16) / 15), 16, 16)
+        lin = lambda n, k: torch.from_numpy((rngt.uniform(-1, 1, (n, k)) / np.sqrt(k)).astype(np.float32))
+        sdt = {"anchor_points": torch.tensor([[0.01, 0.01, 0.1, 1], [-0.1, -0.1, 0.1, 1], [0.1, -0.1, 0.1, 1]]),
+               "torso_deform_net.net.0.weight": lin(32, 84), "torso_deform_net.net.1.weight": lin(32, 32),
+               "torso_deform_net.net.2.weight": lin(2, 32), "torso_net.net.0.weight": lin(32, 116), "torso_net.net.1.weight": lin(32, 32),
+               "torso_net.net.2.weight": lin(4, 32), "torso_encoder.offsets": torch.from_numpy(offs.astype(np.int32)),
+               "torso_encoder.embeddings": torch.from_numpy(rngt.uniform(-1, 1, (int(offs[-1]), 2)).astype(np.float32))}
+        torso = FusedTorso(sdt, device=device)
+        lin1 = torch.linspace(-1, 1, H, device=device)
+        bgc = torch.stack(torch.meshgrid(lin1, lin1, indexing="xy"), -1).reshape(-1, 2).contiguous()
+        enc_anchor = torso.encode_anchor(dev(pose)[None])
+        indt = torch.zeros(8, device=device)
+        for _ in range(3):
+            torso(bgc, ind_code=indt, enc_anchor=enc_anchor)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ta, tc, _ = torso(bgc, ind_code=indt, enc_anchor=enc_anchor)
+        torch.cuda.synchronize()
+        result["torso_branch"] = dict(ms=round((time.perf_counter() - t0) / 20 * 1e3, 4), pixels=H * W, launches=1,
+                                      note="all pixels queried (no 2-D occupancy mask); 5.4 kMAC per pixel on the VALU")
+        del torso, bgc
     # ---- CPU baseline: the checker arranged like the reference loop, on a bounded sub-frame of the SAME rays ----
     if not args.no_cpu_baseline and world == 1:   # rank 0, N = 1 only
         from oracle.head import TriplaneSpec

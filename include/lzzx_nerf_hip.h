@@ -198,6 +198,31 @@ int lz_density_grid_points(const float* noise, uint32_t C, uint32_t G, float bou
 int lz_density_grid_update(const float* sigmas, float density_scale, float decay, float density_thresh, uint32_t C, uint32_t G,
                            float* density_grid, uint8_t* bitfield, float* stats, void* workspace, lz_stream_t stream);
 
+/* Torso branch of a frame: run_torso's masked query (nerf_triplane/renderer.py:572-631) + forward_torso
+ * (nerf_triplane/network.py:170-205) as one kernel, one lane per pixel.  All pointers are device pointers; weights are the
+ * reference's bias-free Linear matrices, row-major [out, in], input order [per-pixel features | anchor encoding 42 | ind code]:
+ *   deform net  34 + 42 + ind -> 32 -> 32 -> 2,   torso net  32 + 34 + 42 + ind -> 32 -> 32 -> 4.
+ * enc_anchor: the frame-constant frequency encoding of the wrapped anchor points (computed by the caller, network.py:179-183). */
+typedef struct {
+    const float *deform_w0, *deform_w1, *deform_w2;
+    const float *torso_w0, *torso_w1, *torso_w2;
+    const float* emb;            /* torso_encoder table [sO, 2] (tiledgrid D=2, L=16, C=2, network.py:166) */
+    const int32_t* offsets;      /* [17] */
+    const float* enc_anchor;     /* [42] */
+    const float* ind_code;       /* [ind_dim] or NULL */
+    uint32_t ind_dim;            /* 0 or 8 */
+    uint32_t gridtype;           /* 0 hash, 1 tiled */
+    float torso_shrink;          /* opt.torso_shrink */
+    float S;                     /* log2(per_level_scale) of the torso encoder */
+    uint32_t H;                  /* its base resolution (16) */
+    const float* density_grid;   /* density_grid_torso [G*G] or NULL: no masking */
+    uint32_t G;
+    float density_thresh;        /* min(density_thresh_torso, mean_density_torso), renderer.py:603 */
+} lz_torso_params;
+/* bg_coords [N,2] in [-1,1] -> alpha [N], color [N,3], deform [N,2] (may be NULL); unmasked pixels get zeros */
+int lz_torso_forward(const lz_torso_params* p, const float* bg_coords, uint32_t N, float* alpha, float* color, float* deform,
+                     lz_stream_t stream);
+
 /* Tall-skinny bias-free Linear for the training path of the heads (the reference's MLP, network.py:73-94, is a stack of
  * nn.Linear(bias=False) with K, N <= 84 over M ~ 1e6..1e7 samples; torch dispatches them to library GEMMs).  Row-major f32,
  * explicit leading dimensions (column slices of wider buffers are fine), v_mfma_f32_16x16x4_f32.

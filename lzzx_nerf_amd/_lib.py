@@ -18,6 +18,13 @@ class HeadParams(C.Structure):
                 ("ind_code", vp), ("eye", vp), ("bound", f32), ("S", f32), ("H", u32), ("testing", i32), ("precision", i32)]
 
 
+class TorsoParams(C.Structure):
+    """mirror of lz_torso_params (include/lzzx_nerf_hip.h)"""
+    _fields_ = [("deform_w0", vp), ("deform_w1", vp), ("deform_w2", vp), ("torso_w0", vp), ("torso_w1", vp), ("torso_w2", vp),
+                ("emb", vp), ("offsets", vp), ("enc_anchor", vp), ("ind_code", vp), ("ind_dim", u32), ("gridtype", u32),
+                ("torso_shrink", f32), ("S", f32), ("H", u32), ("density_grid", vp), ("G", u32), ("density_thresh", f32)]
+
+
 class Frame(C.Structure):
     """mirror of lz_frame (include/lzzx_nerf_hip.h)"""
     _fields_ = [("head", HeadParams), ("state", vp), ("workspace", vp), ("rays_alive", vp * 2), ("rays_t", vp), ("rays_o", vp),
@@ -65,6 +72,7 @@ SIGNATURES = {
     "lz_final_blend_rgb24": [vp, vp, vp, f32, u32, vp, vp, vp],
     "lz_debug_head_clocks": [C.POINTER(C.c_uint64)],
     "lz_head_pack_weights_f16": [vp] * 9 + [i32, i32, vp, vp],
+    "lz_torso_forward": [C.POINTER(TorsoParams), vp, u32, vp, vp, vp, vp],
     "lz_density_grid_points": [vp, u32, u32, f32, vp, vp],
     "lz_density_grid_update": [vp, f32, f32, f32, u32, u32, vp, vp, vp, vp, vp],
     "lz_linear_forward": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, i32, vp],

@@ -131,6 +131,11 @@ void lzo_linear_lanes(const float* x, uint32_t ldx, const float* W, uint32_t ldw
     }
 }
 
+/* elementwise y = fma(a, b, c) in f32 (numpy has no fused multiply-add) */
+void lzo_vec_fma(const float* a, const float* b, const float* c, float* y, size_t n) {
+    for (size_t i = 0; i < n; i++) y[i] = lz_fmaf(a[i], b[i], c[i]);
+}
+
 /* elementwise deterministic transcendentals over a vector (op: 0 exp, 1 sigmoid, 2 softplus, 3 sin, 4 log) */
 void lzo_vec_unary(int op, const float* x, float* y, size_t n) {
 #pragma omp parallel for schedule(static)

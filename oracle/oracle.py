@@ -156,6 +156,15 @@ def freq_encode_backward(grad, outputs, input_dim, degree):
 # ----------------------------------------------------------------------------------------------
 # linear / elementwise
 # ----------------------------------------------------------------------------------------------
+def fma(a, b, c):
+    """elementwise float32 fused multiply-add"""
+    a, b, c = np.broadcast_arrays(_f32(a), _f32(b), _f32(c))
+    a, b, c = np.ascontiguousarray(a), np.ascontiguousarray(b), np.ascontiguousarray(c)
+    y = np.empty_like(a)
+    lib().lzo_vec_fma(_p(a), _p(b), _p(c), _p(y), C.c_size_t(a.size))
+    return y
+
+
 def linear_lanes(x, W=None):
     """y = x @ W.T in the lane-partial order of the fused head's VALU layers (lzo_linear_lanes); W None: sum of squares of x"""
     x = _f32(x)

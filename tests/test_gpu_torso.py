@@ -1,0 +1,72 @@
+"""Torso branch: lzzx_nerf_amd.torso.FusedTorso (one kernel per frame) against the CPU restatement of
+run_torso / forward_torso (oracle/torso.py) on seeded weights: masks, alpha, colour and deformation bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from oracle.torso import run_torso
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def _torso_state(ind_dim, seed=0):
+    rng = np.random.default_rng(seed)
+    lin = lambda n, k: rng.uniform(-1, 1, (n, k)).astype(F32) / F32(np.sqrt(k))
+    pls = np.exp2(np.log2(2048 / 16) / 15)
+    offsets = O.grid_offsets(2, 16, pls, 16, 16)
+    K0 = 34 + 42 + ind_dim
+    sd = {"anchor_points": np.array([[0.01, 0.01, 0.1, 1], [-0.1, -0.1, 0.1, 1], [0.1, -0.1, 0.1, 1]], F32),
+          "torso_deform_net.net.0.weight": lin(32, K0), "torso_deform_net.net.1.weight": lin(32, 32),
+          "torso_deform_net.net.2.weight": lin(2, 32) * F32(0.2),
+          "torso_net.net.0.weight": lin(32, 32 + K0), "torso_net.net.1.weight": lin(32, 32), "torso_net.net.2.weight": lin(4, 32),
+          "torso_encoder.embeddings": rng.uniform(-1, 1, (int(offsets[-1]), 2)).astype(F32),
+          "torso_encoder.offsets": offsets.astype(np.int32)}
+    return sd
+
+
+@pytest.mark.parametrize("ind_dim,masked", [(8, True), (0, True), (8, False)])
+def test_fused_torso_matches_checker(ind_dim, masked):
+    from lzzx_nerf_amd.torso import FusedTorso
+    sd = _torso_state(ind_dim)
+    rng = np.random.default_rng(5)
+    H = W = 96
+    ys, xs = np.meshgrid(np.linspace(-1, 1, H, dtype=F32), np.linspace(-1, 1, W, dtype=F32), indexing="ij")
+    bg = np.stack([xs.ravel(), ys.ravel()], 1).astype(F32)                    # get_bg_coords: pixel grid in [-1, 1]
+    bg[:5] = [[-1, -1], [1, 1], [1, -1], [0, 0], [0.999999, -0.999999]]
+    G = 128
+    yy, xx = np.meshgrid(np.arange(G), np.arange(G), indexing="ij")
+    dens = np.exp(-(((xx - 64) / 30.0) ** 2 + ((yy - 80) / 40.0) ** 2)).astype(F32).reshape(-1)   # a torso-like blob
+    pose = np.eye(4, dtype=F32)
+    pose[:3, 3] = [0.05, -0.02, 3.3]
+    th = 0.1
+    pose[:3, :3] = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], F32)
+    ind = rng.normal(size=(1, ind_dim)).astype(F32) * F32(0.1) if ind_dim else None
+    torso = FusedTorso({k: torch.from_numpy(v) for k, v in sd.items()}, torso_shrink=0.8)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    enc_anchor = torso.encode_anchor(dev(pose[None]))                          # torch + the frequency operator, caller side
+    a_g, c_g, d_g = torso(dev(bg), ind_code=None if ind is None else dev(ind), density_grid=dev(dens) if masked else None,
+                          density_thresh=0.05, enc_anchor=enc_anchor)
+    a_o, c_o, d_o, mask = run_torso(sd, bg, enc_anchor.cpu().numpy().reshape(-1), ind, dens if masked else None, 0.05, 0.8)
+    assert np.array_equal(a_g.cpu().numpy(), a_o) and np.array_equal(c_g.cpu().numpy(), c_o) and np.array_equal(d_g.cpu().numpy(), d_o)
+    if masked:
+        assert 0.05 < mask.mean() < 0.95 and (a_o[~mask] == 0).all()
+    assert np.abs(d_o).max() > 1e-3 and a_o.max() > 0.3
+    # mixing with the background (renderer.py:621) feeds the head renderer's bg_color
+    mixed = FusedTorso.mix_background(a_g, c_g, 1.0)
+    assert mixed.shape == (H * W, 3) and bool(((mixed >= -0.01) & (mixed <= 1.01)).all())
+
+
+def test_torso_anchor_encoding_matches_numpy():
+    """network.py:179-183 on the caller side: anchors @ inverse(pose^T), perspective divide, frequency encoding (deg 3)"""
+    from lzzx_nerf_amd.torso import FusedTorso
+    sd = _torso_state(8)
+    torso = FusedTorso({k: torch.from_numpy(v) for k, v in sd.items()})
+    pose = np.eye(4, dtype=F32)
+    pose[:3, 3] = [0.1, 0.2, 3.0]
+    e = torso.encode_anchor(torch.from_numpy(pose[None]).cuda()).cpu().numpy().reshape(-1)
+    wa = sd["anchor_points"].astype(np.float64) @ np.linalg.inv(pose.T.astype(np.float64))
+    wa = (wa[:, :2] / wa[:, 3:4] / wa[:, 2:3]).reshape(1, -1).astype(F32)
+    ref = O.freq_encode_forward(wa, 3).reshape(-1)
+    assert e.shape == (42,) and np.allclose(e, ref, atol=2e-5)

@@ -444,3 +444,16 @@ def test_occupancy_update_restatement_small():
             assert grid[0, mi] == expect[(coords == c).all(1)][0]
     assert thresh == 0.25 and mean == pytest.approx(np.clip(grid, 0, None).mean())
     assert np.array_equal(np.unpackbits(bits, bitorder="little")[:64].astype(bool), grid[0] > 0.25)
+
+
+def test_torso_grid_sample_restatement_matches_torch():
+    """oracle/torso.py:grid_sample_2d (run_torso's occupancy lookup, renderer.py:604-605) vs torch's own F.grid_sample on the CPU"""
+    import torch
+    from oracle.torso import grid_sample_2d
+    rng = np.random.default_rng(0)
+    g = rng.uniform(0, 1, (128, 128)).astype(np.float32)
+    c = rng.uniform(-1.05, 1.05, (5000, 2)).astype(np.float32)
+    c[:3] = [[-1, -1], [1, 1], [0, 0]]
+    ref = torch.nn.functional.grid_sample(torch.from_numpy(g).view(1, 1, 128, 128), torch.from_numpy(c).view(1, -1, 1, 2),
+                                          mode="bilinear", padding_mode="zeros", align_corners=True).view(-1).numpy()
+    assert np.abs(grid_sample_2d(g, c) - ref).max() <= 1e-6
