@@ -391,9 +391,9 @@ def main():
     if world == 1 and not args.no_occupancy:
         # torso branch of the frame (run_torso + forward_torso) as one kernel, 512 x 512 pixels, random weights
         from lzzx_nerf_amd.torso import FusedTorso
-        from oracle import oracle as O_   # table layout helper only (offsets of the reference's tiled grid)
+        from lzzx_nerf_amd.gridencoder import grid_offsets
         rngt = np.random.default_rng(7)
-        offs = O_.grid_offsets(2, 16, np.exp2(np.log2(2048 / 16) / 15), 16, 16)
+        offs = np.asarray(grid_offsets(2, 16, np.exp2(np.log2(2048 / 16) / 15), 16, 16))
         lin = lambda n, k: torch.from_numpy((rngt.uniform(-1, 1, (n, k)) / np.sqrt(k)).astype(np.float32))
         sdt = {"anchor_points": torch.tensor([[0.01, 0.01, 0.1, 1], [-0.1, -0.1, 0.1, 1], [0.1, -0.1, 0.1, 1]]),
                "torso_deform_net.net.0.weight": lin(32, 84), "torso_deform_net.net.1.weight": lin(32, 32),
