@@ -415,6 +415,32 @@ def main():
         result["torso_branch"] = dict(ms=round((time.perf_counter() - t0) / 20 * 1e3, 4), pixels=H * W, launches=1,
                                       note="all pixels queried (no 2-D occupancy mask); 5.4 kMAC per pixel on the VALU")
         del torso, bgc
+        # encode_audio (AudioNet on 8 HuBERT windows [8, 1024, 16] + AudioAttNet) as one launch, random weights
+        from lzzx_nerf_amd.audio import FusedAudioEncoder
+        ga = torch.Generator().manual_seed(3)
+        sda = {}
+        for idx, (ci, co) in zip((0, 2, 4, 6), ((1024, 32), (32, 32), (32, 64), (64, 64))):
+            sda[f"audio_net.encoder_conv.{idx}.weight"] = (torch.rand(co, ci, 3, generator=ga) * 2 - 1) / (3 * ci) ** 0.5
+            sda[f"audio_net.encoder_conv.{idx}.bias"] = torch.zeros(co)
+        for idx, (ci, co) in zip((0, 2), ((64, 64), (64, 32))):
+            sda[f"audio_net.encoder_fc1.{idx}.weight"] = (torch.rand(co, ci, generator=ga) * 2 - 1) / ci ** 0.5
+            sda[f"audio_net.encoder_fc1.{idx}.bias"] = torch.zeros(co)
+        for idx, (ci, co) in zip((0, 2, 4, 6, 8), ((32, 16), (16, 8), (8, 4), (4, 2), (2, 1))):
+            sda[f"audio_att_net.attentionConvNet.{idx}.weight"] = (torch.rand(co, ci, 3, generator=ga) * 2 - 1) / (3 * ci) ** 0.5
+            sda[f"audio_att_net.attentionConvNet.{idx}.bias"] = torch.zeros(co)
+        sda["audio_att_net.attentionNet.0.weight"] = torch.eye(8)
+        sda["audio_att_net.attentionNet.0.bias"] = torch.zeros(8)
+        aenc = FusedAudioEncoder(sda, device=device)
+        auds = torch.randn(8, 1024, 16, device=device, generator=torch.Generator(device=device).manual_seed(4))
+        for _ in range(3):
+            aenc(auds)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            aenc(auds)
+        torch.cuda.synchronize()
+        result["audio_frontend"] = dict(ms=round((time.perf_counter() - t0) / 20 * 1e3, 4), windows=8, dim_in=1024, launches=1)
+        del aenc, auds
     # ---- CPU baseline: the checker arranged like the reference loop, on a bounded sub-frame of the SAME rays ----
     if not args.no_cpu_baseline and world == 1:   # rank 0, N = 1 only
         from oracle.head import TriplaneSpec

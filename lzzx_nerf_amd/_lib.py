@@ -25,6 +25,12 @@ class TorsoParams(C.Structure):
                 ("torso_shrink", f32), ("S", f32), ("H", u32), ("density_grid", vp), ("G", u32), ("density_thresh", f32)]
 
 
+class AudioParams(C.Structure):
+    """mirror of lz_audio_params (include/lzzx_nerf_hip.h)"""
+    _fields_ = [("c_w", vp * 4), ("c_b", vp * 4), ("fc_w", vp * 2), ("fc_b", vp * 2), ("ac_w", vp * 5), ("ac_b", vp * 5),
+                ("al_w", vp), ("al_b", vp), ("dim_in", u32), ("dim_aud", u32), ("n_win", u32), ("use_att", u32)]
+
+
 class Frame(C.Structure):
     """mirror of lz_frame (include/lzzx_nerf_hip.h)"""
     _fields_ = [("head", HeadParams), ("state", vp), ("workspace", vp), ("rays_alive", vp * 2), ("rays_t", vp), ("rays_o", vp),
@@ -73,6 +79,7 @@ SIGNATURES = {
     "lz_debug_head_clocks": [C.POINTER(C.c_uint64)],
     "lz_head_pack_weights_f16": [vp] * 9 + [i32, i32, vp, vp],
     "lz_torso_forward": [C.POINTER(TorsoParams), vp, u32, vp, vp, vp, vp],
+    "lz_audio_encode": [C.POINTER(AudioParams), vp, vp, vp],
     "lz_density_grid_points": [vp, u32, u32, f32, vp, vp],
     "lz_density_grid_update": [vp, f32, f32, f32, u32, u32, vp, vp, vp, vp, vp],
     "lz_linear_forward": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, i32, vp],
