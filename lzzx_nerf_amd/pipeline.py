@@ -1,0 +1,40 @@
+"""One inference frame end to end on device, in the order of `NeRFRenderer.run_cuda` / `run_cuda_for_inference`
+(/root/reference/nerf_triplane/renderer.py:406-570):
+
+    audio windows --encode_audio--> enc_a        (1 launch,  lzzx_nerf_amd.audio)
+    bg_coords, head pose --torso--> background   (1 launch,  lzzx_nerf_amd.torso; skipped without torso weights)
+    rays --march / head / composite loop--> rgb  (3 + 4 per iteration launches, lzzx_nerf_amd.renderer), blended over that background
+
+All stages read the reference's state_dict; nothing synchronises with the host except the render loop's bounded look-ahead."""
+import torch
+
+from .audio import FusedAudioEncoder
+from .head import FusedTriplaneHead
+from .renderer import TriplaneRenderer
+from .torso import FusedTorso
+
+
+class TalkingHeadFrame:
+    def __init__(self, state_dict, density_bitfield, bound=1.0, exp_eye=True, torso_shrink=0.8, precision="f32", device="cuda", **renderer_kw):
+        self.audio = FusedAudioEncoder(state_dict, device=device)
+        self.head = FusedTriplaneHead(state_dict, bound=bound, exp_eye=exp_eye, device=device, precision=precision)
+        self.torso = FusedTorso(state_dict, torso_shrink=torso_shrink, device=device) if "torso_net.net.0.weight" in state_dict else None
+        self.renderer = TriplaneRenderer(self.head, density_bitfield, bound=bound, **renderer_kw)
+
+    @torch.no_grad()
+    def render(self, rays_o, rays_d, auds, eye=None, ind_code=None, bg_coords=None, poses=None, ind_code_torso=None, bg_color=1.0,
+               density_grid_torso=None, density_thresh_torso=0.0, **render_kw):
+        """auds [8, dim_in, 16]; bg_color: scalar or [N,3]; returns the renderer's dict plus enc_a and (with a torso) torso_alpha,
+        torso_color (= the mixed background, as results['torso_color'] in run_torso) and deform."""
+        enc_a = self.audio(auds)                                                            # renderer.py:455-460
+        extra = dict(enc_a=enc_a)
+        if self.torso is not None and bg_coords is not None:
+            alpha, color, deform = self.torso(bg_coords, poses, ind_code_torso, density_grid=density_grid_torso,
+                                              density_thresh=density_thresh_torso)         # renderer.py:572-617
+            if not torch.is_tensor(bg_color):
+                bg_color = torch.full_like(color, float(bg_color))
+            bg_color = FusedTorso.mix_background(alpha, color, bg_color.reshape(-1, 3))     # renderer.py:621
+            extra.update(torso_alpha=alpha, torso_color=bg_color, deform=deform)
+        out = self.renderer.render(rays_o, rays_d, enc_a, ind_code, eye, bg_color=bg_color, **render_kw)
+        out.update(extra)
+        return out

@@ -70,3 +70,40 @@ def test_torso_anchor_encoding_matches_numpy():
     wa = (wa[:, :2] / wa[:, 3:4] / wa[:, 2:3]).reshape(1, -1).astype(F32)
     ref = O.freq_encode_forward(wa, 3).reshape(-1)
     assert e.shape == (42,) and np.allclose(e, ref, atol=2e-5)
+
+
+def test_full_frame_pipeline_matches_composed_checker(params, golden):
+    """audio -> enc_a, torso -> background, head render over it (run_cuda order, renderer.py:406-570): every stage against its
+    checker, composed the same way; frame bit for bit"""
+    from conftest import ellipsoid_bitfield, synthetic_camera
+    from lzzx_nerf_amd.pipeline import TalkingHeadFrame
+    from oracle.audio import encode_audio
+    from oracle.head import TriplaneSpec, get_rays
+    from oracle.render import render_inference
+    from test_audio_oracle import audio_state
+    sd = dict(params)
+    sd.update(_torso_state(8))
+    sd.update(audio_state(29, 32, True))
+    H = W = 48
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    bits = ellipsoid_bitfield()[0]
+    rng = np.random.default_rng(9)
+    auds = rng.normal(size=(8, 29, 16)).astype(F32)
+    ys, xs = np.meshgrid(np.linspace(-1, 1, H, dtype=F32), np.linspace(-1, 1, W, dtype=F32), indexing="ij")
+    bg = np.stack([xs.ravel(), ys.ravel()], 1).astype(F32)
+    ind_t = (rng.normal(size=(1, 8)) * 0.1).astype(F32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    frame = TalkingHeadFrame({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, dev(bits), bound=1.0)
+    out = frame.render(dev(ro), dev(rd), dev(auds), eye=dev(golden["net_eye"]), ind_code=dev(golden["net_ind"]), bg_coords=dev(bg),
+                       poses=dev(pose[None]), ind_code_torso=dev(ind_t), bg_color=1.0, max_steps=48)
+    # checker, stage by stage
+    enc_a = encode_audio(sd, auds, True)
+    assert np.array_equal(out["enc_a"].cpu().numpy(), enc_a)
+    enc_anchor = frame.torso.encode_anchor(dev(pose[None])).cpu().numpy().reshape(-1)
+    a_o, c_o, d_o, _ = run_torso(sd, bg, enc_anchor, ind_t, None, 0.0, 0.8)
+    bg_mixed = c_o * a_o + F32(1.0) * (F32(1) - a_o)
+    assert np.array_equal(out["torso_color"].cpu().numpy(), bg_mixed)
+    ref = render_inference(TriplaneSpec(1.0), sd, ro, rd, bits, enc_a, golden["net_ind"], golden["net_eye"], max_steps=48, bg_color=1.0)
+    final = np.clip(ref["image_raw"] + (F32(1) - ref["weights_sum"])[:, None] * bg_mixed, F32(0), F32(1))
+    assert np.array_equal(out["image"].cpu().numpy(), final)
