@@ -241,7 +241,11 @@ lz_k_triplane_head_f16(LzHead16Args P, const float* __restrict__ xyzs, const flo
                     const uint32_t c0 = g0 + (c & 1), c1 = g1 + (c >> 1);
                     const uint32_t hsh = c0 ^ (c1 * 2654435761u);
                     const uint32_t index = lv_dense[mrec] ? c0 + c1 * lv_stride[mrec] : (hsh & (lv_hs[mrec] - 1u));
+#ifdef LZ_EXPERIMENT_NO_GATHER
+                    gv[i][c] = gl[index & 15u];
+#else
                     gv[i][c] = gl[index];
+#endif
                 }
             }
             asm volatile("" ::"v"(gv[0][0]), "v"(gv[0][1]), "v"(gv[0][2]), "v"(gv[0][3]), "v"(gv[1][0]), "v"(gv[1][1]), "v"(gv[1][2]),
