@@ -19,6 +19,7 @@ from .head import FusedTriplaneHead
 
 _STATE_INTS = 80         # LZ_LOOP_STATE_INTS: lz_loop_state (8 ints) + 64 sample-count slots + statistics
 STAT_ROWS = 72           # LZ_LOOP_STAT_ROWS: sample rows handed to the head (exhausted rows included)
+MAX_RAYS_PER_PASS = 4096 * 256   # lz_loop_advance scans at most 4096 workgroup counts
 _N_SAMPLES_OFF = 16      # offsetof(lz_loop_state, n_samples)
 
 
@@ -164,6 +165,23 @@ class TriplaneRenderer:
         rays_o = rays_o.reshape(-1, 3).float().contiguous()
         rays_d = rays_d.reshape(-1, 3).float().contiguous()
         N = rays_o.shape[0]
+        if N > MAX_RAYS_PER_PASS:
+            # rays are independent: larger batches are rendered in passes of <= 2^20 rays (the device loop scans at most 4096
+            # workgroup counts per iteration) and concatenated; pixels do not depend on the split
+            outs = []
+            for lo in range(0, N, MAX_RAYS_PER_PASS):
+                hi = min(lo + MAX_RAYS_PER_PASS, N)
+                bg = bg_color[lo:hi] if torch.is_tensor(bg_color) and bg_color.dim() > 1 and bg_color.shape[0] == N else bg_color
+                o = self.render(rays_o[lo:hi], rays_d[lo:hi], enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg, count_samples,
+                                sync_free, rgb24)
+                outs.append({k: v.clone() for k, v in o.items()})
+            res = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0] if k not in ("state",)}
+            st = torch.stack([o["state"] for o in outs])
+            res["state"] = st[-1].clone()
+            res["state"][5] = st[:, 5].sum()      # marched samples of the whole batch
+            res["state"][72] = st[:, 72].sum()
+            res["state"][6] = st[:, 6].max()
+            return res
         b = self._buffers(N, rays_o.device)
         self._rays_o, self._rays_d = rays_o, rays_d
         call("lz_near_far_from_aabb", ptr(rays_o), ptr(rays_d), ptr(self.aabb), N, self.min_near, ptr(b.nears), ptr(b.fars), stream())

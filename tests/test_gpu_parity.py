@@ -799,6 +799,22 @@ def test_full_size_frame_properties(params, golden):
     assert torch.equal(again["image"], img)
 
 
+def test_render_more_rays_than_one_pass(params, golden, monkeypatch):
+    """batches above the device loop's 2^20-ray limit are rendered in passes; pixels equal the single-pass render"""
+    import lzzx_nerf_amd.renderer as RR
+    H = W = 96
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    r = RR.TriplaneRenderer(_head(_scene(params, 40.0)), dev(ellipsoid_bitfield()[0]), bound=1.0)
+    args = (dev(ro), dev(rd), dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]))
+    one = {k: v.clone() for k, v in r.render(*args, max_steps=48, count_samples=True).items()}
+    monkeypatch.setattr(RR, "MAX_RAYS_PER_PASS", 4000)   # 9216 rays -> 3 passes, ragged last one
+    many = r.render(*args, max_steps=48, count_samples=True)
+    for k in ("image", "depth", "weights_sum", "ray_counts"):
+        assert torch.equal(one[k], many[k]), k
+    assert int(many["state"][5]) == int(one["state"][5])
+
+
 def test_full_size_grid_linearity_and_layouts():
     """B = 2^22 samples, cfg2 table (49 MB): f(a e1 + b e2) = a f(e1) + b f(e2) up to rounding; both output layouts agree"""
     from lzzx_nerf_amd._util import call, ptr, stream
