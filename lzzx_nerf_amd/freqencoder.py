@@ -1,37 +1,35 @@
-"""Frequency (positional) encoder -- operator API of the reference's `freqencoder` package
-(/root/reference/freqencoder/freq.py:15-76) on the gfx950 kernel (csrc/lz_encoders.hip).
-Layout: [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...], each block input_dim wide."""
-import torch
+"""Positional (frequency) encoding `[x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]`, every block `input_dim` wide -- the
+`freqencoder` operator of the reference (/root/reference/freqencoder/freq.py:15-76: `freq_encode(inputs, degree, output_dim)`,
+`FreqEncoder(input_dim, degree)`) evaluated by `lz_freq_encode_forward/backward` (csrc/lz_encoders.hip)."""
 import torch.nn as nn
-from torch.autograd import Function
 
-from ._util import call, ptr, require_cuda, stream
+from ._pointwise import F32_BWD, F32_FWD, PointwiseOp, as_rows, launch, new_rows, ptr
 
 
-class _freq_encoder(Function):
+class _freq_encoder(PointwiseOp):
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @F32_FWD
     def forward(ctx, inputs, degree, output_dim):
-        if not inputs.is_cuda:
+        degree, output_dim = int(degree), int(output_dim)
+        if not inputs.is_cuda:     # the reference moves host tensors over silently (freq.py:22)
             inputs = inputs.cuda()
-        inputs = inputs.contiguous()
-        B, input_dim = inputs.shape
-        require_cuda(inputs=inputs)
-        outputs = torch.empty(B, output_dim, dtype=inputs.dtype, device=inputs.device)
-        call("lz_freq_encode_forward", ptr(inputs), B, input_dim, int(degree), int(output_dim), ptr(outputs), stream())
-        ctx.save_for_backward(inputs, outputs)
-        ctx.dims = [B, input_dim, degree, output_dim]
-        return outputs
+
+        def run(x, y, _jac, B, D):
+            launch("lz_freq_encode_forward", ptr(x), B, D, degree, output_dim, ptr(y))
+
+        x, y, _ = _freq_encoder._run_forward(ctx, inputs, output_dim, False, run)
+        ctx.save_for_backward(x, y)   # the backward pass reuses the sines and cosines it already has (freqencoder.cu:97-128)
+        ctx.cfg = (degree, output_dim)
+        return y
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
+    @F32_BWD
     def backward(ctx, grad):
-        grad = grad.contiguous()
-        inputs, outputs = ctx.saved_tensors
-        B, input_dim, degree, output_dim = ctx.dims
-        grad_inputs = torch.zeros_like(inputs)
-        call("lz_freq_encode_backward", ptr(grad), ptr(outputs), B, input_dim, int(degree), int(output_dim), ptr(grad_inputs), stream())
-        return grad_inputs, None, None
+        x, y = ctx.saved_tensors
+        degree, output_dim = ctx.cfg
+        gx = new_rows(x, x.shape[0], x.shape[1], zero=True)
+        launch("lz_freq_encode_backward", ptr(grad.contiguous()), ptr(y), x.shape[0], x.shape[1], degree, output_dim, ptr(gx))
+        return gx, None, None
 
 
 freq_encode = _freq_encoder.apply
@@ -40,15 +38,15 @@ freq_encode = _freq_encoder.apply
 class FreqEncoder(nn.Module):
     def __init__(self, input_dim=3, degree=4):
         super().__init__()
-        self.input_dim = input_dim
-        self.degree = degree
-        self.output_dim = input_dim + input_dim * 2 * degree
+        self.input_dim, self.degree = input_dim, degree
+        self.output_dim = input_dim * (1 + 2 * degree)
+
+    def extra_repr(self):
+        return "input_dim=%d degree=%d output_dim=%d" % (self.input_dim, self.degree, self.output_dim)
 
     def __repr__(self):
-        return f"FreqEncoder: input_dim={self.input_dim} degree={self.degree} output_dim={self.output_dim}"
+        return "FreqEncoder: " + self.extra_repr()
 
     def forward(self, inputs, **kwargs):
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.reshape(-1, self.input_dim)
-        outputs = freq_encode(inputs, self.degree, self.output_dim)
-        return outputs.reshape(prefix_shape + [self.output_dim])
+        rows, lead = as_rows(inputs, self.input_dim)
+        return freq_encode(rows, self.degree, self.output_dim).reshape(*lead, self.output_dim)

@@ -104,58 +104,55 @@ grid_encode = _grid_encode.apply
 
 
 def grid_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners=False):
-    """table layout of GridEncoder.__init__ (grid.py:108-121): float64 resolution, cap, round up to 8"""
-    offsets, offset = [], 0
-    max_params = 2 ** log2_hashmap_size
-    for i in range(num_levels):
-        resolution = int(np.ceil(base_resolution * per_level_scale ** i))
-        params_in_level = min(max_params, (resolution if align_corners else resolution + 1) ** input_dim)
-        params_in_level = int(np.ceil(params_in_level / 8) * 8)
-        offsets.append(offset)
-        offset += params_in_level
-    offsets.append(offset)
-    return offsets
+    """Start of every level's table (plus the total) as GridEncoder lays them out (grid.py:108-121): side = ceil(H * s^l) in
+    float64 (+1 cell corner unless align_corners), entries = min(2^T, side^D) rounded up to a multiple of 8."""
+    cap = 1 << log2_hashmap_size
+    starts = [0]
+    for level in range(num_levels):
+        side = int(np.ceil(base_resolution * per_level_scale ** level)) + (0 if align_corners else 1)
+        entries = min(cap, side ** input_dim)
+        starts.append(starts[-1] + 8 * ((entries + 7) // 8))
+    return starts
 
 
 class GridEncoder(nn.Module):
+    """`[..., D]` points in `[-bound, bound]` -> `[..., L * C]` features.  Parameter `embeddings` [sum of level sizes, C]
+    (U(-1e-4, 1e-4)), buffer `offsets` int32 [L + 1]: the reference's state-dict contract (grid.py:91-137)."""
+
     def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
                  desired_resolution=None, gridtype="hash", align_corners=False):
         super().__init__()
-        if desired_resolution is not None:  # overrides per_level_scale (grid.py:95-96)
+        if desired_resolution is not None:   # geometric growth that reaches desired_resolution at the last level (grid.py:95-96)
             per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
-        self.input_dim = input_dim
-        self.num_levels = num_levels
-        self.level_dim = level_dim
-        self.per_level_scale = per_level_scale
-        self.log2_hashmap_size = log2_hashmap_size
-        self.base_resolution = base_resolution
-        self.output_dim = num_levels * level_dim
-        self.gridtype = gridtype
+        hyper = dict(input_dim=input_dim, num_levels=num_levels, level_dim=level_dim, per_level_scale=per_level_scale,
+                     log2_hashmap_size=log2_hashmap_size, base_resolution=base_resolution, gridtype=gridtype,
+                     align_corners=align_corners)
+        for name, value in hyper.items():
+            setattr(self, name, value)
         self.gridtype_id = _gridtype_to_id[gridtype]
-        self.align_corners = align_corners
-        self.max_params = 2 ** log2_hashmap_size
-
-        offsets = grid_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
-        self.register_buffer("offsets", torch.from_numpy(np.array(offsets, dtype=np.int32)))
-        self.n_params = offsets[-1] * level_dim
-        self.embeddings = nn.Parameter(torch.empty(offsets[-1], level_dim))
+        self.output_dim = num_levels * level_dim
+        self.max_params = 1 << log2_hashmap_size
+        starts = grid_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
+        self.register_buffer("offsets", torch.tensor(starts, dtype=torch.int32))
+        self.n_params = starts[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(starts[-1], level_dim))
         self.reset_parameters()
 
     def reset_parameters(self):
-        std = 1e-4
-        self.embeddings.data.uniform_(-std, std)
+        nn.init.uniform_(self.embeddings, -1e-4, 1e-4)
+
+    def extra_repr(self):
+        finest = int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))
+        return ("input_dim=%d num_levels=%d level_dim=%d resolution=%d -> %d per_level_scale=%.4f params=%s gridtype=%s align_corners=%s"
+                % (self.input_dim, self.num_levels, self.level_dim, self.base_resolution, finest, self.per_level_scale,
+                   tuple(self.embeddings.shape), self.gridtype, self.align_corners))
 
     def __repr__(self):
-        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
-                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
-                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
-                f"align_corners={self.align_corners}")
+        return "GridEncoder: " + self.extra_repr()
 
     def forward(self, inputs, bound=1):
-        # inputs: [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]
-        inputs = (inputs + bound) / (2 * bound)
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.view(-1, self.input_dim)
-        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
-                              inputs.requires_grad, self.gridtype_id, self.align_corners)
-        return outputs.view(prefix_shape + [self.output_dim])
+        unit = (inputs + bound) / (2 * bound)               # [-bound, bound] -> [0, 1] (grid.py:143)
+        rows = unit.view(-1, self.input_dim)
+        feats = grid_encode(rows, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, rows.requires_grad,
+                            self.gridtype_id, self.align_corners)
+        return feats.view(*inputs.shape[:-1], self.output_dim)
