@@ -248,26 +248,34 @@ int lz_linear_forward(const float* X, uint32_t ldx, const float* mask, const flo
 int lz_linear_grad_w(const float* dY, uint32_t ldd, const float* mask, const float* X, uint32_t ldx, float* dW, uint32_t ldw,
                      uint32_t M, uint32_t K, uint32_t N, lz_stream_t stream);
 
-/* Device-resident inference loop state (renderer.py:495-548): no host synchronisation inside the frame.
- * The device buffer passed as `lz_loop_state*` must hold LZ_LOOP_STATE_INTS int32: the struct below, 64 scratch words
- * (per-workgroup sample-count slots, folded into total_samples by lz_loop_advance), then statistics:
- * word 72 = sample rows handed to the head so far (sum of n_alive * n_step, exhausted rows included). */
+/* Device-resident inference loop (renderer.py:495-548): no host synchronisation inside the frame, 3 launches per iteration:
+ *     lz_loop_march -> lz_triplane_head_forward(count = state words + LZ_LOOP_NEXT + 2) -> lz_loop_composite.
+ * The device buffer passed as `lz_loop_state*` must hold LZ_LOOP_STATE_INTS int32:
+ *   words  0..7   the struct below: the state as of the last COMMITTED iteration (what the host inspects);
+ *   words  8..71  per-workgroup sample-count slots of the march (folded into total_samples at commit);
+ *   word   72     LZ_LOOP_STAT_ROWS: sample rows handed to the head so far (sum of n_alive * n_step, exhausted rows included);
+ *   words 74..79  LZ_LOOP_NEXT: {n_alive, n_step, n_samples, step, done, iterations} of the iteration in flight.
+ * lz_loop_march advances the state itself: every workgroup sums the per-workgroup survivor counts the previous compositing
+ * launch left in `workspace` (its own prefix = compaction offset, and the total = n_alive), applies the schedule rule, and
+ * workgroup 0 publishes the "next" record; lz_loop_composite reads that record and its workgroup 0 commits it to the struct.
+ * Once `done` is set every later launch is a no-op; the host must enqueue one iteration after the last real one for the
+ * struct to show done = 1. */
 #define LZ_LOOP_STATE_INTS 80
 #define LZ_LOOP_STAT_ROWS 72
+#define LZ_LOOP_NEXT 74
 typedef struct {
-    int32_t n_alive;      /* rays alive at the start of the current iteration */
+    int32_t n_alive;      /* rays alive in the last committed iteration = length of the list the next march compacts */
     int32_t n_step;       /* max(min(sample_budget / n_alive, n_step_cap), 1); budget = N, cap = 8: renderer.py:513 */
-    int32_t step;         /* sum of n_step so far */
+    int32_t step;         /* sum of n_step before that iteration */
     int32_t done;         /* 1 once n_alive == 0 or step >= max_steps */
-    int32_t n_samples;    /* n_alive * n_step of the current iteration */
+    int32_t n_samples;    /* n_alive * n_step of that iteration */
     int32_t total_samples;/* marched samples so far (delta != 0) */
-    int32_t iterations;
+    int32_t iterations;   /* iterations executed (-1 right after lz_loop_begin) */
     int32_t pad;
 } lz_loop_state;
 
-/* One iteration = lz_loop_march -> lz_triplane_head_forward(count = &state->n_samples) -> lz_loop_composite ->
- * lz_loop_advance.  `workspace`: >= 4096 int32 of device scratch shared by the four calls (per-workgroup survivor
- * counts / offsets); at most 4096 * 256 rays per frame.  The alive list ping-pongs between two [N] int32 buffers. */
+/* `workspace`: >= 4096 int32 of device scratch (per-workgroup survivor counts); at most 4096 * 256 rays per frame.  The alive
+ * list ping-pongs between two [N] int32 buffers. */
 
 /* Iteration schedule: the reference marches n_step = max(min(N / n_alive, 8), 1) samples per alive ray per iteration
  * (renderer.py:513), i.e. a budget of N sample rows per iteration and at most 8 steps.  `sample_budget` / `n_step_cap`
@@ -275,26 +283,25 @@ typedef struct {
  * not depend on the schedule (rays are independent and compositing resumes exactly); per-ray marched-sample counts do
  * only for rays that terminate early inside a chunk.  Sample buffers must hold max(sample_budget, N) rows. */
 
-/* rays_alive <- 0..N-1, rays_t <- nears, accumulators <- 0, state <- (N, n_step(N), 0, ...), workspace <- identity offsets */
+/* rays_alive <- 0..N-1, rays_t <- nears, accumulators <- 0, state <- pre-state (list of N survivors, no steps taken),
+ * workspace <- workgroup sizes */
 int lz_loop_begin(uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap, const float* nears,
                   int32_t* rays_alive, float* rays_t,
                   float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum, float* unc_sum,
                   lz_loop_state* state, void* workspace, lz_stream_t stream);
-/* order-preserving stream compaction of rays_alive_in (drops the -1 entries compositing left, renderer.py:542) into
- * rays_alive_out, fused with the march of the survivors (n_step read on device); writes zero rows for exhausted rays;
- * adds the marched sample count to state->total_samples and, when ray_counts != NULL, per ray to ray_counts[ray id] */
-int lz_loop_march(lz_loop_state* state, uint32_t N, const int32_t* rays_alive_in, int32_t* rays_alive_out,
-                  const void* workspace, const float* rays_t, const float* rays_o, const float* rays_d, float bound,
-                  float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
-                  const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* ray_counts, lz_stream_t stream);
-/* triplane compositing on the current list (in place), plus per-workgroup survivor counts into workspace */
-int lz_loop_composite(const lz_loop_state* state, uint32_t N, float T_thresh, int32_t* rays_alive, float* rays_t,
+/* state advance (see above) + order-preserving stream compaction of rays_alive_in (drops the -1 entries compositing left,
+ * renderer.py:542) into rays_alive_out + march of the survivors; writes zero rows for exhausted rays; adds the marched sample
+ * count to the slots and, when ray_counts != NULL, per ray to ray_counts[ray id] */
+int lz_loop_march(lz_loop_state* state, uint32_t N, uint32_t sample_budget, uint32_t n_step_cap, const int32_t* rays_alive_in,
+                  int32_t* rays_alive_out, const void* workspace, const float* rays_t, const float* rays_o,
+                  const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                  const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                  int32_t* ray_counts, lz_stream_t stream);
+/* triplane compositing on the current list (in place), per-workgroup survivor counts into workspace, commit of the state */
+int lz_loop_composite(lz_loop_state* state, uint32_t N, float T_thresh, int32_t* rays_alive, float* rays_t,
                       const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,
                       const float* unc, float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum,
                       float* unc_sum, void* workspace, lz_stream_t stream);
-/* scan the survivor counts into offsets and advance the loop state (n_alive, n_step, step, done, n_samples) */
-int lz_loop_advance(lz_loop_state* state, uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap,
-                    void* workspace, lz_stream_t stream);
 /* diagnostic (synchronises the device): out2[0] = shader-clock cycles, out2[1] = 100 MHz wall-clock ticks that wave 0 of
  * workgroup 0 spent inside the most recent lz_triplane_head_forward launch; ratio x 100 MHz = sustained shader clock */
 int lz_debug_head_clocks(uint64_t* out2);

@@ -66,9 +66,8 @@ SIGNATURES = {
     "lz_head_pack_weights": [vp] * 11 + [i32, i32, vp, vp],
     "lz_triplane_head_forward": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_begin": [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "lz_loop_march": [vp, u32, vp, vp, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_loop_march": [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_composite": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "lz_loop_advance": [vp, u32, u32, u32, u32, vp, vp],
     "lz_loop_run": [C.POINTER(Frame), u32, u32, vp, vp],
     "lz_timing_create": [u32, C.POINTER(vp)],
     "lz_timing_destroy": [vp],

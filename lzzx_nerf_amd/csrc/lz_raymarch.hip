@@ -532,24 +532,60 @@ extern "C" int lz_march_rays_train_backward(const float* grad_xyzs, const float*
 
 // inference march (raymarching.cu:827-929).
 // STATE = false: the reference's entry point (host scalars, caller pre-zeroed outputs).
-// STATE = true : device-resident loop.  The kernel ALSO performs the stream compaction of the alive list (the
-//   reference's `rays_alive[rays_alive >= 0]`, renderer.py:542): thread n owns entry n of the PREVIOUS iteration's list
-//   (entries killed by compositing are -1), ranks the survivors with a wave ballot + the per-workgroup offsets that
-//   lz_k_loop_scan produced, writes the compacted list, and marches its ray into sample rows [pos * n_step, ...).
-//   Order is preserved, so the list equals the reference's.  Exhausted rows are zero-filled here.
+// STATE = true : device-resident loop, 3 launches per iteration (march, head, composite).  Every workgroup first ADVANCES
+//   THE LOOP STATE for itself: it sums the per-workgroup survivor counts the previous compositing launch left (its own prefix
+//   and the total), applies the schedule rule, and workgroup 0 publishes the result as the "next" record (state words
+//   LZ_LOOP_NEXT..) that the head's `count` and the compositing launch read.  Then it performs the stream compaction of the
+//   alive list (the reference's `rays_alive[rays_alive >= 0]`, renderer.py:542): thread n owns entry n of the PREVIOUS
+//   iteration's list (entries killed by compositing are -1), ranks the survivors with a wave ballot on top of its prefix,
+//   writes the compacted list, and marches its ray into sample rows [pos * n_step, ...).  Order is preserved, so the list
+//   equals the reference's.  Exhausted rows are zero-filled here.  The state struct itself is only rewritten by workgroup 0
+//   of the compositing launch (nobody reads it there), so no launch both reads and writes it.
+__device__ __forceinline__ int lz_n_step_rule(uint32_t N, uint32_t sample_budget, uint32_t n_step_cap, int n_alive);
+
 template <bool STATE>
 __global__ void __launch_bounds__(256)
 lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict__ state, const int* __restrict__ rays_alive,
-                const int* __restrict__ block_offsets, int* __restrict__ rays_alive_out,
+                const int* __restrict__ block_counts, int* __restrict__ rays_alive_out,
                 const float* __restrict__ rays_t, const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound,
                 float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
                 const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
-                const float* __restrict__ noises, int* __restrict__ ray_counts) {
+                const float* __restrict__ noises, int* __restrict__ ray_counts, uint32_t N, uint32_t sample_budget, uint32_t n_step_cap) {
     __shared__ uint32_t wsum[4];
-    const uint32_t n_list = STATE ? (uint32_t)state->pad : n_alive_h;   // entries in the incoming list
-    const uint32_t n_step = STATE ? (uint32_t)state->n_step : n_step_h;
+    __shared__ int rsum[8];
+    uint32_t n_list = n_alive_h, n_step = n_step_h, prefix = 0;
+    if (STATE) {
+        const lz_loop_state S = *state;
+        n_list = S.done ? 0u : (uint32_t)S.n_alive;                     // entries in the incoming list
+        if (blockIdx.x != 0 && blockIdx.x * blockDim.x >= n_list) return;   // whole workgroup past the list
+        const uint32_t live_blocks = (n_list + 255u) / 256u;
+        int tot = 0, pre = 0;
+        for (uint32_t i = threadIdx.x; i < live_blocks; i += blockDim.x) {
+            const int c = block_counts[i];
+            tot += c;
+            if (i < blockIdx.x) pre += c;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { tot += __shfl_xor(tot, off, 64); pre += __shfl_xor(pre, off, 64); }
+        if ((threadIdx.x & 63) == 0) { rsum[threadIdx.x >> 6] = tot; rsum[4 + (threadIdx.x >> 6)] = pre; }
+        __syncthreads();
+        tot = rsum[0] + rsum[1] + rsum[2] + rsum[3];
+        pre = rsum[4] + rsum[5] + rsum[6] + rsum[7];
+        int n_alive_new = S.done ? 0 : tot;                             // renderer.py:542
+        const int step_new = S.step + S.n_step;                         // renderer.py:546
+        const int done_new = (S.done || n_alive_new <= 0 || step_new >= (int)max_steps) ? 1 : 0;
+        if (done_new) n_alive_new = 0;
+        const int n_step_new = lz_n_step_rule(N, sample_budget, n_step_cap, n_alive_new);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            int* nx = reinterpret_cast<int*>(state) + LZ_LOOP_NEXT;
+            nx[0] = n_alive_new; nx[1] = n_step_new; nx[2] = n_alive_new * n_step_new; nx[3] = step_new; nx[4] = done_new;
+            nx[5] = S.done ? S.iterations : S.iterations + 1;
+        }
+        if (done_new) return;
+        n_step = (uint32_t)n_step_new;
+        prefix = (uint32_t)pre;
+    }
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (STATE && blockIdx.x * blockDim.x >= n_list) return;            // whole workgroup past the list
     int index = (n < n_list) ? rays_alive[n] : -1;
     uint32_t row = n;                                                   // first sample row = row * n_step
     if (STATE) {
@@ -560,7 +596,7 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
         __syncthreads();
         uint32_t woff = 0;
         for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
-        row = (uint32_t)block_offsets[blockIdx.x] + woff + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        row = prefix + woff + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         if (keep) rays_alive_out[row] = index;
         __syncthreads();                                                // wsum is reused below
     }
@@ -598,7 +634,7 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
     if (STATE) {
         // marched-sample statistics: wave shuffle -> LDS -> ONE atomic per workgroup, spread over the 64 slot words
         // that follow the state struct (a single hot word saturates at ~88 atomics/us: 4096 waves on one address cost
-        // more than the march itself); lz_k_loop_scan folds the slots into state->total_samples.
+        // more than the march itself); workgroup 0 of the compositing launch folds the slots into state->total_samples.
         uint32_t s = step;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -619,7 +655,8 @@ extern "C" int lz_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* r
     LZ_REQUIRE(C >= 1 && C <= 8 && H > 0, LZ_ERR_BAD_ARGUMENT, "march_rays: cascade must be in [1, 8]");
     if (n_alive == 0) return LZ_OK;
     hipLaunchKernelGGL((lz_k_march_rays<false>), dim3(lz_div_up(n_alive, 256)), dim3(256), 0, lz_st(stream), n_alive, n_step, (lz_loop_state*)nullptr,
-                       rays_alive, (const int*)nullptr, (int*)nullptr, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, (int*)nullptr);
+                       rays_alive, (const int*)nullptr, (int*)nullptr, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, (int*)nullptr,
+                       0u, 0u, 0u);
     LZ_CHECK_LAUNCH("march_rays");
     return LZ_OK;
 }
@@ -727,8 +764,10 @@ lz_k_composite_rays(uint32_t n_alive_h, uint32_t n_step_h, const lz_loop_state* 
                     const float* __restrict__ amb1, const float* __restrict__ unc, float* __restrict__ weights_sum,
                     float* __restrict__ depth, float* __restrict__ image, float* __restrict__ amb0_sum,
                     float* __restrict__ amb1_sum, float* __restrict__ unc_sum, int* __restrict__ block_counts) {
-    const uint32_t n_alive = STATE ? (uint32_t)state->n_alive : n_alive_h;
-    const uint32_t n_step = STATE ? (uint32_t)state->n_step : n_step_h;
+    // device loop: (n_alive, n_step) of THIS iteration are in the "next" record the march launch published
+    const int* nx = STATE ? reinterpret_cast<const int*>(state) + LZ_LOOP_NEXT : nullptr;
+    const uint32_t n_alive = STATE ? (uint32_t)nx[0] : n_alive_h;
+    const uint32_t n_step = STATE ? (uint32_t)nx[1] : n_step_h;
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     bool survives = false;
     if (n < n_alive) {
@@ -766,12 +805,26 @@ lz_k_composite_rays(uint32_t n_alive_h, uint32_t n_step_h, const lz_loop_state* 
         if (NAMB > 1) amb1_sum[index] = a1;
         if (UNC) unc_sum[index] = u;
     }
-    if (STATE) {  // per-workgroup survivor count for the next iteration's compaction (consumed by lz_k_loop_scan)
+    if (STATE) {  // per-workgroup survivor count for the next iteration's compaction (summed by the next march launch)
         __shared__ int wcnt[4];
         const int c = __popcll(__ballot(survives));
         if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = c;
         __syncthreads();
         if (threadIdx.x == 0) block_counts[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            // Commit the iteration to the state struct.  No other workgroup of this launch reads the struct (they read the
+            // "next" record), the march launch that wrote the sample-count slots has completed, the next one has not started.
+            lz_loop_state* st = const_cast<lz_loop_state*>(state);
+            lz_loop_state s = *st;
+            int* slots = reinterpret_cast<int*>(st + 1);
+            int slot_sum = 0;
+            for (int i = 0; i < 64; i++) { slot_sum += slots[i]; slots[i] = 0; }
+            s.total_samples += slot_sum;
+            reinterpret_cast<int*>(st)[LZ_LOOP_STAT_ROWS] += nx[2];
+            s.n_alive = nx[0]; s.n_step = nx[1]; s.n_samples = nx[2]; s.step = nx[3]; s.done = nx[4]; s.iterations = nx[5];
+            s.pad = nx[0];
+            *st = s;
+        }
     }
 }
 
@@ -835,11 +888,11 @@ extern "C" int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thre
 }
 
 // ------------------------------------------------------------------------------------------------
-// device-resident inference loop (renderer.py:495-548): 4 launches per iteration
+// device-resident inference loop (renderer.py:495-548): 3 launches per iteration
 //   lz_loop_march      compaction of the previous list (ballot + offsets) fused with the march of the survivors
 //   lz_triplane_head_forward (lz_head.hip), bounded by state->n_samples
 //   lz_loop_composite  accumulate, kill rays, count survivors per workgroup
-//   lz_loop_advance    one workgroup: scan the counts -> offsets, advance (n_alive, n_step, step, done)
+//   (the state advance -- scan of the survivor counts, schedule rule -- happens at the top of lz_loop_march)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lz_n_step_rule(uint32_t N, uint32_t sample_budget, uint32_t n_step_cap, int n_alive) {
     // renderer.py:513 is max(min(N // n_alive, 8), 1); budget / cap generalise N / 8 (0 = the reference's value)
@@ -856,21 +909,26 @@ lz_k_loop_begin(uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t
                 int* __restrict__ block_offsets) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n == 0) {
+        // "pre-state": the first march launch advances it like any other (identity list of N rays, all "survivors")
         lz_loop_state s;
-        s.n_alive = (int)N;
-        s.n_step = lz_n_step_rule(N, sample_budget, n_step_cap, (int)N);
+        s.n_alive = (int)N;          // length of the list the first march compacts
+        s.n_step = 0;                // no steps taken yet
         s.step = 0;
         s.done = (N == 0 || max_steps == 0) ? 1 : 0;
-        if (s.done) s.n_alive = 0;
-        s.n_samples = s.n_alive * s.n_step;
+        s.n_samples = 0;
         s.total_samples = 0;
-        s.iterations = 0;
-        s.pad = s.n_alive;   // entries of the list the first march will compact (the identity list)
+        s.iterations = -1;           // becomes 0 when the first march advances the state
+        s.pad = s.n_alive;
         *state = s;
-        reinterpret_cast<int*>(state)[LZ_LOOP_STAT_ROWS] = 0;
+        int* w = reinterpret_cast<int*>(state);
+        w[LZ_LOOP_STAT_ROWS] = 0;
+        for (int i = 0; i < 6; i++) w[LZ_LOOP_NEXT + i] = 0;
     }
     if (n < 64) reinterpret_cast<int*>(state + 1)[n] = 0;  // sample-count slots (see lz_k_march_rays)
-    if (threadIdx.x == 0) block_offsets[blockIdx.x] = (int)(blockIdx.x * blockDim.x);  // identity list: offset = first index
+    if (threadIdx.x == 0) {   // identity list: every entry of workgroup b "survived"
+        const uint32_t first = blockIdx.x * blockDim.x;
+        block_offsets[blockIdx.x] = first >= N ? 0 : (int)((N - first < blockDim.x) ? N - first : blockDim.x);
+    }
     if (n >= N) return;
     rays_alive[n] = (int)n;
     rays_t[n] = nears[n];
@@ -893,22 +951,24 @@ extern "C" int lz_loop_begin(uint32_t N, uint32_t max_steps, uint32_t sample_bud
     return LZ_OK;
 }
 
-extern "C" int lz_loop_march(lz_loop_state* state, uint32_t N, const int32_t* rays_alive_in, int32_t* rays_alive_out, const void* workspace,
-                             const float* rays_t, const float* rays_o, const float* rays_d, float bound, float dt_gamma,
-                             uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
-                             float* xyzs, float* dirs, float* deltas, int32_t* ray_counts, lz_stream_t stream) {
+extern "C" int lz_loop_march(lz_loop_state* state, uint32_t N, uint32_t sample_budget, uint32_t n_step_cap, const int32_t* rays_alive_in,
+                             int32_t* rays_alive_out, const void* workspace, const float* rays_t, const float* rays_o, const float* rays_d,
+                             float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid,
+                             const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* ray_counts,
+                             lz_stream_t stream) {
     (void)nears;
     LZ_REQUIRE(C >= 1 && C <= 8 && H > 0, LZ_ERR_BAD_ARGUMENT, "loop_march: cascade must be in [1, 8]");
     LZ_REQUIRE(state && workspace && rays_alive_in && rays_alive_out, LZ_ERR_BAD_ARGUMENT, "loop_march: null argument");
     if (N == 0) return LZ_OK;
+    LZ_REQUIRE(lz_div_up(N, 256) <= 4096, LZ_ERR_UNSUPPORTED, "loop_march: at most %u rays per call", 4096u * 256u);
     hipLaunchKernelGGL((lz_k_march_rays<true>), dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), 0u, 0u, state, rays_alive_in,
                        reinterpret_cast<const int*>(workspace), rays_alive_out, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid,
-                       fars, xyzs, dirs, deltas, (const float*)nullptr, ray_counts);
+                       fars, xyzs, dirs, deltas, (const float*)nullptr, ray_counts, N, sample_budget, n_step_cap);
     LZ_CHECK_LAUNCH("loop_march");
     return LZ_OK;
 }
 
-extern "C" int lz_loop_composite(const lz_loop_state* state, uint32_t N, float T_thresh, int32_t* rays_alive, float* rays_t,
+extern "C" int lz_loop_composite(lz_loop_state* state, uint32_t N, float T_thresh, int32_t* rays_alive, float* rays_t,
                                  const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,
                                  const float* unc, float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum,
                                  float* unc_sum, void* workspace, lz_stream_t stream) {
@@ -921,75 +981,6 @@ extern "C" int lz_loop_composite(const lz_loop_state* state, uint32_t N, float T
     return LZ_OK;
 }
 
-// one workgroup: exclusive scan of the per-workgroup survivor counts (in place -> offsets) + state advance
-__global__ void __launch_bounds__(1024)
-lz_k_loop_scan(lz_loop_state* __restrict__ state, uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap,
-               uint32_t n_blocks, int* __restrict__ block_counts) {
-    __shared__ int wave_sums[16];
-    __shared__ int carry_s;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    // only the workgroups that covered the current list wrote a count; the others hold stale values: treat as 0
-    const uint32_t live_blocks = ((uint32_t)state->n_alive + 255u) / 256u;
-    for (uint32_t start = 0; start < n_blocks; start += 1024) {
-        const uint32_t i = start + tid;
-        const int v = (i < live_blocks) ? block_counts[i] : 0;
-        int incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int u = __shfl_up(incl, off, 64);
-            if ((int)lane >= off) incl += u;
-        }
-        if (lane == 63) wave_sums[wave] = incl;
-        __syncthreads();
-        int wave_prefix = 0;
-        for (uint32_t w = 0; w < wave; w++) wave_prefix += wave_sums[w];
-        const int carry = carry_s;
-        if (i < n_blocks) block_counts[i] = carry + wave_prefix + incl - v;
-        __syncthreads();
-        if (tid == 1023) carry_s = carry + wave_prefix + incl;
-        __syncthreads();
-    }
-    // fold the march kernel's 64 sample-count slots (stored right after the struct) into total_samples
-    int slot_sum = 0;
-    if (tid < 64) {
-        int* slots = reinterpret_cast<int*>(state + 1);
-        slot_sum = slots[tid];
-        slots[tid] = 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) slot_sum += __shfl_down(slot_sum, off, 64);
-    }
-    if (tid == 0) {
-        lz_loop_state s = *state;
-        s.total_samples += slot_sum;
-        if (!s.done) reinterpret_cast<int*>(state)[LZ_LOOP_STAT_ROWS] += s.n_samples;   // rows of the iteration just finished
-        s.pad = s.n_alive;                  // length of the list the next march compacts
-        if (!s.done) {
-            s.step += s.n_step;             // renderer.py:546
-            s.iterations += 1;
-            s.n_alive = carry_s;            // renderer.py:542
-            s.done = (s.n_alive <= 0 || s.step >= (int)max_steps) ? 1 : 0;
-            if (s.done) { s.n_alive = 0; s.pad = 0; }
-            s.n_step = lz_n_step_rule(N, sample_budget, n_step_cap, s.n_alive);
-            s.n_samples = s.n_alive * s.n_step;
-        } else {
-            s.pad = 0;
-        }
-        *state = s;
-    }
-}
-
-extern "C" int lz_loop_advance(lz_loop_state* state, uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap,
-                               void* workspace, lz_stream_t stream) {
-    LZ_REQUIRE(state && workspace, LZ_ERR_BAD_ARGUMENT, "loop_advance: null state / workspace");
-    const uint32_t n_blocks = lz_div_up(N > 0 ? N : 1, 256);
-    LZ_REQUIRE(n_blocks <= 4096, LZ_ERR_UNSUPPORTED, "loop_advance: at most %u rays per call", 4096u * 256u);
-    hipLaunchKernelGGL(lz_k_loop_scan, dim3(1), dim3(1024), 0, lz_st(stream), state, N, max_steps, sample_budget, n_step_cap, n_blocks,
-                       reinterpret_cast<int*>(workspace));
-    LZ_CHECK_LAUNCH("loop_advance");
-    return LZ_OK;
-}
 
 __global__ void __launch_bounds__(256)
 lz_k_final_blend(const float* __restrict__ image, const float* __restrict__ weights_sum, const float* __restrict__ bg, float bg_scalar,

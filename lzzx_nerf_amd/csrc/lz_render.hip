@@ -2,8 +2,8 @@
 //
 // The reference drives its loop from Python (nerf_triplane/renderer.py:503-548): per iteration ~20 kernel launches
 // and one device->host synchronisation.  Here one C call enqueues `n_iterations` iterations of
-//     lz_loop_march -> lz_triplane_head_forward -> lz_loop_composite -> lz_loop_advance
-// back to back on the caller's stream (4 launches each, no host round trip, no Python between launches).  Iterations
+//     lz_loop_march (state advance + compaction + march) -> lz_triplane_head_forward -> lz_loop_composite (+ state commit)
+// back to back on the caller's stream (3 launches each, no host round trip, no Python between launches).  Iterations
 // enqueued after the frame finished are no-ops on the device (every kernel is bounded by the device-side state).
 //
 // Optional timing: an lz_timing object owns pairs of HIP events; when one is passed, every head launch is bracketed
@@ -65,13 +65,13 @@ extern "C" int lz_timing_elapsed_ms(lz_timing* t, float* out_ms, uint32_t capaci
 extern "C" int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterations, lz_timing* timing, lz_stream_t stream) {
     LZ_REQUIRE(f && f->state && f->workspace && f->rays_alive[0] && f->rays_alive[1], LZ_ERR_BAD_ARGUMENT, "loop_run: incomplete lz_frame");
     uint32_t cur = parity & 1u;
-    const int32_t* count = reinterpret_cast<const int32_t*>(f->state) + 4;  // &state->n_samples
+    const int32_t* count = reinterpret_cast<const int32_t*>(f->state) + LZ_LOOP_NEXT + 2;  // n_samples of the iteration in flight
     const uint32_t rows = f->sample_budget > f->N ? f->sample_budget : f->N;  // capacity of the sample buffers
     for (uint32_t it = 0; it < n_iterations; it++) {
         const uint32_t nxt = cur ^ 1u;
-        int rc = lz_loop_march(f->state, f->N, f->rays_alive[cur], f->rays_alive[nxt], f->workspace, f->rays_t, f->rays_o, f->rays_d,
-                               f->bound, f->dt_gamma, f->max_steps, f->C, f->H, f->grid, f->nears, f->fars, f->xyzs, f->dirs, f->deltas,
-                               f->ray_counts, stream);
+        int rc = lz_loop_march(f->state, f->N, f->sample_budget, f->n_step_cap, f->rays_alive[cur], f->rays_alive[nxt], f->workspace, f->rays_t,
+                               f->rays_o, f->rays_d, f->bound, f->dt_gamma, f->max_steps, f->C, f->H, f->grid, f->nears, f->fars, f->xyzs,
+                               f->dirs, f->deltas, f->ray_counts, stream);
         if (rc != LZ_OK) return rc;
         const bool timed = timing && (size_t)(timing->used + 1) * 2 <= timing->ev.size();
         if (timed) (void)hipEventRecord(timing->ev[2 * timing->used], lz_st(stream));
@@ -84,8 +84,6 @@ extern "C" int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterat
         rc = lz_loop_composite(f->state, f->N, f->T_thresh, f->rays_alive[nxt], f->rays_t, f->sigmas, f->rgbs, f->deltas, f->amb_aud,
                                f->amb_eye, f->unc, f->weights_sum, f->depth, f->image, f->amb_aud_sum, f->amb_eye_sum, f->unc_sum,
                                f->workspace, stream);
-        if (rc != LZ_OK) return rc;
-        rc = lz_loop_advance(f->state, f->N, f->max_steps, f->sample_budget, f->n_step_cap, f->workspace, stream);
         if (rc != LZ_OK) return rc;
         cur = nxt;
     }

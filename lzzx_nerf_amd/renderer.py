@@ -19,8 +19,8 @@ from .head import FusedTriplaneHead
 
 _STATE_INTS = 80         # LZ_LOOP_STATE_INTS: lz_loop_state (8 ints) + 64 sample-count slots + statistics
 STAT_ROWS = 72           # LZ_LOOP_STAT_ROWS: sample rows handed to the head (exhausted rows included)
-MAX_RAYS_PER_PASS = 4096 * 256   # lz_loop_advance scans at most 4096 workgroup counts
-_N_SAMPLES_OFF = 16      # offsetof(lz_loop_state, n_samples)
+MAX_RAYS_PER_PASS = 4096 * 256   # lz_loop_march sums at most 4096 workgroup counts
+_N_SAMPLES_OFF = (74 + 2) * 4   # LZ_LOOP_NEXT + 2: n_samples of the iteration in flight (the head's `count`)
 
 
 def get_rays(pose, intrinsics, H, W):
@@ -115,7 +115,7 @@ class TriplaneRenderer:
         st, ws = ptr(b.state), ptr(b.workspace)
         nxt = 1 - cur
         # compaction of list[cur] -> list[nxt], fused with the march of the survivors
-        call("lz_loop_march", st, N, ptr(b.rays_alive[cur]), ptr(b.rays_alive[nxt]), ws, ptr(b.rays_t), ptr(self._rays_o),
+        call("lz_loop_march", st, N, N * self.budget_factor, self.n_step_cap, ptr(b.rays_alive[cur]), ptr(b.rays_alive[nxt]), ws, ptr(b.rays_t), ptr(self._rays_o),
              ptr(self._rays_d), self.bound, float(dt_gamma), int(max_steps), int(self.cascade), int(self.grid_size), ptr(self.bitfield),
              ptr(b.nears), ptr(b.fars), ptr(b.xyzs), ptr(b.dirs), ptr(b.deltas), ptr(b.ray_counts) if count_samples else None, stream())
         ev = self._head_events
@@ -130,7 +130,6 @@ class TriplaneRenderer:
         call("lz_loop_composite", st, N, float(T_thresh), ptr(b.rays_alive[nxt]), ptr(b.rays_t), ptr(b.sigmas), ptr(b.rgbs),
              ptr(b.deltas), ptr(b.amb_aud), ptr(b.amb_eye), ptr(b.unc), ptr(b.weights_sum), ptr(b.depth), ptr(b.image),
              ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ws, stream())
-        call("lz_loop_advance", st, N, int(max_steps), N * self.budget_factor, self.n_step_cap, ws, stream())
 
     def _frame(self, b, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples):
         """lz_frame for lz_loop_run; the small conditioning tensors are kept alive on self until the next frame"""
@@ -194,8 +193,9 @@ class TriplaneRenderer:
         native = self._head_events is None   # the Python-driven loop is kept for debugging with torch events
         if native:
             frame = self._frame(b, N, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, count_samples)
-        while it < max_steps:  # n_step >= 1, so max_steps iterations always suffice (renderer.py:503,546)
-            n = min(self.chunk, max_steps - it)
+        limit = int(max_steps) + 1   # n_step >= 1: max_steps iterations always suffice (renderer.py:503,546); the state of
+        while it < limit:            # iteration k is committed by iteration k + 1's launches, hence one more
+            n = min(self.chunk, limit - it)
             if native:   # one C call enqueues n x (march, head, composite, advance)
                 call("lz_loop_run", C.byref(frame), cur, n, self._timing, stream())
                 cur = (cur + n) & 1
