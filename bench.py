@@ -439,7 +439,7 @@ def main():
         for _ in range(20):
             aenc(auds)
         torch.cuda.synchronize()
-        result["audio_frontend"] = dict(ms=round((time.perf_counter() - t0) / 20 * 1e3, 4), windows=8, dim_in=1024, launches=1)
+        result["audio_frontend"] = dict(ms=round((time.perf_counter() - t0) / 20 * 1e3, 4), windows=8, dim_in=1024, launches=2)
         del aenc, auds
     # ---- CPU baseline: the checker arranged like the reference loop, on a bounded sub-frame of the SAME rays ----
     if not args.no_cpu_baseline and world == 1:   # rank 0, N = 1 only

@@ -226,7 +226,7 @@ int lz_torso_forward(const lz_torso_params* p, const float* bg_coords, uint32_t 
 /* Audio conditioning front-end: NeRFNetwork.encode_audio (nerf_triplane/network.py:226-240) = AudioNet
  * (network.py:40-70) on each of n_win windows a[n_win, dim_in, 16], then, when use_att, AudioAttNet (network.py:9-37) -> enc_a
  * [dim_aud]; without attention enc_a is [n_win, dim_aud].  Weights are the reference's Conv1d [out, in, 3] / Linear [out, in]
- * tensors and biases (device pointers).  One workgroup, one launch. */
+ * tensors and biases (device pointers).  One workgroup, one launch (two for wide inputs, see workspace). */
 typedef struct {
     const float* c_w[4]; const float* c_b[4];     /* audio_net.encoder_conv.{0,2,4,6}: dim_in->32->32->64->64, k 3, stride 2 */
     const float* fc_w[2]; const float* fc_b[2];   /* audio_net.encoder_fc1.{0,2}: 64->64->dim_aud */
@@ -234,7 +234,9 @@ typedef struct {
     const float* al_w; const float* al_b;         /* audio_att_net.attentionNet.0: Linear(n_win, n_win) */
     uint32_t dim_in, dim_aud, n_win, use_att;
 } lz_audio_params;
-int lz_audio_encode(const lz_audio_params* p, const float* a, float* enc_a, lz_stream_t stream);
+/* workspace: n_win * 256 floats (device), used when dim_in >= 128 (the first layer then runs as its own chip-wide launch, one
+ * wave per output, with a lane-strided summation order); may be NULL for narrower inputs */
+int lz_audio_encode(const lz_audio_params* p, const float* a, float* enc_a, void* workspace, lz_stream_t stream);
 
 /* Tall-skinny bias-free Linear for the training path of the heads (the reference's MLP, network.py:73-94, is a stack of
  * nn.Linear(bias=False) with K, N <= 84 over M ~ 1e6..1e7 samples; torch dispatches them to library GEMMs).  Row-major f32,

@@ -78,7 +78,7 @@ SIGNATURES = {
     "lz_debug_head_clocks": [C.POINTER(C.c_uint64)],
     "lz_head_pack_weights_f16": [vp] * 9 + [i32, i32, vp, vp],
     "lz_torso_forward": [C.POINTER(TorsoParams), vp, u32, vp, vp, vp, vp],
-    "lz_audio_encode": [C.POINTER(AudioParams), vp, vp, vp],
+    "lz_audio_encode": [C.POINTER(AudioParams), vp, vp, vp, vp],
     "lz_density_grid_points": [vp, u32, u32, f32, vp, vp],
     "lz_density_grid_update": [vp, f32, f32, f32, u32, u32, vp, vp, vp, vp, vp],
     "lz_linear_forward": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, i32, vp],

@@ -51,7 +51,8 @@ class FusedAudioEncoder:
             p.al_w, p.al_b = self.lw.data_ptr(), self.lb.data_ptr()
         p.dim_in, p.dim_aud, p.n_win, p.use_att = self.dim_in, self.dim_aud, n, int(self.use_att)
         out = torch.empty((1 if self.use_att else n), self.dim_aud, dtype=torch.float32, device=self.device)
-        call("lz_audio_encode", C.byref(p), ptr(a), ptr(out), stream())
+        ws = torch.empty(n * 256, dtype=torch.float32, device=self.device) if self.dim_in >= 128 else None
+        call("lz_audio_encode", C.byref(p), ptr(a), ptr(out), ptr(ws), stream())
         return out
 
     __call__ = forward

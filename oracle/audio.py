@@ -29,6 +29,28 @@ def conv1d_k3(x, w, b, stride):
     return _lrelu(acc + b[None, :, None].astype(F32))
 
 
+def conv1_wide(x, w, b):
+    """first AudioNet layer in the order csrc/lz_audio.hip uses for dim_in >= 128 (lz_k_audio_conv1_wide): lane l of a wave owns
+    channels l, l + 64, ... (fma chain, channel outer, tap inner); the 64 partials are combined by an xor-shuffle tree"""
+    n, Cin, Lin = x.shape
+    Cout, Lout = w.shape[0], 8
+    part = np.zeros((64, n, Cout, Lout), F32)
+    t = np.arange(Lout)
+    for ci in range(Cin):
+        l = ci % 64
+        for k in range(3):
+            pos = t * 2 + k - 1
+            ok = (pos >= 0) & (pos < Lin)
+            xv = np.where(ok[None, :], x[:, ci, np.clip(pos, 0, Lin - 1)], F32(0)).astype(F32)
+            new = O.fma(np.broadcast_to(w[None, :, ci, k, None], part[l].shape), np.broadcast_to(xv[:, None, :], part[l].shape), part[l])
+            part[l] = np.where(ok[None, None, :], new, part[l])
+    off = 32
+    while off:   # acc += shfl_xor(acc, off): every lane adds its partner; lane 0 ends with the tree sum
+        part = (part + part[np.arange(64) ^ off]).astype(F32)
+        off >>= 1
+    return _lrelu(part[0] + b[None, :, None].astype(F32))
+
+
 def fc(x, w, b, lrelu):
     y = O.linear(np.ascontiguousarray(x, F32), np.ascontiguousarray(w, F32)) + b[None, :].astype(F32)
     return _lrelu(y) if lrelu else y.astype(F32)
@@ -38,6 +60,9 @@ def encode_audio(P, a, use_att=True):
     """a [n_win, dim_in, 16] -> enc_a [1, dim_aud] (attention) or [n_win, dim_aud]"""
     x = np.ascontiguousarray(a, F32)
     for i, s in zip((0, 2, 4, 6), (2, 2, 2, 2)):
+        if i == 0 and x.shape[1] >= 128:
+            x = conv1_wide(x, P["audio_net.encoder_conv.0.weight"], P["audio_net.encoder_conv.0.bias"])
+            continue
         x = conv1d_k3(x, P["audio_net.encoder_conv.%d.weight" % i], P["audio_net.encoder_conv.%d.bias" % i], s)
     x = x[:, :, 0]
     x = fc(x, P["audio_net.encoder_fc1.0.weight"], P["audio_net.encoder_fc1.0.bias"], True)
