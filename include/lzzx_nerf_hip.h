@@ -198,6 +198,15 @@ int lz_density_grid_points(const float* noise, uint32_t C, uint32_t G, float bou
 int lz_density_grid_update(const float* sigmas, float density_scale, float decay, float density_thresh, uint32_t C, uint32_t G,
                            float* density_grid, uint8_t* bitfield, float* stats, void* workspace, lz_stream_t stream);
 
+/* Torso half of update_extra_state (renderer.py:772-808).  lz_density_grid_torso_points: query point of every cell of the G x G
+ * torso grid in meshgrid order (x slowest), xy = (2 c / (G-1) - 1) * (1 - 1/G) + (noise * 2 - 1) / G; noise [G*G, 2] in [0,1).
+ * lz_density_grid_torso_update: alphas [G*G] = forward_torso alpha at those points (lz_torso_forward) -> tmp[y*G + x] -> 5x5 max
+ * pool -> density_grid_torso = max(grid * decay, tmp) in place; stats[0] = mean(grid), stats[1] = min(stats[0], density_thresh)
+ * (the threshold run_torso masks with, renderer.py:603).  workspace: >= ceil(G*G/256) floats. */
+int lz_density_grid_torso_points(const float* noise, uint32_t G, float* xys, lz_stream_t stream);
+int lz_density_grid_torso_update(const float* alphas, float decay, float density_thresh, uint32_t G, float* density_grid,
+                                 float* stats, void* workspace, lz_stream_t stream);
+
 /* Torso branch of a frame: run_torso's masked query (nerf_triplane/renderer.py:572-631) + forward_torso
  * (nerf_triplane/network.py:170-205) as one kernel, one lane per pixel.  All pointers are device pointers; weights are the
  * reference's bias-free Linear matrices, row-major [out, in], input order [per-pixel features | anchor encoding 42 | ind code]:

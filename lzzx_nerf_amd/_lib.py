@@ -80,6 +80,8 @@ SIGNATURES = {
     "lz_torso_forward": [C.POINTER(TorsoParams), vp, u32, vp, vp, vp, vp],
     "lz_audio_encode": [C.POINTER(AudioParams), vp, vp, vp, vp],
     "lz_density_grid_points": [vp, u32, u32, f32, vp, vp],
+    "lz_density_grid_torso_points": [vp, u32, vp, vp],
+    "lz_density_grid_torso_update": [vp, f32, f32, u32, vp, vp, vp, vp],
     "lz_density_grid_update": [vp, f32, f32, f32, u32, u32, vp, vp, vp, vp, vp],
     "lz_linear_forward": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, i32, vp],
     "lz_linear_grad_w": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, vp],

@@ -314,6 +314,71 @@ lz_k_packbits_dev(const float* __restrict__ grid, uint32_t N, const float* __res
     bitfield[n] = (uint8_t)bits;
 }
 
+// ---- torso half of update_extra_state (renderer.py:772-808): 2-D grid of torso alphas ----
+__global__ void __launch_bounds__(256)
+lz_k_density_torso_points(const float* __restrict__ noise, uint32_t G, float* __restrict__ xys) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= G * G) return;
+    const uint32_t c[2] = {p / G, p % G};                 // custom_meshgrid(xs, ys): x slowest (renderer.py:790-791)
+    const float hgs = (float)(1.0 / (double)G), scale = (float)(1.0 - 1.0 / (double)G);
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        float v = (2.0f * (float)c[d]) / (float)(G - 1) - 1.0f;     // renderer.py:793
+        v = v * scale;                                              // xys * (1 - half_grid_size)
+        xys[(size_t)p * 2 + d] = v + (noise[(size_t)p * 2 + d] * 2.0f - 1.0f) * hgs;   // renderer.py:796
+    }
+}
+
+extern "C" int lz_density_grid_torso_points(const float* noise, uint32_t G, float* xys, lz_stream_t stream) {
+    if (G == 0) return LZ_OK;
+    LZ_REQUIRE(noise && xys && G >= 2 && G <= 4096, LZ_ERR_BAD_ARGUMENT, "density_grid_torso_points: bad argument");
+    hipLaunchKernelGGL(lz_k_density_torso_points, dim3(lz_div_up((uint64_t)G * G, 256)), dim3(256), 0, lz_st(stream), noise, G, xys);
+    LZ_CHECK_LAUNCH("density_grid_torso_points");
+    return LZ_OK;
+}
+
+// alphas [G*G] in point order (p = x*G + y) -> tmp[y*G + x] ("xy transposed", renderer.py:792) -> 5x5 max pool (stride 1,
+// padding 2: out-of-range neighbours do not take part) -> grid = max(grid * decay, tmp) -> partial sums of the new grid
+__global__ void __launch_bounds__(256)
+lz_k_density_torso_ema(const float* __restrict__ alphas, float decay, uint32_t G, float* __restrict__ grid, float* __restrict__ partial) {
+    __shared__ float wsum[4];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    float contrib = 0.0f;
+    if (n < G * G) {
+        const int y = (int)(n / G), x = (int)(n % G);
+        float t = -INFINITY;
+        for (int dy = -2; dy <= 2; dy++)
+            for (int dx = -2; dx <= 2; dx++) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && xx >= 0 && yy < (int)G && xx < (int)G) t = lz_fmaxf(t, alphas[(size_t)xx * G + yy]);
+            }
+        const float d = lz_fmaxf(grid[n] * decay, t);               // renderer.py:806
+        grid[n] = d;
+        contrib = d;                                                // torch.mean(density_grid_torso), renderer.py:807
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+
+__global__ void __launch_bounds__(1024)
+lz_k_density_stats(const float* __restrict__ partial, uint32_t n_partial, uint32_t n_cells, float density_thresh, float* __restrict__ stats);
+
+extern "C" int lz_density_grid_torso_update(const float* alphas, float decay, float density_thresh, uint32_t G, float* density_grid,
+                                            float* stats, void* workspace, lz_stream_t stream) {
+    if (G == 0) return LZ_OK;
+    LZ_REQUIRE(alphas && density_grid && stats && workspace, LZ_ERR_BAD_ARGUMENT, "density_grid_torso_update: null tensor");
+    const uint32_t cells = G * G, nb = lz_div_up(cells, 256);
+    hipStream_t st = lz_st(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(lz_k_density_torso_ema, dim3(nb), dim3(256), 0, st, alphas, decay, G, density_grid, partial);
+    hipLaunchKernelGGL(lz_k_density_stats, dim3(1), dim3(1024), 0, st, partial, nb, cells, density_thresh, stats);
+    LZ_CHECK_LAUNCH("density_grid_torso_update");
+    return LZ_OK;
+}
+
 extern "C" int lz_density_grid_update(const float* sigmas, float density_scale, float decay, float density_thresh, uint32_t C, uint32_t G,
                                       float* density_grid, uint8_t* bitfield, float* stats, void* workspace, lz_stream_t stream) {
     if (C * G == 0) return LZ_OK;

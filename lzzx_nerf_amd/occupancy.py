@@ -40,3 +40,26 @@ def update_density_grid(head, density_grid, density_bitfield, enc_a, eye=None, b
     call("lz_density_grid_update", ptr(sigma), float(density_scale), float(decay), float(density_thresh), cascade, G, ptr(density_grid),
          ptr(density_bitfield), ptr(stats), ptr(workspace), stream())
     return stats[0], stats[1]
+
+
+@torch.no_grad()
+def update_density_grid_torso(torso, density_grid_torso, poses, ind_code=None, decay=0.95, density_thresh=0.01, noise=None, enc_anchor=None):
+    """Torso half of `update_extra_state` (renderer.py:772-808): alpha of `forward_torso` at one jittered point per cell of the
+    G x G torso grid, 5 x 5 max pool, EMA in place.  `torso`: lzzx_nerf_amd.torso.FusedTorso.  Returns device scalars
+    (mean_density_torso, min(mean, density_thresh)); the second is the threshold `run_torso` masks with (renderer.py:603)."""
+    cells = density_grid_torso.numel()
+    G = round(cells ** 0.5)
+    if G * G != cells or density_grid_torso.dtype != torch.float32 or not density_grid_torso.is_contiguous():
+        raise RuntimeError("density_grid_torso must be a contiguous float32 tensor of grid_size^2 values")
+    dev = density_grid_torso.device
+    if noise is None:
+        noise = torch.rand(cells, 2, dtype=torch.float32, device=dev)
+    noise = noise.to(dev, torch.float32).contiguous()
+    xys = torch.empty(cells, 2, dtype=torch.float32, device=dev)
+    call("lz_density_grid_torso_points", ptr(noise), G, ptr(xys), stream())
+    alpha = torso(xys, poses, ind_code, enc_anchor=enc_anchor)[0]
+    stats = torch.empty(2, dtype=torch.float32, device=dev)
+    workspace = torch.empty((cells + 255) // 256, dtype=torch.float32, device=dev)
+    call("lz_density_grid_torso_update", ptr(alpha), float(decay), float(density_thresh), G, ptr(density_grid_torso), ptr(stats),
+         ptr(workspace), stream())
+    return stats[0], stats[1]

@@ -32,3 +32,26 @@ def update_density_grid(spec, P, density_grid, enc_a, eye, bound, noise, decay=0
     mean = float(np.mean(np.clip(density_grid, 0, None), dtype=np.float64))    # :765 (torch sums in f32; the order is its own)
     thresh = min(mean, density_thresh)                                         # :770
     return mean, thresh, O.packbits(density_grid, thresh)
+
+
+def update_density_grid_torso(P, density_grid_torso, enc_anchor, ind_code, noise, decay=0.95, torso_shrink=0.8):
+    """torso half of update_extra_state (renderer.py:772-808); density_grid_torso [G*G] is updated in place; returns its mean"""
+    from .torso import forward_torso
+    cells = density_grid_torso.size
+    G = round(cells ** 0.5)
+    ax = np.arange(G, dtype=np.int32)
+    xx, yy = np.meshgrid(ax, ax, indexing="ij")                                           # custom_meshgrid(xs, ys), :790
+    coords = np.stack([xx.ravel(), yy.ravel()], 1)
+    indices = (coords[:, 1].astype(np.int64) * G + coords[:, 0])                         # xy transposed, :792
+    xys = F32(2) * coords.astype(F32) / F32(G - 1) - F32(1)                               # :793
+    xys = xys * F32(1 - 1 / G)                                                            # :794
+    xys = xys + (noise.astype(F32) * F32(2) - F32(1)) * F32(1 / G)                        # :796
+    alphas, _, _ = forward_torso(P, xys, enc_anchor, ind_code, torso_shrink)             # :798
+    tmp = np.zeros(cells, F32)
+    tmp[indices] = alphas[:, 0]
+    t2 = tmp.reshape(G, G)
+    pad = np.full((G + 4, G + 4), -np.inf, F32)
+    pad[2:-2, 2:-2] = t2
+    dil = np.max(np.stack([pad[dy:dy + G, dx:dx + G] for dy in range(5) for dx in range(5)]), 0)   # F.max_pool2d(k=5, s=1, p=2), :804
+    density_grid_torso[:] = np.maximum(density_grid_torso * F32(decay), dil.reshape(-1))              # :806
+    return float(np.mean(density_grid_torso, dtype=np.float64))                                     # :807

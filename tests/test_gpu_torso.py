@@ -107,3 +107,28 @@ def test_full_frame_pipeline_matches_composed_checker(params, golden):
     ref = render_inference(TriplaneSpec(1.0), sd, ro, rd, bits, enc_a, golden["net_ind"], golden["net_eye"], max_steps=48, bg_color=1.0)
     final = np.clip(ref["image_raw"] + (F32(1) - ref["weights_sum"])[:, None] * bg_mixed, F32(0), F32(1))
     assert np.array_equal(out["image"].cpu().numpy(), final)
+
+
+def test_update_density_grid_torso_matches_checker():
+    """torso half of update_extra_state (renderer.py:772-808): jittered points, forward_torso alpha, 5x5 max pool, EMA -- bit for bit"""
+    from lzzx_nerf_amd.occupancy import update_density_grid_torso
+    from lzzx_nerf_amd.torso import FusedTorso
+    from oracle.occupancy import update_density_grid_torso as oracle_update
+    sd = _torso_state(8)
+    rng = np.random.default_rng(12)
+    G = 64
+    grid0 = rng.uniform(0, 0.6, G * G).astype(F32)
+    noise = rng.uniform(0, 1, (G * G, 2)).astype(F32)
+    ind = (rng.normal(size=(1, 8)) * 0.1).astype(F32)
+    pose = np.eye(4, dtype=F32)
+    pose[:3, 3] = [0.0, 0.1, 3.2]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    torso = FusedTorso({k: torch.from_numpy(v) for k, v in sd.items()})
+    enc_anchor = torso.encode_anchor(dev(pose[None]))
+    dg = dev(grid0.copy())
+    mean_g, thr_g = update_density_grid_torso(torso, dg, None, dev(ind), noise=dev(noise), enc_anchor=enc_anchor, density_thresh=0.01)
+    ref = grid0.copy()
+    mean_o = oracle_update(sd, ref, enc_anchor.cpu().numpy().reshape(-1), ind, noise)
+    assert np.array_equal(dg.cpu().numpy(), ref)
+    assert float(mean_g) == pytest.approx(mean_o, rel=2e-6) and float(thr_g) == pytest.approx(min(mean_o, 0.01), rel=2e-6)
+    assert (ref != grid0 * F32(0.95)).mean() > 0.2     # the new alphas win somewhere, the decayed old grid elsewhere
