@@ -45,6 +45,38 @@ def orbit_pose(k, n):
     return pose
 
 
+# kernels behind each grid_roofline case and the batch size tools/grid_bench.py profiled them at (tools/profile_grid.sh)
+_GRID_PMC = {"triplane_plane_D2_L12_C1_f32": (["lz_k_grid_forward_lds<float, 2u, 1u>"], 1 << 22),
+             "hashgrid_D3_L16_C2_f32": (["lz_k_grid_forward_lmp<float, 3u, 2u>", "lz_k_grid_untile"], 1 << 23),
+             "hashgrid_D3_L16_C2_f16": (["lz_k_grid_forward_lmp<__half, 3u, 2u>", "lz_k_grid_untile"], 1 << 23),
+             "triplane_plane_D2_L12_C1_f32_backward": (["lz_k_grid_backward_lds<2u, 1u>"], 1 << 22)}
+
+
+def _grid_traffic(tag, B):
+    """HBM-side bytes per launch at batch size B from the committed PMC summary (KiB per launch at the profiled batch size, scaled
+    per sample; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 -- calibrated there for wide streaming reads, so an
+    upper bound for the gather-dominated kernels).  None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_grid_pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        pmc = json.load(open(path))
+        kernels, b_prof = _GRID_PMC[tag]
+        kib = 0.0
+        for k in kernels:
+            f, w = pmc["FETCH_SIZE"][k], pmc["WRITE_SIZE"][k]
+            # lz_k_grid_untile is shared by several cases of the profiled script: take its largest launch (the f32 cfg2 one) for f32,
+            # half of it for f16
+            if k == "lz_k_grid_untile":
+                scale = 0.5 if "f16" in tag else 1.0
+                kib += (2 * f["max"] + w["max"]) * scale
+            else:
+                kib += 2 * f["avg_per_launch"] + w["avg_per_launch"]
+        return round(kib * 1024 / b_prof * B)
+    except (KeyError, ValueError):
+        return None
+
+
 def grid_roofline(device):
     """stand-alone grid encoder: algorithmic bytes / event-timed launch duration"""
     from lzzx_nerf_amd.gridencoder import GridEncoder, grid_encode
@@ -81,7 +113,7 @@ def grid_roofline(device):
         ms = e0.elapsed_time(e1) / n
         gbs = bytes_per_sample * B / (ms * 1e-3) / 1e9
         res[tag] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-                        traffic=None, samples=B, ms=round(ms, 4), bytes_per_sample=bytes_per_sample)
+                        traffic=_grid_traffic(tag, B), samples=B, ms=round(ms, 4), bytes_per_sample=bytes_per_sample)
         del enc, x
     return res
 
@@ -201,6 +233,7 @@ def main():
     ap.add_argument("--no-fat-schedule", action="store_true")
     ap.add_argument("--no-fp16-leg", action="store_true")
     ap.add_argument("--no-occupancy", action="store_true")
+    ap.add_argument("--no-dense192", action="store_true")
     ap.add_argument("--gather", default="f32", choices=["f32", "rgb24"],
                     help="what the per-step all-gather moves: f32 RGB tiles, or the video pipe's RGB24 quantised on device (4x fewer bytes)")
     args = ap.parse_args()
@@ -368,6 +401,39 @@ def main():
                    fat_schedule_image_equal=bool(torch.equal(img16, img16b)))
         result["fp16_head"] = leg
         del h16
+    if world == 1 and not args.no_dense192:
+        # SURVEY 8d "dense-192 micro-benchmark": the NOMINAL 512 x 512 x 192 = 50.33 M samples (uniform points in [-1,1]^3, the ray
+        # directions, delta = 2 sqrt(3) / 192) straight through encode -> MLP (fused head) -> composite_rays_train_triplane
+        from lzzx_nerf_amd import raymarching as R
+        S = args.max_steps
+        gd = torch.Generator(device=device).manual_seed(5)
+        M = N * S
+        xyz = torch.rand(M, 3, device=device, generator=gd) * 2 - 1
+        dirs_d = rays_d.repeat_interleave(S, dim=0)
+        dt = float(2 * np.sqrt(3) / S)
+        deltas = torch.empty(M, 2, device=device)
+        deltas[:, 0] = dt
+        deltas[:, 1] = (torch.arange(M, device=device) % S).float() * dt + 2.35
+        rays_tbl = torch.stack([torch.arange(N, device=device), torch.arange(N, device=device) * S, torch.full((N,), S, device=device)],
+                               1).int().contiguous()
+        outd = tuple(torch.empty(s, device=device) for s in ((M,), (M, 3), (M, 1), (M, 1), (M, 1)))
+
+        def dense():
+            sg, rg, aa, ae, un = head.forward(xyz, dirs_d, enc_a, ind, eye, testing=True, out=outd)
+            return R.composite_rays_train_triplane(sg, rg, aa.view(-1), ae.view(-1), un.view(-1), deltas, rays_tbl)
+
+        for _ in range(2):
+            dense()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            comp = dense()
+        torch.cuda.synchronize()
+        dms = (time.perf_counter() - t0) / 5 * 1e3
+        result["dense192"] = dict(samples=M, ms=round(dms, 3), samples_per_s=round(M / dms * 1e3, 1), rays_per_s=round(N / dms * 1e3, 1),
+                                  note="nominal 512x512x192 samples: uniform points -> fused head -> composite_rays_train_triplane forward",
+                                  image_mean=float(comp[5].mean()))
+        del xyz, dirs_d, deltas, rays_tbl, outd, comp
     if not args.no_grid_roofline and world == 1:
         result["roofline_gridencoder"] = grid_roofline(device)
     if args.train and world == 1:
