@@ -799,6 +799,39 @@ def test_full_size_frame_properties(params, golden):
     assert torch.equal(again["image"], img)
 
 
+@pytest.mark.parametrize("bound,n_rays,max_steps", [(2.0, 1000, 40), (1.0, 37, 5), (4.0, 513, 24)])
+def test_render_odd_sizes_and_cascades(params, golden, bound, n_rays, max_steps):
+    """ray counts that are not multiples of a workgroup, very few steps, bound > 1 (cascade 2 / 3: mip levels in the march, larger
+    tables in the head): whole frame against the checker, bit for bit"""
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    rng = np.random.default_rng(int(bound * 7) + n_rays)
+    spec = TriplaneSpec(bound)
+    p = dict(_scene(params, 30.0))
+    if bound != 1.0:
+        for n in ("xy", "yz", "xz"):
+            p[f"encoder_{n}.embeddings"] = rng.uniform(-1, 1, (spec.n_params, 1)).astype(np.float32)
+            p[f"encoder_{n}.offsets"] = spec.offsets.astype(np.int32)
+    cascade = 1 + int(np.ceil(np.log2(bound)))
+    # random occupancy, 30 % of the cells of every cascade
+    grid = (rng.uniform(size=(cascade, 128 ** 3)) < 0.3).astype(np.float32)
+    bits = O.packbits(grid, 0.5)
+    pose, intr = synthetic_camera(64, 64)
+    ro, rd = get_rays(pose, intr, 64, 64)
+    sel = rng.choice(64 * 64, n_rays, replace=False)
+    ro, rd = np.ascontiguousarray(ro[sel]) * np.float32(bound), np.ascontiguousarray(rd[sel])
+    enc_a, eye, ind = golden["net_enc_a"], golden["net_eye"], golden["net_ind"]
+    st = {}
+    ref = render_inference(spec, p, ro, rd, bits, enc_a, ind, eye, cascade=cascade, max_steps=max_steps, stats=st)
+    head = FusedTriplaneHead({k: torch.from_numpy(np.asarray(v)) for k, v in p.items()}, bound=bound)
+    r = TriplaneRenderer(head, dev(bits), bound=bound)
+    out = r.render(dev(ro), dev(rd), dev(enc_a), dev(ind), dev(eye), max_steps=max_steps, count_samples=True)
+    assert np.array_equal(host(out["ray_counts"]).astype(np.int64), st["samples_per_ray"])
+    assert np.array_equal(host(out["image"]), ref["image"]) and np.array_equal(host(out["depth"]), ref["depth"])
+    state = host(out["state"])
+    assert state[3] == 1 and state[5] == st["samples_per_ray"].sum() and state[6] == len(st["schedule"]) and st["samples_per_ray"].sum() > 0
+
+
 def test_render_more_rays_than_one_pass(params, golden, monkeypatch):
     """batches above the device loop's 2^20-ray limit are rendered in passes; pixels equal the single-pass render"""
     import lzzx_nerf_amd.renderer as RR
