@@ -259,6 +259,31 @@ int lz_linear_forward(const float* X, uint32_t ldx, const float* mask, const flo
 int lz_linear_grad_w(const float* dY, uint32_t ldd, const float* mask, const float* X, uint32_t ldx, float* dW, uint32_t ldw,
                      uint32_t M, uint32_t K, uint32_t N, lz_stream_t stream);
 
+/* Backward of the fused head for training (f32, testing = 0): recomputes the forward from (xyzs, dirs) and runs the data-gradient
+ * chain of NeRFNetwork.forward (network.py:252-311) in one kernel.  Inputs: the upstream gradients of the five head outputs
+ * (what composite_rays_train_triplane's backward produces): g_sigma [M], g_rgb [M,3], g_amb_aud [M] (of ||att||), g_amb_eye [M]
+ * (of eye_att; may be NULL), g_unc [M].  Outputs (all caller-allocated, row-major f32):
+ *   denc[p]  [M,12]  d loss / d (plane p's 12 grid features)  -> lz_grid_encode_backward(grad_layout 1 or 2) per plane
+ *   d_enc_a  [32], d_ind [4]: accumulated over the samples with atomics (zero them first; may be NULL)
+ *   X_*      the input of every Linear layer, G_* the gradient of its output (ReLU mask applied), for the weight gradients:
+ *            dW = lz_linear_grad_w(G, mask = NULL, X) per layer.  Shapes (leading dimension = width unless noted):
+ *            X_encx [M,36]  X_a1 [M,64]  X_e1 [M,16]  X_sig0 [M,69] (ld 72)  X_s1 [M,64]  X_s2 [M,64]  X_col0 [M,84]  X_c1 [M,64]
+ *            X_u1 [M,32];  G_a1 [M,64]  G_att [M,32]  G_e1 [M,16]  G_e2 [M]  G_s1 [M,64]  G_s2 [M,64]  G_s3 [M,65] (column 0 = sigma
+ *            row)  G_c1 [M,64]  G_c [M,3]  G_u1 [M,32]  G_u [M].
+ *   Layer <- (X, G): aud_ch_att_net.0 <- (X_encx, G_a1), .1 <- (X_a1, G_att); eye_att_net.0 <- (X_encx, G_e1), .1 <- (X_e1, G_e2);
+ *   sigma_net.0 <- (X_sig0, G_s1), .1 <- (X_s1, G_s2), .2 <- (X_s2, G_s3); color_net.0 <- (X_col0, G_c1), .1 <- (X_c1, G_c);
+ *   unc_net.0 <- (X_encx, G_u1), .1 <- (X_u1, G_u). */
+typedef struct {
+    float* denc[3];
+    float* d_enc_a;
+    float* d_ind;
+    float *X_encx, *X_a1, *X_e1, *X_sig0, *X_s1, *X_s2, *X_col0, *X_c1, *X_u1;
+    float *G_a1, *G_att, *G_e1, *G_e2, *G_s1, *G_s2, *G_s3, *G_c1, *G_c, *G_u1, *G_u;
+} lz_head_bwd_out;
+int lz_triplane_head_backward(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M, const float* g_sigma,
+                              const float* g_rgb, const float* g_amb_aud, const float* g_amb_eye, const float* g_unc,
+                              const lz_head_bwd_out* out, lz_stream_t stream);
+
 /* Device-resident inference loop (renderer.py:495-548): no host synchronisation inside the frame, 3 launches per iteration:
  *     lz_loop_march -> lz_triplane_head_forward(count = state words + LZ_LOOP_NEXT + 2) -> lz_loop_composite.
  * The device buffer passed as `lz_loop_state*` must hold LZ_LOOP_STATE_INTS int32:

@@ -18,6 +18,13 @@ class HeadParams(C.Structure):
                 ("ind_code", vp), ("eye", vp), ("bound", f32), ("S", f32), ("H", u32), ("testing", i32), ("precision", i32)]
 
 
+class HeadBwdOut(C.Structure):
+    """mirror of lz_head_bwd_out (include/lzzx_nerf_hip.h)"""
+    _fields_ = [("denc", vp * 3), ("d_enc_a", vp), ("d_ind", vp)] + \
+               [(n, vp) for n in ("X_encx", "X_a1", "X_e1", "X_sig0", "X_s1", "X_s2", "X_col0", "X_c1", "X_u1",
+                                  "G_a1", "G_att", "G_e1", "G_e2", "G_s1", "G_s2", "G_s3", "G_c1", "G_c", "G_u1", "G_u")]
+
+
 class TorsoParams(C.Structure):
     """mirror of lz_torso_params (include/lzzx_nerf_hip.h)"""
     _fields_ = [("deform_w0", vp), ("deform_w1", vp), ("deform_w2", vp), ("torso_w0", vp), ("torso_w1", vp), ("torso_w2", vp),
@@ -76,6 +83,7 @@ SIGNATURES = {
     "lz_final_blend": [vp, vp, vp, f32, u32, vp, vp],
     "lz_final_blend_rgb24": [vp, vp, vp, f32, u32, vp, vp, vp],
     "lz_debug_head_clocks": [C.POINTER(C.c_uint64)],
+    "lz_triplane_head_backward": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, C.POINTER(HeadBwdOut), vp],
     "lz_head_pack_weights_f16": [vp] * 9 + [i32, i32, vp, vp],
     "lz_torso_forward": [C.POINTER(TorsoParams), vp, u32, vp, vp, vp, vp],
     "lz_audio_encode": [C.POINTER(AudioParams), vp, vp, vp, vp],

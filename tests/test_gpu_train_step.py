@@ -207,3 +207,96 @@ def test_train_step_gradients(params, golden, mlp):
     for e, g, n in zip(encs, E, ("xy", "yz", "xz")):
         close(e.embeddings.grad, g.grad, "encoder_" + n)
         assert float(e.embeddings.grad.abs().sum()) > 0
+
+
+def test_fused_train_head_gradients(params, golden):
+    """FusedTriplaneTrainHead: forward = the fused head kernel in training mode (bit-exact against the checker), backward = ONE
+    kernel for the data-gradient chain + per-layer weight-gradient reductions + LDS grid scatter.  Every gradient against the float64
+    model of the whole step (same model as test_train_step_gradients)."""
+    from lzzx_nerf_amd import raymarching as R
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    from oracle.head import head_forward
+    H = W = 24
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    bits = ellipsoid_bitfield()[0]
+    spec = TriplaneSpec(1.0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    enc_a, eye, ind = golden["net_enc_a"], golden["net_eye"], golden["net_ind"]
+    net = FusedTriplaneTrainHead({k: v for k, v in params.items()}, bound=1.0).cuda()
+    aabb = dev(np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32))
+    nears, fars = R.near_far_from_aabb(dev(ro), dev(rd), aabb, 0.05)
+    ctr = torch.zeros(2, dtype=torch.int32, device="cuda")
+    xyzs, dirs, deltas, rays = R.march_rays_train(dev(ro), dev(rd), 1.0, dev(bits), 1, 128, nears, fars, ctr, -1, False, 128, True, 1 / 256, 32)
+    enc_a_t, ind_t = dev(enc_a).requires_grad_(True), dev(ind).requires_grad_(True)
+    sigma, rgb, aa, ae, unc = net(xyzs.contiguous(), dirs.contiguous(), enc_a_t, ind_t, dev(eye))
+    # forward: the training-mode head, bit for bit
+    so, ro_, ao, eo, uo = head_forward(spec, params, xyzs.cpu().numpy(), dirs.cpu().numpy(), enc_a, ind, eye, testing=False)
+    assert np.array_equal(sigma.detach().cpu().numpy(), so) and np.array_equal(rgb.detach().cpu().numpy(), ro_)
+    assert np.array_equal(unc.detach().cpu().numpy(), uo) and np.array_equal(aa.detach().cpu().numpy(), ao)
+    ws, a0s, a1s, us, dep, img = R.composite_rays_train_triplane(sigma, rgb, aa[:, 0], ae[:, 0], unc[:, 0], deltas, rays)
+    target = torch.linspace(0, 1, H * W * 3, device="cuda").reshape(-1, 3)
+    loss = ((img - target) ** 2).mean() + 0.1 * ws.mean() + 1e-3 * a0s.mean() + 1e-3 * a1s.mean() + 1e-2 * us.mean()
+    loss.backward()
+    # ---------------- float64 model (as in test_train_step_gradients) ----------------
+    dd = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()
+    E = [dd(params[f"encoder_{n}.embeddings"]).requires_grad_(True) for n in ("xy", "yz", "xz")]
+    Wc = {k: dd(v).requires_grad_(True) for k, v in params.items() if k.endswith(".weight")}
+    ea_c, ind_c = dd(enc_a).requires_grad_(True), dd(ind).requires_grad_(True)
+    sc, rs = O.grid_level_params(12, np.float32(np.log2(spec.per_level_scale)), 64)
+    xc = dd(xyzs.cpu().numpy())
+    x01 = (xc + 1) / 2
+
+    def mlpc(h, name, n):
+        for i in range(n):
+            h = h @ Wc[f"{name}.net.{i}.weight"].T
+            if i < n - 1:
+                h = torch.relu(h)
+        return h
+
+    enc_xc = torch.cat([_grid64(x01[:, [0, 1]], E[0], spec.offsets, sc, rs), _grid64(x01[:, [1, 2]], E[1], spec.offsets, sc, rs),
+                        _grid64(x01[:, [0, 2]], E[2], spec.offsets, sc, rs)], -1)
+    attc = mlpc(enc_xc, "aud_ch_att_net", 2)
+    eyec = torch.sigmoid(mlpc(enc_xc, "eye_att_net", 2))
+    hc = mlpc(torch.cat([enc_xc, ea_c * attc, dd(eye) * eyec], -1), "sigma_net", 3)
+    sigc = torch.exp(hc[:, 0])
+    shc = dd(O.sh_encode_forward(dirs.cpu().numpy(), 4)[0])
+    rgbc = torch.sigmoid(mlpc(torch.cat([shc, hc[:, 1:], ind_c.repeat(xc.shape[0], 1)], -1), "color_net", 2)) * 1.002 - 0.001
+    uncc = torch.log(1 + torch.exp(mlpc(enc_xc.detach(), "unc_net", 2)))[:, 0]
+    dl = dd(deltas.cpu().numpy())
+    rays_np = rays.cpu().numpy()
+    N = rays_np.shape[0]
+    imgs, wss, a0c, a1c, usc = [None] * N, [None] * N, [None] * N, [None] * N, [None] * N
+    zero = torch.zeros((), dtype=torch.float64)
+    for n in range(N):
+        i, o, c = [int(v) for v in rays_np[n]]
+        T, r, w_, a0_, a1_, u_ = 1.0, torch.zeros(3, dtype=torch.float64), zero, zero, zero, zero
+        for s in range(o, o + c):
+            alpha = 1 - torch.exp(-sigc[s] * dl[s, 0])
+            wgt = alpha * T
+            r = r + wgt * rgbc[s]
+            w_ = w_ + wgt
+            a0_ = a0_ + attc[s].norm()
+            a1_ = a1_ + eyec[s].abs().sum()
+            u_ = u_ + wgt * uncc[s]
+            T = T * (1 - alpha)
+            if float(T.detach()) < 1e-4:
+                break
+        imgs[i], wss[i], a0c[i], a1c[i], usc[i] = r, w_, a0_, a1_, u_
+    lossc = ((torch.stack(imgs) - target.cpu().double()) ** 2).mean() + 0.1 * torch.stack(wss).mean() + 1e-3 * torch.stack(a0c).mean() + \
+        1e-3 * torch.stack(a1c).mean() + 1e-2 * torch.stack(usc).mean()
+    lossc.backward()
+    assert float(loss) == pytest.approx(float(lossc), rel=1e-5)
+
+    def close(g_gpu, g_cpu, name, tol=2e-3):
+        a, b = g_gpu.detach().cpu().double().numpy(), g_cpu.numpy()
+        scale = max(np.abs(b).max(), 1e-12)
+        assert np.max(np.abs(a - b)) / scale < tol, (name, np.max(np.abs(a - b)) / scale)
+
+    sd = dict(net.named_parameters())
+    for k in Wc:
+        close(sd[k].grad, Wc[k].grad, k)
+    for n, g in zip(("xy", "yz", "xz"), E):
+        close(sd[f"encoder_{n}.embeddings"].grad, g.grad, "encoder_" + n)
+    close(enc_a_t.grad, ea_c.grad, "enc_a")
+    close(ind_t.grad, ind_c.grad, "ind_code")
