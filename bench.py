@@ -176,7 +176,11 @@ def train_bench(args, device, P, golden, bits):
     sel = torch.randperm(H * W, device=device, generator=g)[:n_rays]
     ro, rd = ro[sel].contiguous(), rd[sel].contiguous()
     target = torch.rand(n_rays, 3, device=device, generator=g)
-    net = TriplaneTrainNet(P, device, mlp=args.train_mlp)
+    if args.train_mlp == "fused":   # one kernel forward, one kernel for the backward data chain (lzzx_nerf_amd/head_train.py)
+        from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+        net = FusedTriplaneTrainHead(P, bound=1.0).to(device)
+    else:
+        net = TriplaneTrainNet(P, device, mlp=args.train_mlp)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-15)
     enc_a, ind, eye = dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"])
     aabb = dev(np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32))
@@ -190,6 +194,8 @@ def train_bench(args, device, P, golden, bits):
         xyzs, dirs, deltas, rays = R.march_rays_train(ro, rd, 1.0, bitfield, 1, 128, nears, fars, ctr, -1, True, 128, True, 1 / 256,
                                                       args.max_steps)
         sigma, rgb, a0, a1, unc = net(xyzs, dirs, enc_a, ind, eye)
+        if args.train_mlp == "fused":
+            a0, a1, unc = a0[:, 0], a1[:, 0], unc[:, 0]
         ws, a0s, a1s, us, dep, img = R.composite_rays_train_triplane(sigma, rgb, a0, a1, unc, deltas, rays)
         loss = ((img + (1 - ws).unsqueeze(-1) - target) ** 2).mean() + 1e-4 * a0s.mean() + 1e-4 * a1s.mean() + 1e-3 * us.mean()
         opt.zero_grad(set_to_none=True)
@@ -210,7 +216,8 @@ def train_bench(args, device, P, golden, bits):
                          "march_rays_train -> 3 grid + SH encoders -> torch Linear heads -> composite_rays_train_triplane -> MSE -> "
                          "backward (grid scatter-add) -> Adam", rays=n_rays, samples_per_step=int(n_samples[0]),
                 ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
-                loss=float(loss.detach()), dtype="f32", mlp="csrc/lz_linear.hip (MFMA f32)" if args.train_mlp == "lz" else "torch/rocBLAS")
+                loss=float(loss.detach()), dtype="f32", mlp={"fused": "fused head forward + backward kernels (csrc/lz_head.hip, lz_head_bwd.hip)", "lz": "csrc/lz_linear.hip (MFMA f32)",
+                     "torch": "torch/rocBLAS"}[args.train_mlp])
 
 
 def main():
@@ -221,7 +228,8 @@ def main():
                     help="f16 = the reference's opt.fp16 / autocast arithmetic on the f16 matrix cores (not bit-exact vs the f32 checker)")
     ap.add_argument("--train", action="store_true", help="also time a cfg3 training step (operator API) and add it as 'train_step'")
     ap.add_argument("--train-rays", type=int, default=65536)
-    ap.add_argument("--train-mlp", default="lz", choices=["lz", "torch"], help="Linear layers of the training step: lz_linear kernels or torch")
+    ap.add_argument("--train-mlp", default="fused", choices=["fused", "lz", "torch"],
+                    help="training step: fused head forward/backward kernels, per-layer lz_linear kernels, or torch Linear")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)

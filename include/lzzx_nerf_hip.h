@@ -263,7 +263,7 @@ int lz_linear_grad_w(const float* dY, uint32_t ldd, const float* mask, const flo
  * chain of NeRFNetwork.forward (network.py:252-311) in one kernel.  Inputs: the upstream gradients of the five head outputs
  * (what composite_rays_train_triplane's backward produces): g_sigma [M], g_rgb [M,3], g_amb_aud [M] (of ||att||), g_amb_eye [M]
  * (of eye_att; may be NULL), g_unc [M].  Outputs (all caller-allocated, row-major f32):
- *   denc[p]  [M,12]  d loss / d (plane p's 12 grid features)  -> lz_grid_encode_backward(grad_layout 1 or 2) per plane
+ *   denc[p]  [12,M]  d loss / d (plane p's 12 grid features), level-major -> lz_grid_encode_backward(grad_layout 0 or 3) per plane
  *   d_enc_a  [32], d_ind [4]: accumulated over the samples with atomics (zero them first; may be NULL)
  *   X_*      the input of every Linear layer, G_* the gradient of its output (ReLU mask applied), for the weight gradients:
  *            dW = lz_linear_grad_w(G, mask = NULL, X) per layer.  Shapes (leading dimension = width unless noted):

@@ -9,7 +9,7 @@
 // the value that lane supplied to k-step 4 kt + r' of the forward layer, so gradients stay in the layout of the activations they
 // belong to: ReLU masks (kept as one bit per value) apply elementwise and a tile is directly the B operand of the next layer back.
 //
-// Outputs: d(enc_x) as three [M,12] tensors (-> lz_grid_encode_backward per plane), d(enc_a) [32] and d(ind_code) [4] (reduced over
+// Outputs: d(enc_x) as three level-major [12, M] tensors (-> lz_grid_encode_backward per plane, grad_layout 3: coalesced reads), d(enc_a) [32] and d(ind_code) [4] (reduced over
 // the samples in registers, one atomic per lane and workgroup at the end), and, for the weight gradients, the layer inputs X_l and
 // the (ReLU-masked) output gradients G_l in row-major [M, *] buffers that lz_linear_grad_w reduces over M.  dW inside this kernel
 // would need 379 accumulator tiles per wave or a second 96 KB LDS image next to the weights; the dump costs 3.6 KB per sample of
@@ -55,10 +55,15 @@ __device__ __forceinline__ void lz_layer_bwd(const float* __restrict__ wl, int l
 template <int NTILE>
 __device__ __forceinline__ void lz_dump_chained(float* __restrict__ dst, size_t row, uint32_t ld, uint32_t col0, int q, const float (&v)[4 * NTILE]) {
     float* p = dst + row * ld + col0 + 4 * q;
+    if (((ld | col0) & 3u) == 0u) {   // 16-byte aligned rows: one dwordx4 store per tile (the buffers themselves are 16-byte aligned)
 #pragma unroll
-    for (int t = 0; t < NTILE; t++)
+        for (int t = 0; t < NTILE; t++) *reinterpret_cast<float4*>(p + 16 * t) = make_float4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; r++) p[16 * t + r] = v[4 * t + r];
+        for (int t = 0; t < NTILE; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) p[16 * t + r] = v[4 * t + r];
+    }
 }
 
 template <int N>
@@ -386,7 +391,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
         // d(enc_x): feature 4 i + q = plane i / 3, level 4 (i % 3) + q
         if (valid) {
 #pragma unroll
-            for (int i = 0; i < 9; i++) O.denc[i / 3][row * 12 + 4 * (i % 3) + q] = dencx[i];
+            for (int i = 0; i < 9; i++) O.denc[i / 3][(size_t)(4 * (i % 3) + q) * M + row] = dencx[i];   // level-major [12, M]
         }
     }
     // d(enc_a), d(ind_code): sum over the 16 sample lanes of every q group, then one atomic per value and wave

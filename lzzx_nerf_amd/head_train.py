@@ -58,12 +58,13 @@ class _FusedHeadTrain(Function):
         g_sig, g_rgb, g_aa, g_ae, g_un = z(g_sig, (M,)), z(g_rgb, (M, 3)), z(g_aa, (M, 1)), z(g_ae, (M, 1)), z(g_un, (M, 1))
         widths = {**_X, **_G}
         names = list(widths)
-        work = torch.empty(M * sum(widths.values()), **kw)                      # one allocation for every dump buffer
+        al = lambda n: (n + 3) // 4 * 4                                         # every buffer starts 16-byte aligned (dwordx4 stores)
+        work = torch.empty(sum(al(M * wd) for wd in widths.values()), **kw)     # one allocation for every dump buffer
         bufs, off = {}, 0
         for n in names:
             bufs[n] = work[off: off + M * widths[n]].view(M, widths[n])
-            off += M * widths[n]
-        denc = [torch.empty(M, 12, **kw) for _ in range(3)]
+            off += al(M * widths[n])
+        denc = [torch.empty(12, M, **kw) for _ in range(3)]   # level-major: the grid backward reads one level at a time
         d_enc_a, d_ind = torch.zeros(32, **kw), torch.zeros(4, **kw)
         o = _lib.HeadBwdOut()
         for i in range(3):
@@ -89,7 +90,7 @@ class _FusedHeadTrain(Function):
             x01 = ((xyzs[:, list(cols)] + mod.bound) / (2 * mod.bound)).contiguous()
             ge = torch.zeros_like(e)
             call("lz_grid_encode_backward", ptr(g), ptr(x01), ptr(e), ptr(mod.offsets), ptr(ge), M, 2, 1, 12, mod.S, mod.H, None, None, 0, 0,
-                 0, 2 if M >= 16384 else 1, stream())
+                 0, 3 if M >= 16384 else 0, stream())
             demb.append(ge)
         enc_a_shape, ind_shape = ctx.shapes
         g_enc_a = d_enc_a.view(enc_a_shape) if ctx.needs_input_grad[3] else None
