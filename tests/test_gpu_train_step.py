@@ -300,3 +300,64 @@ def test_fused_train_head_gradients(params, golden):
         close(sd[f"encoder_{n}.embeddings"].grad, g.grad, "encoder_" + n)
     close(enc_a_t.grad, ea_c.grad, "enc_a")
     close(ind_t.grad, ind_c.grad, "ind_code")
+
+
+@pytest.mark.parametrize("exp_eye,ind_dim", [(False, 0), (True, 0), (False, 4)])
+def test_fused_train_head_variants_match_operator_graph(params, golden, exp_eye, ind_dim):
+    """exp_eye off / no individual code: the fused forward + backward against the same network built from the operator API
+    (GridEncoder + SHEncoder + torch Linear under autograd) on the GPU, f32 vs f32"""
+    from lzzx_nerf_amd.encoding import get_encoder
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    rng = np.random.default_rng(3)
+    p = dict(params)
+    p["sigma_net.net.0.weight"] = np.ascontiguousarray(params["sigma_net.net.0.weight"][:, :68 + int(exp_eye)])
+    p["color_net.net.0.weight"] = np.ascontiguousarray(params["color_net.net.0.weight"][:, :80 + ind_dim])
+    net = FusedTriplaneTrainHead(p, bound=1.0, exp_eye=exp_eye, ind_dim=ind_dim).cuda()
+    M = 4096 + 48
+    xyz = torch.from_numpy(rng.uniform(-1, 1, (M, 3)).astype(np.float32)).cuda()
+    d = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)), dim=-1).cuda()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    enc_a, eye, ind = dev(golden["net_enc_a"]), dev(golden["net_eye"]) if exp_eye else None, dev(golden["net_ind"]) if ind_dim else None
+    gout = [torch.from_numpy(rng.normal(size=sh).astype(np.float32)).cuda() for sh in ((M,), (M, 3), (M, 1), (M, 1), (M, 1))]
+    outs = net(xyz, d, enc_a, ind, eye)
+    torch.autograd.backward([o for o, g in zip(outs, gout) if o.requires_grad], [g for o, g in zip(outs, gout) if o.requires_grad])
+    # the same network from operators
+    encs = []
+    for n in ("xy", "yz", "xz"):
+        e = get_encoder("hashgrid", input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14, desired_resolution=512)[0].cuda()
+        e.embeddings.data.copy_(dev(p[f"encoder_{n}.embeddings"]))
+        encs.append(e)
+    sh = get_encoder("spherical_harmonics")[0]
+    Wg = {k: dev(v).requires_grad_(True) for k, v in p.items() if k.endswith(".weight")}
+    lin = torch.nn.functional.linear
+
+    def mlp(h, name, n):
+        for i in range(n):
+            h = lin(h, Wg[f"{name}.net.{i}.weight"])
+            if i < n - 1:
+                h = torch.relu(h)
+        return h
+
+    enc_x = torch.cat([encs[0](xyz[:, :2], bound=1), encs[1](xyz[:, 1:], bound=1), encs[2](xyz[:, [0, 2]], bound=1)], -1)
+    att = mlp(enc_x, "aud_ch_att_net", 2)
+    parts = [enc_x, enc_a * att]
+    if exp_eye:
+        eye_att = torch.sigmoid(mlp(enc_x, "eye_att_net", 2))
+        parts.append(eye * eye_att)
+    h = mlp(torch.cat(parts, -1), "sigma_net", 3)
+    cin = [sh(d), h[:, 1:]] + ([ind.repeat(M, 1)] if ind_dim else [])
+    ref = [torch.exp(h[:, 0]), torch.sigmoid(mlp(torch.cat(cin, -1), "color_net", 2)) * 1.002 - 0.001, att.norm(dim=-1, keepdim=True),
+           eye_att if exp_eye else None, torch.nn.functional.softplus(mlp(enc_x.detach(), "unc_net", 2))]
+    for o, r in zip(outs, ref):
+        if r is not None:
+            assert torch.allclose(o, r, rtol=2e-4, atol=2e-5)
+    torch.autograd.backward([r for r in ref if r is not None], [g for r, g in zip(ref, gout) if r is not None])
+    sd = dict(net.named_parameters())
+    for k, wg in Wg.items():
+        if not exp_eye and k.startswith("eye_att_net"):
+            continue
+        a, b = sd[k].grad, wg.grad
+        assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-6), k
+    for n, e in zip(("xy", "yz", "xz"), encs):
+        a, b = sd[f"encoder_{n}.embeddings"].grad, e.embeddings.grad
+        assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-6), n
