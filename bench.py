@@ -49,7 +49,7 @@ def orbit_pose(k, n):
 _GRID_PMC = {"triplane_plane_D2_L12_C1_f32": (["lz_k_grid_forward_lds<float, 2u, 1u>"], 1 << 22),
              "hashgrid_D3_L16_C2_f32": (["lz_k_grid_forward_lmp<float, 3u, 2u>", "lz_k_grid_untile"], 1 << 23),
              "hashgrid_D3_L16_C2_f16": (["lz_k_grid_forward_lmp<__half, 3u, 2u>", "lz_k_grid_untile"], 1 << 23),
-             "triplane_plane_D2_L12_C1_f32_backward": (["lz_k_grid_backward_lds<2u, 1u>"], 1 << 22)}
+             "triplane_plane_D2_L12_C1_f32_backward": (["lz_k_grid_backward_lds_fx<2u, 1u>"], 1 << 22)}
 
 
 def _grid_traffic(tag, B):

@@ -165,7 +165,7 @@ def test_grid_forward_tiled_level_major_bit_exact(D, L, C, H, T, res, gt, half):
     (3, 8, 2, 16, 16, 256, "hash"),      # fine levels do not fit: in-kernel fallback to global atomics
 ])
 def test_grid_backward_level_resident(D, L, C, H, T, res, gt):
-    """grad_layout 2 / 3: lz_k_grid_backward_lds (per-level accumulation in LDS, contiguous flush) vs the checker and vs the
+    """grad_layout 2 / 3: lz_k_grid_backward_lds_fx (per-level 64-bit fixed-point accumulation in LDS, contiguous flush) vs the checker and vs the
     plain scatter kernel; the summation order is free, so tolerance, not bits"""
     from lzzx_nerf_amd.gridencoder import GridEncoder
     from lzzx_nerf_amd._util import call, ptr, stream
