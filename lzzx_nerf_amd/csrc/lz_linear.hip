@@ -182,7 +182,7 @@ extern "C" int lz_linear_grad_w(const float* dY, uint32_t ldd, const float* mask
     const uint32_t KB = (K + 15) / 16, NB = (N + 15) / 16;
     const uint32_t groups = lz_div_up(M, 16);
     uint32_t g = lz_div_up(groups, 4 * 8);   // >= 8 sample groups per wave before paying for the reduction
-    if (g > 512) g = 512;
+    if (g > 1536) g = 1536;   // ~6 workgroups per CU: the loads feed the MFMAs directly, occupancy is what hides their latency
     if (g < 1) g = 1;
     const dim3 grid(g);
     hipStream_t st = lz_st(stream);
