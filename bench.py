@@ -160,11 +160,12 @@ class TriplaneTrainNet(torch.nn.Module):
         return sigma, rgb, att.norm(dim=-1), eye_att.abs().sum(-1), unc
 
 
-def train_bench(args, device, P, golden, bits):
+def train_bench(args, device, P, golden, bits, rank=0, world=1):
     """BASELINE cfg3: one training step (fwd + bwd + Adam) on `--train-rays` random rays of the 512x512 frame through the
     operator API as the reference's run_cuda arranges it (renderer.py:279-304).  The MLP GEMMs are torch/rocBLAS here;
     everything else is this repo's HIP kernels.  Reported beside the headline line, never instead of it."""
     from conftest import synthetic_camera
+    from lzzx_nerf_amd import dist as D
     from lzzx_nerf_amd import raymarching as R
     from lzzx_nerf_amd.renderer import get_rays
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
@@ -174,14 +175,16 @@ def train_bench(args, device, P, golden, bits):
     g = torch.Generator(device=device).manual_seed(0)
     n_rays = min(args.train_rays, H * W)
     sel = torch.randperm(H * W, device=device, generator=g)[:n_rays]
-    ro, rd = ro[sel].contiguous(), rd[sel].contiguous()
     target = torch.rand(n_rays, 3, device=device, generator=g)
+    lo, hi = D.shard_bounds(n_rays, rank, world)   # data parallel over the sampled rays (world == 1: everything)
+    ro, rd, target = ro[sel[lo:hi]].contiguous(), rd[sel[lo:hi]].contiguous(), target[lo:hi].contiguous()
     if args.train_mlp == "fused":   # one kernel forward, one kernel for the backward data chain (lzzx_nerf_amd/head_train.py)
         from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
         net = FusedTriplaneTrainHead(P, bound=1.0).to(device)
     else:
         net = TriplaneTrainNet(P, device, mlp=args.train_mlp)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-15)
+    bucket = D.GradientBucket(net.parameters()) if world > 1 else None   # every .grad a view of one flat buffer: ONE all-reduce per step
     enc_a, ind, eye = dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"])
     aabb = dev(np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32))
     bitfield = dev(bits)
@@ -198,8 +201,13 @@ def train_bench(args, device, P, golden, bits):
             a0, a1, unc = a0[:, 0], a1[:, 0], unc[:, 0]
         ws, a0s, a1s, us, dep, img = R.composite_rays_train_triplane(sigma, rgb, a0, a1, unc, deltas, rays)
         loss = ((img + (1 - ws).unsqueeze(-1) - target) ** 2).mean() + 1e-4 * a0s.mean() + 1e-4 * a1s.mean() + 1e-3 * us.mean()
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
+        if bucket is None:
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+        else:
+            bucket.zero()
+            loss.backward()
+            bucket.all_reduce()
         opt.step()
         n_samples[0] = xyzs.shape[0]
         return loss
@@ -207,14 +215,24 @@ def train_bench(args, device, P, golden, bits):
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    return dict(workload=f"cfg3: {n_rays} random rays of a {H}x{W} frame, max_steps {args.max_steps}, occupancy={args.scene}, "
-                         "march_rays_train -> 3 grid + SH encoders -> torch Linear heads -> composite_rays_train_triplane -> MSE -> "
-                         "backward (grid scatter-add) -> Adam", rays=n_rays, samples_per_step=int(n_samples[0]),
+    if world > 1:
+        red = torch.tensor([dt, float(n_samples[0])], dtype=torch.float64, device=device)
+        mx = red.clone()
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(red)
+        dt, n_samples[0] = float(mx[0]), int(red[1])
+    return dict(parallelism=f"data parallel over ray shards x{world}, one all-reduce of the flat gradient buffer "
+                            f"({bucket.flat.numel() * 4 / 1e6:.2f} MB) per step" if world > 1 else "single GPU",
+                workload=f"cfg3: {n_rays} random rays of a {H}x{W} frame, max_steps {args.max_steps}, occupancy={args.scene}, "
+                         "march_rays_train -> head (see 'mlp') -> composite_rays_train_triplane -> MSE -> backward (weight gradients + grid "
+                         "scatter-add) -> Adam", rays=n_rays, samples_per_step=int(n_samples[0]),
                 ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
                 loss=float(loss.detach()), dtype="f32", mlp={"fused": "fused head forward + backward kernels (csrc/lz_head.hip, lz_head_bwd.hip)", "lz": "csrc/lz_linear.hip (MFMA f32)",
                      "torch": "torch/rocBLAS"}[args.train_mlp])
@@ -229,6 +247,9 @@ def main():
     ap.add_argument("--train", action="store_true", help="(default now) time a cfg3 training step and add it as 'train_step'")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-rays", type=int, default=65536)
+    ap.add_argument("--train-dp", action="store_true",
+                    help="N > 1 only: also time the cfg3 training step data-parallel over ray shards (strong scaling of one step, "
+                         "one gradient all-reduce per step); off by default so the scaling run measures the headline path alone")
     ap.add_argument("--train-mlp", default="fused", choices=["fused", "lz", "torch"],
                     help="training step: fused head forward/backward kernels, per-layer lz_linear kernels, or torch Linear")
     ap.add_argument("--gpus", type=int, default=1)
@@ -319,6 +340,9 @@ def main():
     value = total_samples * args.steps / dt
     rays_per_s = N * world * args.steps / dt
 
+    train_dp = None
+    if world > 1 and args.train_dp:   # every rank takes part: one gradient all-reduce per step
+        train_dp = train_bench(args, device, P, golden, bits, rank, world)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -462,6 +486,8 @@ def main():
             result["train_step"] = train_bench(args, device, P, golden, bits)
         except Exception as exc:   # an optional leg must never take the headline line down
             result.setdefault("leg_errors", {})["train_step"] = repr(exc)
+    if train_dp is not None:
+        result["train_step"] = train_dp
     if world == 1 and not args.no_occupancy and args.precision == "f32":
         try:
             # the occupancy-grid maintenance of update_extra_state (renderer.py:699-766) as 5 launches, no sync

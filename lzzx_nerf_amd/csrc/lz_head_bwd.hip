@@ -113,6 +113,13 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
     const float eye_v = has_eye ? P.eye[0] : 0.0f;
     const float indq = P.ind_code ? P.ind_code[q] : 0.0f;
     int* queue = reinterpret_cast<int*>(wl + TAB) + 48;
+    // The two waves that share a SIMD would otherwise run in lockstep (same code, same start): both in their matrix phases, then both in
+    // their VALU / store phases.  Delaying the second one by about half a slice lets one wave's MFMAs overlap the other's VALU work.
+    if ((threadIdx.x >> 6) >= 4) {
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+    }
     float acc_enca[8], acc_ind = 0.0f;   // d(enc_a)[16 t + 4 q + r], d(ind_code)[q], summed over this lane's samples
 #pragma unroll
     for (int k = 0; k < 8; k++) acc_enca[k] = 0.0f;

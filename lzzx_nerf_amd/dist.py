@@ -63,3 +63,56 @@ def gather_tiles(tile, n_total=None, group=None):
 def to_rgb24(image):
     """[N,3] f32 in [0,1] -> uint8, the hand-off format of the reference's video pipe (TrainerUtil.py:550-555)"""
     return (image * 255).to(torch.uint8)
+
+
+class GradientBucket:
+    """Data-parallel training over ray shards (training variant): every rank runs forward / backward on its shard of the
+    sampled rays with a full replica, then the gradients are summed across ranks.  The whole model is small (3 x 163 584 table
+    entries + ~24 k MLP weights + the audio nets, about 2.6 MB of f32), so instead of per-parameter or size-bucketed collectives all
+    `.grad` tensors are VIEWS into one flat buffer and a step issues exactly ONE all-reduce over it -- latency-bound on xGMI, which is
+    why it is one call.  Autograd accumulates into an existing `.grad` in place, so the views survive backward; clear gradients
+    with `bucket.zero()` (an optimizer's `zero_grad(set_to_none=True)` would detach the views -- `attach()` re-creates them).
+
+        bucket = GradientBucket(model.parameters())
+        for batch in ...:
+            bucket.zero(); loss(model, shard_of(batch)).backward(); bucket.all_reduce(); optimizer.step()
+    """
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradientBucket: no parameter requires grad")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in self.params):
+            raise ValueError("GradientBucket: parameters must share one device and dtype")
+        self.group = group
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        self.attach()
+
+    def attach(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view(p.shape)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self, average=True):
+        """sum (average=False) or mean over ranks of every gradient, in one collective; a no-op in a single process"""
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            for p in self.params:   # a view was replaced (set_to_none / first backward after detach): the collective would miss it
+                if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size():
+                    raise RuntimeError("GradientBucket: a .grad no longer aliases the flat buffer; call attach() after zero_grad(set_to_none=True)")
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if average:
+                self.flat.mul_(1.0 / dist.get_world_size(self.group))
+        return self.flat
+
+
+def broadcast_state(tensors, src=0, group=None):
+    """replicate rank `src`'s tensors (initial weights, the 256 KB density bitfield after an occupancy update) on every rank, in place"""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        for t in tensors:
+            dist.broadcast(t, src=src, group=group)

@@ -66,3 +66,82 @@ def test_shard_bounds_partition():
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [h - l for l, h in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _tiny_model():
+    torch.manual_seed(3)
+    table = torch.nn.Parameter(torch.rand(64, 2) * 2 - 1)
+    mlp = torch.nn.Sequential(torch.nn.Linear(5, 16, bias=False), torch.nn.ReLU(), torch.nn.Linear(16, 3, bias=False))
+    return table, mlp
+
+
+def _tiny_loss(table, mlp, rays_o, rays_d, target):
+    idx = (rays_o[:, 0].abs() * 1000).long() % table.shape[0]
+    feat = torch.cat([table[idx], rays_d], -1)
+    return ((torch.sigmoid(mlp(feat)) - target) ** 2).mean()
+
+
+def _train_worker(rank, world, port, n_rays, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(1)
+    rays_o, rays_d, target = torch.randn(n_rays, 3, generator=g), torch.randn(n_rays, 3, generator=g), torch.rand(n_rays, 3, generator=g)
+    table, mlp = _tiny_model()
+    if rank != 0:   # replicas start from rank 0's weights
+        with torch.no_grad():
+            for p in [table, *mlp.parameters()]:
+                p.add_(1.0)
+    D.broadcast_state([table.data, *[p.data for p in mlp.parameters()]])
+    params = [table, *mlp.parameters()]
+    bucket = D.GradientBucket(params)
+    opt = torch.optim.Adam(params, lr=1e-2)
+    lo, hi = D.shard_bounds(n_rays, rank, world)
+    for _ in range(2):
+        bucket.zero()
+        _tiny_loss(table, mlp, rays_o[lo:hi], rays_d[lo:hi], target[lo:hi]).backward()
+        bucket.all_reduce()
+        opt.step()
+    # single-process full-batch reference on the same data
+    rt, rm = _tiny_model()
+    rp = [rt, *rm.parameters()]
+    ropt = torch.optim.Adam(rp, lr=1e-2)
+    for _ in range(2):
+        ropt.zero_grad()
+        _tiny_loss(rt, rm, rays_o, rays_d, target).backward()
+        ropt.step()
+    ok = all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(params, rp))
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    ok = ok and all(torch.equal(both[0], b) for b in both)   # replicas stay bit-identical
+    opt.zero_grad(set_to_none=True)
+    try:
+        bucket.all_reduce()
+        ok = False
+    except RuntimeError:
+        bucket.attach()
+        bucket.all_reduce()
+    np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_matches_full_batch(tmp_path):
+    """data-parallel training over equal ray shards + ONE all-reduce of the flat gradient buffer == full-batch training"""
+    port = _free_port()
+    mp.spawn(_train_worker, args=(2, port, 2048, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert int(np.load(tmp_path / f"ok_{r}.npy")[0]) == 1
+
+
+def test_gradient_bucket_single_process():
+    table, mlp = _tiny_model()
+    params = [table, *mlp.parameters()]
+    bucket = D.GradientBucket(params)
+    g = torch.Generator().manual_seed(1)
+    _tiny_loss(table, mlp, torch.randn(64, 3, generator=g), torch.randn(64, 3, generator=g), torch.rand(64, 3, generator=g)).backward()
+    assert bucket.flat.abs().sum() > 0 and all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in params)
+    before = bucket.flat.clone()
+    assert torch.equal(bucket.all_reduce(), before)
+    bucket.zero()
+    assert float(table.grad.abs().sum()) == 0.0

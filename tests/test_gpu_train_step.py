@@ -361,3 +361,47 @@ def test_fused_train_head_variants_match_operator_graph(params, golden, exp_eye,
     for n, e in zip(("xy", "yz", "xz"), encs):
         a, b = sd[f"encoder_{n}.embeddings"].grad, e.embeddings.grad
         assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-6), n
+
+
+def test_fused_train_head_gradient_bucket_sharded_step(params, golden):
+    """Data-parallel arrangement (training variant) in one process: gradients of two ray shards accumulated into the flat
+    GradientBucket (every .grad a view of one buffer, what the ONE all-reduce per step operates on) equal the full-batch gradients
+    of the summed loss, and backward through the fused kernels keeps the views attached."""
+    from lzzx_nerf_amd import raymarching as R
+    from lzzx_nerf_amd.dist import GradientBucket, shard_bounds
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    H = W = 24
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ro, rd, bits = dev(ro), dev(rd), dev(ellipsoid_bitfield()[0])
+    enc_a, eye, ind = dev(golden["net_enc_a"]), dev(golden["net_eye"]), dev(golden["net_ind"])
+    aabb = dev(np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32))
+    target = torch.linspace(0, 1, H * W * 3, device="cuda").reshape(-1, 3)
+
+    def shard_loss(net, lo, hi):
+        o, d = ro[lo:hi].contiguous(), rd[lo:hi].contiguous()
+        nears, fars = R.near_far_from_aabb(o, d, aabb, 0.05)
+        ctr = torch.zeros(2, dtype=torch.int32, device="cuda")
+        xyzs, dirs, deltas, rays = R.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, ctr, -1, False, 128, True, 1 / 256, 32)
+        sigma, rgb, aa, ae, unc = net(xyzs.contiguous(), dirs.contiguous(), enc_a, ind, eye)
+        ws, a0s, a1s, us, dep, img = R.composite_rays_train_triplane(sigma, rgb, aa[:, 0], ae[:, 0], unc[:, 0], deltas, rays)
+        return ((img - target[lo:hi]) ** 2).sum() + 0.1 * ws.sum() + 1e-2 * us.sum()
+
+    n = H * W
+    full = FusedTriplaneTrainHead({k: v for k, v in params.items()}, bound=1.0).cuda()
+    shard_loss(full, 0, n).backward()
+    net = FusedTriplaneTrainHead({k: v for k, v in params.items()}, bound=1.0).cuda()
+    bucket = GradientBucket(net.parameters())
+    lo_hi = [shard_bounds(n, r, 2) for r in range(2)]
+    for lo, hi in lo_hi:
+        shard_loss(net, lo, hi).backward()
+    end = bucket.flat.data_ptr() + bucket.flat.numel() * 4
+    for (name, p), q in zip(net.named_parameters(), full.parameters()):
+        assert bucket.flat.data_ptr() <= p.grad.data_ptr() < end, name      # still a view of the flat buffer
+        scale = float(q.grad.abs().max()) + 1e-20
+        assert float((p.grad - q.grad).abs().max()) <= 2e-5 * scale, name   # same sums, different association of the reduction
+    assert float(bucket.flat.abs().sum()) > 0
+    assert torch.equal(bucket.all_reduce(), bucket.flat)                     # single process: no-op
+    bucket.zero()
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in net.parameters())
