@@ -18,6 +18,7 @@
 #ifndef LZZX_NERF_HIP_H
 #define LZZX_NERF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -255,7 +256,8 @@ int lz_audio_encode(const lz_audio_params* p, const float* a, float* enc_a, void
 int lz_linear_forward(const float* X, uint32_t ldx, const float* mask, const float* W, uint32_t ldw, float* Y, uint32_t ldy,
                       uint32_t M, uint32_t K, uint32_t N, int relu_out, lz_stream_t stream);
 /* weight gradient: dW[N,K] += (dY where mask > 0)[M,N]^T . X[M,K]; the reduction over M happens inside the kernel (registers ->
- * LDS -> one float atomic per element and workgroup); dW is accumulated into, zero it first.  ceil(N/16)*ceil(K/16) <= 24. */
+ * LDS -> one float atomic per element and workgroup); dW is accumulated into, zero it first.  ceil(N/16)*ceil(K/16) <= 24,
+ * K <= 96, N <= 128. */
 int lz_linear_grad_w(const float* dY, uint32_t ldd, const float* mask, const float* X, uint32_t ldx, float* dW, uint32_t ldw,
                      uint32_t M, uint32_t K, uint32_t N, lz_stream_t stream);
 
@@ -263,26 +265,54 @@ int lz_linear_grad_w(const float* dY, uint32_t ldd, const float* mask, const flo
  * chain of NeRFNetwork.forward (network.py:252-311) in one kernel.  Inputs: the upstream gradients of the five head outputs
  * (what composite_rays_train_triplane's backward produces): g_sigma [M], g_rgb [M,3], g_amb_aud [M] (of ||att||), g_amb_eye [M]
  * (of eye_att; may be NULL), g_unc [M].  Outputs (all caller-allocated, row-major f32):
- *   denc[p]  [12,M]  d loss / d (plane p's 12 grid features), level-major -> lz_grid_encode_backward(grad_layout 0 or 3) per plane
- *   d_enc_a  [32], d_ind [4]: accumulated over the samples with atomics (zero them first; may be NULL)
- *   X_*      the input of every Linear layer, G_* the gradient of its output (ReLU mask applied), for the weight gradients:
- *            dW = lz_linear_grad_w(G, mask = NULL, X) per layer.  Shapes (leading dimension = width unless noted):
- *            X_encx [M,36]  X_a1 [M,64]  X_e1 [M,16]  X_sig0 [M,69] (ld 72)  X_s1 [M,64]  X_s2 [M,64]  X_col0 [M,84]  X_c1 [M,64]
- *            X_u1 [M,32];  G_a1 [M,64]  G_att [M,32]  G_e1 [M,16]  G_e2 [M]  G_s1 [M,64]  G_s2 [M,64]  G_s3 [M,65] (column 0 = sigma
- *            row)  G_c1 [M,64]  G_c [M,3]  G_u1 [M,32]  G_u [M].
- *   Layer <- (X, G): aud_ch_att_net.0 <- (X_encx, G_a1), .1 <- (X_a1, G_att); eye_att_net.0 <- (X_encx, G_e1), .1 <- (X_e1, G_e2);
- *   sigma_net.0 <- (X_sig0, G_s1), .1 <- (X_s1, G_s2), .2 <- (X_s2, G_s3); color_net.0 <- (X_col0, G_c1), .1 <- (X_c1, G_c);
- *   unc_net.0 <- (X_encx, G_u1), .1 <- (X_u1, G_u). */
+ *   denc   [3,12,M]  d loss / d (plane p's 12 grid features), level-major: denc + p*12*M -> lz_grid_encode_backward(grad_layout 0 / 3)
+ *   small  [LZ_BWD_SMALL]  sums over the samples, reduced INSIDE the kernel (registers -> LDS -> one atomic per element and workgroup;
+ *          zero it first): d_enc_a [32] | d_ind_code [4] | then the weight gradients of the three skinny output layers
+ *          eye_att_net.1 [16] | unc_net.1 [32] | color_net.1 [3,64]
+ *   rec    [M, LZ_BWD_REC]  one record per sample (16-byte aligned) holding the input X of the wide Linear layers and the gradient G
+ *          of their outputs (ReLU mask applied), consumed by lz_triplane_head_grad_w.  One buffer, fixed columns: the kernel needs one
+ *          address per sample and immediate offsets (separate buffers cost it two address registers each, spilled), every slot
+ *          starts on a 64-byte boundary:
+ *            LZ_BWD_X_A1   [64]  input of aud_ch_att_net.1
+ *            LZ_BWD_X_SIG0 [69]  input of sigma_net.0; columns 0..35 are enc_x, the input of the three layers stacked in G_X
+ *            LZ_BWD_X_S1   [64]  input of sigma_net.1
+ *            LZ_BWD_X_S2C  [84]  = [input of sigma_net.2 (s2) 64 | SH(dir) 16 | ind_code 4]: color_net.0's input with geo = s2 . Wg^T
+ *                                replaced by s2 itself (Wg = sigma_net.2 rows 1..64)
+ *            LZ_BWD_G_X    [112] = [aud_ch_att_net.0 64 | eye_att_net.0 16 (zeros without an eye input) | unc_net.0 32]
+ *            LZ_BWD_G_ATT  [32]  aud_ch_att_net.1      LZ_BWD_G_S1 [64]  sigma_net.0      LZ_BWD_G_S2 [64]  sigma_net.1
+ *            LZ_BWD_G_C1H  [65]  = [color_net.0 64 | sigma row of sigma_net.2 1]
+ *          Neither geo nor d geo is stored: both are linear maps of stored columns, so their weight gradients are finished from the
+ *          64 x 64 sum R = G_c1^T s2 (lz_triplane_head_grad_w).  2 624 bytes per sample (3 664 with one buffer per layer). */
+#define LZ_BWD_REC 656
+#define LZ_BWD_SMALL 276
+#define LZ_BWD_X_A1 0
+#define LZ_BWD_X_SIG0 64
+#define LZ_BWD_X_S1 144
+#define LZ_BWD_X_S2C 208
+#define LZ_BWD_G_X 304
+#define LZ_BWD_G_ATT 416
+#define LZ_BWD_G_S1 448
+#define LZ_BWD_G_S2 512
+#define LZ_BWD_G_C1H 576
 typedef struct {
-    float* denc[3];
-    float* d_enc_a;
-    float* d_ind;
-    float *X_encx, *X_a1, *X_e1, *X_sig0, *X_s1, *X_s2, *X_col0, *X_c1, *X_u1;
-    float *G_a1, *G_att, *G_e1, *G_e2, *G_s1, *G_s2, *G_s3, *G_c1, *G_c, *G_u1, *G_u;
+    float* denc;
+    float* small;
+    float* rec;
 } lz_head_bwd_out;
 int lz_triplane_head_backward(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M, const float* g_sigma,
                               const float* g_rgb, const float* g_amb_aud, const float* g_amb_eye, const float* g_unc,
                               const lz_head_bwd_out* out, lz_stream_t stream);
+/* Weight gradients of the wide layers from the records, in ONE pass over them (five waves per workgroup, each owning the
+ * accumulator tiles of one product; partial tiles per workgroup in `workspace`, summed by a second small launch: no atomics).
+ * Outputs are overwritten, row-major [N, K]: dW_x3 [112,36] = aud_ch_att_net.0 (rows 0..63) | eye_att_net.0 (64..79) | unc_net.0
+ * (80..111); dW_aud1 [32,64]; dW_sig0 [64,k_sig0] (k_sig0 = 69 with the eye column, else 68); dW_sig1 [64,64]; dW_c1h [65,84] =
+ * [G_c1 | d h0]^T . [s2 | SH | ind]: with R = rows 0..63 x columns 0..63, Wg = sigma_net.2.weight[1:65] and Wc = color_net.0.weight,
+ *   color_net.0.weight.grad = [dW_c1h[0:64, 64:80] | R . Wg^T | dW_c1h[0:64, 80:84]]
+ *   sigma_net.2.weight.grad = [dW_c1h[64, 0:64] ; Wc[:, 16:80]^T . R]
+ * (two 64^3 products, left to the caller).  workspace: lz_triplane_head_grad_w_workspace() bytes of device memory. */
+size_t lz_triplane_head_grad_w_workspace(void);
+int lz_triplane_head_grad_w(const float* rec, uint32_t M, uint32_t k_sig0, float* dW_x3, float* dW_aud1, float* dW_sig0,
+                            float* dW_sig1, float* dW_c1h, void* workspace, lz_stream_t stream);
 
 /* Device-resident inference loop (renderer.py:495-548): no host synchronisation inside the frame, 3 launches per iteration:
  *     lz_loop_march -> lz_triplane_head_forward(count = state words + LZ_LOOP_NEXT + 2) -> lz_loop_composite.

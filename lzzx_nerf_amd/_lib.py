@@ -20,9 +20,7 @@ class HeadParams(C.Structure):
 
 class HeadBwdOut(C.Structure):
     """mirror of lz_head_bwd_out (include/lzzx_nerf_hip.h)"""
-    _fields_ = [("denc", vp * 3), ("d_enc_a", vp), ("d_ind", vp)] + \
-               [(n, vp) for n in ("X_encx", "X_a1", "X_e1", "X_sig0", "X_s1", "X_s2", "X_col0", "X_c1", "X_u1",
-                                  "G_a1", "G_att", "G_e1", "G_e2", "G_s1", "G_s2", "G_s3", "G_c1", "G_c", "G_u1", "G_u")]
+    _fields_ = [("denc", vp), ("small", vp), ("rec", vp)]
 
 
 class TorsoParams(C.Structure):
@@ -93,9 +91,11 @@ SIGNATURES = {
     "lz_density_grid_update": [vp, f32, f32, f32, u32, u32, vp, vp, vp, vp, vp],
     "lz_linear_forward": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, i32, vp],
     "lz_linear_grad_w": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, vp],
+    "lz_triplane_head_grad_w": [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp],
 }
 PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),
-         "lz_head_packed_size": ([], u32), "lz_head_packed_size_f16": ([], u32)}
+         "lz_head_packed_size": ([], u32), "lz_head_packed_size_f16": ([], u32),
+         "lz_triplane_head_grad_w_workspace": ([], C.c_size_t)}
 
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
 

@@ -32,37 +32,44 @@ __device__ __forceinline__ void lz_layer_bwd(const float* __restrict__ wl, int l
     constexpr int KS = LZ_KS[LAYER], NT = LZ_NT[LAYER], KT = (KS + 3) / 4;
     const int m = lane & 15, q = lane >> 4;
     const float* base = wl + lz_frag_base(LAYER) * 64 + 4 * q + 16 * (m >> 2);
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++) {
+    // One 16-byte LDS read feeds four MFMAs (128 cycles); the read of step i + 1 is issued BEFORE the MFMAs of step i and the
+    // scheduling barrier keeps it there, so its latency (4-way bank conflict included) hides under them.
+    auto frag = [&](int i) -> lz_f4 {   // raw read (rows past KS are clamped to row 0 and zeroed at use)
+        const int kt = i / NT, ft = i - kt * NT;
         const int ks = 4 * kt + (m & 3);
-        const bool ok = ks < KS;
-        const float* row = base + (size_t)(ok ? ks : 0) * NT * 64;
-        lz_f4 acc = lz_f4{0, 0, 0, 0};
+        return *reinterpret_cast<const lz_f4*>(base + (size_t)(ks < KS ? ks : 0) * NT * 64 + ft * 64);
+    };
+    lz_f4 a_cur = frag(0);
+    lz_f4 acc = lz_f4{0, 0, 0, 0};
 #pragma unroll
-        for (int ft = 0; ft < NT; ft++)
+    for (int i = 0; i < KT * NT; i++) {
+        const int kt = i / NT, ft = i - kt * NT;
+        lz_f4 a_nxt = a_cur;
+        if (i + 1 < KT * NT) a_nxt = frag(i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ft == 0) acc = lz_f4{0, 0, 0, 0};
+        const bool ok = 4 * kt + (m & 3) < KS;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float a = ok ? row[ft * 64 + r] : 0.0f;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dy[4 * ft + r], acc, 0, 0, 0);
-            }
+        for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? a_cur[r] : 0.0f, dy[4 * ft + r], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ft == NT - 1) {
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            if (4 * kt + r < KS) dx[4 * kt + r] = acc[r];
+            for (int r = 0; r < 4; r++)
+                if (4 * kt + r < KS) dx[4 * kt + r] = acc[r];
+        }
+        a_cur = a_nxt;
     }
 }
 
-// chained-layout vector v[4 t + r] = feature 16 t + 4 q + r -> dst[row * ld + col0 + feature]
+// chained-layout vector v[4 t + r] = feature 16 t + 4 q + r -> record columns col0 + feature; `recq` = this sample's record + 4 q, so every
+// store is (one per-slice address) + (an immediate offset): one dwordx4 per tile (records and slots are 16-byte aligned)
 template <int NTILE>
-__device__ __forceinline__ void lz_dump_chained(float* __restrict__ dst, size_t row, uint32_t ld, uint32_t col0, int q, const float (&v)[4 * NTILE]) {
-    float* p = dst + row * ld + col0 + 4 * q;
-    if (((ld | col0) & 3u) == 0u) {   // 16-byte aligned rows: one dwordx4 store per tile (the buffers themselves are 16-byte aligned)
+__device__ __forceinline__ void lz_dump_chained(float* __restrict__ recq, int col0, const float (&v)[4 * NTILE]) {
+    typedef float lz_v4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int t = 0; t < NTILE; t++) *reinterpret_cast<float4*>(p + 16 * t) = make_float4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
-    } else {
-#pragma unroll
-        for (int t = 0; t < NTILE; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) p[16 * t + r] = v[4 * t + r];
+    for (int t = 0; t < NTILE; t++) {
+        lz_v4 w = {v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
+        __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(recq + col0 + 16 * t));   // streamed: read back once by the weight-gradient pass
     }
 }
 
@@ -123,6 +130,16 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
     float acc_enca[8], acc_ind = 0.0f;   // d(enc_a)[16 t + 4 q + r], d(ind_code)[q], summed over this lane's samples
 #pragma unroll
     for (int k = 0; k < 8; k++) acc_enca[k] = 0.0f;
+    // weight gradients of the skinny output layers, per lane: feature 16 t + 4 q + r of this lane's samples
+    float acc_e2[4], acc_u2[8], acc_c2[3][16];
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc_e2[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc_u2[k] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc_c2[c][k] = 0.0f;
 
     for (;;) {
         int slice = 0;
@@ -133,16 +150,20 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
         const bool valid = base + s < M;
         const uint32_t m = valid ? base + s : M - 1;   // clamped rows are computed, never stored or accumulated
         const size_t row = m;
+        float* rec1 = O.rec + row * LZ_BWD_REC + q;   // this sample's record, + q / + 4 q: the two lane patterns of the dumps
+        float* recq = rec1 + 3 * q;
+        float* dencq = O.denc + (size_t)q * M + row;
 
         // =============================== forward (as lz_k_triplane_head<true>) ===============================
         float encx[9];
         lz_head_gather(P.emb, offs, lscale, lres, xyzs, m, q, P.bound, two_bound, encx);
+        // every per-sample input is loaded here, before the first dump store of the slice: a load issued after stores can only be waited
+        // for once those stores have been acknowledged (one counter, in order), which under this kernel's write stream takes microseconds
+        const float g_sig = A.g_sigma[row], g_aa = A.g_amb_aud[row], g_ae = A.g_amb_eye ? A.g_amb_eye[row] : 0.0f, g_un = A.g_unc[row];
+        const float g_r0 = A.g_rgb[row * 3], g_r1 = A.g_rgb[row * 3 + 1], g_r2 = A.g_rgb[row * 3 + 2];
+        const float dir0 = dirs[row * 3], dir1 = dirs[row * 3 + 1], dir2 = dirs[row * 3 + 2];
         __builtin_amdgcn_sched_barrier(0);
         const float bx[1][9] = {{encx[0], encx[1], encx[2], encx[3], encx[4], encx[5], encx[6], encx[7], encx[8]}};
-        if (valid) {
-#pragma unroll
-            for (int i = 0; i < 9; i++) O.X_encx[row * 36 + 4 * i + q] = encx[i];
-        }
         // audio channel attention
         float att[8];
         uint32_t mk_a1;
@@ -155,7 +176,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) a1[0][4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_a1 = lz_mask_pos(a1[0]);
-            if (valid) lz_dump_chained<4>(O.X_a1, row, 64, 0, q, a1[0]);
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_A1, a1[0]);
             lz_f4 acc2[2][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_A2, 1>(wl, lane, a1, acc2);
 #pragma unroll
@@ -175,18 +196,17 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
         // eye attention
         float eyeatt = 0.0f;
         uint32_t mk_e1 = 0;
+        float e1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (has_eye) {
             lz_f4 acce[1][1] = {{lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_E1, 1>(wl, lane, bx, acce);
-            float e1[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) e1[r] = lz_relu(acce[0][0][r]);
             mk_e1 = lz_mask_pos(e1);
-            if (valid) lz_dump_chained<1>(O.X_e1, row, 16, 0, q, e1);
             eyeatt = lz_sigmoidf(lz_lane_dot<1>(wv + LZ_WV_E2, q, e1));
         }
         // uncertainty
-        float upre;
+        float du;   // unc = softplus(u): d loss / d u
         uint32_t mk_u1;
         {
             lz_f4 accu[2][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
@@ -197,8 +217,11 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) u1[4 * ft + r] = lz_relu(accu[ft][0][r]);
             mk_u1 = lz_mask_pos(u1);
-            if (valid) lz_dump_chained<2>(O.X_u1, row, 32, 0, q, u1);
-            upre = lz_lane_dot<2>(wv + LZ_WV_U2, q, u1);
+            du = g_un * lz_sigmoidf(lz_lane_dot<2>(wv + LZ_WV_U2, q, u1));
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc_u2[k] = lz_fmaf(du, u1[k], acc_u2[k]);
+            }
         }
         // sigma net
         float sigma;
@@ -218,9 +241,9 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
             b1[0][17] = (has_eye && q == 0) ? eye_v * eyeatt : 0.0f;
             if (valid) {   // sigma_net.0 input [enc_x 36 | enc_a * att 32 | eye * eye_att 1], leading dimension 72
 #pragma unroll
-                for (int i = 0; i < 9; i++) O.X_sig0[row * 72 + 4 * i + q] = encx[i];
-                lz_dump_chained<2>(O.X_sig0, row, 72, 36, q, encw);
-                if (q == 0) O.X_sig0[row * 72 + 68] = b1[0][17];
+                for (int i = 0; i < 9; i++) rec1[LZ_BWD_X_SIG0 + 4 * i] = encx[i];
+                lz_dump_chained<2>(recq, LZ_BWD_X_SIG0 + 36, encw);
+                if (q == 0) rec1[LZ_BWD_X_SIG0 + 68] = b1[0][17];
             }
             lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_S1, 1>(wl, lane, b1, acc1);
@@ -230,7 +253,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) s1[0][4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_s1 = lz_mask_pos(s1[0]);
-            if (valid) lz_dump_chained<4>(O.X_s1, row, 64, 0, q, s1[0]);
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_S1, s1[0]);
             lz_f4 acc2[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_S2, 1>(wl, lane, s1, acc2);
             float s2[1][16];
@@ -239,7 +262,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) s2[0][4 * ft + r] = lz_relu(acc2[ft][0][r]);
             mk_s2 = lz_mask_pos(s2[0]);
-            if (valid) lz_dump_chained<4>(O.X_s2, row, 64, 0, q, s2[0]);
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_S2C, s2[0]);
             lz_f4 acc3[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_S3, 1>(wl, lane, s2, acc3);
 #pragma unroll
@@ -249,11 +272,11 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
             sigma = lz_expf(lz_lane_dot<4>(wv + LZ_WV_SIG, q, s2[0]));
         }
         // colour net
-        float sg[3];
+        float dc[3];   // colour head: rgb = sigmoid(c) * 1.002 - 0.001
         uint32_t mk_c1;
         {
             float o[16];
-            lz_sh_eval(dirs[row * 3], dirs[row * 3 + 1], dirs[row * 3 + 2], 4, o, nullptr, nullptr, nullptr);
+            lz_sh_eval(dir0, dir1, dir2, 4, o, nullptr, nullptr, nullptr);
             float b1[1][21];
 #pragma unroll
             for (int i = 0; i < 4; i++) b1[0][i] = q == 0 ? o[4 * i] : (q == 1 ? o[4 * i + 1] : (q == 2 ? o[4 * i + 2] : o[4 * i + 3]));
@@ -262,9 +285,8 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
             b1[0][20] = indq;
             if (valid) {   // colour_net.0 input [SH 16 | geo 64 | ind 4]
 #pragma unroll
-                for (int i = 0; i < 4; i++) O.X_col0[row * 84 + 4 * i + q] = b1[0][i];
-                lz_dump_chained<4>(O.X_col0, row, 84, 16, q, geo[0]);
-                O.X_col0[row * 84 + 80 + q] = indq;
+                for (int i = 0; i < 4; i++) rec1[LZ_BWD_X_S2C + 64 + 4 * i] = b1[0][i];
+                rec1[LZ_BWD_X_S2C + 80] = indq;   // geo = s2 . Wg^T is not stored: its weight gradient is finished from sum G_c1^T s2
             }
             lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_C1, 1>(wl, lane, b1, acc1);
@@ -274,18 +296,18 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) c1[4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_c1 = lz_mask_pos(c1);
-            if (valid) lz_dump_chained<4>(O.X_c1, row, 64, 0, q, c1);
 #pragma unroll
-            for (int c = 0; c < 3; c++) sg[c] = lz_sigmoidf(lz_lane_dot<4>(wv + LZ_WV_C2 + 64 * c, q, c1));
+            for (int c = 0; c < 3; c++) {
+                const float sg = lz_sigmoidf(lz_lane_dot<4>(wv + LZ_WV_C2 + 64 * c, q, c1));
+                dc[c] = (c == 0 ? g_r0 : (c == 1 ? g_r1 : g_r2)) * 1.002f * sg * (1.0f - sg);
+                if (valid) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) acc_c2[c][k] = lz_fmaf(dc[c], c1[k], acc_c2[c][k]);
+                }
+            }
         }
 
         // =============================== backward ===============================
-        const float g_sig = A.g_sigma[row], g_aa = A.g_amb_aud[row], g_ae = A.g_amb_eye ? A.g_amb_eye[row] : 0.0f, g_un = A.g_unc[row];
-        // colour head: rgb = sigmoid(c) * 1.002 - 0.001
-        float dc[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) dc[c] = A.g_rgb[row * 3 + c] * 1.002f * sg[c] * (1.0f - sg[c]);
-        if (valid && q == 0) { O.G_c[row * 3] = dc[0]; O.G_c[row * 3 + 1] = dc[1]; O.G_c[row * 3 + 2] = dc[2]; }
         float dgeo[16];
         float dind;
         {
@@ -300,7 +322,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
                     v = lz_fmaf(wv[LZ_WV_C2 + 128 + f], dc[2], v);
                     dc1[k] = ((mk_c1 >> k) & 1u) ? v : 0.0f;
                 }
-            if (valid) lz_dump_chained<4>(O.G_c1, row, 64, 0, q, dc1);
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_C1H, dc1);
             float dxc[21];
             lz_layer_bwd<LZ_L_C1>(wl, lane, dc1, dxc);
 #pragma unroll
@@ -310,9 +332,8 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
         if (valid) acc_ind += dind;
         // sigma net
         const float dh0 = g_sig * sigma;
-        if (valid) {   // sigma_net.2 output gradient [d h0 | d geo 64], leading dimension 65
-            if (q == 0) O.G_s3[row * 65] = dh0;
-            lz_dump_chained<4>(O.G_s3, row, 65, 1, q, dgeo);
+        if (valid) {   // sigma_net.2 output gradient [d geo 64 | d h0], leading dimension 68 (16-byte rows: dwordx4 stores)
+            if (q == 0) rec1[LZ_BWD_G_C1H + 64] = dh0;   // d geo = G_c1 . W_c0[:, geo] is not stored either
         }
         float dencx[9], dencw[8], determ;
         {
@@ -326,12 +347,12 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
                     const float v = lz_fmaf(wv[LZ_WV_SIG + 16 * t + 4 * q + r], dh0, ds2[k]);
                     ds2[k] = ((mk_s2 >> k) & 1u) ? v : 0.0f;
                 }
-            if (valid) lz_dump_chained<4>(O.G_s2, row, 64, 0, q, ds2);
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_S2, ds2);
             float ds1[16];
             lz_layer_bwd<LZ_L_S2>(wl, lane, ds2, ds1);
 #pragma unroll
             for (int k = 0; k < 16; k++) ds1[k] = ((mk_s1 >> k) & 1u) ? ds1[k] : 0.0f;
-            if (valid) lz_dump_chained<4>(O.G_s1, row, 64, 0, q, ds1);
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_S1, ds1);
             float dxs[18];
             lz_layer_bwd<LZ_L_S1>(wl, lane, ds1, dxs);
 #pragma unroll
@@ -352,22 +373,28 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
                     datt[k] = lz_fmaf(lenca[16 * t + 4 * q + r], dencw[k], inv * att[k]);
                     if (valid) acc_enca[k] = lz_fmaf(att[k], dencw[k], acc_enca[k]);
                 }
-            if (valid) lz_dump_chained<2>(O.G_att, row, 32, 0, q, datt);
+            if (valid) lz_dump_chained<2>(recq, LZ_BWD_G_ATT, datt);
         }
         // eye attention: eterm = eye * eye_att (lane q == 0 holds its gradient), ambient_eye = |eye_att| = eye_att
         if (has_eye) {
             const float det0 = __shfl(determ, s, 64);   // from lane (s, q = 0)
             const float deye = lz_fmaf(eye_v, det0, g_ae);
             const float de2 = deye * eyeatt * (1.0f - eyeatt);
-            if (valid && q == 0) O.G_e2[row] = de2;
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc_e2[r] = lz_fmaf(de2, e1[r], acc_e2[r]);
+            }
             float de1[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) de1[r] = ((mk_e1 >> r) & 1u) ? wv[LZ_WV_E2 + 4 * q + r] * de2 : 0.0f;
-            if (valid) lz_dump_chained<1>(O.G_e1, row, 16, 0, q, de1);
+            if (valid) lz_dump_chained<1>(recq, LZ_BWD_G_X + 64, de1);
             float dxe[9];
             lz_layer_bwd<LZ_L_E1>(wl, lane, de1, dxe);
 #pragma unroll
             for (int i = 0; i < 9; i++) dencx[i] += dxe[i];
+        } else if (valid) {   // the stacked reduction over G_x reads these columns: no eye input, no gradient
+            const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            lz_dump_chained<1>(recq, LZ_BWD_G_X + 64, zero);
         }
         // audio channel attention
         {
@@ -375,7 +402,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
             lz_layer_bwd<LZ_L_A2>(wl, lane, datt, da1);
 #pragma unroll
             for (int k = 0; k < 16; k++) da1[k] = ((mk_a1 >> k) & 1u) ? da1[k] : 0.0f;
-            if (valid) lz_dump_chained<4>(O.G_a1, row, 64, 0, q, da1);
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_X, da1);
             float dxa[9];
             lz_layer_bwd<LZ_L_A1>(wl, lane, da1, dxa);
 #pragma unroll
@@ -383,8 +410,6 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
         }
         // uncertainty: unc = softplus(u); its input is detached (network.py:241-249): weight gradients only
         {
-            const float du = g_un * lz_sigmoidf(upre);
-            if (valid && q == 0) O.G_u[row] = du;
             float du1[8];
 #pragma unroll
             for (int t = 0; t < 2; t++)
@@ -393,27 +418,42 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
                     const int k = 4 * t + r;
                     du1[k] = ((mk_u1 >> k) & 1u) ? wv[LZ_WV_U2 + 16 * t + 4 * q + r] * du : 0.0f;
                 }
-            if (valid) lz_dump_chained<2>(O.G_u1, row, 32, 0, q, du1);
+            if (valid) lz_dump_chained<2>(recq, LZ_BWD_G_X + 80, du1);
         }
         // d(enc_x): feature 4 i + q = plane i / 3, level 4 (i % 3) + q
         if (valid) {
 #pragma unroll
-            for (int i = 0; i < 9; i++) O.denc[i / 3][(size_t)(4 * (i % 3) + q) * M + row] = dencx[i];   // level-major [12, M]
+            for (int i = 0; i < 9; i++) dencq[(size_t)(4 * i) * M] = dencx[i];   // [3 planes][12 levels][M], level-major; feature 4 i + q
         }
     }
-    // d(enc_a), d(ind_code): sum over the 16 sample lanes of every q group, then one atomic per value and wave
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        float v = acc_enca[k];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (s == 0 && O.d_enc_a) atomicAdd(O.d_enc_a + 16 * (k >> 2) + 4 * q + (k & 3), v);
-    }
-    {
-        float v = acc_ind;
+    // Per-lane sums -> sum over the 16 sample lanes of every q group -> sum over the workgroup's waves in LDS (the weight image is no
+    // longer needed) -> one atomic per value and workgroup.  Slots: d(enc_a) 32 | d(ind) 4 | dW_e2 16 | dW_u2 32 | dW_c2 192.
+    constexpr int NRED = 32 + 4 + 16 + 32 + 192;
+    __syncthreads();
+    float* red = wl;                       // [waves][NRED]
+    float* mine = red + (threadIdx.x >> 6) * NRED;
+    auto put = [&](float v, int slot) {
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (s == 0 && O.d_ind && P.ind_code) atomicAdd(O.d_ind + q, v);
+        if (s == 0) mine[slot] = v;
+    };
+#pragma unroll
+    for (int k = 0; k < 8; k++) put(acc_enca[k], 16 * (k >> 2) + 4 * q + (k & 3));
+    put(acc_ind, 32 + q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) put(acc_e2[k], 36 + 4 * q + k);
+#pragma unroll
+    for (int k = 0; k < 8; k++) put(acc_u2[k], 52 + 16 * (k >> 2) + 4 * q + (k & 3));
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) put(acc_c2[c][k], 84 + 64 * c + 16 * (k >> 2) + 4 * q + (k & 3));
+    __syncthreads();
+    if (threadIdx.x < NRED) {
+        float v = 0.0f;
+        for (int w = 0; w < LZ_BWD_WG / 64; w++) v += red[w * NRED + threadIdx.x];
+        const int i = threadIdx.x;
+        if (v != 0.0f) atomicAdd(O.small + threadIdx.x, v);   // slot order = the layout of lz_head_bwd_out.small
     }
 }
 
@@ -425,10 +465,8 @@ extern "C" int lz_triplane_head_backward(const lz_head_params* p, const float* x
                "triplane_head_backward: incomplete lz_head_params");
     LZ_REQUIRE(p->precision == 0 && !p->testing, LZ_ERR_UNSUPPORTED, "triplane_head_backward: f32 training mode only");
     const lz_head_bwd_out& o = *out;
-    LZ_REQUIRE(o.denc[0] && o.denc[1] && o.denc[2] && o.X_encx && o.X_a1 && o.X_sig0 && o.X_s1 && o.X_s2 && o.X_col0 && o.X_c1 && o.X_u1 &&
-                   o.G_a1 && o.G_att && o.G_s1 && o.G_s2 && o.G_s3 && o.G_c1 && o.G_c && o.G_u1 && o.G_u,
-               LZ_ERR_BAD_ARGUMENT, "triplane_head_backward: incomplete lz_head_bwd_out");
-    LZ_REQUIRE(!p->eye || (o.X_e1 && o.G_e1 && o.G_e2), LZ_ERR_BAD_ARGUMENT, "triplane_head_backward: eye buffers required with an eye input");
+    LZ_REQUIRE(o.denc && o.small && o.rec, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward: incomplete lz_head_bwd_out");
+    LZ_REQUIRE(((uintptr_t)o.rec & 15u) == 0, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward: rec must be 16-byte aligned");
     if (M == 0) return LZ_OK;
     LzHeadBwdArgs a;
     a.fwd.emb[0] = p->emb_xy; a.fwd.emb[1] = p->emb_yz; a.fwd.emb[2] = p->emb_xz;

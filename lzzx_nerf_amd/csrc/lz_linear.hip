@@ -170,7 +170,7 @@ static int lz_linear_grad_w_k(uint32_t KB, dim3 grid, hipStream_t st, const floa
         break;
     switch (KB) { LZ_GW(1) LZ_GW(2) LZ_GW(3) LZ_GW(4) LZ_GW(5) LZ_GW(6) default: break; }
 #undef LZ_GW
-    lz_set_error("linear_grad_w: ceil(N/16) * ceil(K/16) must be <= %d and both <= 6", LZ_LIN_MAXT);
+    lz_set_error("linear_grad_w: ceil(N/16) * ceil(K/16) must be <= %d, K <= 96, N <= 128", LZ_LIN_MAXT);
     return LZ_ERR_UNSUPPORTED;
 }
 
@@ -194,7 +194,9 @@ extern "C" int lz_linear_grad_w(const float* dY, uint32_t ldd, const float* mask
         case 4: rc = lz_linear_grad_w_k<4>(KB, grid, st, dY, ldd, mask, X, ldx, dW, ldw, M, K, N); break;
         case 5: rc = lz_linear_grad_w_k<5>(KB, grid, st, dY, ldd, mask, X, ldx, dW, ldw, M, K, N); break;
         case 6: rc = lz_linear_grad_w_k<6>(KB, grid, st, dY, ldd, mask, X, ldx, dW, ldw, M, K, N); break;
-        default: lz_set_error("linear_grad_w: N must be <= 96"); return LZ_ERR_UNSUPPORTED;
+        case 7: rc = lz_linear_grad_w_k<7>(KB, grid, st, dY, ldd, mask, X, ldx, dW, ldw, M, K, N); break;
+        case 8: rc = lz_linear_grad_w_k<8>(KB, grid, st, dY, ldd, mask, X, ldx, dW, ldw, M, K, N); break;
+        default: lz_set_error("linear_grad_w: N must be <= 128"); return LZ_ERR_UNSUPPORTED;
     }
     if (rc != LZ_OK) return rc;
     LZ_CHECK_LAUNCH("linear_grad_w");

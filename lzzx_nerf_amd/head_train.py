@@ -18,13 +18,7 @@ from ._util import call, ptr, stream
 from .gridencoder import GridEncoder
 from .linear import MLP
 
-_X = dict(X_encx=36, X_a1=64, X_e1=16, X_sig0=72, X_s1=64, X_s2=64, X_col0=84, X_c1=64, X_u1=32)
-_G = dict(G_a1=64, G_att=32, G_e1=16, G_e2=1, G_s1=64, G_s2=64, G_s3=65, G_c1=64, G_c=3, G_u1=32, G_u=1)
-# layer -> (X buffer, its leading dimension, K, G buffer, N)
-_LAYERS = [("aud0", "X_encx", 36, 36, "G_a1", 64), ("aud1", "X_a1", 64, 64, "G_att", 32), ("eye0", "X_encx", 36, 36, "G_e1", 16),
-           ("eye1", "X_e1", 16, 16, "G_e2", 1), ("sig0", "X_sig0", 72, 69, "G_s1", 64), ("sig1", "X_s1", 64, 64, "G_s2", 64),
-           ("sig2", "X_s2", 64, 64, "G_s3", 65), ("col0", "X_col0", 84, 84, "G_c1", 64), ("col1", "X_c1", 64, 64, "G_c", 3),
-           ("unc0", "X_encx", 36, 36, "G_u1", 32), ("unc1", "X_u1", 32, 32, "G_u", 1)]
+_REC = 656   # floats per sample record of lz_triplane_head_backward (LZ_BWD_REC; slot columns: include/lzzx_nerf_hip.h LZ_BWD_*)
 _ORDER = ["aud0", "aud1", "eye0", "eye1", "sig0", "sig1", "sig2", "col0", "col1", "unc0", "unc1"]
 
 
@@ -56,34 +50,31 @@ class _FusedHeadTrain(Function):
         kw = dict(dtype=torch.float32, device=dev)
         z = lambda g, shape: (torch.zeros(shape, **kw) if g is None else g.float().contiguous())
         g_sig, g_rgb, g_aa, g_ae, g_un = z(g_sig, (M,)), z(g_rgb, (M, 3)), z(g_aa, (M, 1)), z(g_ae, (M, 1)), z(g_un, (M, 1))
-        widths = {**_X, **_G}
-        names = list(widths)
-        al = lambda n: (n + 3) // 4 * 4                                         # every buffer starts 16-byte aligned (dwordx4 stores)
-        work = torch.empty(sum(al(M * wd) for wd in widths.values()), **kw)     # one allocation for every dump buffer
-        bufs, off = {}, 0
-        for n in names:
-            bufs[n] = work[off: off + M * widths[n]].view(M, widths[n])
-            off += al(M * widths[n])
-        denc = [torch.empty(12, M, **kw) for _ in range(3)]   # level-major: the grid backward reads one level at a time
-        d_enc_a, d_ind = torch.zeros(32, **kw), torch.zeros(4, **kw)
+        rec = torch.empty(M, _REC, **kw)            # one record per sample: every layer input / output gradient the reductions need
+        denc = torch.empty(3, 12, M, **kw)          # level-major: the grid backward reads one level at a time
+        small = torch.zeros(32 + 4 + 16 + 32 + 192, **kw)   # d_enc_a | d_ind | dW of the three skinny output layers (reduced in the kernel)
+        d_enc_a, d_ind, dw_e2, dw_u2, dw_c2 = small[:32], small[32:36], small[36:52], small[52:84], small[84:]
         o = _lib.HeadBwdOut()
-        for i in range(3):
-            o.denc[i] = denc[i].data_ptr()
-        o.d_enc_a, o.d_ind = d_enc_a.data_ptr(), d_ind.data_ptr()
-        for n in names:
-            setattr(o, n, bufs[n].data_ptr())
+        o.denc, o.small, o.rec = denc.data_ptr(), small.data_ptr(), rec.data_ptr()
         p = mod._params(emb, enc_a_f, ind_f, eye_f)
         call("lz_triplane_head_backward", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
              C.byref(o), stream())
-        # weight gradients: one in-kernel reduction over the M samples per layer
-        dws = {}
-        for (name, xb, ldx, K, gb, N), wt in zip(_LAYERS, w):
-            if not mod.has_eye and name.startswith("eye"):
-                dws[name] = torch.zeros_like(wt)
-                continue
-            dw = torch.zeros_like(wt)
-            call("lz_linear_grad_w", ptr(bufs[gb]), widths[gb], None, ptr(bufs[xb]), ldx, ptr(dw), wt.shape[1], M, wt.shape[1], N, stream())
-            dws[name] = dw
+        # weight gradients of the wide layers: ONE pass over the records (the skinny ones came out of the backward kernel)
+        k_sig0, k_col0 = w[4].shape[1], w[7].shape[1]   # 68 without the eye column, 80 without an individual code
+        shapes = dict(x3=(112, 36), aud1=(32, 64), sig0=(64, k_sig0), sig1=(64, 64), c1h=(65, 84))
+        red = {n: torch.empty(sh, **kw) for n, sh in shapes.items()}
+        if mod._gw_ws is None or mod._gw_ws.device != dev:
+            mod._gw_ws = torch.empty(_lib.load().lz_triplane_head_grad_w_workspace() // 4, **kw)
+        call("lz_triplane_head_grad_w", ptr(rec), M, k_sig0, *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")],
+             ptr(mod._gw_ws), stream())
+        # geo = s2 . Wg^T and d geo = G_c1 . Wc[:, geo] never left the kernel: both weight gradients follow from R = sum G_c1^T s2
+        x3, c1h = red["x3"], red["c1h"]
+        R, w_sig2, w_col0 = c1h[:64, :64], w[6], w[7]
+        d_col0 = torch.cat([c1h[:64, 64:80], R @ w_sig2[1:65].T, c1h[:64, 80:80 + (k_col0 - 80)]], 1)
+        d_sig2 = torch.cat([c1h[64:65, :64], w_col0[:, 16:80].T @ R], 0)
+        dws = dict(aud0=x3[:64], eye0=x3[64:80], unc0=x3[80:112], aud1=red["aud1"], sig0=red["sig0"], sig1=red["sig1"],
+                   sig2=d_sig2, col0=d_col0, eye1=dw_e2.view(1, 16), unc1=dw_u2.view(1, 32), col1=dw_c2.view(3, 64))
+        dws = {n: dws[n].reshape(wt.shape) for n, wt in zip(_ORDER, w)}
         # table gradients: LDS-accumulated scatter per plane, inputs mapped exactly like the forward ((x + bound) / (2 bound))
         demb = []
         for cols, e, g in zip(((0, 1), (1, 2), (0, 2)), emb, denc):
@@ -114,6 +105,7 @@ class FusedTriplaneTrainHead(nn.Module):
         self.H = 64
         self.S = float(np.float32(np.log2(self.encoder_xy.per_level_scale)))
         self.register_buffer("packed", torch.empty(_lib.load().lz_head_packed_size(), dtype=torch.float32), persistent=False)
+        self._gw_ws = None   # partial-tile workspace of lz_triplane_head_grad_w, allocated on first backward
         if state_dict is not None:
             own = self.state_dict()
             self.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items() if k in own}, strict=False)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "lzzx_nerf_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|uint32_t)\s+(lz_[a-zA-Z0-9_]+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|uint32_t|size_t)\s+(lz_[a-zA-Z0-9_]+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
