@@ -112,12 +112,27 @@ struct LzGwOut {
 };
 
 // element e = (tile, r, lane) of the partial image: D row 4 (lane >> 4) + r -> n = 16 t + row, column lane & 15 -> k = 16 u + column
-__global__ void __launch_bounds__(256)
+// One workgroup per tile: 256 elements x 4 interleaved slices of the partials (thread = element + 256 * slice), four independent
+// sums per thread so that 16 loads per element are in flight, slices combined through LDS in a fixed order.
+__global__ void __launch_bounds__(1024)
 lz_k_head_grad_w_reduce(const float* __restrict__ parts, uint32_t n_parts, LzGwOut o) {
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= LZ_GW_TILES * 256) return;
-    float v = 0.0f;
-    for (uint32_t p = 0; p < n_parts; p++) v += parts[(size_t)p * (LZ_GW_TILES * 256) + e];
+    __shared__ float red[4][256];
+    const uint32_t el = threadIdx.x & 255, slice = threadIdx.x >> 8;
+    const uint32_t e = blockIdx.x * 256 + el;
+    const float* src = parts + e;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    uint32_t p = slice;
+    for (; p + 12 < n_parts; p += 16) {
+        s0 += src[(size_t)p * (LZ_GW_TILES * 256)];
+        s1 += src[(size_t)(p + 4) * (LZ_GW_TILES * 256)];
+        s2 += src[(size_t)(p + 8) * (LZ_GW_TILES * 256)];
+        s3 += src[(size_t)(p + 12) * (LZ_GW_TILES * 256)];
+    }
+    for (; p < n_parts; p += 4) s0 += src[(size_t)p * (LZ_GW_TILES * 256)];
+    red[slice][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice != 0) return;
+    const float v = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
     const int tile = e >> 8, r = (e >> 6) & 3, lane = e & 63;
     int job = 0;
 #pragma unroll
@@ -159,7 +174,7 @@ extern "C" int lz_triplane_head_grad_w(const float* rec, uint32_t M, uint32_t k_
     const int t0[6] = {T_X3, T_AUD1, T_SIG1, T_SIG0, T_C1H, LZ_GW_TILES};
     for (int j = 0; j < 5; j++) { o.dw[j] = dws[j]; o.N[j] = Ns[j]; o.K[j] = Ks[j]; o.KBT[j] = KB[j]; }
     for (int j = 0; j < 6; j++) o.tile0[j] = t0[j];
-    hipLaunchKernelGGL(lz_k_head_grad_w_reduce, dim3(LZ_GW_TILES), dim3(256), 0, st, parts, grid, o);
+    hipLaunchKernelGGL(lz_k_head_grad_w_reduce, dim3(LZ_GW_TILES), dim3(1024), 0, st, parts, grid, o);
     LZ_CHECK_LAUNCH("head_grad_w_reduce");
     return LZ_OK;
 }
