@@ -15,8 +15,8 @@ renders frame r; every step ends with ONE RCCL all-gather of the rendered RGB ti
 whole batch.
 
 Iteration schedule: every loop iteration marches n_step = max(min(F * N // n_alive, C), 1) samples per alive ray.  The reference uses
-F = 1, C = 8 (renderer.py:513), i.e. N sample rows per iteration and thin launches while most rays are alive; per-ray results do not
-depend on F and C (each ray marches the same sample sequence and stops at the same sample), so the headline runs F = C = 4 (4 N rows
+F = 1, C = 8 (renderer.py:513), i.e. N sample rows per iteration and thin launches while most rays are alive; pixels do not depend on F
+and C (each ray marches the same sample sequence and compositing resumes exactly), so the headline runs F = C = 4 (4 N rows
 per iteration, 29 instead of 114 iterations for this frame) and the `reference_schedule` leg times F = 1, C = 8 on the same frame and
 checks that the image and the sample count are identical.
 

@@ -691,7 +691,8 @@ def test_render_frame_matches_checker(params, golden, scene, max_steps, boost):
     assert mse == 0.0  # PSNR vs checker = inf
 
 
-@pytest.mark.parametrize("scene,boost,factor,cap", [("ones", 0.0, 8, 8), ("ellipsoid", 40.0, 8, 8), ("ellipsoid", 40.0, 4, 16)])
+@pytest.mark.parametrize("scene,boost,factor,cap", [("ones", 0.0, 8, 8), ("ellipsoid", 40.0, 8, 8), ("ellipsoid", 40.0, 4, 16),
+                                                    ("ones", 0.0, 4, 4), ("ellipsoid", 40.0, 4, 4)])   # (4, 4) = bench.py's headline
 def test_render_frame_fat_schedule(params, golden, scene, boost, factor, cap):
     """sample budget / n_step cap other than the reference's (N, 8): same schedule rule in the checker -> same sample
     counts bit for bit; and the pixels equal those of the reference schedule (rays are independent)"""
