@@ -10,9 +10,11 @@ the frame.  Workload: camera at (0,0,-3.35) looking down +z, fovy 21
 tables U(-1,1), MLP weights = the reference's torch init under seed 0 (tests/golden fixture), enc_a ~ N(0,1),
 eye 0.25.  Data is synthetic.
 
-N > 1 (weak scaling): the global batch is N frames of one camera orbit, ray-sharded contiguously, i.e. rank r
-renders frame r; every step ends with ONE RCCL all-gather of the rendered RGB tiles so that every rank holds the
-whole batch.
+N > 1 (weak scaling): the global batch is N consecutive frames of a talking-head clip -- what the reference renders
+(TrainerUtil.test): the head pose sways a little from frame to frame (0.01 rad per frame about the vertical axis) and every
+frame has its own audio feature -- ray-sharded contiguously, i.e. rank r renders frame r; every step ends with ONE RCCL
+all-gather of the rendered RGB tiles so that every rank holds the whole batch.  Frame 0 (N = 1) is the frontal pose with the
+fixture's audio feature.
 
 Iteration schedule: every loop iteration marches n_step = max(min(F * N // n_alive, C), 1) samples per alive ray.  The reference uses
 F = 1, C = 8 (renderer.py:513), i.e. N sample rows per iteration and thin launches while most rays are alive; pixels do not depend on F
@@ -43,7 +45,8 @@ HBM_PEAK_GBS = 8000.0
 
 
 def orbit_pose(k, n):
-    th = 0.15 * (k - (n - 1) / 2)
+    """head pose of frame k of an n-frame clip: camera on a circle of radius 3.35 about the vertical axis, 0.01 rad per frame, frame 0 frontal"""
+    th = 0.01 * k
     R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], dtype=np.float32)
     pose = np.eye(4, dtype=np.float32)
     pose[:3, :3] = R
@@ -297,9 +300,11 @@ def main():
     renderer = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=args.budget_factor, n_step_cap=args.n_step_cap)
     H = W = args.size
     _, intr = synthetic_camera(H, W)
-    pose = orbit_pose(rank, world)
+    pose = orbit_pose(rank, world)   # frame `rank` of the clip
     rays_o, rays_d = get_rays(dev(pose), intr, H, W)   # this rank's shard of the global ray batch = frame `rank`
     enc_a, ind, eye = dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"])
+    if rank > 0:   # every frame of the clip has its own audio feature (frame 0: the fixture's)
+        enc_a = enc_a + 0.5 * torch.randn(enc_a.shape, device=device, generator=torch.Generator(device=device).manual_seed(100 + rank))
     N = H * W
 
     def step():
