@@ -405,3 +405,35 @@ def test_fused_train_head_gradient_bucket_sharded_step(params, golden):
     assert torch.equal(bucket.all_reduce(), bucket.flat)                     # single process: no-op
     bucket.zero()
     assert all(float(p.grad.abs().sum()) == 0.0 for p in net.parameters())
+
+
+@pytest.mark.parametrize("M,k_sig0", [(1, 69), (15, 68), (1000, 69), (70001, 69)])
+def test_head_grad_w_products_match_float64(M, k_sig0):
+    """lz_triplane_head_grad_w on random records: the five products (one pass, partial tiles per workgroup, second launch sums them)
+    against float64 matmuls of the same column slots; ragged sample counts (tail groups read record 0 with a zero factor)."""
+    from lzzx_nerf_amd import _lib
+    from lzzx_nerf_amd._util import call, ptr, stream
+    REC = 656
+    col = dict(X_A1=0, X_SIG0=64, X_S1=144, X_S2C=208, G_X=304, G_ATT=416, G_S1=448, G_S2=512, G_C1H=576)
+    g = torch.Generator(device="cuda").manual_seed(M)
+    rec = torch.randn(M, REC, device="cuda", generator=g)
+    rec[:, col["X_SIG0"] + 69: col["X_S1"]] = float("nan")      # slot padding is never read into a written output
+    rec[:, col["G_C1H"] + 65:] = float("nan")
+    shapes = dict(x3=(112, 36), aud1=(32, 64), sig0=(64, k_sig0), sig1=(64, 64), c1h=(65, 84))
+    out = {n: torch.full(sh, 7.0, device="cuda") for n, sh in shapes.items()}
+    ws = torch.empty(_lib.load().lz_triplane_head_grad_w_workspace() // 4, device="cuda")
+    call("lz_triplane_head_grad_w", ptr(rec), M, k_sig0, *[ptr(out[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")], ptr(ws), stream())
+    r = rec.double()
+    sl = lambda name, w: r[:, col[name]: col[name] + w]
+    want = dict(x3=sl("G_X", 112).T @ sl("X_SIG0", 36), aud1=sl("G_ATT", 32).T @ sl("X_A1", 64), sig0=sl("G_S1", 64).T @ sl("X_SIG0", k_sig0),
+                sig1=sl("G_S2", 64).T @ sl("X_S1", 64), c1h=sl("G_C1H", 65).T @ sl("X_S2C", 84))
+    for n in shapes:
+        got = out[n].double()
+        assert torch.isfinite(got).all(), n
+        assert float((got - want[n]).abs().max()) <= 2e-5 * float(want[n].abs().max()) + 1e-6, n
+    # deterministic: no atomics anywhere in the reduction
+    out2 = {n: torch.empty(sh, device="cuda") for n, sh in shapes.items()}
+    call("lz_triplane_head_grad_w", ptr(rec), M, k_sig0, *[ptr(out2[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")], ptr(ws), stream())
+    assert all(torch.equal(out[n], out2[n]) for n in shapes)
+    with pytest.raises(RuntimeError):
+        call("lz_triplane_head_grad_w", ptr(rec), M, 70, *[ptr(out[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")], ptr(ws), stream())
