@@ -95,11 +95,20 @@ def grid_roofline(device):
     for tag, kw, bytes_per_sample, B, mode in (
             ("triplane_plane_D2_L12_C1_f32", tri, 8 + 12 * 4 * 4 + 48, 1 << 24, "fwd"),
             ("hashgrid_D3_L16_C2_f32", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23, "fwd"),
+            ("hashgrid_D3_L16_C2_f32_ray_ordered", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23, "fwd_rays"),
             ("hashgrid_D3_L16_C2_f16", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 2 + 64, 1 << 23, "fwd16"),
             ("triplane_plane_D2_L12_C1_f32_backward", tri, 8 + 48 + 12 * 4 * 4 * 2, 1 << 22, "bwd")):
         enc = GridEncoder(**kw).to(device)
         enc.embeddings.data.uniform_(-1, 1, generator=g)
-        x = torch.rand(B, enc.input_dim, device=device, generator=g)
+        if mode == "fwd_rays":   # BASELINE cfg2 as march_rays hands it to the encoder: 256 x 256 rays x 128 samples, ray-major
+            from conftest import synthetic_camera
+            from lzzx_nerf_amd.renderer import get_rays
+            pose, intr = synthetic_camera(256, 256)
+            ro, rd = get_rays(torch.from_numpy(pose).to(device), intr, 256, 256)
+            t = torch.linspace(2.35, 4.35, 128, device=device)
+            x = (((ro[:, None, :] + rd[:, None, :] * t[None, :, None]).clamp(-1, 1) + 1) / 2).reshape(-1, 3).contiguous()
+        else:
+            x = torch.rand(B, enc.input_dim, device=device, generator=g)
         emb = enc.embeddings.data.half() if mode == "fwd16" else enc.embeddings.data
         if mode == "bwd":
             from lzzx_nerf_amd._util import call, ptr, stream
