@@ -729,6 +729,7 @@ extern "C" int lz_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* r
 // ------------------------------------------------------------------------------------------------
 // compositing
 // ------------------------------------------------------------------------------------------------
+#define LZ_CT_CHUNK 8   // steps whose samples a ray's thread requests together
 template <int NAMB, bool AMBW, bool UNC>
 __global__ void __launch_bounds__(256)
 lz_k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ amb0,
@@ -741,21 +742,41 @@ lz_k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restri
     const uint32_t index = (uint32_t)rays[(size_t)n * 3], offset = (uint32_t)rays[(size_t)n * 3 + 1], num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
     float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0, a0 = 0, a1 = 0, u = 0;
     if (!(num_steps == 0 || offset + num_steps > M)) {
-        for (uint32_t step = 0; step < num_steps; step++) {
-            const size_t i = (size_t)offset + step;
-            const float2 dl = *reinterpret_cast<const float2*>(deltas + i * 2);
-            const float alpha = 1.0f - lz_expf(-sigmas[i] * dl.x);
-            const float weight = alpha * T;
-            r = lz_fmaf(weight, rgbs[i * 3], r);
-            g = lz_fmaf(weight, rgbs[i * 3 + 1], g);
-            b = lz_fmaf(weight, rgbs[i * 3 + 2], b);
-            d = lz_fmaf(weight, dl.y, d);
-            ws += weight;
-            if (NAMB > 0) a0 = AMBW ? lz_fmaf(weight, amb0[i], a0) : a0 + amb0[i];
-            if (NAMB > 1) a1 = AMBW ? lz_fmaf(weight, amb1[i], a1) : a1 + amb1[i];
-            if (UNC) u = lz_fmaf(weight, unc[i], u);
-            T *= 1.0f - alpha;
-            if (T < T_thresh) break;
+        // One thread walks one ray (the running product makes the steps sequential) and a launch has one wave per SIMD, so nothing
+        // hides a load: the samples of LZ_CT_CHUNK steps are requested together, then consumed in order (same arithmetic, same
+        // order; steps past the end re-read the last sample and are skipped).
+        bool live = true;
+        for (uint32_t base = 0; base < num_steps && live; base += LZ_CT_CHUNK) {
+            float sg[LZ_CT_CHUNK], c0[LZ_CT_CHUNK], c1[LZ_CT_CHUNK], c2[LZ_CT_CHUNK], v0[LZ_CT_CHUNK], v1[LZ_CT_CHUNK], vu[LZ_CT_CHUNK];
+            float2 dl[LZ_CT_CHUNK];
+#pragma unroll
+            for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
+                const uint32_t step = base + k < num_steps ? base + k : num_steps - 1;
+                const size_t i = (size_t)offset + step;
+                dl[k] = *reinterpret_cast<const float2*>(deltas + i * 2);
+                sg[k] = sigmas[i];
+                c0[k] = rgbs[i * 3]; c1[k] = rgbs[i * 3 + 1]; c2[k] = rgbs[i * 3 + 2];
+                v0[k] = NAMB > 0 ? amb0[i] : 0.0f;
+                v1[k] = NAMB > 1 ? amb1[i] : 0.0f;
+                vu[k] = UNC ? unc[i] : 0.0f;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
+                if (live && base + k < num_steps) {
+                    const float alpha = 1.0f - lz_expf(-sg[k] * dl[k].x);
+                    const float weight = alpha * T;
+                    r = lz_fmaf(weight, c0[k], r);
+                    g = lz_fmaf(weight, c1[k], g);
+                    b = lz_fmaf(weight, c2[k], b);
+                    d = lz_fmaf(weight, dl[k].y, d);
+                    ws += weight;
+                    if (NAMB > 0) a0 = AMBW ? lz_fmaf(weight, v0[k], a0) : a0 + v0[k];
+                    if (NAMB > 1) a1 = AMBW ? lz_fmaf(weight, v1[k], a1) : a1 + v1[k];
+                    if (UNC) u = lz_fmaf(weight, vu[k], u);
+                    T *= 1.0f - alpha;
+                    if (T < T_thresh) live = false;
+                }
+            }
         }
     }
     weights_sum[index] = ws;
@@ -790,34 +811,50 @@ lz_k_composite_train_bwd(const float* __restrict__ grad_weights_sum, const float
     const float amb_final = (NAMB > 0 && AMBW) ? amb0_sum[index] : 0.0f;
     const float unc_final = UNC ? unc_sum[index] : 0.0f;
     float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, amb = 0, u = 0;
-    for (uint32_t step = 0; step < num_steps; step++) {
-        const size_t i = (size_t)offset + step;
-        const float dl0 = deltas[i * 2];
-        const float c0 = rgbs[i * 3], c1 = rgbs[i * 3 + 1], c2 = rgbs[i * 3 + 2];
-        const float alpha = 1.0f - lz_expf(-sigmas[i] * dl0);
-        const float weight = alpha * T;
-        r = lz_fmaf(weight, c0, r);
-        g = lz_fmaf(weight, c1, g);
-        b = lz_fmaf(weight, c2, b);
-        float av = 0.0f, uv = 0.0f;
-        if (NAMB > 0 && AMBW) { av = amb0[i]; amb = lz_fmaf(weight, av, amb); }
-        if (UNC) { uv = unc[i]; u = lz_fmaf(weight, uv, u); }
-        ws += weight;
-        T *= 1.0f - alpha;
-        grad_rgbs[i * 3] = gi0 * weight;
-        grad_rgbs[i * 3 + 1] = gi1 * weight;
-        grad_rgbs[i * 3 + 2] = gi2 * weight;
-        if (NAMB > 0) grad_amb0[i] = AMBW ? ga0 * weight : ga0;
-        if (NAMB > 1) grad_amb1[i] = ga1;
-        if (UNC) grad_unc[i] = gu * weight;
-        float s = gi0 * lz_fmaf(T, c0, -(r_final - r));
-        s = lz_fmaf(gi1, lz_fmaf(T, c1, -(g_final - g)), s);
-        s = lz_fmaf(gi2, lz_fmaf(T, c2, -(b_final - b)), s);
-        if (NAMB > 0 && AMBW) s = lz_fmaf(ga0, lz_fmaf(T, av, -(amb_final - amb)), s);
-        if (UNC) s = lz_fmaf(gu, lz_fmaf(T, uv, -(unc_final - u)), s);
-        s = lz_fmaf(gws, 1 - ws_final, s);
-        grad_sigmas[i] = dl0 * s;
-        if (T < T_thresh) break;
+    bool live = true;
+    for (uint32_t base = 0; base < num_steps && live; base += LZ_CT_CHUNK) {   // chunked loads as in the forward kernel
+        float sg[LZ_CT_CHUNK], d0[LZ_CT_CHUNK], q0[LZ_CT_CHUNK], q1[LZ_CT_CHUNK], q2[LZ_CT_CHUNK], va[LZ_CT_CHUNK], vu[LZ_CT_CHUNK];
+#pragma unroll
+        for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
+            const uint32_t step = base + k < num_steps ? base + k : num_steps - 1;
+            const size_t i = (size_t)offset + step;
+            d0[k] = deltas[i * 2];
+            sg[k] = sigmas[i];
+            q0[k] = rgbs[i * 3]; q1[k] = rgbs[i * 3 + 1]; q2[k] = rgbs[i * 3 + 2];
+            va[k] = (NAMB > 0 && AMBW) ? amb0[i] : 0.0f;
+            vu[k] = UNC ? unc[i] : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
+            if (live && base + k < num_steps) {
+                const size_t i = (size_t)offset + base + k;
+                const float dl0 = d0[k], c0 = q0[k], c1 = q1[k], c2 = q2[k];
+                const float alpha = 1.0f - lz_expf(-sg[k] * dl0);
+                const float weight = alpha * T;
+                r = lz_fmaf(weight, c0, r);
+                g = lz_fmaf(weight, c1, g);
+                b = lz_fmaf(weight, c2, b);
+                const float av = va[k], uv = vu[k];
+                if (NAMB > 0 && AMBW) amb = lz_fmaf(weight, av, amb);
+                if (UNC) u = lz_fmaf(weight, uv, u);
+                ws += weight;
+                T *= 1.0f - alpha;
+                grad_rgbs[i * 3] = gi0 * weight;
+                grad_rgbs[i * 3 + 1] = gi1 * weight;
+                grad_rgbs[i * 3 + 2] = gi2 * weight;
+                if (NAMB > 0) grad_amb0[i] = AMBW ? ga0 * weight : ga0;
+                if (NAMB > 1) grad_amb1[i] = ga1;
+                if (UNC) grad_unc[i] = gu * weight;
+                float s = gi0 * lz_fmaf(T, c0, -(r_final - r));
+                s = lz_fmaf(gi1, lz_fmaf(T, c1, -(g_final - g)), s);
+                s = lz_fmaf(gi2, lz_fmaf(T, c2, -(b_final - b)), s);
+                if (NAMB > 0 && AMBW) s = lz_fmaf(ga0, lz_fmaf(T, av, -(amb_final - amb)), s);
+                if (UNC) s = lz_fmaf(gu, lz_fmaf(T, uv, -(unc_final - u)), s);
+                s = lz_fmaf(gws, 1 - ws_final, s);
+                grad_sigmas[i] = dl0 * s;
+                if (T < T_thresh) live = false;
+            }
+        }
     }
 }
 
