@@ -201,7 +201,7 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1):
         net = FusedTriplaneTrainHead(P, bound=1.0).to(device)
     else:
         net = TriplaneTrainNet(P, device, mlp=args.train_mlp)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-15)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-15, fused=True)
     bucket = D.GradientBucket(net.parameters()) if world > 1 else None   # every .grad a view of one flat buffer: ONE all-reduce per step
     enc_a, ind, eye = dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"])
     aabb = dev(np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32))
