@@ -37,7 +37,8 @@ class _FusedHeadTrain(Function):
         p = mod._params(emb, enc_a_f, ind_f, eye_f)
         kw = dict(dtype=torch.float32, device=dev)
         sig, rgb, aa, ae, un = torch.empty(M, **kw), torch.empty(M, 3, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw)
-        call("lz_triplane_head_forward", C.byref(p), ptr(xyzs), ptr(dirs), M, None, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un), stream())
+        if M > 0:   # an empty batch (every ray missed the box) has empty outputs and zero gradients
+            call("lz_triplane_head_forward", C.byref(p), ptr(xyzs), ptr(dirs), M, None, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un), stream())
         ctx.mod, ctx.saved = mod, (xyzs, dirs, enc_a_f, ind_f, eye_f, emb, w)
         ctx.shapes = (enc_a.shape, None if ind_code is None else ind_code.shape)
         return sig, rgb, aa, ae, un
@@ -48,6 +49,11 @@ class _FusedHeadTrain(Function):
         xyzs, dirs, enc_a_f, ind_f, eye_f, emb, w = ctx.saved
         M, dev = xyzs.shape[0], xyzs.device
         kw = dict(dtype=torch.float32, device=dev)
+        if M == 0:
+            enc_a_shape, ind_shape = ctx.shapes
+            g_enc_a = torch.zeros(enc_a_shape, **kw) if ctx.needs_input_grad[3] else None
+            g_ind = torch.zeros(ind_shape, **kw) if (ind_shape is not None and ctx.needs_input_grad[4] and mod.has_ind) else None
+            return (None, None, None, g_enc_a, g_ind, None) + tuple(torch.zeros_like(t) for t in emb) + tuple(torch.zeros_like(t) for t in w)
         z = lambda g, shape: (torch.zeros(shape, **kw) if g is None else g.float().contiguous())
         g_sig, g_rgb, g_aa, g_ae, g_un = z(g_sig, (M,)), z(g_rgb, (M, 3)), z(g_aa, (M, 1)), z(g_ae, (M, 1)), z(g_un, (M, 1))
         rec = torch.empty(M, _REC, **kw)            # one record per sample: every layer input / output gradient the reductions need

@@ -437,3 +437,34 @@ def test_head_grad_w_products_match_float64(M, k_sig0):
     assert all(torch.equal(out[n], out2[n]) for n in shapes)
     with pytest.raises(RuntimeError):
         call("lz_triplane_head_grad_w", ptr(rec), M, 70, *[ptr(out[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")], ptr(ws), stream())
+
+
+@pytest.mark.parametrize("M", [0, 1, 5, 17])
+def test_fused_train_head_tiny_batches(params, golden, M):
+    """sample counts below one 16-row slice (and none at all: a batch of rays that misses the box) through forward + backward:
+    outputs and every gradient against the same head fed with the batch padded to 64 rows whose padding gets zero upstream gradient"""
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    xyz = (torch.rand(64, 3, device="cuda", generator=g) * 2 - 1) * torch.tensor([1.0, 0.5, 1.0], device="cuda")
+    dirs = torch.nn.functional.normalize(torch.randn(64, 3, device="cuda", generator=g), dim=-1)
+    up = [torch.randn(64, device="cuda", generator=g), torch.randn(64, 3, device="cuda", generator=g)] + \
+         [torch.randn(64, 1, device="cuda", generator=g) for _ in range(3)]
+    enc_a, eye, ind = dev(golden["net_enc_a"]), dev(golden["net_eye"]), dev(golden["net_ind"])
+
+    def run(n_rows, n_live):
+        net = FusedTriplaneTrainHead({k: v for k, v in params.items()}, bound=1.0).cuda()
+        ea, ic = enc_a.clone().requires_grad_(True), ind.clone().requires_grad_(True)
+        outs = net(xyz[:n_rows].contiguous(), dirs[:n_rows].contiguous(), ea, ic, eye)
+        loss = sum((o[:n_live] * u[:n_live]).sum() for o, u in zip(outs, up))
+        loss.backward()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in net.parameters()]
+        return [o[:n_live].detach() for o in outs], grads + [ea.grad if ea.grad is not None else torch.zeros_like(ea),
+                                                              ic.grad if ic.grad is not None else torch.zeros_like(ic)]
+
+    out_s, g_s = run(M, M)
+    out_p, g_p = run(64, M)
+    for a, b in zip(out_s, out_p):
+        assert torch.equal(a, b)
+    for a, b in zip(g_s, g_p):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5 * (float(b.abs().max()) + 1e-12) + 1e-12
