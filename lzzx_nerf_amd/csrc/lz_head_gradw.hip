@@ -1,4 +1,4 @@
-// lz_head_gradw.hip -- weight gradients of the six wide Linear layers of the triplane head from the per-sample records that
+// lz_head_gradw.hip -- weight gradients of the wide Linear layers of the triplane head from the per-sample records that
 // lz_triplane_head_backward writes (include/lzzx_nerf_hip.h: LZ_BWD_*), in ONE pass over the records.
 //
 // dW_layer[n, k] = sum over samples of G[s, n] * X[s, k] (network.py:73-94: bias-free nn.Linear; torch derives the same sums through
@@ -25,7 +25,7 @@ typedef float lz_f4 __attribute__((ext_vector_type(4)));
 #define LZ_GW_MAX_PARTS 768
 
 namespace {
-// tile offsets of the six products in the partial image
+// first tile of each of the five products in the partial image
 constexpr int T_X3 = 0, T_AUD1 = 21, T_SIG1 = 29, T_SIG0 = 45, T_C1H = 65;
 
 template <int NBT, int KBT>
