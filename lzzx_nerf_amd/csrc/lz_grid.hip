@@ -848,6 +848,7 @@ __device__ __forceinline__ void lz_grid_level_scatter(const float* __restrict__ 
 // (<= 1.2e-13 of the chunk's largest gradient) and independent of the order -- tighter than f32 atomics for all but terms ~1e-9 of the
 // maximum.  Levels whose 8-byte table does not fit 128 KB take the global float-atomic path inside the same kernel.
 #define LZ_GRID_FX_LDS_BYTES 131072
+#define LZ_GRID_FX_KEEP 72   // gradients a thread keeps in registers between the two passes (C == 1)
 template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(1024)
 lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restrict__ inputs, const int* __restrict__ offsets,
@@ -867,12 +868,25 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
         lz_grid_level_scatter<D, C, false>(grad, inputs, gg, b0, b1, B, L, level, scale_l, res, hs, mode, gridtype, align_corners, sample_major);
         return;
     }
-    // pass 1: largest |grad| of this (level, chunk)
+    // pass 1: largest |grad| of this (level, chunk).  For C == 1 (the triplane planes) a thread keeps its <= LZ_GRID_FX_KEEP gradients in
+    // registers, so pass 2 reads only the inputs again (12 instead of 16 bytes per sample and level).
+    constexpr bool kKeep = (C == 1);
+    float gkeep[kKeep ? LZ_GRID_FX_KEEP : 1];
+    const bool kept = kKeep && blockDim.x == 1024 && (b1 - b0) <= LZ_GRID_FX_KEEP * 1024u;   // workgroup-uniform
     float gm = 0.0f;
-    for (uint32_t b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
-        const float* gsrc = grad + (sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C);
+    if (kept) {
 #pragma unroll
-        for (uint32_t ch = 0; ch < C; ch++) gm = fmaxf(gm, fabsf(gsrc[ch]));
+        for (uint32_t k = 0; k < (kKeep ? LZ_GRID_FX_KEEP : 1); k++) {
+            const uint32_t b = b0 + threadIdx.x + k * 1024u;
+            gkeep[k] = b < b1 ? grad[sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C] : 0.0f;
+            gm = fmaxf(gm, fabsf(gkeep[k]));
+        }
+    } else {
+        for (uint32_t b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
+            const float* gsrc = grad + (sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C);
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) gm = fmaxf(gm, fabsf(gsrc[ch]));
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
@@ -892,7 +906,7 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
     int e = 62 - hb - ex;
     e = e > 100 ? 100 : (e < -100 ? -100 : e);
     const float fx = ldexpf(1.0f, e), inv = ldexpf(1.0f, -e);
-    for (uint32_t b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
+    auto scatter = [&](uint32_t b, const float (&gcur)[C]) {
         float x[D];
         bool oob = false;
 #pragma unroll
@@ -900,11 +914,7 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
             x[d] = inputs[(size_t)b * D + d];
             if (x[d] < 0 || x[d] > 1) oob = true;
         }
-        if (oob) continue;
-        const float* gsrc = grad + (sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C);
-        float gcur[C];
-#pragma unroll
-        for (uint32_t ch = 0; ch < C; ch++) gcur[ch] = gsrc[ch];
+        if (oob) return;
         float pos[D];
         uint32_t pg[D];
 #pragma unroll
@@ -942,6 +952,25 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
                 __hip_atomic_fetch_add(lz_grid_acc64 + index + ch, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+    };
+    if (kept) {
+#pragma unroll
+        for (uint32_t k = 0; k < (kKeep ? LZ_GRID_FX_KEEP : 1); k++) {
+            const uint32_t b = b0 + threadIdx.x + k * 1024u;
+            if (b < b1) {
+                float gcur[C];
+                gcur[0] = gkeep[k];
+                scatter(b, gcur);
+            }
+        }
+    } else {
+        for (uint32_t b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
+            const float* gsrc = grad + (sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C);
+            float gcur[C];
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) gcur[ch] = gsrc[ch];
+            scatter(b, gcur);
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -957,6 +986,12 @@ static void lz_grid_bwd_lds_launch(const float* grad, const float* inputs, const
     uint32_t n_chunks = lz_div_up(B, 4096);
     const uint32_t cap = 1024 / L > 0 ? 1024 / L : 1;
     if (n_chunks > cap) n_chunks = cap;
+    const uint32_t fit = lz_div_up(B, LZ_GRID_FX_KEEP * 1024u);   // chunks small enough for the register-kept gradients (C == 1)
+    if (C == 1 && n_chunks < fit && fit * L <= 4096) n_chunks = fit;
+    {   // whole rounds of workgroups (one per CU: 128 KB of LDS each) when that keeps the chunks register-sized: fewer chunks = fewer flushes
+        const uint32_t per_round = 256, down = (n_chunks * L / per_round) * per_round / L;
+        if (down >= 1 && down >= fit && down * L >= per_round) n_chunks = down;
+    }
     const uint32_t chunk = lz_div_up(B, n_chunks);
     n_chunks = lz_div_up(B, chunk);
     static bool attr_set = false;   // per instantiation: more than 64 KB of dynamic LDS has to be requested once
