@@ -5,7 +5,7 @@
 set -e
 export TMPDIR=/tmp
 REPO=$(pwd)
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-grid-roofline --no-fat-schedule --no-fp16-leg --no-occupancy --no-dense192 --no-train"
+ARGS="--steps 5 --warmup 2 --no-clock-probe --no-cpu-baseline --no-grid-roofline --no-fat-schedule --no-fp16-leg --no-occupancy --no-dense192 --no-train"
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp
