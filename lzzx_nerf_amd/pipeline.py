@@ -14,19 +14,53 @@ from .renderer import TriplaneRenderer
 from .torso import FusedTorso
 
 
+def audio_window(features, att_mode, index):
+    """The per-frame slice of the audio feature track that feeds `encode_audio` (nerf_triplane/utils.py:20-52): att_mode 0 -> frame
+    `index` alone, 1 -> the 8 frames before it, 2 -> frames [index - 4, index + 4); windows running off either end of the track
+    are zero-padded to their full length (the reference pads with `zeros_like` of the rows it has, so for a track shorter than
+    the window it returns fewer than 8 rows; tracks of at least 8 frames give identical windows)."""
+    n = features.shape[0]
+    if att_mode == 0:
+        return features[[index]]
+    if att_mode == 1:
+        lo, hi = index - 8, index
+    elif att_mode == 2:
+        lo, hi = index - 4, index + 4
+    else:
+        raise NotImplementedError(f"wrong att_mode: {att_mode}")
+    out = features.new_zeros((hi - lo,) + tuple(features.shape[1:]))
+    a, b = max(lo, 0), min(hi, n)
+    if b > a:
+        out[a - lo: b - lo] = features[a:b]
+    return out
+
+
 class TalkingHeadFrame:
-    def __init__(self, state_dict, density_bitfield, bound=1.0, exp_eye=True, torso_shrink=0.8, precision="f32", device="cuda", **renderer_kw):
+    SMOOTH_LIPS_LAMBDA = 0.35   # renderer.py:254-258, 456-460
+
+    def __init__(self, state_dict, density_bitfield, bound=1.0, exp_eye=True, torso_shrink=0.8, precision="f32", device="cuda",
+                 smooth_lips=False, **renderer_kw):
+        self.smooth_lips = bool(smooth_lips)   # opt.smooth_lips: enc_a of a frame is blended with the previous frame's
+        self._enc_a_prev = None
         self.audio = FusedAudioEncoder(state_dict, device=device)
         self.head = FusedTriplaneHead(state_dict, bound=bound, exp_eye=exp_eye, device=device, precision=precision)
         self.torso = FusedTorso(state_dict, torso_shrink=torso_shrink, device=device) if "torso_net.net.0.weight" in state_dict else None
         self.renderer = TriplaneRenderer(self.head, density_bitfield, bound=bound, **renderer_kw)
+
+    def reset(self):
+        """forget the previous frame's audio code (start of a new clip)"""
+        self._enc_a_prev = None
 
     @torch.no_grad()
     def render(self, rays_o, rays_d, auds, eye=None, ind_code=None, bg_coords=None, poses=None, ind_code_torso=None, bg_color=1.0,
                density_grid_torso=None, density_thresh_torso=0.0, **render_kw):
         """auds [8, dim_in, 16]; bg_color: scalar or [N,3]; returns the renderer's dict plus enc_a and (with a torso) torso_alpha,
         torso_color (= the mixed background, as results['torso_color'] in run_torso) and deform."""
-        enc_a = self.audio(auds)                                                            # renderer.py:455-460
+        enc_a = self.audio(auds)                                                            # renderer.py:455
+        if self.smooth_lips:                                                                # renderer.py:456-460 (stateful across frames)
+            if self._enc_a_prev is not None:
+                enc_a = self.SMOOTH_LIPS_LAMBDA * self._enc_a_prev + (1 - self.SMOOTH_LIPS_LAMBDA) * enc_a
+            self._enc_a_prev = enc_a
         extra = dict(enc_a=enc_a)
         if self.torso is not None and bg_coords is not None:
             alpha, color, deform = self.torso(bg_coords, poses, ind_code_torso, density_grid=density_grid_torso,

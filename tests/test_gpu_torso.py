@@ -132,3 +132,37 @@ def test_update_density_grid_torso_matches_checker():
     assert np.array_equal(dg.cpu().numpy(), ref)
     assert float(mean_g) == pytest.approx(mean_o, rel=2e-6) and float(thr_g) == pytest.approx(min(mean_o, 0.01), rel=2e-6)
     assert (ref != grid0 * F32(0.95)).mean() > 0.2     # the new alphas win somewhere, the decayed old grid elsewhere
+
+
+def test_pipeline_smooth_lips_blends_audio_code_across_frames(params, golden):
+    """opt.smooth_lips (renderer.py:254-258, 456-460): enc_a of frame k is 0.35 * (the blended code of frame k - 1) + 0.65 * its own,
+    stateful across frames, and the frame is rendered with the blended code; bit for bit against the checker fed the same code"""
+    from conftest import ellipsoid_bitfield, synthetic_camera
+    from lzzx_nerf_amd.pipeline import TalkingHeadFrame, audio_window
+    from oracle.audio import encode_audio
+    from oracle.head import TriplaneSpec, get_rays
+    from oracle.render import render_inference
+    from test_audio_oracle import audio_state
+    sd = dict(params)
+    sd.update(audio_state(29, 32, True))
+    H = W = 24
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    bits = ellipsoid_bitfield()[0]
+    track = np.random.default_rng(3).normal(size=(12, 29, 16)).astype(F32)          # a 12-frame audio feature track
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    frame = TalkingHeadFrame({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, dev(bits), bound=1.0, smooth_lips=True)
+    prev = None
+    for index in (0, 1, 2, 11):
+        auds = audio_window(torch.from_numpy(track), 2, index)                      # att_mode 2: frames [index - 4, index + 4), zero-padded
+        assert auds.shape == (8, 29, 16)
+        out = frame.render(dev(ro), dev(rd), auds.cuda(), eye=dev(golden["net_eye"]), ind_code=dev(golden["net_ind"]), max_steps=32)
+        own = encode_audio(sd, auds.numpy(), True)
+        want = own if prev is None else F32(0.35) * prev + F32(1 - 0.35) * own
+        assert np.array_equal(out["enc_a"].cpu().numpy(), want)
+        ref = render_inference(TriplaneSpec(1.0), sd, ro, rd, bits, want, golden["net_ind"], golden["net_eye"], max_steps=32)
+        assert np.array_equal(out["image"].cpu().numpy(), ref["image"])
+        prev = want
+    frame.reset()
+    out = frame.render(dev(ro), dev(rd), auds.cuda(), eye=dev(golden["net_eye"]), ind_code=dev(golden["net_ind"]), max_steps=32)
+    assert np.array_equal(out["enc_a"].cpu().numpy(), own)                          # a new clip starts from its own code
