@@ -729,56 +729,81 @@ extern "C" int lz_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* r
 // ------------------------------------------------------------------------------------------------
 // compositing
 // ------------------------------------------------------------------------------------------------
-#define LZ_CT_CHUNK 8   // steps whose samples a ray's thread requests together
+// composite_rays_train: one lane walks one ray (the running product T *= 1 - alpha makes a ray sequential), but the SAMPLES of a
+// wave's 64 rays are fetched cooperatively: lane (sub = l >> 3, j = l & 7) loads step base + j of ray 8 it + sub, so a load
+// instruction touches 8 rays x 8 consecutive samples (8 cache lines instead of 64 when every lane reads its own ray), the values
+// cross to the owning lane through LDS ([step][field][ray], one extra word per step slab against bank conflicts), and the lane
+// consumes them in order -- same arithmetic, same order as the reference kernel (raymarching.cu:1877-2133).  One wave per
+// workgroup, so the barriers of a chunk are wave-local.  The backward kernel sends its per-sample gradients back through LDS to
+// stores of the same shape.  cfg3 (65 536 rays, 5.95 M samples): forward 0.49 -> 0.12 ms, backward 0.89 -> 0.19 ms.
+#define LZ_CT_CHUNK 8
+#define LZ_CT_FWD_NF 9    // sigma, dt, t, r, g, b, amb0, amb1, unc
+#define LZ_CT_BWD_NF 7    // sigma, dt, r, g, b, amb0, unc
+#define LZ_CT_BWD_NO 7    // d sigma, d r, d g, d b, d amb0, d amb1, d unc
 template <int NAMB, bool AMBW, bool UNC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 lz_k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ amb0,
                          const float* __restrict__ amb1, const float* __restrict__ unc, const float* __restrict__ deltas,
                          const int* __restrict__ rays, uint32_t M, uint32_t N, float T_thresh, float* __restrict__ weights_sum,
                          float* __restrict__ amb0_sum, float* __restrict__ amb1_sum, float* __restrict__ unc_sum,
                          float* __restrict__ depth, float* __restrict__ image) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[(size_t)n * 3], offset = (uint32_t)rays[(size_t)n * 3 + 1], num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
+    constexpr int ROW = LZ_CT_FWD_NF * 64 + 1;
+    __shared__ float st[LZ_CT_CHUNK * ROW];
+    const uint32_t lane = threadIdx.x, n = blockIdx.x * 64 + lane;
+    const bool have = n < N;
+    uint32_t index = 0, offset = 0, ns = 0;
+    if (have) {
+        index = (uint32_t)rays[(size_t)n * 3];
+        offset = (uint32_t)rays[(size_t)n * 3 + 1];
+        ns = (uint32_t)rays[(size_t)n * 3 + 2];
+        if (ns == 0 || offset + ns > M) ns = 0;   // dropped ray (raymarching.cu:1905): zero outputs
+    }
     float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0, a0 = 0, a1 = 0, u = 0;
-    if (!(num_steps == 0 || offset + num_steps > M)) {
-        // One thread walks one ray (the running product makes the steps sequential) and a launch has one wave per SIMD, so nothing
-        // hides a load: the samples of LZ_CT_CHUNK steps are requested together, then consumed in order (same arithmetic, same
-        // order; steps past the end re-read the last sample and are skipped).
-        bool live = true;
-        for (uint32_t base = 0; base < num_steps && live; base += LZ_CT_CHUNK) {
-            float sg[LZ_CT_CHUNK], c0[LZ_CT_CHUNK], c1[LZ_CT_CHUNK], c2[LZ_CT_CHUNK], v0[LZ_CT_CHUNK], v1[LZ_CT_CHUNK], vu[LZ_CT_CHUNK];
-            float2 dl[LZ_CT_CHUNK];
+    bool live = ns > 0;
+    const uint32_t sub = lane >> 3, j = lane & 7;
+    for (uint32_t base = 0; __any(live && base < ns); base += LZ_CT_CHUNK) {
+        const uint32_t want = (live && base < ns) ? ns : 0u;   // 0: this ray needs nothing more
 #pragma unroll
-            for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
-                const uint32_t step = base + k < num_steps ? base + k : num_steps - 1;
-                const size_t i = (size_t)offset + step;
-                dl[k] = *reinterpret_cast<const float2*>(deltas + i * 2);
-                sg[k] = sigmas[i];
-                c0[k] = rgbs[i * 3]; c1[k] = rgbs[i * 3 + 1]; c2[k] = rgbs[i * 3 + 2];
-                v0[k] = NAMB > 0 ? amb0[i] : 0.0f;
-                v1[k] = NAMB > 1 ? amb1[i] : 0.0f;
-                vu[k] = UNC ? unc[i] : 0.0f;
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
-                if (live && base + k < num_steps) {
-                    const float alpha = 1.0f - lz_expf(-sg[k] * dl[k].x);
-                    const float weight = alpha * T;
-                    r = lz_fmaf(weight, c0[k], r);
-                    g = lz_fmaf(weight, c1[k], g);
-                    b = lz_fmaf(weight, c2[k], b);
-                    d = lz_fmaf(weight, dl[k].y, d);
-                    ws += weight;
-                    if (NAMB > 0) a0 = AMBW ? lz_fmaf(weight, v0[k], a0) : a0 + v0[k];
-                    if (NAMB > 1) a1 = AMBW ? lz_fmaf(weight, v1[k], a1) : a1 + v1[k];
-                    if (UNC) u = lz_fmaf(weight, vu[k], u);
-                    T *= 1.0f - alpha;
-                    if (T < T_thresh) live = false;
-                }
+        for (uint32_t it = 0; it < 8; it++) {
+            const uint32_t rl = 8 * it + sub;
+            const uint32_t r_ns = (uint32_t)__shfl((int)want, (int)rl, 64), r_off = (uint32_t)__shfl((int)offset, (int)rl, 64);
+            if (base + j < r_ns) {
+                const size_t i = (size_t)r_off + base + j;
+                float* dst = st + j * ROW + rl;
+                const float2 dl = *reinterpret_cast<const float2*>(deltas + i * 2);
+                dst[0] = sigmas[i];
+                dst[64] = dl.x;
+                dst[128] = dl.y;
+                dst[192] = rgbs[i * 3];
+                dst[256] = rgbs[i * 3 + 1];
+                dst[320] = rgbs[i * 3 + 2];
+                if (NAMB > 0) dst[384] = amb0[i];
+                if (NAMB > 1) dst[448] = amb1[i];
+                if (UNC) dst[512] = unc[i];
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
+            if (live && base + k < ns) {
+                const float* src = st + k * ROW + lane;
+                const float alpha = 1.0f - lz_expf(-src[0] * src[64]);
+                const float weight = alpha * T;
+                r = lz_fmaf(weight, src[192], r);
+                g = lz_fmaf(weight, src[256], g);
+                b = lz_fmaf(weight, src[320], b);
+                d = lz_fmaf(weight, src[128], d);
+                ws += weight;
+                if (NAMB > 0) a0 = AMBW ? lz_fmaf(weight, src[384], a0) : a0 + src[384];
+                if (NAMB > 1) a1 = AMBW ? lz_fmaf(weight, src[448], a1) : a1 + src[448];
+                if (UNC) u = lz_fmaf(weight, src[512], u);
+                T *= 1.0f - alpha;
+                if (T < T_thresh) live = false;
+            }
+        }
+        __syncthreads();
     }
+    if (!have) return;
     weights_sum[index] = ws;
     if (NAMB > 0) amb0_sum[index] = a0;
     if (NAMB > 1) amb1_sum[index] = a1;
@@ -788,7 +813,7 @@ lz_k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restri
 }
 
 template <int NAMB, bool AMBW, bool UNC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 lz_k_composite_train_bwd(const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_amb0_sum,
                          const float* __restrict__ grad_amb1_sum, const float* __restrict__ grad_unc_sum,
                          const float* __restrict__ grad_image, const float* __restrict__ sigmas, const float* __restrict__ rgbs,
@@ -797,64 +822,104 @@ lz_k_composite_train_bwd(const float* __restrict__ grad_weights_sum, const float
                          const float* __restrict__ unc_sum, const float* __restrict__ image, uint32_t M, uint32_t N, float T_thresh,
                          float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs, float* __restrict__ grad_amb0,
                          float* __restrict__ grad_amb1, float* __restrict__ grad_unc) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[(size_t)n * 3], offset = (uint32_t)rays[(size_t)n * 3 + 1], num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
-    if (num_steps == 0 || offset + num_steps > M) return;
-    const float gi0 = grad_image[(size_t)index * 3], gi1 = grad_image[(size_t)index * 3 + 1], gi2 = grad_image[(size_t)index * 3 + 2];
-    const float gws = grad_weights_sum[index];
-    const float ga0 = NAMB > 0 ? grad_amb0_sum[index] : 0.0f;
-    const float ga1 = NAMB > 1 ? grad_amb1_sum[index] : 0.0f;
-    const float gu = UNC ? grad_unc_sum[index] : 0.0f;
-    const float r_final = image[(size_t)index * 3], g_final = image[(size_t)index * 3 + 1], b_final = image[(size_t)index * 3 + 2];
-    const float ws_final = weights_sum[index];
-    const float amb_final = (NAMB > 0 && AMBW) ? amb0_sum[index] : 0.0f;
-    const float unc_final = UNC ? unc_sum[index] : 0.0f;
+    constexpr int ROW = LZ_CT_BWD_NF * 64 + 1, ROWO = LZ_CT_BWD_NO * 64 + 1;
+    __shared__ float st[LZ_CT_CHUNK * ROW];
+    __shared__ float so[LZ_CT_CHUNK * ROWO];
+    const uint32_t lane = threadIdx.x, n = blockIdx.x * 64 + lane;
+    uint32_t index = 0, offset = 0, ns = 0;
+    if (n < N) {
+        index = (uint32_t)rays[(size_t)n * 3];
+        offset = (uint32_t)rays[(size_t)n * 3 + 1];
+        ns = (uint32_t)rays[(size_t)n * 3 + 2];
+        if (ns == 0 || offset + ns > M) ns = 0;   // dropped ray: its gradients stay as the caller initialised them
+    }
+    float gi0 = 0, gi1 = 0, gi2 = 0, gws = 0, ga0 = 0, ga1 = 0, gu = 0, r_final = 0, g_final = 0, b_final = 0, ws_final = 0, amb_final = 0,
+          unc_final = 0;
+    if (ns > 0) {
+        gi0 = grad_image[(size_t)index * 3]; gi1 = grad_image[(size_t)index * 3 + 1]; gi2 = grad_image[(size_t)index * 3 + 2];
+        gws = grad_weights_sum[index];
+        if (NAMB > 0) ga0 = grad_amb0_sum[index];
+        if (NAMB > 1) ga1 = grad_amb1_sum[index];
+        if (UNC) gu = grad_unc_sum[index];
+        r_final = image[(size_t)index * 3]; g_final = image[(size_t)index * 3 + 1]; b_final = image[(size_t)index * 3 + 2];
+        ws_final = weights_sum[index];
+        if (NAMB > 0 && AMBW) amb_final = amb0_sum[index];
+        if (UNC) unc_final = unc_sum[index];
+    }
     float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, amb = 0, u = 0;
-    bool live = true;
-    for (uint32_t base = 0; base < num_steps && live; base += LZ_CT_CHUNK) {   // chunked loads as in the forward kernel
-        float sg[LZ_CT_CHUNK], d0[LZ_CT_CHUNK], q0[LZ_CT_CHUNK], q1[LZ_CT_CHUNK], q2[LZ_CT_CHUNK], va[LZ_CT_CHUNK], vu[LZ_CT_CHUNK];
+    bool live = ns > 0;
+    const uint32_t sub = lane >> 3, j = lane & 7;
+    for (uint32_t base = 0; __any(live && base < ns); base += LZ_CT_CHUNK) {
+        const uint32_t want = (live && base < ns) ? ns : 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
-            const uint32_t step = base + k < num_steps ? base + k : num_steps - 1;
-            const size_t i = (size_t)offset + step;
-            d0[k] = deltas[i * 2];
-            sg[k] = sigmas[i];
-            q0[k] = rgbs[i * 3]; q1[k] = rgbs[i * 3 + 1]; q2[k] = rgbs[i * 3 + 2];
-            va[k] = (NAMB > 0 && AMBW) ? amb0[i] : 0.0f;
-            vu[k] = UNC ? unc[i] : 0.0f;
+        for (uint32_t it = 0; it < 8; it++) {
+            const uint32_t rl = 8 * it + sub;
+            const uint32_t r_ns = (uint32_t)__shfl((int)want, (int)rl, 64), r_off = (uint32_t)__shfl((int)offset, (int)rl, 64);
+            if (base + j < r_ns) {
+                const size_t i = (size_t)r_off + base + j;
+                float* dst = st + j * ROW + rl;
+                dst[0] = sigmas[i];
+                dst[64] = deltas[i * 2];
+                dst[128] = rgbs[i * 3];
+                dst[192] = rgbs[i * 3 + 1];
+                dst[256] = rgbs[i * 3 + 2];
+                if (NAMB > 0 && AMBW) dst[320] = amb0[i];
+                if (UNC) dst[384] = unc[i];
+            }
         }
+        __syncthreads();
+        uint32_t done = 0;   // steps of this chunk this ray went through (a prefix of the chunk)
 #pragma unroll
         for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
-            if (live && base + k < num_steps) {
-                const size_t i = (size_t)offset + base + k;
-                const float dl0 = d0[k], c0 = q0[k], c1 = q1[k], c2 = q2[k];
-                const float alpha = 1.0f - lz_expf(-sg[k] * dl0);
+            if (live && base + k < ns) {
+                const float* src = st + k * ROW + lane;
+                float* out = so + k * ROWO + lane;
+                const float dl0 = src[64], c0 = src[128], c1 = src[192], c2 = src[256];
+                const float alpha = 1.0f - lz_expf(-src[0] * dl0);
                 const float weight = alpha * T;
                 r = lz_fmaf(weight, c0, r);
                 g = lz_fmaf(weight, c1, g);
                 b = lz_fmaf(weight, c2, b);
-                const float av = va[k], uv = vu[k];
-                if (NAMB > 0 && AMBW) amb = lz_fmaf(weight, av, amb);
-                if (UNC) u = lz_fmaf(weight, uv, u);
+                float av = 0.0f, uv = 0.0f;
+                if (NAMB > 0 && AMBW) { av = src[320]; amb = lz_fmaf(weight, av, amb); }
+                if (UNC) { uv = src[384]; u = lz_fmaf(weight, uv, u); }
                 ws += weight;
                 T *= 1.0f - alpha;
-                grad_rgbs[i * 3] = gi0 * weight;
-                grad_rgbs[i * 3 + 1] = gi1 * weight;
-                grad_rgbs[i * 3 + 2] = gi2 * weight;
-                if (NAMB > 0) grad_amb0[i] = AMBW ? ga0 * weight : ga0;
-                if (NAMB > 1) grad_amb1[i] = ga1;
-                if (UNC) grad_unc[i] = gu * weight;
+                out[64] = gi0 * weight;
+                out[128] = gi1 * weight;
+                out[192] = gi2 * weight;
+                if (NAMB > 0) out[256] = AMBW ? ga0 * weight : ga0;
+                if (NAMB > 1) out[320] = ga1;
+                if (UNC) out[384] = gu * weight;
                 float s = gi0 * lz_fmaf(T, c0, -(r_final - r));
                 s = lz_fmaf(gi1, lz_fmaf(T, c1, -(g_final - g)), s);
                 s = lz_fmaf(gi2, lz_fmaf(T, c2, -(b_final - b)), s);
                 if (NAMB > 0 && AMBW) s = lz_fmaf(ga0, lz_fmaf(T, av, -(amb_final - amb)), s);
                 if (UNC) s = lz_fmaf(gu, lz_fmaf(T, uv, -(unc_final - u)), s);
                 s = lz_fmaf(gws, 1 - ws_final, s);
-                grad_sigmas[i] = dl0 * s;
+                out[0] = dl0 * s;
+                done = k + 1;
                 if (T < T_thresh) live = false;
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t it = 0; it < 8; it++) {   // the gradients of the steps a ray went through, 8 rays x 8 consecutive samples per store
+            const uint32_t rl = 8 * it + sub;
+            const uint32_t r_done = (uint32_t)__shfl((int)done, (int)rl, 64), r_off = (uint32_t)__shfl((int)offset, (int)rl, 64);
+            if (j < r_done) {
+                const size_t i = (size_t)r_off + base + j;
+                const float* out = so + j * ROWO + rl;
+                grad_sigmas[i] = out[0];
+                grad_rgbs[i * 3] = out[64];
+                grad_rgbs[i * 3 + 1] = out[128];
+                grad_rgbs[i * 3 + 2] = out[192];
+                if (NAMB > 0) grad_amb0[i] = out[256];
+                if (NAMB > 1) grad_amb1[i] = out[320];
+                if (UNC) grad_unc[i] = out[384];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -947,7 +1012,7 @@ extern "C" int lz_composite_rays_train_forward(const float* sigmas, const float*
                                                float* amb0_sum, float* amb1_sum, float* unc_sum, float* depth, float* image,
                                                lz_stream_t stream) {
     if (N == 0) return LZ_OK;
-    dim3 grid(lz_div_up(N, 256)), block(256);
+    dim3 grid(lz_div_up(N, 64)), block(64);   // one wave per workgroup (wave-local barriers)
     hipStream_t st = lz_st(stream);
 #define CALL(NA, AW, HU) hipLaunchKernelGGL((lz_k_composite_train_fwd<NA, AW, HU>), grid, block, 0, st, sigmas, rgbs, amb0, amb1, unc, deltas, rays, M, N, T_thresh, weights_sum, amb0_sum, amb1_sum, unc_sum, depth, image)
     LZ_VARIANT_SWITCH(n_amb, amb_weighted, has_unc, CALL);
@@ -966,7 +1031,7 @@ extern "C" int lz_composite_rays_train_backward(const float* grad_weights_sum, c
                                                 float* grad_unc, lz_stream_t stream) {
     (void)amb1;
     if (N == 0) return LZ_OK;
-    dim3 grid(lz_div_up(N, 256)), block(256);
+    dim3 grid(lz_div_up(N, 64)), block(64);
     hipStream_t st = lz_st(stream);
 #define CALL(NA, AW, HU) hipLaunchKernelGGL((lz_k_composite_train_bwd<NA, AW, HU>), grid, block, 0, st, grad_weights_sum, grad_amb0_sum, grad_amb1_sum, grad_unc_sum, grad_image, sigmas, rgbs, amb0, unc, deltas, rays, weights_sum, amb0_sum, unc_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, grad_amb0, grad_amb1, grad_unc)
     LZ_VARIANT_SWITCH(n_amb, amb_weighted, has_unc, CALL);
