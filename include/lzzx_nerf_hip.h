@@ -143,9 +143,13 @@ int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t
  * 5. extensions (no reference counterpart at the FFI level)
  * ------------------------------------------------------------------------------------------------ */
 
-/* full-image ray generation, nerf_triplane/utils.py:226-312 (N = -1 branch); pose: device [4,4] row-major c2w */
-int lz_get_rays(const float* pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, float* rays_o,
-                float* rays_d, lz_stream_t stream);
+/* ray generation, nerf_triplane/utils.py:226-312: poses device [B,4,4] row-major c2w; rays_o / rays_d [B,N,3].
+ * inds: device int64 [N] pixel indices (row * W + col, each in [0, H*W)) shared by the batch, or NULL for every pixel in
+ * order (then N must be H * W).  out_i / out_j: optional [B,N] pixel-centre coordinates (results['i'], ['j']). */
+int lz_get_rays(const float* poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, uint32_t B, uint32_t N,
+                const int64_t* inds, float* rays_o, float* rays_d, float* out_i, float* out_j, lz_stream_t stream);
+/* get_bg_coords, nerf_triplane/utils.py:217-223: out [H*W, 2] in [-1, 1] */
+int lz_bg_coords(uint32_t H, uint32_t W, float* out, lz_stream_t stream);
 
 /* Fused triplane head: xyz -> 3 x hash-grid (D=2, L=12, C=1) -> aud/eye attention -> sigma net -> SH(4) -> colour net.
  * Weights are consumed in the packed "A-fragment" layout produced by lz_head_pack_weights; all arithmetic is f32

@@ -67,7 +67,8 @@ SIGNATURES = {
     "lz_composite_rays_train_forward": [vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "lz_composite_rays_train_backward": [vp] * 16 + [u32, u32, f32, i32, i32, i32] + [vp] * 6,
     "lz_composite_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
-    "lz_get_rays": [vp, f32, f32, f32, f32, u32, u32, vp, vp, vp],
+    "lz_get_rays": [vp, f32, f32, f32, f32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp],
+    "lz_bg_coords": [u32, u32, vp, vp],
     "lz_head_pack_weights": [vp] * 11 + [i32, i32, vp, vp],
     "lz_triplane_head_forward": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_begin": [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],

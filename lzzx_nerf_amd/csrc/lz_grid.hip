@@ -848,6 +848,13 @@ __device__ __forceinline__ void lz_grid_level_scatter(const float* __restrict__ 
 // (<= 1.2e-13 of the chunk's largest gradient) and independent of the order -- tighter than f32 atomics for all but terms ~1e-9 of the
 // maximum.  Levels whose 8-byte table does not fit 128 KB take the global float-atomic path inside the same kernel.
 #define LZ_GRID_FX_LDS_BYTES 131072
+// |g| for the max pass, with NaN mapped to +inf: fmaxf drops NaN operands and __float2ll_rn(NaN) adds 0, so a NaN gradient would vanish
+// in the fixed-point path, while the reference's float atomicAdd propagates it into grad_embeddings (what GradScaler's non-finite check
+// looks at).  A (level, chunk) with any non-finite gradient takes the float-atomic path, like inf always did.
+__device__ __forceinline__ float lz_abs_nan_inf(float g) {
+    const float a = fabsf(g);
+    return a == a ? a : INFINITY;
+}
 #define LZ_GRID_FX_KEEP 72   // gradients a thread keeps in registers between the two passes (C == 1)
 template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(1024)
@@ -879,13 +886,13 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
         for (uint32_t k = 0; k < (kKeep ? LZ_GRID_FX_KEEP : 1); k++) {
             const uint32_t b = b0 + threadIdx.x + k * 1024u;
             gkeep[k] = b < b1 ? grad[sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C] : 0.0f;
-            gm = fmaxf(gm, fabsf(gkeep[k]));
+            gm = fmaxf(gm, lz_abs_nan_inf(gkeep[k]));
         }
     } else {
         for (uint32_t b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
             const float* gsrc = grad + (sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C);
 #pragma unroll
-            for (uint32_t ch = 0; ch < C; ch++) gm = fmaxf(gm, fabsf(gsrc[ch]));
+            for (uint32_t ch = 0; ch < C; ch++) gm = fmaxf(gm, lz_abs_nan_inf(gsrc[ch]));
         }
     }
 #pragma unroll

@@ -54,30 +54,58 @@ __device__ __forceinline__ int lz_mip_from_dt(float dt, float H, float max_casca
 }
 
 // ------------------------------------------------------------------------------------------------
-// ray generation (nerf_triplane/utils.py:226-312, full-image branch)
+// ray generation (nerf_triplane/utils.py:226-312): B poses x N pixels.  `inds` (pixel = row * W + col, shared by the batch like the
+// reference's `inds.expand([B, N])`) selects pixels for the random / patch / rect branches; NULL = every pixel in order (N = H * W).
+// Optionally also the pixel-centre coordinates results['i'] / ['j'] (:290-291).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-lz_k_get_rays(const float* __restrict__ pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
-              float* __restrict__ rays_o, float* __restrict__ rays_d) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= H * W) return;
+lz_k_get_rays(const float* __restrict__ poses, float fx, float fy, float cx, float cy, uint32_t W, uint32_t B, uint32_t N,
+              const long long* __restrict__ inds, float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ out_i,
+              float* __restrict__ out_j) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)B * N) return;
+    const uint32_t b = (uint32_t)(t / N), n = (uint32_t)(t % N);
+    const uint32_t p = inds ? (uint32_t)inds[n] : n;
+    const float* pose = poses + (size_t)b * 16;
     const float fi = (float)(p % W) + 0.5f, fj = (float)(p / W) + 0.5f;
     const float xs = (fi - cx) / fx, ys = (fj - cy) / fy, zs = 1.0f;
     const float nrm = sqrtf(lz_fmaf(zs, zs, lz_fmaf(ys, ys, xs * xs)));
     const float d0 = xs / nrm, d1 = ys / nrm, d2 = zs / nrm;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        rays_d[(size_t)p * 3 + k] = lz_fmaf(d2, pose[k * 4 + 2], lz_fmaf(d1, pose[k * 4 + 1], d0 * pose[k * 4 + 0]));
-        rays_o[(size_t)p * 3 + k] = pose[k * 4 + 3];
+        rays_d[t * 3 + k] = lz_fmaf(d2, pose[k * 4 + 2], lz_fmaf(d1, pose[k * 4 + 1], d0 * pose[k * 4 + 0]));
+        rays_o[t * 3 + k] = pose[k * 4 + 3];
     }
+    if (out_i) out_i[t] = fi;
+    if (out_j) out_j[t] = fj;
 }
 
-extern "C" int lz_get_rays(const float* pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, float* rays_o,
-                           float* rays_d, lz_stream_t stream) {
-    LZ_REQUIRE(pose && rays_o && rays_d, LZ_ERR_BAD_ARGUMENT, "get_rays: null tensor");
-    if (H * W == 0) return LZ_OK;
-    hipLaunchKernelGGL(lz_k_get_rays, dim3(lz_div_up((uint64_t)H * W, 256)), dim3(256), 0, lz_st(stream), pose, fx, fy, cx, cy, H, W, rays_o, rays_d);
+extern "C" int lz_get_rays(const float* poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, uint32_t B, uint32_t N,
+                           const int64_t* inds, float* rays_o, float* rays_d, float* out_i, float* out_j, lz_stream_t stream) {
+    LZ_REQUIRE(poses && rays_o && rays_d, LZ_ERR_BAD_ARGUMENT, "get_rays: null tensor");
+    LZ_REQUIRE(inds || (uint64_t)N == (uint64_t)H * W, LZ_ERR_BAD_ARGUMENT, "get_rays: without inds N must be H * W");
+    if ((uint64_t)B * N == 0) return LZ_OK;
+    LZ_REQUIRE((uint64_t)B * N < (1ull << 32) * 256, LZ_ERR_BAD_ARGUMENT, "get_rays: too many rays for one launch");
+    hipLaunchKernelGGL(lz_k_get_rays, dim3((uint32_t)lz_div_up((uint64_t)B * N, 256)), dim3(256), 0, lz_st(stream), poses, fx, fy, cx, cy, W,
+                       B, N, reinterpret_cast<const long long*>(inds), rays_o, rays_d, out_i, out_j);
     LZ_CHECK_LAUNCH("get_rays");
+    return LZ_OK;
+}
+
+// get_bg_coords (utils.py:217-223): [H*W, 2], (row / (H-1) * 2 - 1, col / (W-1) * 2 - 1) -- torch's float32 operation order
+__global__ void __launch_bounds__(256)
+lz_k_bg_coords(uint32_t H, uint32_t W, float* __restrict__ out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    out[(size_t)p * 2] = (float)(p / W) / (float)(H - 1) * 2.0f - 1.0f;
+    out[(size_t)p * 2 + 1] = (float)(p % W) / (float)(W - 1) * 2.0f - 1.0f;
+}
+
+extern "C" int lz_bg_coords(uint32_t H, uint32_t W, float* out, lz_stream_t stream) {
+    LZ_REQUIRE(out, LZ_ERR_BAD_ARGUMENT, "bg_coords: null tensor");
+    if (H * W == 0) return LZ_OK;
+    hipLaunchKernelGGL(lz_k_bg_coords, dim3(lz_div_up((uint64_t)H * W, 256)), dim3(256), 0, lz_st(stream), H, W, out);
+    LZ_CHECK_LAUNCH("bg_coords");
     return LZ_OK;
 }
 

@@ -86,7 +86,9 @@ class GradientBucket:
         if any(p.device != dev or p.dtype != dt for p in self.params):
             raise ValueError("GradientBucket: parameters must share one device and dtype")
         self.group = group
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        n = sum(p.numel() for p in self.params)
+        self._buf = torch.zeros(n + 1, dtype=dt, device=dev)   # last slot: this rank's weight (ray count), reduced in the same collective
+        self.flat = self._buf[:n]
         self.attach()
 
     def attach(self):
@@ -99,15 +101,32 @@ class GradientBucket:
     def zero(self):
         self.flat.zero_()
 
-    def all_reduce(self, average=True):
-        """sum (average=False) or mean over ranks of every gradient, in one collective; a no-op in a single process"""
+    def all_reduce(self, average=True, weight=None):
+        """One collective over the flat buffer; a no-op in a single process.
+
+        Contract (what makes sharded training equal full-batch training):
+        * `average=False`: plain sum -- for a SUM-reduced local loss (divide by the global count yourself);
+        * `average=True, weight=None`: mean over ranks -- right only when every rank's loss is a mean over the SAME number of
+          terms (equal ray shards and a per-ray loss);
+        * `average=True, weight=w`: sum_r w_r g_r / sum_r w_r, with w = the number of terms this rank's mean-normalised loss
+          averaged over (its local ray count: `shard_bounds` is ragged when the batch does not divide).  The weight rides in the
+          last slot of the same buffer, so it is still ONE all-reduce.
+        Losses normalised per SAMPLE (march_rays_train emits a different number per rank) must use the sum form."""
+        if weight is not None and not average:
+            raise ValueError("GradientBucket.all_reduce: weight only applies to average=True")
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             for p in self.params:   # a view was replaced (set_to_none / first backward after detach): the collective would miss it
                 if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size():
                     raise RuntimeError("GradientBucket: a .grad no longer aliases the flat buffer; call attach() after zero_grad(set_to_none=True)")
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            if average:
-                self.flat.mul_(1.0 / dist.get_world_size(self.group))
+            if weight is not None:
+                self.flat.mul_(float(weight))
+                self._buf[-1] = float(weight)
+                dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.div_(self._buf[-1])   # device-side divide: no host round trip
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                if average:
+                    self.flat.mul_(1.0 / dist.get_world_size(self.group))
         return self.flat
 
 

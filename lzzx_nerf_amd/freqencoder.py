@@ -28,7 +28,8 @@ class _freq_encoder(PointwiseOp):
         x, y = ctx.saved_tensors
         degree, output_dim = ctx.cfg
         gx = new_rows(x, x.shape[0], x.shape[1], zero=True)
-        launch("lz_freq_encode_backward", ptr(grad.contiguous()), ptr(y), x.shape[0], x.shape[1], degree, output_dim, ptr(gx))
+        grad = grad.contiguous()
+        launch("lz_freq_encode_backward", ptr(grad), ptr(y), x.shape[0], x.shape[1], degree, output_dim, ptr(gx))
         return gx, None, None
 
 

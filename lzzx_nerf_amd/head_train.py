@@ -26,6 +26,11 @@ class _FusedHeadTrain(Function):
     @staticmethod
     def forward(ctx, mod, xyzs, dirs, enc_a, ind_code, eye, e_xy, e_yz, e_xz, *weights):
         dev = xyzs.device
+        if xyzs.requires_grad or dirs.requires_grad:
+            # the reference reaches sample positions through dy_dx when opt.train_camera is set (grid.py:60-84); this fused
+            # head has no such path, and silently dropping the gradient would train a wrong camera
+            raise RuntimeError("FusedTriplaneTrainHead does not propagate gradients to xyzs / dirs (train_camera): "
+                               "use the operator path (encoding.get_encoder + MLP) for that")
         xyzs, dirs = xyzs.detach().float().contiguous(), dirs.detach().float().contiguous()
         M = xyzs.shape[0]
         w = [t.detach().float().contiguous() for t in weights]
@@ -39,14 +44,26 @@ class _FusedHeadTrain(Function):
         sig, rgb, aa, ae, un = torch.empty(M, **kw), torch.empty(M, 3, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw)
         if M > 0:   # an empty batch (every ray missed the box) has empty outputs and zero gradients
             call("lz_triplane_head_forward", C.byref(p), ptr(xyzs), ptr(dirs), M, None, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un), stream())
-        ctx.mod, ctx.saved = mod, (xyzs, dirs, enc_a_f, ind_f, eye_f, emb, w)
+        # save_for_backward (not attributes): autograd then detects an in-place update of a weight / table between forward and
+        # backward (detach() shares the version counter), and the tensors are released with the graph
+        opt = [t for t in (ind_f, eye_f) if t is not None]
+        ctx.mod, ctx.has = mod, (ind_f is not None, eye_f is not None)
+        ctx.save_for_backward(xyzs, dirs, enc_a_f, *opt, *emb, *w)
         ctx.shapes = (enc_a.shape, None if ind_code is None else ind_code.shape)
         return sig, rgb, aa, ae, un
 
     @staticmethod
     def backward(ctx, g_sig, g_rgb, g_aa, g_ae, g_un):
         mod = ctx.mod
-        xyzs, dirs, enc_a_f, ind_f, eye_f, emb, w = ctx.saved
+        sv = list(ctx.saved_tensors)
+        xyzs, dirs, enc_a_f = sv[:3]
+        k = 3
+        ind_f = eye_f = None
+        if ctx.has[0]:
+            ind_f, k = sv[k], k + 1
+        if ctx.has[1]:
+            eye_f, k = sv[k], k + 1
+        emb, w = sv[k:k + 3], sv[k + 3:]
         M, dev = xyzs.shape[0], xyzs.device
         kw = dict(dtype=torch.float32, device=dev)
         if M == 0:
@@ -62,6 +79,8 @@ class _FusedHeadTrain(Function):
         d_enc_a, d_ind, dw_e2, dw_u2, dw_c2 = small[:32], small[32:36], small[36:52], small[52:84], small[84:]
         o = _lib.HeadBwdOut()
         o.denc, o.small, o.rec = denc.data_ptr(), small.data_ptr(), rec.data_ptr()
+        # `mod.packed` is shared by every forward of this module: re-pack from the weights THIS forward saw
+        call("lz_head_pack_weights", *[ptr(t) for t in w], int(mod.has_eye), int(mod.has_ind), ptr(mod.packed), stream())
         p = mod._params(emb, enc_a_f, ind_f, eye_f)
         call("lz_triplane_head_backward", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
              C.byref(o), stream())

@@ -32,7 +32,8 @@ class _near_far_from_aabb(Function):
         N = rays_o.shape[0]
         nears = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
         fars = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
-        call("lz_near_far_from_aabb", ptr(rays_o), ptr(rays_d), ptr(aabb.contiguous()), N, float(min_near), ptr(nears), ptr(fars), stream())
+        aabb = aabb.contiguous()   # converted copies stay bound to a name until the launch is enqueued
+        call("lz_near_far_from_aabb", ptr(rays_o), ptr(rays_d), ptr(aabb), N, float(min_near), ptr(nears), ptr(fars), stream())
         return nears, fars
 
 
@@ -140,8 +141,9 @@ class _march_rays_train(Function):
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=rays_o.dtype, device=dev) if perturb else torch.zeros(N, dtype=rays_o.dtype, device=dev)
         workspace = torch.empty(N + 2, dtype=torch.int32, device=dev)
+        nears, fars = nears.contiguous(), fars.contiguous()   # two live names: a freed temporary's block could be handed to the next one
         call("lz_march_rays_train", ptr(rays_o), ptr(rays_d), ptr(density_bitfield), float(bound), float(dt_gamma), int(max_steps), N,
-             int(C), int(H), M, ptr(nears.contiguous()), ptr(fars.contiguous()), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays),
+             int(C), int(H), M, ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays),
              ptr(step_counter), ptr(noises), ptr(workspace), stream())
         if force_all_rays or mean_count <= 0:
             m = step_counter[0].item()  # D2H copy, as in the reference (raymarching.py:249)
@@ -158,8 +160,8 @@ class _march_rays_train(Function):
         N, M = rays.shape[0], grad_xyzs.shape[0]
         grad_rays_o = torch.zeros(N, 3, device=rays.device)
         grad_rays_d = torch.zeros(N, 3, device=rays.device)
-        call("lz_march_rays_train_backward", ptr(grad_xyzs.float().contiguous()), ptr(grad_dirs.float().contiguous()), ptr(rays),
-             ptr(deltas.contiguous()), N, M, ptr(grad_rays_o), ptr(grad_rays_d), stream())
+        gx, gd, deltas = grad_xyzs.float().contiguous(), grad_dirs.float().contiguous(), deltas.contiguous()
+        call("lz_march_rays_train_backward", ptr(gx), ptr(gd), ptr(rays), ptr(deltas), N, M, ptr(grad_rays_o), ptr(grad_rays_d), stream())
         return (grad_rays_o, grad_rays_d) + (None,) * 13
 
 
@@ -307,8 +309,9 @@ def _composite_infer(variant, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs,
                      a0s, a1s, us, T_thresh):
     na, aw, hu = variant
     cont = lambda t: None if t is None else t.contiguous()
-    call("lz_composite_rays", int(n_alive), int(n_step), float(T_thresh), ptr(rays_alive), ptr(rays_t), ptr(cont(sigmas)), ptr(cont(rgbs)),
-         ptr(cont(deltas)), ptr(cont(amb0)), ptr(cont(amb1)), ptr(cont(unc)), na, aw, hu, ptr(weights_sum), ptr(depth), ptr(image),
+    sigmas, rgbs, deltas, amb0, amb1, unc = [cont(t) for t in (sigmas, rgbs, deltas, amb0, amb1, unc)]   # all alive until the launch
+    call("lz_composite_rays", int(n_alive), int(n_step), float(T_thresh), ptr(rays_alive), ptr(rays_t), ptr(sigmas), ptr(rgbs),
+         ptr(deltas), ptr(amb0), ptr(amb1), ptr(unc), na, aw, hu, ptr(weights_sum), ptr(depth), ptr(image),
          ptr(a0s), ptr(a1s), ptr(us), stream())
 
 

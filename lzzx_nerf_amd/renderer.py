@@ -23,15 +23,9 @@ MAX_RAYS_PER_PASS = 4096 * 256   # lz_loop_march sums at most 4096 workgroup cou
 _N_SAMPLES_OFF = (74 + 2) * 4   # LZ_LOOP_NEXT + 2: n_samples of the iteration in flight (the head's `count`)
 
 
-def get_rays(pose, intrinsics, H, W):
-    """Full-image rays (nerf_triplane/utils.py:226-312, N = -1 branch) for one cam2world pose [4,4] (cuda).
-    Returns rays_o, rays_d [H*W, 3]."""
-    pose = pose.reshape(4, 4).float().contiguous()
-    fx, fy, cx, cy = [float(v) for v in intrinsics]
-    rays_o = torch.empty(H * W, 3, dtype=torch.float32, device=pose.device)
-    rays_d = torch.empty(H * W, 3, dtype=torch.float32, device=pose.device)
-    call("lz_get_rays", ptr(pose), fx, fy, cx, cy, int(H), int(W), ptr(rays_o), ptr(rays_d), stream())
-    return rays_o, rays_d
+from .utils import frame_rays   # noqa: E402,F401  (full-image rays of one pose; utils.get_rays has the reference's signature)
+
+get_rays = frame_rays   # round-1 name, kept for callers of (pose, intrinsics, H, W) -> (rays_o, rays_d)
 
 
 class _Buffers:

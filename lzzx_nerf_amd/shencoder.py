@@ -27,7 +27,8 @@ class _sh_encoder(PointwiseOp):
         if jac is None:            # directions were not asked for a gradient (sphere_harmonics.py:44-46)
             return None, None, None
         gx = new_rows(x, x.shape[0], x.shape[1], zero=True)
-        launch("lz_sh_encode_backward", ptr(grad.contiguous()), ptr(x), x.shape[0], x.shape[1], ctx.degree, ptr(jac), ptr(gx))
+        grad = grad.contiguous()
+        launch("lz_sh_encode_backward", ptr(grad), ptr(x), x.shape[0], x.shape[1], ctx.degree, ptr(jac), ptr(gx))
         return gx, None, None
 
 

@@ -55,3 +55,37 @@ def update_density_grid_torso(P, density_grid_torso, enc_anchor, ind_code, noise
     dil = np.max(np.stack([pad[dy:dy + G, dx:dx + G] for dy in range(5) for dx in range(5)]), 0)   # F.max_pool2d(k=5, s=1, p=2), :804
     density_grid_torso[:] = np.maximum(density_grid_torso * F32(decay), dil.reshape(-1))              # :806
     return float(np.mean(density_grid_torso, dtype=np.float64))                                     # :807
+
+
+def mark_untrained_grid(density_grid, poses, intrinsic, bound, return_margin=False):
+    """NeRFRenderer.mark_untrained_grid (renderer.py:633-695): cells no camera sees get density -1, in place.
+    density_grid [C, G^3] f32 Morton-ordered; poses [B,4,4] c2w; intrinsic (fx, fy, cx, cy).  The block / batch splitting (S = 64) of the
+    reference only bounds memory; counts are per cell.  return_margin: also the smallest |lhs - rhs| of the three frustum tests per cell
+    and cascade (cells decided by less than rounding can legitimately differ between matmul orders)."""
+    C, cells = density_grid.shape
+    G = round(cells ** (1 / 3))
+    fx, fy, cx, cy = [float(v) for v in intrinsic]
+    poses = np.asarray(poses, F32).reshape(-1, 4, 4)
+    ax = np.arange(G, dtype=np.int32)
+    xx, yy, zz = np.meshgrid(ax, ax, ax, indexing="ij")                                   # custom_meshgrid, :662
+    coords = np.stack([xx.ravel(), yy.ravel(), zz.ravel()], 1)
+    indices = O.morton3D(coords).astype(np.int64)                                         # :665
+    world = F32(2) * coords.astype(F32) / F32(G - 1) - F32(1)                             # :666
+    count = np.zeros((C, cells), np.int64)
+    margin = np.full((C, cells), np.inf)
+    for cas in range(C):
+        bc = min(2 ** cas, bound)
+        half = bc / G
+        cw = world * F32(bc - half)                                                       # :672
+        for pose in poses:
+            v = cw - pose[:3, 3][None, :]                                                 # :679
+            cam = (v[:, 0:1] * pose[0:1, :3] + v[:, 1:2] * pose[1:2, :3]) + v[:, 2:3] * pose[2:3, :3]   # `@ poses[:, :3, :3]`, :680
+            cam = cam.astype(F32)
+            rx = (F32(cx / fx) * cam[:, 2] + F32(half * 2)).astype(F32)                   # :684 (python float scalars: cx / fx in double, then f32)
+            ry = (F32(cy / fy) * cam[:, 2] + F32(half * 2)).astype(F32)
+            m = (cam[:, 2] > 0) & (np.abs(cam[:, 0]) < rx) & (np.abs(cam[:, 1]) < ry)     # :683-686
+            count[cas, indices] += m
+            mg = np.minimum(np.abs(cam[:, 2]), np.minimum(np.abs(np.abs(cam[:, 0]) - rx), np.abs(np.abs(cam[:, 1]) - ry)))
+            margin[cas, indices] = np.minimum(margin[cas, indices], mg)
+    density_grid[count == 0] = -1                                                         # :692
+    return (count, margin) if return_margin else count

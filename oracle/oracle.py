@@ -16,8 +16,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liblzzx_oracle.so")
 
 
+def _stale():
+    if not os.path.exists(_SO):
+        return True
+    t = os.path.getmtime(_SO)
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")] + [os.path.join(inc, f) for f in os.listdir(inc)]
+    return any(os.path.getmtime(f) > t for f in srcs)
+
+
 def build(force=False):
-    if force or not os.path.exists(_SO):
+    if force or _stale():
         subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
     return _SO
 
@@ -211,12 +220,30 @@ def unary(op, x):
 # raymarching
 # ----------------------------------------------------------------------------------------------
 def get_rays(pose, intrinsics, H, W):
-    pose = _f32(pose).reshape(4, 4)
+    """full image, one pose [4,4] -> rays_o, rays_d [H*W, 3]"""
+    r = get_rays_batched(_f32(pose).reshape(1, 4, 4), intrinsics, H, W)
+    return r["rays_o"][0], r["rays_d"][0]
+
+
+def get_rays_batched(poses, intrinsics, H, W, inds=None):
+    """utils.py:226-312 for given pixel indices: poses [B,4,4], inds int64 [N] or None (all pixels) -> dict(i, j, rays_o, rays_d)"""
+    poses = _f32(poses).reshape(-1, 4, 4)
+    B = poses.shape[0]
     fx, fy, cx, cy = [float(v) for v in intrinsics]
-    ro = np.empty((H * W, 3), dtype=np.float32)
-    rd = np.empty((H * W, 3), dtype=np.float32)
-    lib().lzo_get_rays(_p(pose), f32c(fx), f32c(fy), f32c(cx), f32c(cy), u32(H), u32(W), _p(ro), _p(rd))
-    return ro, rd
+    if inds is not None:
+        inds = np.ascontiguousarray(inds, dtype=np.int64).reshape(-1)
+    N = H * W if inds is None else inds.shape[0]
+    ro, rd = np.empty((B, N, 3), dtype=np.float32), np.empty((B, N, 3), dtype=np.float32)
+    oi, oj = np.empty((B, N), dtype=np.float32), np.empty((B, N), dtype=np.float32)
+    lib().lzo_get_rays(_p(poses), f32c(fx), f32c(fy), f32c(cx), f32c(cy), u32(H), u32(W), u32(B), u32(N),
+                       None if inds is None else _p(inds), _p(ro), _p(rd), _p(oi), _p(oj))
+    return dict(i=oi, j=oj, rays_o=ro, rays_d=rd)
+
+
+def bg_coords(H, W):
+    out = np.empty((H * W, 2), dtype=np.float32)
+    lib().lzo_bg_coords(u32(H), u32(W), _p(out))
+    return out
 
 
 def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):

@@ -62,22 +62,37 @@ static inline int mip_from_dt(float dt, float H, float max_cascade) { /* :49-54 
     return (int)lz_fminf(max_cascade - 1, lz_fmaxf(0, (float)exponent));
 }
 
-/* Full-image ray generation, /root/reference/nerf_triplane/utils.py:226-312 (N = -1 branch, one pose).
- * Pixel p = row * W + col, centre (col + 0.5, row + 0.5); dir = ((i-cx)/fx, (j-cy)/fy, 1) / |.|;
- * rays_d[k] = sum_c dir[c] * R[k][c] (`directions @ R^T`, utils.py:304) accumulated c = 0,1,2 as an
- * fma chain (torch.matmul fixes no order); rays_o = pose[:3, 3].  pose: row-major 4x4 cam2world. */
-void lzo_get_rays(const float* pose, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
-                  float* rays_o, float* rays_d) {
+/* Ray generation, /root/reference/nerf_triplane/utils.py:226-312, B poses x N pixels.
+ * Pixel p = row * W + col (inds[n], or n itself when inds is NULL = the N = -1 branch :287), centre (col + 0.5, row + 0.5) (:243-244);
+ * dir = ((i-cx)/fx, (j-cy)/fy, 1) / |.| (:297-301); rays_d[k] = sum_c dir[c] * R[k][c] (`directions @ R^T`, :303) accumulated
+ * c = 0,1,2 as an fma chain (torch.matmul fixes no order); rays_o = pose[:3, 3] (:305-306).  poses: row-major 4x4 cam2world.
+ * out_i / out_j (optional): results['i'], results['j'] (:290-291). */
+void lzo_get_rays(const float* poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, uint32_t B, uint32_t N,
+                  const int64_t* inds, float* rays_o, float* rays_d, float* out_i, float* out_j) {
+    (void)H;
 #pragma omp parallel for schedule(static)
-    for (uint32_t p = 0; p < H * W; p++) {
+    for (int64_t t = 0; t < (int64_t)B * N; t++) {
+        const uint32_t b = (uint32_t)(t / N), n = (uint32_t)(t % N);
+        const uint32_t p = inds ? (uint32_t)inds[n] : n;
+        const float* pose = poses + (size_t)b * 16;
         const float fi = (float)(p % W) + 0.5f, fj = (float)(p / W) + 0.5f;
         const float xs = (fi - cx) / fx, ys = (fj - cy) / fy, zs = 1.0f;
         const float nrm = sqrtf(lz_fmaf(zs, zs, lz_fmaf(ys, ys, xs * xs)));
         const float d0 = xs / nrm, d1 = ys / nrm, d2 = zs / nrm;
         for (int k = 0; k < 3; k++) {
-            rays_d[(size_t)p * 3 + k] = lz_fmaf(d2, pose[k * 4 + 2], lz_fmaf(d1, pose[k * 4 + 1], d0 * pose[k * 4 + 0]));
-            rays_o[(size_t)p * 3 + k] = pose[k * 4 + 3];
+            rays_d[(size_t)t * 3 + k] = lz_fmaf(d2, pose[k * 4 + 2], lz_fmaf(d1, pose[k * 4 + 1], d0 * pose[k * 4 + 0]));
+            rays_o[(size_t)t * 3 + k] = pose[k * 4 + 3];
         }
+        if (out_i) out_i[t] = fi;
+        if (out_j) out_j[t] = fj;
+    }
+}
+
+/* get_bg_coords, utils.py:217-223: torch evaluates arange(H) / (H-1) * 2 - 1 in float32, one IEEE operation per step */
+void lzo_bg_coords(uint32_t H, uint32_t W, float* out) {
+    for (uint32_t p = 0; p < H * W; p++) {
+        out[(size_t)p * 2] = (float)(p / W) / (float)(H - 1) * 2.0f - 1.0f;
+        out[(size_t)p * 2 + 1] = (float)(p % W) / (float)(W - 1) * 2.0f - 1.0f;
     }
 }
 

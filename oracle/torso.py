@@ -69,3 +69,12 @@ def run_torso(P, bg_coords, enc_anchor, ind_code, density_grid=None, density_thr
         a, c, dx = forward_torso(P, bg_coords[mask], enc_anchor, ind_code, torso_shrink)
         alpha[mask], color[mask], deform[mask] = a, c, dx
     return alpha, color, deform, mask
+
+
+def encode_anchor(P, pose):
+    """network.py:179-183: the three anchor points through inverse(pose^T), perspective divide, frequency encoding (deg 3) -> [1, 42]"""
+    A = np.asarray(P["anchor_points"], F32)                                               # [3, 4]
+    inv = np.linalg.inv(np.asarray(pose, F32).reshape(4, 4).T.astype(np.float64))          # torch inverts in f32 (LU); pinned to 1e-5 by the fixture
+    w = (A.astype(np.float64) @ inv).astype(F32)
+    w = (w[:, :2] / w[:, 3:4] / w[:, 2:3]).astype(F32).reshape(1, -1)
+    return O.freq_encode_forward(np.ascontiguousarray(w), 3)

@@ -30,15 +30,7 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_python.npz"), allow_pickle=False)
 
 
-def make_params(golden, seed_tables=1234):
-    """state-dict-shaped numpy weights: MLP weights from the reference fixture, tables regenerated from the seed
-    used by tests/golden/make_golden.py"""
-    P = {k[3:]: golden[k] for k in golden.files if k.startswith("sd/")}
-    rng = np.random.default_rng(seed_tables)
-    n = int(P["encoder_xy.offsets"][-1])
-    for name in ("xy", "yz", "xz"):
-        P[f"encoder_{name}.embeddings"] = rng.uniform(-1, 1, (n, 1)).astype(np.float32)
-    return P
+from lzzx_nerf_amd.synthetic import ellipsoid_grid, make_params, synthetic_camera  # noqa: E402,F401  (shared with bench.py / smoke())
 
 
 @pytest.fixture(scope="session")
@@ -46,22 +38,11 @@ def params(golden):
     return make_params(golden)
 
 
-def synthetic_camera(H, W):
-    """SURVEY 8d synthetic camera: identity rotation, t = (0, 0, -3.35), fovy 21.24 deg"""
-    fl = H / (2 * np.tan(np.radians(21.24) / 2))
-    pose = np.eye(4, dtype=np.float32)
-    pose[2, 3] = -3.35
-    return pose, [fl, fl, W / 2, H / 2]
-
-
 def ellipsoid_bitfield(grid_size=128, semi=(0.35, 0.45, 0.35), bound=1.0):
-    """SURVEY 8d occupancy variant (i): head-like ellipsoid, Morton-ordered, packed"""
+    """SURVEY 8d occupancy variant (i) through the CHECKER's morton3D / packbits (CPU tests have no GPU; the product builds the same
+    bitfield with its HIP operators: lzzx_nerf_amd.synthetic.ellipsoid_bitfield_device, compared in test_gpu_parity)"""
     from oracle import oracle as O
-    c = np.arange(grid_size, dtype=np.int32)
-    X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
-    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
-    xyz = (coords.astype(np.float32) + 0.5) / grid_size * 2 * bound - bound
-    inside = ((xyz / np.array(semi, dtype=np.float32)) ** 2).sum(1) <= 1.0
+    inside, coords = ellipsoid_grid(grid_size, semi, bound)
     idx = O.morton3D(coords)
     grid = np.zeros((1, grid_size ** 3), dtype=np.float32)
     grid[0, idx] = inside.astype(np.float32)

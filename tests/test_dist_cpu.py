@@ -99,7 +99,7 @@ def _train_worker(rank, world, port, n_rays, out_dir):
     for _ in range(2):
         bucket.zero()
         _tiny_loss(table, mlp, rays_o[lo:hi], rays_d[lo:hi], target[lo:hi]).backward()
-        bucket.all_reduce()
+        bucket.all_reduce(weight=hi - lo)   # ragged shards: weight every rank's mean-normalised gradient by its ray count
         opt.step()
     # single-process full-batch reference on the same data
     rt, rm = _tiny_model()
@@ -126,11 +126,12 @@ def _train_worker(rank, world, port, n_rays, out_dir):
     dist.destroy_process_group()
 
 
-def test_gradient_bucket_matches_full_batch(tmp_path):
-    """data-parallel training over equal ray shards + ONE all-reduce of the flat gradient buffer == full-batch training"""
+@pytest.mark.parametrize("world,n_rays", [(2, 2048), (3, 2050)])
+def test_gradient_bucket_matches_full_batch(tmp_path, world, n_rays):
+    """data-parallel training over (ragged) ray shards + ONE count-weighted all-reduce of the flat gradient buffer == full-batch training"""
     port = _free_port()
-    mp.spawn(_train_worker, args=(2, port, 2048, str(tmp_path)), nprocs=2, join=True)
-    for r in range(2):
+    mp.spawn(_train_worker, args=(world, port, n_rays, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
         assert int(np.load(tmp_path / f"ok_{r}.npy")[0]) == 1
 
 

@@ -198,6 +198,35 @@ def test_grid_backward_level_resident(D, L, C, H, T, res, gt):
         assert np.max(np.abs(host(enc.embeddings.grad) - ge)) < 1e-4 * np.abs(ge).max()
 
 
+def test_grid_backward_level_resident_propagates_nan():
+    """a NaN (or inf) output gradient reaches grad_embeddings like the reference's float atomicAdd (gridencoder.cu:226-313): GradScaler's
+    non-finite check looks at exactly these tensors.  The fixed-point LDS path cannot represent it, so the (level, chunk) is rerouted."""
+    from lzzx_nerf_amd.gridencoder import GridEncoder
+    from lzzx_nerf_amd._util import call, ptr, stream
+    enc = GridEncoder(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14, desired_resolution=512).cuda()
+    rng = np.random.default_rng(80)
+    B, L = 40000, 12
+    x = rng.uniform(0, 1, (B, 2)).astype(np.float32)
+    g = rng.normal(size=(B, L)).astype(np.float32)
+    g[1234, 5] = np.nan
+    g[777, 0] = np.inf
+    S = float(np.float32(np.log2(enc.per_level_scale)))
+    off = host(enc.offsets)
+    idx = O.grid_corner_indices(x, off, 1, enc.per_level_scale, 64, 0)   # [L, B, 4] entry indices incl. the level offset
+    for layout in (2, 3):
+        gin = dev(g) if layout == 2 else dev(np.ascontiguousarray(g.T))
+        gemb = torch.zeros_like(enc.embeddings.data)
+        call("lz_grid_encode_backward", ptr(gin), ptr(dev(x)), ptr(enc.embeddings.data), ptr(enc.offsets), ptr(gemb), B, 2, 1, L, S, 64,
+             None, None, 0, 0, 0, layout, stream())
+        ge = host(gemb)[:, 0]
+        assert np.isnan(ge[idx[5, 1234]]).all(), layout
+        assert not np.isfinite(ge[idx[0, 777]]).any(), layout
+        other = np.ones(ge.shape[0], bool)
+        other[off[5]:off[6]] = False
+        other[off[0]:off[1]] = False
+        assert np.isfinite(ge[other]).all(), layout
+
+
 def test_grid_forward_half_tables_bit_exact():
     from lzzx_nerf_amd.gridencoder import GridEncoder
     enc = GridEncoder(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=15, desired_resolution=512).cuda()
