@@ -1,26 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: 512x512 triplane-head inference render at max_steps = 192 on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" renders one full synthetic frame per rank through the whole hot path (near/far -> [march -> fused
-head -> composite -> compaction] until every ray is done -> blend), inputs resident in HBM, no host sync inside
-the frame.  Workload: camera at (0,0,-3.35) looking down +z, fovy 21.24 deg, bound 1, aabb
-[-1,-.5,-1,1,.5,1], dt_gamma 1/256, T_thresh 1e-4, all-ones occupancy grid (dense: nothing is skipped), triplane
-tables U(-1,1), MLP weights = the reference's torch init under seed 0 (tests/golden fixture), enc_a ~ N(0,1),
-eye 0.25.  Data is synthetic.
+N > 1 without WORLD_SIZE in the environment: this process spawns `python -m torch.distributed.run --nproc-per-node N` on itself
+BEFORE touching the GPU and exits with the children's code; under torch.distributed.run it is one rank per GPU over RCCL.
 
-N > 1 (weak scaling): the global batch is N consecutive frames of a talking-head clip -- what the reference renders
-(TrainerUtil.test): the head pose sways a little from frame to frame (0.01 rad per frame about the vertical axis) and every
-frame has its own audio feature -- ray-sharded contiguously, i.e. rank r renders frame r; every step ends with ONE RCCL
-all-gather of the rendered RGB tiles so that every rank holds the whole batch.  Frame 0 (N = 1) is the frontal pose with the
-fixture's audio feature.
+A "step" renders one full synthetic frame through the whole hot path: ray generation -> near/far -> [march -> fused head -> composite ->
+compaction] until every ray is done -> blend (-> tile all-gather), inputs resident in HBM, no host sync inside the frame.  Workload
+(SURVEY 8d): camera at (0,0,-3.35) looking down +z, fovy 21.24 deg, bound 1, aabb [-1,-.5,-1,1,.5,1], dt_gamma 1/256, T_thresh 1e-4,
+all-ones occupancy grid (dense: nothing is skipped), triplane tables U(-1,1), MLP weights = the reference's torch init under seed 0
+(tests/golden fixture), enc_a ~ N(0,1), eye 0.25.  Data is synthetic.
+
+N > 1, `--shard frame` (default; BASELINE cfg4 as north_star states it, STRONG scaling): ONE 512x512 frame per step whose rays are
+sharded over the N ranks in row tiles -- `--tiles interleaved` (default: 8-row stripes dealt round-robin, balances the expensive
+middle of the frame) or `contiguous` (rank g renders rays [g N/G, (g+1) N/G)) --, every rank renders its tile with a full model
+replica and ONE RCCL all-gather per frame makes every rank hold the frame (overlapped with the next frame's march).  The other
+tiling and the round-1 clip mode (`--shard clip`: N consecutive frames of a talking-head clip, rank r renders frame r, weak scaling)
+are timed in the same run and reported as labelled legs.
 
 Iteration schedule: every loop iteration marches n_step = max(min(F * N // n_alive, C), 1) samples per alive ray.  The reference uses
 F = 1, C = 8 (renderer.py:513), i.e. N sample rows per iteration and thin launches while most rays are alive; pixels do not depend on F
-and C (each ray marches the same sample sequence and compositing resumes exactly), so the headline runs F = C = 4 (4 N rows
-per iteration, 29 instead of 114 iterations for this frame) and the `reference_schedule` leg times F = 1, C = 8 on the same frame and
-checks that the image and the sample count are identical.
+and C (each ray marches the same sample sequence and compositing resumes exactly), so the headline runs F = C = 4 and the
+`reference_schedule` leg times F = 1, C = 8 on the same frame and checks that the image and the sample count are identical.
 
 Prints one JSON line on rank 0.  `value` = marched samples (delta != 0) per second over all ranks.
 """
@@ -28,6 +30,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,22 +40,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_SAMPLE = 46368          # 23 184 MAC per sample, inference head
 ISSUED_FLOP_PER_ROW = 361 * 2048 // 16   # the head issues 361 v_mfma_f32_16x16x4_f32 (2048 FLOP each) per 16-row slice
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
-
-
-def orbit_pose(k, n):
-    """head pose of frame k of an n-frame clip: camera on a circle of radius 3.35 about the vertical axis, 0.01 rad per frame, frame 0 frontal"""
-    th = 0.01 * k
-    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], dtype=np.float32)
-    pose = np.eye(4, dtype=np.float32)
-    pose[:3, :3] = R
-    pose[:3, 3] = R @ np.array([0, 0, -3.35], dtype=np.float32)
-    return pose
 
 
 # kernels behind each grid_roofline case and the batch size tools/grid_bench.py profiled them at (tools/profile_grid.sh)
@@ -101,10 +94,10 @@ def grid_roofline(device):
         enc = GridEncoder(**kw).to(device)
         enc.embeddings.data.uniform_(-1, 1, generator=g)
         if mode == "fwd_rays":   # BASELINE cfg2 as march_rays hands it to the encoder: 256 x 256 rays x 128 samples, ray-major
-            from conftest import synthetic_camera
-            from lzzx_nerf_amd.renderer import get_rays
+            from lzzx_nerf_amd.synthetic import synthetic_camera
+            from lzzx_nerf_amd.utils import frame_rays
             pose, intr = synthetic_camera(256, 256)
-            ro, rd = get_rays(torch.from_numpy(pose).to(device), intr, 256, 256)
+            ro, rd = frame_rays(torch.from_numpy(pose).to(device), intr, 256, 256)
             t = torch.linspace(2.35, 4.35, 128, device=device)
             x = (((ro[:, None, :] + rd[:, None, :] * t[None, :, None]).clamp(-1, 1) + 1) / 2).reshape(-1, 3).contiguous()
         else:
@@ -182,14 +175,14 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1):
     """BASELINE cfg3: one training step (fwd + bwd + Adam) on `--train-rays` random rays of the 512x512 frame through the
     operator API as the reference's run_cuda arranges it (renderer.py:279-304).  The MLP GEMMs are torch/rocBLAS here;
     everything else is this repo's HIP kernels.  Reported beside the headline line, never instead of it."""
-    from conftest import synthetic_camera
     from lzzx_nerf_amd import dist as D
     from lzzx_nerf_amd import raymarching as R
-    from lzzx_nerf_amd.renderer import get_rays
+    from lzzx_nerf_amd.synthetic import synthetic_camera
+    from lzzx_nerf_amd.utils import frame_rays
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     H = W = args.size
     pose, intr = synthetic_camera(H, W)
-    ro, rd = get_rays(dev(pose), intr, H, W)
+    ro, rd = frame_rays(dev(pose), intr, H, W)
     g = torch.Generator(device=device).manual_seed(0)
     n_rays = min(args.train_rays, H * W)
     sel = torch.randperm(H * W, device=device, generator=g)[:n_rays]
@@ -256,14 +249,26 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1):
                      "torch": "torch/rocBLAS"}[args.train_mlp])
 
 
-def main():
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run on this same script, one rank per GPU.  Runs before
+    anything touches the GPU (an exec / fork from a process that has initialised HIP is not allowed on the pool); the ranks' stdout
+    (rank 0 prints the JSON line) and exit code pass through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--budget-factor", type=int, default=4,
                     help="sample rows per iteration = factor x rays (reference: 1; pixels and sample counts do not depend on it)")
     ap.add_argument("--n-step-cap", type=int, default=4, help="max samples per ray per iteration (reference: 8)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
                     help="f16 = the reference's opt.fp16 / autocast arithmetic on the f16 matrix cores (not bit-exact vs the f32 checker)")
-    ap.add_argument("--train", action="store_true", help="(default now) time a cfg3 training step and add it as 'train_step'")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-rays", type=int, default=65536)
     ap.add_argument("--train-dp", action="store_true",
@@ -277,6 +282,13 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--max-steps", type=int, default=192)
     ap.add_argument("--scene", default="ones", choices=["ones", "ellipsoid"])
+    ap.add_argument("--shard", default="frame", choices=["frame", "clip"],
+                    help="N > 1: 'frame' = one frame ray-sharded N ways + one all-gather (cfg4, strong scaling); 'clip' = rank r renders "
+                         "frame r of an N-frame clip (weak scaling)")
+    ap.add_argument("--tiles", default="interleaved", choices=["interleaved", "contiguous"], help="--shard frame: how rows are dealt to ranks")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="single GPU: render rank 0's tile of a frame sharded this many ways (no collective) -- what one rank of cfg4 does")
+    ap.add_argument("--no-side-legs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="skip the 8 extra 2M-row head launches that measure the sustained shader clock (tools/profile_bench.sh: the kernel "
@@ -287,192 +299,251 @@ def main():
     ap.add_argument("--no-fp16-leg", action="store_true")
     ap.add_argument("--no-occupancy", action="store_true")
     ap.add_argument("--no-dense192", action="store_true")
+    ap.add_argument("--no-cfg5", action="store_true")
     ap.add_argument("--gather", default="f32", choices=["f32", "rgb24"],
                     help="what the per-step all-gather moves: f32 RGB tiles, or the video pipe's RGB24 quantised on device (4x fewer bytes)")
     args = ap.parse_args()
+    if args.no_side_legs:
+        args.no_train = args.no_cpu_baseline = args.no_grid_roofline = args.no_fat_schedule = args.no_fp16_leg = True
+        args.no_occupancy = args.no_dense192 = args.no_cfg5 = True
+    return args
 
-    from lzzx_nerf_amd import _lib, dist as D
-    rank, world = D.init_from_env()
-    if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if world == 1:
-        torch.cuda.set_device(0)
-    device = torch.device("cuda", torch.cuda.current_device())
-    assert _lib.load().lz_device_ok() == 1, "bench needs a gfx950 device; there is no fallback path"
 
-    from conftest import ellipsoid_bitfield, make_params, synthetic_camera
-    from lzzx_nerf_amd.head import FusedTriplaneHead
-    from lzzx_nerf_amd.renderer import TriplaneRenderer, get_rays
+class FrameJob:
+    """one rank's share of the per-step work: ray generation for its pixels -> render -> (tile all-gather)"""
 
-    golden = np.load(os.path.join(ROOT, "tests", "golden", "reference_python.npz"))
-    P = make_params(golden)
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in P.items()}, bound=1.0, device=device, precision=args.precision)
-    bits = np.full(128 ** 3 // 8, 255, np.uint8) if args.scene == "ones" else ellipsoid_bitfield()[0]
-    renderer = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=args.budget_factor, n_step_cap=args.n_step_cap)
-    H = W = args.size
-    _, intr = synthetic_camera(H, W)
-    pose = orbit_pose(rank, world)   # frame `rank` of the clip
-    rays_o, rays_d = get_rays(dev(pose), intr, H, W)   # this rank's shard of the global ray batch = frame `rank`
-    enc_a, ind, eye = dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"])
-    if rank > 0:   # every frame of the clip has its own audio feature (frame 0: the fixture's)
-        enc_a = enc_a + 0.5 * torch.randn(enc_a.shape, device=device, generator=torch.Generator(device=device).manual_seed(100 + rank))
-    N = H * W
+    def __init__(self, renderer, H, W, pose, intr, cond, max_steps, rank, world, shard, tiles, gather, device, shard_of=0):
+        from lzzx_nerf_amd import dist as D
+        self.r, self.H, self.W, self.intr, self.cond, self.max_steps, self.gather_fmt = renderer, H, W, intr, cond, max_steps, gather
+        self.pose = torch.from_numpy(np.ascontiguousarray(pose)).to(device)
+        self.shard = shard if world > 1 else "frame"
+        if shard_of > 1:          # single-GPU rehearsal of one rank of an N-way sharded frame
+            self.sf = D.ShardedFrame(H, W, 0, shard_of, tiles, device)
+            self.sf.gatherer = None
+        elif world > 1 and shard == "frame":
+            self.sf = D.ShardedFrame(H, W, rank, world, tiles, device, dtype=torch.uint8 if gather == "rgb24" else torch.float32)
+        else:
+            self.sf = D.ShardedFrame(H, W, 0, 1, device=device)
+            if world > 1:         # clip mode: every rank contributes a whole frame to the gathered batch
+                self.sf.gatherer = D.TileGatherer(H * W, 3, torch.uint8 if gather == "rgb24" else torch.float32, device)
+        self.n_rays = self.sf.n_local
 
-    def step():
-        out = renderer.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4,
-                              rgb24=args.gather == "rgb24")
-        tile = out["image_rgb24"] if args.gather == "rgb24" else out["image"]
-        tiles = D.gather_tiles(tile) if world > 1 else tile
-        return out, tiles
+    def step(self):
+        rays_o, rays_d = self.sf.rays(self.pose, self.intr)          # ray generation is part of the step (north_star lists it on the path)
+        enc_a, ind, eye = self.cond
+        out = self.r.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=self.max_steps, T_thresh=1e-4,
+                            rgb24=self.gather_fmt == "rgb24")
+        tile = out["image_rgb24"] if self.gather_fmt == "rgb24" else out["image"]
+        return out, self.sf.gather(tile)
 
+
+def timed(job, steps, warmup, world, device, timing=True):
+    """W warm-up steps, then exactly K steps bracketed by barrier + synchronize; max over ranks.  -> (dt seconds, head launch ms list, last out, last tiles)"""
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
+    for _ in range(warmup):
+        job.step()
     barrier()
-    renderer.timing_start(args.steps * args.max_steps + 16)   # HIP event pair around every head launch, on the launch stream
+    if timing:
+        job.r.timing_start(steps * job.max_steps + 16)   # HIP event pair around every head launch, on the launch stream
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, tiles = step()
+    for _ in range(steps):
+        out, tiles = job.step()
     barrier()
     dt = time.perf_counter() - t0
-    head_ms = renderer.timing_stop()
-    # sustained shader clock under the head's load: 8 back-to-back 2M-row launches, counters of one wave of the last one
-    probe = (C.c_uint64 * 2)()
-    if not args.no_clock_probe:
-        gp = torch.Generator(device=device).manual_seed(1)
-        xs = torch.rand(1 << 21, 3, device=device, generator=gp) * 2 - 1
-        ds = torch.nn.functional.normalize(torch.randn(1 << 21, 3, device=device, generator=gp), dim=-1)
-        for _ in range(8):
-            head.forward(xs, ds, enc_a, ind, eye)
-        _lib.call("lz_debug_head_clocks", probe)
-        del xs, ds
+    head_ms = job.r.timing_stop() if timing else []
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    state = out["state"].cpu().numpy()
-    samples_per_frame = int(state[5])
-    iters_per_frame = int(state[6])
-    rows_per_frame = int(state[72])   # LZ_LOOP_STAT_ROWS: rows the head evaluated (n_alive * n_step, exhausted rows included)
-    total_samples = torch.tensor([samples_per_frame], dtype=torch.float64, device=device)
-    if world > 1:
-        torch.distributed.all_reduce(total_samples)
-    total_samples = float(total_samples.item())  # one frame per rank per step
-    value = total_samples * args.steps / dt
-    rays_per_s = N * world * args.steps / dt
+    return dt, head_ms, out, tiles
 
-    train_dp = None
-    if world > 1 and args.train_dp:   # every rank takes part: one gradient all-reduce per step
-        train_dp = train_bench(args, device, P, golden, bits, rank, world)
+
+def frame_stats(out, world, device):
+    """(samples, iterations, head rows) of the last frame, summed (max for iterations) over ranks"""
+    st = out["state"].cpu().numpy()
+    v = torch.tensor([float(st[5]), float(st[72])], dtype=torch.float64, device=device)
+    it = torch.tensor([float(st[6])], dtype=torch.float64, device=device)
     if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
-    if rank != 0:
-        return
-    # ---- roofline of the dominant kernel (fused head, MFMA-bound): live HIP events from the timed steps ----
-    head_total_ms = float(np.sum(head_ms))
-    n_launch = len(head_ms)
-    launches_with_work = iters_per_frame * args.steps
-    achieved_tflops = FLOP_PER_SAMPLE * samples_per_frame * args.steps / (head_total_ms * 1e-3) / 1e12
-    roofline = dict(bound="mfma", achieved=round(achieved_tflops, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), traffic=None, kernel="lz_k_triplane_head<false>",
-                    avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5),
-                    avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5), launches=n_launch,
-                    launches_with_work=launches_with_work, flop_per_sample=FLOP_PER_SAMPLE,
-                    head_time_share=round(head_total_ms * 1e-3 / dt, 4), rows_per_frame=rows_per_frame,
-                    shader_clock_mhz_under_load=round(probe[0] / max(probe[1], 1) * 100.0, 1) if (args.precision == "f32" and probe[1]) else None,
-                    issued_frac=round(ISSUED_FLOP_PER_ROW * rows_per_frame * args.steps / (head_total_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
-    if args.precision == "f16":   # 59 v_mfma_f32_16x16x32_f16 per slice: priced against the dense f16 peak; really gather-rate bound
-        roofline.update(peak=2500.0, frac=round(achieved_tflops / 2500.0, 5), kernel="lz_k_triplane_head_f16",
-                        issued_frac=round(59 * 16384 / 16 * rows_per_frame * args.steps / (head_total_ms * 1e-3) / 1e12 / 2500.0, 5),
-                        note="matrix work is 7% of the f32 kernel's; the kernel is bound by the 144 table gathers per sample")
-    # HBM-side traffic of the head per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE in separate runs, tools/profile_bench.sh): KiB per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    # for gfx950 (128-B requests tallied at 64 B).  bench.py cannot collect counters itself; null when the summary is absent.
-    pmc_path = os.path.join(ROOT, "profiles", "r1_final_pmc_summary.json")
-    if os.path.exists(pmc_path) and args.precision == "f32":
-        try:
-            pmc = json.load(open(pmc_path))
-            k = "lz_k_triplane_head<false>"
-            roofline["traffic"] = round((2 * pmc["FETCH_SIZE"][k]["avg_per_launch"] + pmc["WRITE_SIZE"][k]["avg_per_launch"]) * 1024)
-            roofline["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, averaged over all launches of profiles/r1_final_pmc_summary.json)"
-            roofline["algorithmic_bytes_per_launch"] = round(52 * rows_per_frame * args.steps / max(n_launch, 1))
-        except (KeyError, ValueError):
-            pass
-    result = {
-        "metric": f"rendered samples/s ({H}x{W} triplane head, max_steps {args.max_steps})", "value": round(value, 1), "unit": "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16 (f32 accumulate, torch-autocast rounding)", "data": "synthetic",
-        "config": {"workload": f"{H}x{W} inference frame per GPU, max_steps {args.max_steps}, triplane head (3x D2/L12/C1 hash grid + "
-                               f"audio/eye cond + SH4), occupancy={args.scene}, bound 1, dt_gamma 1/256, T_thresh 1e-4",
-                   "rays_per_gpu": N, "samples_per_frame": samples_per_frame, "iterations_per_frame": iters_per_frame,
-                   "nominal_samples_per_frame": N * args.max_steps, "parallelism": f"ray-sharded x{world}, 1 all-gather/step ({args.gather} tiles)",
-                   "schedule": f"n_step = max(min({args.budget_factor} * N // n_alive, {args.n_step_cap}), 1)"
-                               + (" (the reference's, renderer.py:513)" if (args.budget_factor, args.n_step_cap) == (1, 8) else
-                                  " -- sample rows per iteration sized for 288 GB of HBM; the reference's rule is 1 x N rows, <= 8 steps "
-                                  "(renderer.py:513): same pixels and per-ray sample counts, timed in 'reference_schedule'")},
-        "rays_per_s": round(rays_per_s, 1),
-        "samples_per_ray_mean": round(samples_per_frame / N, 2),
-        "roofline": roofline,
-    }
-    def side_leg(h, budget_factor, n_step_cap):
-        """same frame, K timed steps after 2 warm-ups, with another head precision and / or iteration schedule"""
-        r2 = TriplaneRenderer(h, dev(bits), bound=1.0, budget_factor=budget_factor, n_step_cap=n_step_cap)
-        rr = lambda: r2.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4)
-        for _ in range(2):
-            rr()
-        torch.cuda.synchronize()
-        r2.timing_start(args.steps * args.max_steps + 16)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            o2 = rr()
-        torch.cuda.synchronize()
-        d2 = time.perf_counter() - t0
-        hms = float(np.sum(r2.timing_stop()))
+        torch.distributed.all_reduce(v)
+        torch.distributed.all_reduce(it, op=torch.distributed.ReduceOp.MAX)
+    return int(v[0].item()), int(it.item()), int(v[1].item())
+
+
+def cpu_baseline(args, P, golden, bits_np, gpu_image_of, renderer_counts_of):
+    """SURVEY 8(d) / BASELINE.md 3: the reference has no CPU renderer, so the baseline is the CPU checker's kernels (C, OpenMP) arranged
+    exactly like run_cuda_for_inference (renderer.py:495-548) with the reference's pure-torch MLP arrangement on CPU tensors
+    (oracle.head.head_forward_torch: F.linear stacks, fp32, torch intra-op threads = all cores).  cfg1 = whole 64x64 / 32-step frames,
+    median of 5 after a warm-up; cfg3 = a bounded sample of the 512x512 / 192-step frame (every 4th pixel in both directions, 16 384
+    rays, reference schedule), median of 3 -- a whole cfg3 frame is minutes of CPU time.  Also yields PSNR / sample-count parity of the
+    GPU image against the bit-pinned checker on every 8th pixel."""
+    from oracle import oracle as O
+    from oracle.head import TriplaneSpec, head_forward_torch
+    from oracle.render import render_inference
+    from lzzx_nerf_amd.synthetic import ones_bitfield, synthetic_camera
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    spec = TriplaneSpec(1.0)
+    cond = (golden["net_enc_a"], golden["net_ind"], golden["net_eye"])
+    res = {}
+
+    def run(H, W, stride, max_steps, reps, bits):
+        pose, intr = synthetic_camera(H, W)
+        sel = (np.arange(0, H, stride)[:, None] * W + np.arange(0, W, stride)[None, :]).reshape(-1)
+        r = O.get_rays_batched(pose[None], intr, H, W, sel)
+        ro, rd = r["rays_o"][0], r["rays_d"][0]
+        st, times = {}, []
+        f = lambda: render_inference(spec, P, ro, rd, bits, *cond, max_steps=max_steps, stats=st, head=head_forward_torch)
+        f()                                             # warm-up (page in, OpenMP / torch thread teams)
+        for _ in range(reps):
+            t = time.perf_counter()
+            f()
+            times.append(time.perf_counter() - t)
+        med = float(np.median(times))
+        ns = int(st["samples_per_ray"].sum())
+        return dict(rays=len(sel), samples=ns, s_per_frame=round(med, 4), samples_per_s=round(ns / med, 1), rays_per_s=round(len(sel) / med, 1),
+                    runs=reps), sel
+    cfg1, _ = run(64, 64, 1, 32, 5, ones_bitfield())
+    res["cfg1_64x64x32"] = cfg1
+    H = W = args.size
+    stride = max(1, H // 128)
+    cfg3, sel = run(H, W, stride, args.max_steps, 3, bits_np)
+    res["cfg3_sample"] = cfg3
+    base = dict(value=cfg3["samples_per_s"], unit="samples/s", cores=cores, kind="port",
+                sample=f"cfg3 frame ({H}x{W}, max_steps {args.max_steps}) on every {stride}th pixel in both directions = {cfg3['rays']} rays, "
+                       f"{cfg3['samples']} samples, median of 3 after a warm-up: {cfg3['s_per_frame']} s; checker kernels (C, OpenMP) arranged like "
+                       "run_cuda_for_inference (renderer.py:495-548) + the reference's torch-CPU MLP arrangement (network.py:73-94), fp32, "
+                       f"torch.set_num_threads({cores})",
+                legs=res, cfg1_samples_per_s=cfg1["samples_per_s"], cfg1_s_per_frame=cfg1["s_per_frame"])
+    # parity of the GPU frame against the BIT-PINNED checker (order-fixed MLP) on every 8th pixel
+    stride8 = max(1, H // 64)
+    sel8 = (np.arange(0, H, stride8)[:, None] * W + np.arange(0, W, stride8)[None, :]).reshape(-1)
+    pose, intr = synthetic_camera(H, W)
+    r = O.get_rays_batched(pose[None], intr, H, W, sel8)
+    st = {}
+    ref = render_inference(spec, P, r["rays_o"][0], r["rays_d"][0], bits_np, *cond, max_steps=args.max_steps, stats=st,
+                           budget_factor=args.budget_factor, n_step_cap=args.n_step_cap)
+    gpu_img = gpu_image_of(sel8)
+    mse = float(((gpu_img.astype(np.float64) - ref["image"]) ** 2).mean())
+    parity = dict(psnr_vs_checker_db="inf" if mse == 0 else round(-10 * np.log10(mse), 2),
+                  max_abs_diff_vs_checker=float(np.abs(gpu_img - ref["image"]).max()),
+                  sample_counts_equal=bool(np.array_equal(renderer_counts_of(sel8).astype(np.int64), st["samples_per_ray"])),
+                  parity_sample=f"{len(sel8)} rays (every {stride8}th pixel), {int(st['samples_per_ray'].sum())} samples")
+    return base, parity
+
+
+REF_SCHEDULE = (1, 8)   # renderer.py:513
+PMC_SUMMARY = "r2_final_pmc_summary.json"   # written by tools/profile_bench.sh from rocprofv3 --pmc passes of this same command
+F16_SLICE_MFMAS = 59    # v_mfma_f32_16x16x32_f16 per 16-row slice of lz_k_triplane_head_f16
+
+
+def f16_head_roofline(samples, rows, steps, head_total_ms, n_launch, launches_with_work, dt):
+    """roofline object of the f16 head.  Its matrix work is 7 % of the f32 kernel's (59 MFMAs x 16 cycles per 16-row slice), so the dense
+    f16 MFMA peak is not what bounds it; DESIGN 4.1b derives the bound from the PMC passes (profiles/r2_f16_head_pmc_summary.json):
+    the per-sample VALU + table-gather instruction stream.  `frac` is priced against the f16 MFMA peak only as the formal figure of the
+    contract; `bound_detail` names the real limiter and `samples_per_s` is the number to watch."""
+    t = head_total_ms * 1e-3
+    achieved = FLOP_PER_SAMPLE * samples * steps / t / 1e12
+    return dict(bound="mfma", achieved=round(achieved, 3), peak=2500.0, unit="TFLOP/s", frac=round(achieved / 2500.0, 5), traffic=None,
+                kernel="lz_k_triplane_head_f16", avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5),
+                avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5), launches=n_launch, launches_with_work=launches_with_work,
+                head_time_share=round(t / dt, 4), head_ms_per_step=round(head_total_ms / steps, 4), rows_per_frame=rows,
+                samples_per_s=round(samples * steps / t, 1),
+                matrix_pipe_busy_frac=round(F16_SLICE_MFMAS * 16 * (rows / 16) * steps / (t * 2.4e9 * 1024), 4),
+                bound_detail="VALU issue + table gathers (144 per sample): 59 MFMAs x 16 cycles per 16-row slice keep the matrix pipe "
+                             "busy a few % of the time (matrix_pipe_busy_frac, at the nominal 2.4 GHz x 1024 SIMDs); see DESIGN 4.1b")
+
+
+def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, image, samples_per_frame, make_job):
+    """N = 1 only: everything reported beside the headline.  A leg that fails is recorded in `leg_errors`, never fatal."""
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    H = W = args.size
+    N = H * W
+    enc_a, ind, eye = job.cond
+    rays_o, rays_d = job.sf.rays(job.pose, job.intr)
+    pose = job.pose.cpu().numpy()
+
+    def err(name, exc):
+        result.setdefault("leg_errors", {})[name] = repr(exc)
+
+    def side_leg(h, budget_factor, n_step_cap, scene_bits=None, size=None, steps=None):
+        """same frame (or `size`^2 with `scene_bits`), K timed steps after 2 warm-ups, with another head precision and / or schedule"""
+        j2 = make_job("frame", args.tiles, budget_factor, n_step_cap, h)
+        if scene_bits is not None:
+            j2.r.bitfield = scene_bits
+        if size is not None:
+            from lzzx_nerf_amd import dist as D
+            from lzzx_nerf_amd.synthetic import synthetic_camera
+            j2.H = j2.W = size
+            j2.intr = synthetic_camera(size, size)[1]
+            j2.sf = D.ShardedFrame(size, size, 0, 1, device=device)
+        k = steps or args.steps
+        d2, hms, o2, _ = timed(j2, k, 2, 1, device)
         s2 = o2["state"].cpu().numpy()
-        img2 = o2["image"].clone()
-        return dict(schedule=f"n_step = max(min({budget_factor} * N // n_alive, {n_step_cap}), 1)", value=round(int(s2[5]) * args.steps / d2, 1),
-                    unit="samples/s", ms_per_step=round(d2 / args.steps * 1e3, 4), iterations_per_frame=int(s2[6]),
-                    rows_per_frame=int(s2[72]), head_ms_per_step=round(hms / args.steps, 4)), img2, hms, s2
+        return dict(schedule=f"n_step = max(min({budget_factor} * N // n_alive, {n_step_cap}), 1)", value=round(int(s2[5]) * k / d2, 1),
+                    unit="samples/s", ms_per_step=round(d2 / k * 1e3, 4), rays_per_s=round(j2.sf.n_local * k / d2, 1),
+                    samples_per_frame=int(s2[5]), iterations_per_frame=int(s2[6]), rows_per_frame=int(s2[72]),
+                    head_ms_per_step=round(float(np.sum(hms)) / k, 4)), o2["image"].clone(), float(np.sum(hms)), s2
 
-    REF_SCHEDULE = (1, 8)   # renderer.py:513
-    if world == 1 and (args.budget_factor, args.n_step_cap) != REF_SCHEDULE and not args.no_fat_schedule:
+    if (args.budget_factor, args.n_step_cap) != REF_SCHEDULE and not args.no_fat_schedule:
         try:
             # the same frame under the reference's own iteration schedule (1 x N sample rows per iteration, <= 8 steps per ray): more,
             # thinner launches; pixels and per-ray sample counts must be identical
             leg, fimg, fms, fst = side_leg(head, *REF_SCHEDULE)
             leg["schedule"] += " (the reference's, renderer.py:513)"
-            leg["image_equal_to_headline_schedule"] = bool(torch.equal(fimg, out["image"]))
+            leg["image_equal_to_headline_schedule"] = bool(torch.equal(fimg, image))
             leg["samples_equal_to_headline_schedule"] = bool(int(fst[5]) == samples_per_frame)
             if args.precision == "f32":
                 leg["head_frac"] = round(FLOP_PER_SAMPLE * int(fst[5]) * args.steps / (fms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)
                 leg["head_issued_frac"] = round(ISSUED_FLOP_PER_ROW * int(fst[72]) * args.steps / (fms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)
             result["reference_schedule"] = leg
-        except Exception as exc:   # an optional leg must never take the headline line down
-            result.setdefault("leg_errors", {})["reference_schedule"] = repr(exc)
-    if world == 1 and args.precision == "f32" and not args.no_fp16_leg:
+        except Exception as exc:
+            err("reference_schedule", exc)
+    h16 = None
+    if args.precision == "f32" and not args.no_fp16_leg:
         try:
             # the reference's opt.fp16 arithmetic (torch autocast) on the f16 matrix cores: a different rounding sequence, so it is
             # reported beside the bit-exact f32 headline, with its distance from the f32 image
-            h16 = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in P.items()}, bound=1.0, device=device, precision="f16")
-            leg, img16, _, _ = side_leg(h16, args.budget_factor, args.n_step_cap)
+            h16 = FusedTriplaneHead(sd, bound=1.0, device=device, precision="f16")
+            leg, img16, hms16, s16 = side_leg(h16, args.budget_factor, args.n_step_cap)
             leg8, img16b, _, _ = side_leg(h16, *REF_SCHEDULE)
-            diff = (img16 - out["image"]).double()
+            diff = (img16 - image).double()
             mse16 = float((diff ** 2).mean())
             leg.update(dtype="f16 (f32 accumulate, torch-autocast rounding)", kernel="lz_k_triplane_head_f16",
                        max_abs_diff_vs_f32_image=float(diff.abs().max()), psnr_vs_f32_image_db=round(-10 * np.log10(max(mse16, 1e-300)), 2),
                        reference_schedule_value=leg8["value"], reference_schedule_ms_per_step=leg8["ms_per_step"],
-                       reference_schedule_image_equal=bool(torch.equal(img16, img16b)))
+                       reference_schedule_image_equal=bool(torch.equal(img16, img16b)),
+                       roofline=f16_head_roofline(int(s16[5]), int(s16[72]), args.steps, hms16, int(s16[6]) * args.steps, int(s16[6]) * args.steps,
+                                                  leg["ms_per_step"] * 1e-3 * args.steps))
             result["fp16_head"] = leg
-            del h16
-        except Exception as exc:   # an optional leg must never take the headline line down
-            result.setdefault("leg_errors", {})["fp16_head"] = repr(exc)
-    if world == 1 and not args.no_dense192:
+        except Exception as exc:
+            err("fp16_head", exc)
+    if not args.no_cfg5:
+        try:
+            # BASELINE cfg5: 1024 x 1024, ellipsoid occupancy (2.9 % of the cells: skipping + on-device compaction), fp16 MLP on MFMA;
+            # few rays are alive in a sparse scene, so the reference's rule (1, 8) is also the best schedule here
+            from lzzx_nerf_amd.synthetic import ellipsoid_bitfield_device
+            ebits = ellipsoid_bitfield_device(device)[0]
+            if h16 is None:
+                h16 = FusedTriplaneHead(sd, bound=1.0, device=device, precision="f16")
+            leg16, img5h, _, _ = side_leg(h16, *REF_SCHEDULE, scene_bits=ebits, size=1024, steps=max(3, args.steps // 2))
+            leg32, img5, _, _ = side_leg(head, *REF_SCHEDULE, scene_bits=ebits, size=1024, steps=max(3, args.steps // 2)) if args.precision == "f32" else (None, None, None, None)
+            leg16.update(workload="cfg5: 1024x1024 frame, ellipsoid occupancy (2.9 % of cells), march_rays with on-device compaction, "
+                                  "f16 MLP on MFMA (torch-autocast rounding)", dtype="f16", occupancy_fraction=round(float(np.unpackbits(ebits.cpu().numpy()).mean()), 4))
+            if leg32 is not None:
+                d5 = (img5h - img5).double()
+                leg16.update(f32_head=dict(value=leg32["value"], ms_per_step=leg32["ms_per_step"], rays_per_s=leg32["rays_per_s"]),
+                             max_abs_diff_vs_f32_image=float(d5.abs().max()),
+                             psnr_vs_f32_image_db=round(-10 * np.log10(max(float((d5 ** 2).mean()), 1e-300)), 2))
+            result["cfg5_1024_ellipsoid_f16"] = leg16
+        except Exception as exc:
+            err("cfg5_1024_ellipsoid_f16", exc)
+    del h16
+    if not args.no_dense192:
         try:
             # SURVEY 8d "dense-192 micro-benchmark": the NOMINAL 512 x 512 x 192 = 50.33 M samples (uniform points in [-1,1]^3, the ray
             # directions, delta = 2 sqrt(3) / 192) straight through encode -> MLP (fused head) -> composite_rays_train_triplane
@@ -507,20 +578,18 @@ def main():
                                       image_mean=float(comp[5].mean()))
             del xyz, dirs_d, deltas, rays_tbl, outd, comp
         except Exception as exc:   # an optional leg must never take the headline line down
-            result.setdefault("leg_errors", {})["dense192"] = repr(exc)
-    if not args.no_grid_roofline and world == 1:
+            err("dense192", exc)
+    if not args.no_grid_roofline:
         try:
             result["roofline_gridencoder"] = grid_roofline(device)
         except Exception as exc:   # an optional leg must never take the headline line down
             result.setdefault("leg_errors", {})["roofline_gridencoder"] = repr(exc)
-    if not args.no_train and world == 1:
+    if not args.no_train:
         try:
             result["train_step"] = train_bench(args, device, P, golden, bits)
         except Exception as exc:   # an optional leg must never take the headline line down
             result.setdefault("leg_errors", {})["train_step"] = repr(exc)
-    if train_dp is not None:
-        result["train_step"] = train_dp
-    if world == 1 and not args.no_occupancy and args.precision == "f32":
+    if not args.no_occupancy and args.precision == "f32":
         try:
             # the occupancy-grid maintenance of update_extra_state (renderer.py:699-766) as 5 launches, no sync
             from lzzx_nerf_amd.occupancy import update_density_grid
@@ -539,7 +608,7 @@ def main():
             del dg, bf, nz
         except Exception as exc:   # an optional leg must never take the headline line down
             result.setdefault("leg_errors", {})["occupancy_grid_update"] = repr(exc)
-    if world == 1 and not args.no_occupancy:
+    if not args.no_occupancy:
         try:
             # torso branch of the frame (run_torso + forward_torso) as one kernel, 512 x 512 pixels, random weights
             from lzzx_nerf_amd.torso import FusedTorso
@@ -595,35 +664,177 @@ def main():
             del aenc, auds
         except Exception as exc:   # an optional leg must never take the headline line down
             result.setdefault("leg_errors", {})["torso_audio"] = repr(exc)
-    # ---- CPU baseline: the checker arranged like the reference loop, on a bounded sub-frame of the SAME rays ----
-    if not args.no_cpu_baseline and world == 1:   # rank 0, N = 1 only
+    # ---- CPU baseline (rank 0, N = 1): bounded, next to the GPU numbers; also PSNR / sample-count parity against the pinned checker ----
+    if not args.no_cpu_baseline:
         try:
-            from oracle.head import TriplaneSpec
-            from oracle.render import render_inference
-            stride = max(1, H // 64)
-            sel = (np.arange(0, H, stride)[:, None] * W + np.arange(0, W, stride)[None, :]).reshape(-1)
-            ro_c, rd_c = rays_o.cpu().numpy()[sel], rays_d.cpu().numpy()[sel]
-            st = {}
-            render_inference(TriplaneSpec(1.0), P, ro_c[:256], rd_c[:256], bits, golden["net_enc_a"], golden["net_ind"], golden["net_eye"],
-                             max_steps=args.max_steps)  # warm-up (page in, OpenMP team)
-            tc = time.perf_counter()
-            ref = render_inference(TriplaneSpec(1.0), P, ro_c, rd_c, bits, golden["net_enc_a"], golden["net_ind"], golden["net_eye"],
-                                   max_steps=args.max_steps, stats=st, budget_factor=args.budget_factor, n_step_cap=args.n_step_cap)
-            tc = time.perf_counter() - tc
-            cpu_samples = int(st["samples_per_ray"].sum())
-            gpu_img = out["image"].cpu().numpy()[sel]
-            mse = float(((gpu_img.astype(np.float64) - ref["image"]) ** 2).mean())
-            psnr = float("inf") if mse == 0 else -10 * np.log10(mse)
-            result["cpu_baseline"] = dict(value=round(cpu_samples / tc, 1), unit="samples/s", cores=len(os.sched_getaffinity(0)), kind="port",
-                                          sample=f"{len(sel)} rays (every {stride}th pixel of the same frame), {cpu_samples} samples, "
-                                                 f"{tc:.1f} s; checker arranged like run_cuda_for_inference (renderer.py:495-548), OpenMP")
-            result["psnr_vs_checker_db"] = psnr if np.isfinite(psnr) else "inf"
-            result["max_abs_diff_vs_checker"] = float(np.abs(gpu_img - ref["image"]).max())
-            cnt = renderer.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4,
-                                  count_samples=True)["ray_counts"].cpu().numpy()[sel]
-            result["sample_counts_equal"] = bool(np.array_equal(cnt.astype(np.int64), st["samples_per_ray"]))
+            cnt = job.r.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4,
+                               count_samples=True)["ray_counts"].cpu().numpy()
+            img_np = image.cpu().numpy()
+            base, parity = cpu_baseline(args, P, golden, bits, lambda sel: img_np[sel], lambda sel: cnt[sel])
+            result["cpu_baseline"] = base
+            result.update(parity)
         except Exception as exc:   # reported, never fatal for the line
-            result.setdefault("leg_errors", {})["cpu_baseline"] = repr(exc)
+            err("cpu_baseline", exc)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))          # nothing above this line touches the GPU
+
+    from lzzx_nerf_amd import _lib, dist as D
+    rank, world = D.init_from_env()
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world == 1:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+    assert _lib.load().lz_device_ok() == 1, "bench needs a gfx950 device; there is no fallback path"
+
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    from lzzx_nerf_amd.synthetic import ellipsoid_bitfield_device, load_golden, make_params, ones_bitfield, orbit_pose, synthetic_camera
+
+    golden = load_golden()
+    P = make_params(golden)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    sd = {k: torch.from_numpy(v) for k, v in P.items()}
+    head = FusedTriplaneHead(sd, bound=1.0, device=device, precision=args.precision)
+    bits_dev = dev(ones_bitfield()) if args.scene == "ones" else ellipsoid_bitfield_device(device)[0]
+    bits = bits_dev.cpu().numpy()
+    H = W = args.size
+    N = H * W
+    _, intr = synthetic_camera(H, W)
+    enc_a0, ind, eye = dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"])
+
+    def make_job(shard, tiles, budget_factor=None, n_step_cap=None, h=None, shard_of=0):
+        r = TriplaneRenderer(h or head, bits_dev, bound=1.0, budget_factor=budget_factor or args.budget_factor,
+                             n_step_cap=n_step_cap or args.n_step_cap)
+        k = rank if (world > 1 and shard == "clip") else 0     # clip mode: frame `rank` of the clip, with its own audio feature
+        enc_a = enc_a0
+        if k > 0:
+            enc_a = enc_a0 + 0.5 * torch.randn(enc_a0.shape, device=device, generator=torch.Generator(device=device).manual_seed(100 + k))
+        return FrameJob(r, H, W, orbit_pose(k), intr, (enc_a, ind, eye), args.max_steps, rank, world, shard, tiles, args.gather, device, shard_of)
+
+    # ---- headline ----
+    job = make_job(args.shard, args.tiles, shard_of=args.shard_of)
+    dt, head_ms, out, tiles = timed(job, args.steps, args.warmup, world, device)
+    samples_per_step, iters_per_frame, rows_per_step = frame_stats(out, world, device)
+    frames_per_step = world if (world > 1 and args.shard == "clip") else 1
+    rays_per_step = N * frames_per_step if args.shard_of <= 1 else job.n_rays
+    value = samples_per_step * args.steps / dt
+    image = out["image"].clone()
+    probe = (C.c_uint64 * 2)()
+    if not args.no_clock_probe and world == 1 and not args.no_side_legs:
+        # sustained shader clock under the head's load: 8 back-to-back 2M-row launches, counters of one wave of the last one
+        gp = torch.Generator(device=device).manual_seed(1)
+        xs = torch.rand(1 << 21, 3, device=device, generator=gp) * 2 - 1
+        ds = torch.nn.functional.normalize(torch.randn(1 << 21, 3, device=device, generator=gp), dim=-1)
+        for _ in range(8):
+            head.forward(xs, ds, enc_a0, ind, eye)
+        _lib.call("lz_debug_head_clocks", probe)
+        del xs, ds
+
+    # ---- N > 1: the other tiling and the clip (weak-scaling) mode, same run, labelled ----
+    multi = {}
+    if world > 1 and not args.no_side_legs:
+        for tag, shard, tl in (("tiles_" + ("contiguous" if args.tiles == "interleaved" else "interleaved"), "frame",
+                                "contiguous" if args.tiles == "interleaved" else "interleaved"), ("clip_weak_scaling", "clip", args.tiles)):
+            if shard == args.shard and tl == args.tiles:
+                continue
+            j2 = make_job(shard, tl)
+            d2, _, o2, _ = timed(j2, args.steps, 2, world, device, timing=False)
+            s2, it2, _ = frame_stats(o2, world, device)
+            multi[tag] = dict(value=round(s2 * args.steps / d2, 1), unit="samples/s", ms_per_step=round(d2 / args.steps * 1e3, 4),
+                              scaling="weak" if shard == "clip" else "strong", iterations_per_frame=it2,
+                              frames_per_step=world if shard == "clip" else 1, rays_per_rank=j2.n_rays,
+                              parallelism=(f"clip of {world} frames, rank r renders frame r, 1 all-gather/step" if shard == "clip" else
+                                           f"one frame ray-sharded x{world} ({tl} row tiles), 1 all-gather/frame"))
+            del j2
+    train_dp = None
+    if world > 1 and args.train_dp:   # every rank takes part: one gradient all-reduce per step
+        train_dp = train_bench(args, device, P, golden, bits, rank, world)
+    # correctness of the gathered frame on every rank: the assembled tiles equal this rank's own tile where they overlap
+    gather_ok = None
+    if world > 1 and args.shard == "frame":
+        job.sf.wait()
+        frame = job.sf.assemble(tiles)
+        mine = frame[job.sf.pixels]
+        own = out["image_rgb24"] if args.gather == "rgb24" else out["image"]
+        ok = torch.tensor([float(torch.equal(mine, own)), float(frame.shape[0] == N)], device=device)
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        gather_ok = bool(ok.min().item() == 1.0)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank != 0:
+        return
+
+    # ---- roofline of the dominant kernel (fused head): live HIP events from the timed steps of rank 0 ----
+    head_total_ms = float(np.sum(head_ms))
+    n_launch = len(head_ms)
+    st0 = out["state"].cpu().numpy()
+    my_samples, my_rows = int(st0[5]), int(st0[72])
+    launches_with_work = int(st0[6]) * args.steps
+    achieved_tflops = FLOP_PER_SAMPLE * my_samples * args.steps / (head_total_ms * 1e-3) / 1e12
+    roofline = dict(bound="mfma", achieved=round(achieved_tflops, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), traffic=None, kernel="lz_k_triplane_head<false>",
+                    avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5),
+                    avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5), launches=n_launch,
+                    launches_with_work=launches_with_work, flop_per_sample=FLOP_PER_SAMPLE,
+                    head_time_share=round(head_total_ms * 1e-3 / dt, 4), head_ms_per_step=round(head_total_ms / args.steps, 4),
+                    rows_per_frame=my_rows,
+                    shader_clock_mhz_under_load=round(probe[0] / max(probe[1], 1) * 100.0, 1) if (args.precision == "f32" and probe[1]) else None,
+                    issued_frac=round(ISSUED_FLOP_PER_ROW * my_rows * args.steps / (head_total_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
+    if world > 1:
+        roofline["note"] = "rank 0's head launches over rank 0's samples"
+    if args.precision == "f16":
+        roofline = f16_head_roofline(my_samples, my_rows, args.steps, head_total_ms, n_launch, launches_with_work, dt)
+    pmc_path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+    if os.path.exists(pmc_path) and args.precision == "f32":
+        # HBM-side traffic of the head per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, tools/profile_bench.sh): KiB per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+        # for gfx950 (128-B requests tallied at 64 B).  bench.py cannot collect counters itself; null when the summary is absent.
+        try:
+            pmc = json.load(open(pmc_path))
+            k = "lz_k_triplane_head<false>"
+            roofline["traffic"] = round((2 * pmc["FETCH_SIZE"][k]["avg_per_launch"] + pmc["WRITE_SIZE"][k]["avg_per_launch"]) * 1024)
+            roofline["traffic_unit"] = f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, averaged over all launches of profiles/{PMC_SUMMARY})"
+            roofline["algorithmic_bytes_per_launch"] = round(52 * my_rows * args.steps / max(n_launch, 1))
+        except (KeyError, ValueError):
+            pass
+    if world == 1:
+        par = "single GPU" if args.shard_of <= 1 else f"rank 0's tile of a frame ray-sharded x{args.shard_of} ({args.tiles} row tiles), no collective"
+    elif args.shard == "frame":
+        par = f"one frame ray-sharded x{world} ({args.tiles} row tiles), 1 all-gather/frame ({args.gather} tiles), overlapped with the next frame"
+    else:
+        par = f"clip of {world} frames, rank r renders frame r, 1 all-gather/step ({args.gather} tiles)"
+    result = {
+        "metric": f"rendered samples/s ({H}x{W} triplane head, max_steps {args.max_steps})", "value": round(value, 1), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak" if (world > 1 and args.shard == "clip") else "strong", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "f32" else "f16 (f32 accumulate, torch-autocast rounding)", "data": "synthetic",
+        "config": {"workload": f"cfg3/cfg4 inference: {H}x{W} frame, max_steps {args.max_steps}, triplane head (3x D2/L12/C1 hash grid + "
+                               f"audio/eye cond + SH4), occupancy={args.scene}, bound 1, dt_gamma 1/256, T_thresh 1e-4; a step = ray generation "
+                               "+ near/far + march/head/composite loop + blend" + (" + tile all-gather" if world > 1 else ""),
+                   "rays_per_step": rays_per_step, "frames_per_step": frames_per_step, "rays_per_rank": job.n_rays,
+                   "samples_per_step": samples_per_step, "iterations_per_frame": iters_per_frame,
+                   "nominal_samples_per_frame": N * args.max_steps, "parallelism": par,
+                   "schedule": f"n_step = max(min({args.budget_factor} * N // n_alive, {args.n_step_cap}), 1)"
+                               + (" (the reference's, renderer.py:513)" if (args.budget_factor, args.n_step_cap) == (1, 8) else
+                                  " -- sample rows per iteration sized for 288 GB of HBM; the reference's rule is 1 x N rows, <= 8 steps "
+                                  "(renderer.py:513): same pixels and per-ray sample counts, timed in 'reference_schedule'")},
+        "rays_per_s": round(rays_per_step * args.steps / dt, 1),
+        "samples_per_ray_mean": round(samples_per_step / max(rays_per_step, 1), 2),
+        "roofline": roofline,
+    }
+    if gather_ok is not None:
+        result["gathered_frame_ok"] = gather_ok
+    result.update(multi)
+    if train_dp is not None:
+        result["train_step"] = train_dp
+    if world == 1 and not args.no_side_legs:
+        side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, image, samples_per_step, make_job)
     print(json.dumps(result))
 
 

@@ -203,6 +203,11 @@ int lz_density_grid_points(const float* noise, uint32_t C, uint32_t G, float bou
 int lz_density_grid_update(const float* sigmas, float density_scale, float decay, float density_thresh, uint32_t C, uint32_t G,
                            float* density_grid, uint8_t* bitfield, float* stats, void* workspace, lz_stream_t stream);
 
+/* mark_untrained_grid (renderer.py:633-695): density_grid[cas, morton(cell)] = -1 for every cell none of the B cameras
+ * (poses [B,4,4] c2w, device) sees; count (optional, int32 [C, G^3], Morton-ordered) = cameras covering each cell. */
+int lz_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t C, uint32_t G,
+                           float bound, float* density_grid, int32_t* count, lz_stream_t stream);
+
 /* Torso half of update_extra_state (renderer.py:772-808).  lz_density_grid_torso_points: query point of every cell of the G x G
  * torso grid in meshgrid order (x slowest), xy = (2 c / (G-1) - 1) * (1 - 1/G) + (noise * 2 - 1) / G; noise [G*G, 2] in [0,1).
  * lz_density_grid_torso_update: alphas [G*G] = forward_torso alpha at those points (lz_torso_forward) -> tmp[y*G + x] -> 5x5 max

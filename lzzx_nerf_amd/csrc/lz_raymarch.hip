@@ -279,6 +279,51 @@ extern "C" int lz_density_grid_points(const float* noise, uint32_t C, uint32_t G
     return LZ_OK;
 }
 
+// mark_untrained_grid (renderer.py:633-695): a cell no training camera sees gets density -1 and is never updated or marched.
+// One lane per (cascade, cell) walks all B cameras (the reference's 5-level Python loop with [S, N, 3] batched matmuls);
+// world2cam = (p - t) @ R evaluated as ((v0 R0c + v1 R1c) + v2 R2c) without contraction, frustum test with a 2 * half-cell margin.
+__global__ void __launch_bounds__(256)
+lz_k_mark_untrained(const float* __restrict__ poses, uint32_t B, float cx_fx, float cy_fy, uint32_t C, uint32_t G, float bound,
+                    float* __restrict__ density_grid, int32_t* __restrict__ count_out) {
+    const uint32_t G3 = G * G * G;
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= C * G3) return;
+    const uint32_t cas = n / G3, p = n - cas * G3;
+    const uint32_t c[3] = {p / (G * G), (p / G) % G, p % G};
+    const double bc = fmin((double)(1u << cas), (double)bound);
+    const double half = bc / (double)G;
+    const float scale = (float)(bc - half), margin = (float)(half * 2);
+    float w[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) w[d] = ((2.0f * (float)c[d]) / (float)(G - 1) - 1.0f) * scale;
+    int32_t count = 0;
+    for (uint32_t b = 0; b < B; b++) {
+        const float* P = poses + (size_t)b * 16;
+        const float v0 = w[0] - P[3], v1 = w[1] - P[7], v2 = w[2] - P[11];
+        float cam[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) cam[k] = (v0 * P[k] + v1 * P[4 + k]) + v2 * P[8 + k];
+        const bool in = cam[2] > 0.0f && lz_fabsf(cam[0]) < cx_fx * cam[2] + margin && lz_fabsf(cam[1]) < cy_fy * cam[2] + margin;
+        count += in ? 1 : 0;
+    }
+    const uint32_t m = lz_morton3(c[0], c[1], c[2]);
+    if (count == 0) density_grid[(size_t)cas * G3 + m] = -1.0f;
+    if (count_out) count_out[(size_t)cas * G3 + m] = count;
+}
+
+extern "C" int lz_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t C, uint32_t G,
+                                      float bound, float* density_grid, int32_t* count, lz_stream_t stream) {
+    if (C * G == 0) return LZ_OK;
+    LZ_REQUIRE(poses && density_grid, LZ_ERR_BAD_ARGUMENT, "mark_untrained_grid: null tensor");
+    LZ_REQUIRE(C <= 8 && G >= 2 && G <= 1024, LZ_ERR_BAD_ARGUMENT, "mark_untrained_grid: cascade <= 8, 2 <= grid_size <= 1024");
+    // cx / fx is a python double narrowed when it multiplies the f32 tensor (renderer.py:684)
+    const float cx_fx = (float)((double)cx / (double)fx), cy_fy = (float)((double)cy / (double)fy);
+    hipLaunchKernelGGL(lz_k_mark_untrained, dim3(lz_div_up((uint64_t)C * G * G * G, 256)), dim3(256), 0, lz_st(stream), poses, B, cx_fx, cy_fy, C,
+                       G, bound, density_grid, count);
+    LZ_CHECK_LAUNCH("mark_untrained_grid");
+    return LZ_OK;
+}
+
 __global__ void __launch_bounds__(256)
 lz_k_density_ema(const float* __restrict__ sigmas, float density_scale, float decay, uint32_t C, uint32_t G,
                  float* __restrict__ density_grid, float* __restrict__ partial) {

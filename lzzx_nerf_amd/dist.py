@@ -39,25 +39,141 @@ def shard_rays(rays_o, rays_d, rank, world):
     return rays_o[lo:hi].contiguous(), rays_d[lo:hi].contiguous()
 
 
-def gather_tiles(tile, n_total=None, group=None):
-    """all-gather per-rank tiles [n_local, C] (ragged allowed) into [n_total, C] on every rank, in rank order."""
+STRIPE_ROWS = 8   # interleaved tiling: stripes of 8 image rows dealt round-robin
+
+
+def tile_rows(H, rank, world, tiles="contiguous"):
+    """image rows of rank `rank`'s tile(s): "contiguous" = one block of rows (shard_bounds over rows), "interleaved" = stripes of
+    STRIPE_ROWS rows dealt round-robin -- the face in the middle of the frame costs more samples per ray than the margins, and
+    stripes spread it over all ranks.  Returns a python list of row indices (ascending)."""
+    if tiles == "contiguous":
+        lo, hi = shard_bounds(H, rank, world)
+        return list(range(lo, hi))
+    if tiles != "interleaved":
+        raise ValueError("tiles must be 'contiguous' or 'interleaved'")
+    return [r for r in range(H) if (r // STRIPE_ROWS) % world == rank]
+
+
+def tile_pixels(H, W, rank, world, tiles="contiguous", device="cpu"):
+    """int64 [n_local] flat pixel indices (row * W + col) of this rank's tile(s), ascending; None for a single rank (whole frame)"""
+    if world == 1:
+        return None
+    rows = torch.tensor(tile_rows(H, rank, world, tiles), dtype=torch.int64, device=device)
+    return (rows[:, None] * W + torch.arange(W, dtype=torch.int64, device=device)[None, :]).reshape(-1)
+
+
+def frame_permutation(H, W, world, tiles="contiguous", device="cpu"):
+    """pixel index of every row of the rank-major gathered buffer (rank 0's tile, rank 1's, ...): frame[perm] = gathered.
+    With equal tiles it is the concatenation of every rank's tile_pixels; identity for contiguous tiles."""
+    return torch.cat([tile_pixels(H, W, r, world, tiles, device) for r in range(world)]) if world > 1 else torch.arange(H * W, device=device)
+
+
+def assemble_frame(gathered, H, W, world, tiles="contiguous"):
+    """rank-major gathered tiles [H*W, C] -> the frame in pixel order [H*W, C] (a no-op for contiguous tiles)"""
+    if world == 1 or tiles == "contiguous":
+        return gathered
+    out = torch.empty_like(gathered)
+    out[frame_permutation(H, W, world, tiles, gathered.device)] = gathered
+    return out
+
+
+class TileGatherer:
+    """ONE all-gather per frame, overlapped with the next frame's march: the rendered tile is copied to one of two
+    staging buffers on the render stream, and the collective runs on a side stream behind an event, so frame k + 1 renders while
+    frame k's tiles cross xGMI.  `gather(tile)` returns the gathered buffer of THIS frame; it is complete once `wait()` (or a
+    device synchronisation) has run, and stays valid until the second-next call.  CPU tensors (gloo tests) take the same code
+    path without streams."""
+
+    def __init__(self, n_local, channels, dtype, device, sizes=None, group=None):
+        self.group, self.sizes = group, sizes
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuda = torch.device(device).type == "cuda"
+        self.stage = [torch.empty(n_local, channels, dtype=dtype, device=device) for _ in range(2)]
+        self.out = [None, None]
+        self.done = [None, None]
+        self.k = 0
+        self.comm = torch.cuda.Stream(device=device) if (self.cuda and self.world > 1) else None
+
+    def gather(self, tile):
+        if self.world == 1:
+            return tile
+        i = self.k & 1
+        self.k += 1
+        if self.comm is None:
+            self.stage[i].copy_(tile)
+            self.out[i] = gather_tiles(self.stage[i], None, self.group, self.sizes)
+            return self.out[i]
+        cur = torch.cuda.current_stream()
+        if self.done[i] is not None:
+            cur.wait_event(self.done[i])        # the collective that last read this staging buffer has finished
+        self.stage[i].copy_(tile)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ready)
+            self.out[i] = gather_tiles(self.stage[i], None, self.group, self.sizes)
+            self.done[i] = torch.cuda.Event()
+            self.done[i].record(self.comm)
+        return self.out[i]
+
+    def wait(self):
+        """make the current stream wait for every collective issued so far"""
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+
+
+class ShardedFrame:
+    """BASELINE cfg4: ONE H x W frame whose rays are sharded over the ranks (row tiles, contiguous or interleaved stripes), every
+    rank renders its tile with a full model replica, ONE all-gather per frame makes every rank hold the frame.
+
+        sf = ShardedFrame(H, W, rank, world, tiles, device)
+        rays_o, rays_d = sf.rays(pose, intrinsics)          # this rank's tile only (lz_get_rays reads the tile's pixel list)
+        gathered = sf.gather(render(rays_o, rays_d))        # rank-major; overlapped with the next frame (TileGatherer)
+        frame = sf.assemble(gathered)                       # pixel order (no-op for contiguous tiles)
+    """
+
+    def __init__(self, H, W, rank, world, tiles="contiguous", device="cuda", channels=3, dtype=torch.float32, group=None):
+        self.H, self.W, self.rank, self.world, self.tiles = H, W, rank, world, tiles
+        self.pixels = tile_pixels(H, W, rank, world, tiles, device)
+        self.sizes = [len(tile_rows(H, r, world, tiles)) * W for r in range(world)]
+        self.n_local = self.sizes[rank]
+        self.gatherer = TileGatherer(self.n_local, channels, dtype, device, self.sizes, group) if world > 1 else None
+
+    def rays(self, pose, intrinsics):
+        from .utils import frame_rays
+        return frame_rays(pose, intrinsics, self.H, self.W, self.pixels)
+
+    def gather(self, tile):
+        return tile if self.gatherer is None else self.gatherer.gather(tile)
+
+    def wait(self):
+        if self.gatherer is not None:
+            self.gatherer.wait()
+
+    def assemble(self, gathered):
+        return assemble_frame(gathered, self.H, self.W, self.world, self.tiles)
+
+
+def gather_tiles(tile, n_total=None, group=None, sizes=None):
+    """all-gather per-rank tiles [n_local, C] into [sum n_local, C] on every rank, in rank order, with ONE collective.
+    Equal tiles: a plain all_gather_into_tensor.  Ragged tiles: `sizes` = every rank's n_local (or `n_total`, meaning the
+    contiguous `shard_bounds` split of n_total rays); tiles are padded to the largest, gathered once, and stripped."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return tile
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     tile = tile.contiguous()
-    if n_total is None or n_total % world == 0 and tile.shape[0] * world == n_total:
+    if sizes is None and n_total is not None:
+        sizes = [h - l for l, h in (shard_bounds(n_total, r, world) for r in range(world))]
+    if sizes is None or all(sz == sizes[0] for sz in sizes):
         out = torch.empty((tile.shape[0] * world,) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
         dist.all_gather_into_tensor(out, tile, group=group)
         return out
-    # ragged: pad to the largest shard, gather once, strip
-    sizes = [shard_bounds(n_total, r, world) for r in range(world)]
-    mx = max(h - l for l, h in sizes)
+    mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
     pad[: tile.shape[0]] = tile
     out = torch.empty((mx * world,) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
     dist.all_gather_into_tensor(out, pad, group=group)
-    return torch.cat([out[r * mx: r * mx + (h - l)] for r, (l, h) in enumerate(sizes)], 0)
+    return torch.cat([out[r * mx: r * mx + sz] for r, sz in enumerate(sizes)], 0)
 
 
 def to_rgb24(image):

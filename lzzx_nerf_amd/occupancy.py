@@ -43,6 +43,22 @@ def update_density_grid(head, density_grid, density_bitfield, enc_a, eye=None, b
 
 
 @torch.no_grad()
+def mark_untrained_grid(density_grid, poses, intrinsic, bound=1.0, return_count=False):
+    """`NeRFRenderer.mark_untrained_grid` (renderer.py:633-695): cells of `density_grid` [cascade, G^3] that none of the training cameras
+    `poses` [B,4,4] (c2w) with `intrinsic` (fx, fy, cx, cy) sees are set to -1 in place (one launch; the reference runs a 5-level Python
+    loop of batched matmuls).  Such cells are skipped by `update_density_grid` and never marched."""
+    cascade, cells = density_grid.shape
+    G = round(cells ** (1 / 3))
+    if G ** 3 != cells or density_grid.dtype != torch.float32 or not density_grid.is_contiguous():
+        raise RuntimeError("density_grid must be a contiguous float32 [cascade, grid_size^3] tensor")
+    poses = torch.as_tensor(poses).to(density_grid.device, torch.float32).reshape(-1, 4, 4).contiguous()
+    fx, fy, cx, cy = [float(v) for v in intrinsic]
+    count = torch.empty(cascade, cells, dtype=torch.int32, device=density_grid.device) if return_count else None
+    call("lz_mark_untrained_grid", ptr(poses), poses.shape[0], fx, fy, cx, cy, cascade, G, float(bound), ptr(density_grid), ptr(count), stream())
+    return count
+
+
+@torch.no_grad()
 def update_density_grid_torso(torso, density_grid_torso, poses, ind_code=None, decay=0.95, density_thresh=0.01, noise=None, enc_anchor=None):
     """Torso half of `update_extra_state` (renderer.py:772-808): alpha of `forward_torso` at one jittered point per cell of the
     G x G torso grid, 5 x 5 max pool, EMA in place.  `torso`: lzzx_nerf_amd.torso.FusedTorso.  Returns device scalars

@@ -60,13 +60,16 @@ def get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, rect=None):
     return {"i": i, "j": j, "inds": inds, "rays_o": rays_o, "rays_d": rays_d}
 
 
-def frame_rays(pose, intrinsics, H, W):
-    """every pixel of one frame: pose [4,4] -> rays_o, rays_d [H*W, 3] (what the renderer / bench consume); no i / j / inds outputs"""
+def frame_rays(pose, intrinsics, H, W, pixels=None):
+    """rays of one frame: pose [4,4] -> rays_o, rays_d [n, 3] for every pixel in order (pixels None) or for the int64 device index list
+    `pixels` (a rank's tile of a ray-sharded frame, lzzx_nerf_amd.dist.tile_pixels); no i / j / inds outputs.  What the renderer and
+    bench.py consume."""
     pose = pose.reshape(1, 4, 4).float().contiguous()
     fx, fy, cx, cy = [float(v) for v in intrinsics]
-    rays_o = torch.empty(H * W, 3, dtype=torch.float32, device=pose.device)
-    rays_d = torch.empty(H * W, 3, dtype=torch.float32, device=pose.device)
-    call("lz_get_rays", ptr(pose), fx, fy, cx, cy, int(H), int(W), 1, H * W, None, ptr(rays_o), ptr(rays_d), None, None, stream())
+    n = H * W if pixels is None else pixels.shape[0]
+    rays_o = torch.empty(n, 3, dtype=torch.float32, device=pose.device)
+    rays_d = torch.empty(n, 3, dtype=torch.float32, device=pose.device)
+    call("lz_get_rays", ptr(pose), fx, fy, cx, cy, int(H), int(W), 1, n, ptr(pixels), ptr(rays_o), ptr(rays_d), None, None, stream())
     return rays_o, rays_d
 
 

@@ -124,6 +124,52 @@ def head_forward(spec, P, xyz, dirs, enc_a, ind_code, eye, testing=True, unc_los
     return dres["sigma"], rgb.astype(F32), dres["ambient_aud"], dres["ambient_eye"], unc
 
 
+def head_forward_torch(spec, P, xyz, dirs, enc_a, ind_code, eye, testing=True, _cache={}):
+    """NeRFNetwork.forward (network.py:252-311) with the reference's OWN arrangement of the MLPs: bias-free torch Linear stacks on
+    CPU tensors (`F.linear`, in-place relu, `repeat` / `cat` materialising [M,69] and [M,84]; network.py:73-94), fp32, torch's intra-op
+    thread pool; encoders = the C checker.  This is bench.py's `cpu_baseline` head ("the reference's pure-torch MLP on CPU
+    tensors"); library GEMMs fix no summation order, so it agrees with head_forward to ~3e-6, not to the bit."""
+    import torch
+    import torch.nn.functional as F
+    key = id(P)
+    if key not in _cache:
+        _cache.clear()
+        _cache[key] = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=F32)) for k, v in P.items() if k.endswith(".weight")}
+    W = _cache[key]
+
+    def mlp(h, name, n):
+        for i in range(n):
+            h = F.linear(h, W[f"{name}.net.{i}.weight"])
+            if i != n - 1:
+                h = F.relu(h, inplace=True)
+        return h
+
+    with torch.no_grad():
+        enc_x = torch.from_numpy(encode_x(spec, xyz, P))
+        M = enc_x.shape[0]
+        a = torch.from_numpy(np.asarray(enc_a, dtype=F32).reshape(1, -1)).repeat(M, 1)
+        att = mlp(enc_x, "aud_ch_att_net", 2)
+        parts = [enc_x, a * att]
+        eye_att = None
+        if eye is not None:
+            eye_att = torch.sigmoid(mlp(enc_x, "eye_att_net", 2))
+            parts.append(torch.from_numpy(np.asarray(eye, dtype=F32).reshape(1, 1)) * eye_att)
+        h = mlp(torch.cat(parts, -1), "sigma_net", 3)
+        sigma = torch.exp(h[..., 0])
+        enc_d = torch.from_numpy(O.sh_encode_forward(dirs, 4)[0])
+        cparts = [enc_d, h[..., 1:]]
+        if ind_code is not None:
+            cparts.append(torch.from_numpy(np.asarray(ind_code, dtype=F32).reshape(1, -1)).repeat(M, 1))
+        rgb = torch.sigmoid(mlp(torch.cat(cparts, -1), "color_net", 2)) * (1 + 2 * 0.001) - 0.001
+        if testing:
+            unc = torch.log(1 + torch.exp(torch.zeros(M, 1)))
+        else:
+            unc = torch.log(1 + torch.exp(mlp(enc_x, "unc_net", 2)))
+        amb_aud = att.norm(dim=-1, keepdim=True)
+    n = lambda t: None if t is None else np.ascontiguousarray(t.numpy(), dtype=F32)
+    return n(sigma), n(rgb), n(amb_aud), n(eye_att), n(unc)
+
+
 # ---------------------------------------------------------------------------------------------
 # the same forward under torch autocast (opt.fp16): what the reference computes when it renders in half precision
 # ---------------------------------------------------------------------------------------------

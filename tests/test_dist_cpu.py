@@ -146,3 +146,59 @@ def test_gradient_bucket_single_process():
     assert torch.equal(bucket.all_reduce(), before)
     bucket.zero()
     assert float(table.grad.abs().sum()) == 0.0
+
+
+# ---- BASELINE cfg4 on CPU: one frame ray-sharded over the ranks through the product's ShardedFrame (tile lists, staging, ONE
+# all-gather, re-assembly); the renderer under it is the CPU checker (the HIP renderer needs a GPU), on real rays of a real scene ----
+def _frame_worker(rank, world, port, tiles, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      OMP_NUM_THREADS="2", OMP_WAIT_POLICY="passive")   # the checker's OpenMP teams would oversubscribe the host
+    torch.set_num_threads(2)
+    D.init_from_env(backend="gloo")
+    from conftest import ellipsoid_bitfield
+    from lzzx_nerf_amd.synthetic import load_golden, make_params, synthetic_camera
+    from oracle import oracle as O
+    from oracle.head import TriplaneSpec
+    from oracle.render import render_inference
+    golden = load_golden()
+    P = make_params(golden)
+    H, W = 40, 24          # 5 stripes of 8 rows: ragged for every world size used here
+    pose, intr = synthetic_camera(H, W)
+    bits, _ = ellipsoid_bitfield()
+    render = lambda ro, rd: render_inference(TriplaneSpec(1.0), P, ro, rd, bits, golden["net_enc_a"], golden["net_ind"], golden["net_eye"],
+                                             max_steps=24)["image"]
+    sf = D.ShardedFrame(H, W, rank, world, tiles, device="cpu")
+    assert sf.pixels.numel() == sf.n_local and sum(sf.sizes) == H * W
+    r = O.get_rays_batched(pose[None], intr, H, W, sf.pixels.numpy())
+    ok = True
+    for k in range(3):     # three frames through the double-buffered gatherer
+        tile = torch.from_numpy(render(r["rays_o"][0], r["rays_d"][0])) + k
+        frame = sf.assemble(sf.gather(tile))
+        sf.wait()
+        if k == 0:
+            full = O.get_rays_batched(pose[None], intr, H, W)
+            ref = torch.from_numpy(render(full["rays_o"][0], full["rays_d"][0]))
+            ok = ok and float(ref.min()) < 0.99     # the ellipsoid is in view: not an all-background frame
+        ok = ok and torch.equal(frame, ref + k)
+    np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tiles", [(2, "contiguous"), (2, "interleaved"), (3, "interleaved")])
+def test_frame_ray_sharded_equals_unsharded(tmp_path, world, tiles):
+    port = _free_port()
+    mp.spawn(_frame_worker, args=(world, port, tiles, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert int(np.load(tmp_path / f"ok_{r}.npy")[0]) == 1
+
+
+def test_tile_partitions():
+    for tiles in ("contiguous", "interleaved"):
+        for world in (1, 2, 3, 4, 8):
+            for H, W in ((512, 512), (40, 24), (7, 5)):
+                perm = D.frame_permutation(H, W, world, tiles)
+                assert torch.equal(perm.sort().values, torch.arange(H * W))
+                if tiles == "contiguous":
+                    assert torch.equal(perm, torch.arange(H * W))
+    assert D.tile_rows(512, 3, 8, "interleaved")[:9] == [24, 25, 26, 27, 28, 29, 30, 31, 88]

@@ -1,0 +1,80 @@
+"""BASELINE cfg4 on one GPU: the 512 x 512 frame rendered as 8 ray shards (both tilings) through the product's ShardedFrame +
+TriplaneRenderer equals the unsharded frame bit for bit; bench.py's self-spawned 2-rank path (gloo on one card: a rehearsal of the
+launch, sharding, gather and JSON contract -- not a scaling measurement) prints a well-formed strong-scaling line."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("tiles", ["contiguous", "interleaved"])
+def test_frame_as_8_ray_shards_equals_unsharded(params, golden, tiles):
+    from lzzx_nerf_amd import dist as D
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    from lzzx_nerf_amd.synthetic import ellipsoid_bitfield_device, synthetic_camera
+    H = W = 512
+    pose, intr = synthetic_camera(H, W)
+    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in params.items()}, bound=1.0)
+    bits, _ = ellipsoid_bitfield_device("cuda")
+    cond = (dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]))
+    r = TriplaneRenderer(head, bits, bound=1.0, budget_factor=4, n_step_cap=4)
+    full = D.ShardedFrame(H, W, 0, 1, device="cuda")
+    ro, rd = full.rays(dev(pose), intr)
+    ref = r.render(ro, rd, *cond, max_steps=192, count_samples=True)
+    ref_img, ref_cnt = ref["image"].clone(), ref["ray_counts"].clone()
+    assert float(ref_img.min()) < 0.9                                   # the head is in view
+    world = 8
+    tiles_out, counts = [], []
+    for g in range(world):
+        sf = D.ShardedFrame(H, W, g, world, tiles, device="cuda")
+        sf.gatherer = None                                              # one process: concatenate in rank order instead
+        assert sf.n_local == H * W // world
+        so, sd_ = sf.rays(dev(pose), intr)
+        assert torch.equal(so, ro[sf.pixels]) and torch.equal(sd_, rd[sf.pixels])   # the tile's rays are the frame's rays at its pixels
+        o = r.render(so, sd_, *cond, max_steps=192, count_samples=True)
+        tiles_out.append(o["image"].clone())
+        counts.append(o["ray_counts"].clone())
+    frame = D.assemble_frame(torch.cat(tiles_out), H, W, world, tiles)
+    cnt = D.assemble_frame(torch.cat(counts)[:, None], H, W, world, tiles)[:, 0]
+    assert torch.equal(frame, ref_img)                                  # pixels: bit for bit
+    assert torch.equal(cnt, ref_cnt)                                    # per-ray sample counts too
+    if tiles == "interleaved":                                          # stripes balance the load: every shard marches a similar share
+        per = torch.stack([c.sum() for c in counts]).double()
+        assert float(per.max() / per.mean()) < 1.25
+
+
+def test_device_built_ellipsoid_bitfield_equals_checker():
+    from conftest import ellipsoid_bitfield
+    from lzzx_nerf_amd.synthetic import ellipsoid_bitfield_device
+    bits, grid = ellipsoid_bitfield_device("cuda")
+    bits_o, grid_o = ellipsoid_bitfield()
+    assert np.array_equal(bits.cpu().numpy(), bits_o) and np.array_equal(grid.cpu().numpy(), grid_o)
+
+
+def test_bench_self_spawns_two_ranks_and_prints_the_contract_line(tmp_path):
+    env = dict(os.environ, LZ_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "128", "--max-steps", "64"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["steps"] == 2 and r["unit"] == "samples/s" and r["value"] > 0
+    assert r["gathered_frame_ok"] is True
+    assert "one frame ray-sharded x2" in r["config"]["parallelism"] and r["config"]["rays_per_rank"] == 128 * 128 // 2
+    assert r["clip_weak_scaling"]["scaling"] == "weak" and r["clip_weak_scaling"]["frames_per_step"] == 2
+    assert "tiles_contiguous" in r and "roofline" in r
