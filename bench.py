@@ -26,10 +26,11 @@ and C (each ray marches the same sample sequence and compositing resumes exactly
 
 Prints one JSON line on rank 0.  `value` = marched samples (delta != 0) per second over all ranks.
 """
-import argparse
+import os
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # cpu_baseline leg: two OpenMP runtimes (torch's, the checker's) must not spin against each other
+import argparse  # noqa: E402
 import ctypes as C
 import json
-import os
 import socket
 import subprocess
 import sys
@@ -288,6 +289,9 @@ def parse_args():
     ap.add_argument("--tiles", default="interleaved", choices=["interleaved", "contiguous"], help="--shard frame: how rows are dealt to ranks")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="single GPU: render rank 0's tile of a frame sharded this many ways (no collective) -- what one rank of cfg4 does")
+    ap.add_argument("--mode", default="fused", choices=["fused", "loop"],
+                    help="fused: the frame as one persistent kernel (csrc/lz_frame.hip; the loop under the schedule n_step = 1, same pixels); "
+                         "loop: march / head / composite launches per iteration under --budget-factor / --n-step-cap")
     ap.add_argument("--no-side-legs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true",
@@ -383,8 +387,9 @@ def cpu_baseline(args, P, golden, bits_np, gpu_image_of, renderer_counts_of):
     from oracle.head import TriplaneSpec, head_forward_torch
     from oracle.render import render_inference
     from lzzx_nerf_amd.synthetic import ones_bitfield, synthetic_camera
-    cores = len(os.sched_getaffinity(0))
+    cores = O.host_cores()          # affinity mask capped by the cgroup CPU quota: teams larger than the quota only fight each other
     torch.set_num_threads(cores)
+    O.set_threads(cores)
     spec = TriplaneSpec(1.0)
     cond = (golden["net_enc_a"], golden["net_ind"], golden["net_eye"])
     res = {}
@@ -405,7 +410,9 @@ def cpu_baseline(args, P, golden, bits_np, gpu_image_of, renderer_counts_of):
         ns = int(st["samples_per_ray"].sum())
         return dict(rays=len(sel), samples=ns, s_per_frame=round(med, 4), samples_per_s=round(ns / med, 1), rays_per_s=round(len(sel) / med, 1),
                     runs=reps), sel
+    log(f"cpu baseline: cfg1 on {cores} cores")
     cfg1, _ = run(64, 64, 1, 32, 5, ones_bitfield())
+    log(f"cpu baseline: cfg1 {cfg1['s_per_frame']} s/frame; cfg3 sample")
     res["cfg1_64x64x32"] = cfg1
     H = W = args.size
     stride = max(1, H // 128)
@@ -432,6 +439,14 @@ def cpu_baseline(args, P, golden, bits_np, gpu_image_of, renderer_counts_of):
                   sample_counts_equal=bool(np.array_equal(renderer_counts_of(sel8).astype(np.int64), st["samples_per_ray"])),
                   parity_sample=f"{len(sel8)} rays (every {stride8}th pixel), {int(st['samples_per_ray'].sum())} samples")
     return base, parity
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries only the JSON line)"""
+    print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 REF_SCHEDULE = (1, 8)   # renderer.py:513
@@ -469,10 +484,11 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
 
     def err(name, exc):
         result.setdefault("leg_errors", {})[name] = repr(exc)
+        log(f"leg {name} failed: {exc!r}")
 
-    def side_leg(h, budget_factor, n_step_cap, scene_bits=None, size=None, steps=None):
-        """same frame (or `size`^2 with `scene_bits`), K timed steps after 2 warm-ups, with another head precision and / or schedule"""
-        j2 = make_job("frame", args.tiles, budget_factor, n_step_cap, h)
+    def side_leg(h, budget_factor, n_step_cap, scene_bits=None, size=None, steps=None, mode="loop"):
+        """same frame (or `size`^2 with `scene_bits`), K timed steps after 2 warm-ups, with another head precision, schedule or mode"""
+        j2 = make_job("frame", args.tiles, budget_factor, n_step_cap, h, mode=mode)
         if scene_bits is not None:
             j2.r.bitfield = scene_bits
         if size is not None:
@@ -484,12 +500,25 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
         k = steps or args.steps
         d2, hms, o2, _ = timed(j2, k, 2, 1, device)
         s2 = o2["state"].cpu().numpy()
-        return dict(schedule=f"n_step = max(min({budget_factor} * N // n_alive, {n_step_cap}), 1)", value=round(int(s2[5]) * k / d2, 1),
+        return dict(mode=mode, schedule="n_step = 1, slots refilled on the fly (one persistent kernel)" if mode == "fused" else
+                    f"n_step = max(min({budget_factor} * N // n_alive, {n_step_cap}), 1)", value=round(int(s2[5]) * k / d2, 1),
                     unit="samples/s", ms_per_step=round(d2 / k * 1e3, 4), rays_per_s=round(j2.sf.n_local * k / d2, 1),
                     samples_per_frame=int(s2[5]), iterations_per_frame=int(s2[6]), rows_per_frame=int(s2[72]),
                     head_ms_per_step=round(float(np.sum(hms)) / k, 4)), o2["image"].clone(), float(np.sum(hms)), s2
 
-    if (args.budget_factor, args.n_step_cap) != REF_SCHEDULE and not args.no_fat_schedule:
+    log("leg: if (args.budget_factor, args.n_step_cap) != REF_SCHEDULE and not args.")
+    if args.mode == "fused" and not args.no_fat_schedule:
+        try:
+            # the multi-launch loop under --budget-factor / --n-step-cap (round 1's headline path): same pixels
+            leg, limg, lms, lst = side_leg(head, args.budget_factor, args.n_step_cap)
+            leg["image_equal_to_headline"] = bool(torch.equal(limg, image))
+            leg["samples_equal_to_headline"] = bool(int(lst[5]) == samples_per_frame)
+            if args.precision == "f32":
+                leg["head_frac"] = round(FLOP_PER_SAMPLE * int(lst[5]) * args.steps / (lms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)
+            result["loop_mode"] = leg
+        except Exception as exc:
+            err("loop_mode", exc)
+    if ((args.budget_factor, args.n_step_cap) != REF_SCHEDULE or args.mode == "fused") and not args.no_fat_schedule:
         try:
             # the same frame under the reference's own iteration schedule (1 x N sample rows per iteration, <= 8 steps per ray): more,
             # thinner launches; pixels and per-ray sample counts must be identical
@@ -504,13 +533,17 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
         except Exception as exc:
             err("reference_schedule", exc)
     h16 = None
+    log("leg: if args.precision == 'f32' and not args.no_fp16_leg:")
     if args.precision == "f32" and not args.no_fp16_leg:
         try:
             # the reference's opt.fp16 arithmetic (torch autocast) on the f16 matrix cores: a different rounding sequence, so it is
             # reported beside the bit-exact f32 headline, with its distance from the f32 image
             h16 = FusedTriplaneHead(sd, bound=1.0, device=device, precision="f16")
-            leg, img16, hms16, s16 = side_leg(h16, args.budget_factor, args.n_step_cap)
+            leg, img16, hms16, s16 = side_leg(h16, args.budget_factor, args.n_step_cap, mode=args.mode)
             leg8, img16b, _, _ = side_leg(h16, *REF_SCHEDULE)
+            if args.mode == "fused":
+                legl, img16l, _, _ = side_leg(h16, args.budget_factor, args.n_step_cap)
+                leg.update(loop_mode_value=legl["value"], loop_mode_ms_per_step=legl["ms_per_step"], loop_mode_image_equal=bool(torch.equal(img16, img16l)))
             diff = (img16 - image).double()
             mse16 = float((diff ** 2).mean())
             leg.update(dtype="f16 (f32 accumulate, torch-autocast rounding)", kernel="lz_k_triplane_head_f16",
@@ -522,6 +555,7 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             result["fp16_head"] = leg
         except Exception as exc:
             err("fp16_head", exc)
+    log("leg: if not args.no_cfg5:")
     if not args.no_cfg5:
         try:
             # BASELINE cfg5: 1024 x 1024, ellipsoid occupancy (2.9 % of the cells: skipping + on-device compaction), fp16 MLP on MFMA;
@@ -530,8 +564,12 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             ebits = ellipsoid_bitfield_device(device)[0]
             if h16 is None:
                 h16 = FusedTriplaneHead(sd, bound=1.0, device=device, precision="f16")
-            leg16, img5h, _, _ = side_leg(h16, *REF_SCHEDULE, scene_bits=ebits, size=1024, steps=max(3, args.steps // 2))
-            leg32, img5, _, _ = side_leg(head, *REF_SCHEDULE, scene_bits=ebits, size=1024, steps=max(3, args.steps // 2)) if args.precision == "f32" else (None, None, None, None)
+            k5 = max(3, args.steps // 2)
+            leg16, img5h, _, _ = side_leg(h16, *REF_SCHEDULE, scene_bits=ebits, size=1024, steps=k5, mode=args.mode)
+            leg32, img5, _, _ = side_leg(head, *REF_SCHEDULE, scene_bits=ebits, size=1024, steps=k5, mode=args.mode) if args.precision == "f32" else (None, None, None, None)
+            if args.mode == "fused":
+                l5, i5, _, _ = side_leg(h16, *REF_SCHEDULE, scene_bits=ebits, size=1024, steps=k5)
+                leg16.update(loop_mode_value=l5["value"], loop_mode_ms_per_step=l5["ms_per_step"], loop_mode_image_equal=bool(torch.equal(img5h, i5)))
             leg16.update(workload="cfg5: 1024x1024 frame, ellipsoid occupancy (2.9 % of cells), march_rays with on-device compaction, "
                                   "f16 MLP on MFMA (torch-autocast rounding)", dtype="f16", occupancy_fraction=round(float(np.unpackbits(ebits.cpu().numpy()).mean()), 4))
             if leg32 is not None:
@@ -543,6 +581,7 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
         except Exception as exc:
             err("cfg5_1024_ellipsoid_f16", exc)
     del h16
+    log("leg: if not args.no_dense192:")
     if not args.no_dense192:
         try:
             # SURVEY 8d "dense-192 micro-benchmark": the NOMINAL 512 x 512 x 192 = 50.33 M samples (uniform points in [-1,1]^3, the ray
@@ -579,16 +618,19 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             del xyz, dirs_d, deltas, rays_tbl, outd, comp
         except Exception as exc:   # an optional leg must never take the headline line down
             err("dense192", exc)
+    log("leg: if not args.no_grid_roofline:")
     if not args.no_grid_roofline:
         try:
             result["roofline_gridencoder"] = grid_roofline(device)
         except Exception as exc:   # an optional leg must never take the headline line down
             result.setdefault("leg_errors", {})["roofline_gridencoder"] = repr(exc)
+    log("leg: if not args.no_train:")
     if not args.no_train:
         try:
             result["train_step"] = train_bench(args, device, P, golden, bits)
         except Exception as exc:   # an optional leg must never take the headline line down
             result.setdefault("leg_errors", {})["train_step"] = repr(exc)
+    log("leg: if not args.no_occupancy and args.precision == 'f32':")
     if not args.no_occupancy and args.precision == "f32":
         try:
             # the occupancy-grid maintenance of update_extra_state (renderer.py:699-766) as 5 launches, no sync
@@ -608,6 +650,7 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             del dg, bf, nz
         except Exception as exc:   # an optional leg must never take the headline line down
             result.setdefault("leg_errors", {})["occupancy_grid_update"] = repr(exc)
+    log("leg: if not args.no_occupancy:")
     if not args.no_occupancy:
         try:
             # torso branch of the frame (run_torso + forward_torso) as one kernel, 512 x 512 pixels, random weights
@@ -665,6 +708,7 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
         except Exception as exc:   # an optional leg must never take the headline line down
             result.setdefault("leg_errors", {})["torso_audio"] = repr(exc)
     # ---- CPU baseline (rank 0, N = 1): bounded, next to the GPU numbers; also PSNR / sample-count parity against the pinned checker ----
+    log("leg: if not args.no_cpu_baseline:")
     if not args.no_cpu_baseline:
         try:
             cnt = job.r.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4,
@@ -707,19 +751,21 @@ def main():
     _, intr = synthetic_camera(H, W)
     enc_a0, ind, eye = dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"])
 
-    def make_job(shard, tiles, budget_factor=None, n_step_cap=None, h=None, shard_of=0):
+    def make_job(shard, tiles, budget_factor=None, n_step_cap=None, h=None, shard_of=0, mode=None):
         r = TriplaneRenderer(h or head, bits_dev, bound=1.0, budget_factor=budget_factor or args.budget_factor,
-                             n_step_cap=n_step_cap or args.n_step_cap)
+                             n_step_cap=n_step_cap or args.n_step_cap, mode=mode or args.mode)
         k = rank if (world > 1 and shard == "clip") else 0     # clip mode: frame `rank` of the clip, with its own audio feature
         enc_a = enc_a0
         if k > 0:
             enc_a = enc_a0 + 0.5 * torch.randn(enc_a0.shape, device=device, generator=torch.Generator(device=device).manual_seed(100 + k))
         return FrameJob(r, H, W, orbit_pose(k), intr, (enc_a, ind, eye), args.max_steps, rank, world, shard, tiles, args.gather, device, shard_of)
 
+    log(f"rank {rank}/{world}: setup done")
     # ---- headline ----
     job = make_job(args.shard, args.tiles, shard_of=args.shard_of)
     dt, head_ms, out, tiles = timed(job, args.steps, args.warmup, world, device)
     samples_per_step, iters_per_frame, rows_per_step = frame_stats(out, world, device)
+    log(f"headline: {dt / args.steps * 1e3:.3f} ms/step")
     frames_per_step = world if (world > 1 and args.shard == "clip") else 1
     rays_per_step = N * frames_per_step if args.shard_of <= 1 else job.n_rays
     value = samples_per_step * args.steps / dt
@@ -778,7 +824,8 @@ def main():
     launches_with_work = int(st0[6]) * args.steps
     achieved_tflops = FLOP_PER_SAMPLE * my_samples * args.steps / (head_total_ms * 1e-3) / 1e12
     roofline = dict(bound="mfma", achieved=round(achieved_tflops, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), traffic=None, kernel="lz_k_triplane_head<false>",
+                    frac=round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                    kernel="lz_k_frame<0> (march + head + composite, one persistent launch per frame)" if args.mode == "fused" else "lz_k_triplane_head<false>",
                     avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5),
                     avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5), launches=n_launch,
                     launches_with_work=launches_with_work, flop_per_sample=FLOP_PER_SAMPLE,
@@ -797,10 +844,11 @@ def main():
         # for gfx950 (128-B requests tallied at 64 B).  bench.py cannot collect counters itself; null when the summary is absent.
         try:
             pmc = json.load(open(pmc_path))
-            k = "lz_k_triplane_head<false>"
+            k = "lz_k_frame<0>" if args.mode == "fused" else "lz_k_triplane_head<false>"
             roofline["traffic"] = round((2 * pmc["FETCH_SIZE"][k]["avg_per_launch"] + pmc["WRITE_SIZE"][k]["avg_per_launch"]) * 1024)
             roofline["traffic_unit"] = f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, averaged over all launches of profiles/{PMC_SUMMARY})"
-            roofline["algorithmic_bytes_per_launch"] = round(52 * my_rows * args.steps / max(n_launch, 1))
+            roofline["algorithmic_bytes_per_launch"] = (round(92 * job.n_rays) if args.mode == "fused" else   # 24 B/ray in, ~68 B/ray out
+                                                        round(52 * my_rows * args.steps / max(n_launch, 1)))
         except (KeyError, ValueError):
             pass
     if world == 1:
@@ -820,7 +868,11 @@ def main():
                    "rays_per_step": rays_per_step, "frames_per_step": frames_per_step, "rays_per_rank": job.n_rays,
                    "samples_per_step": samples_per_step, "iterations_per_frame": iters_per_frame,
                    "nominal_samples_per_frame": N * args.max_steps, "parallelism": par,
-                   "schedule": f"n_step = max(min({args.budget_factor} * N // n_alive, {args.n_step_cap}), 1)"
+                   "mode": args.mode,
+                   "schedule": "one persistent kernel per frame (csrc/lz_frame.hip): the loop under n_step = 1 with finished ray slots refilled "
+                               "on the fly; same pixels and sample counts as the multi-launch loop ('loop_mode') and as the reference's "
+                               "schedule ('reference_schedule')" if args.mode == "fused" else
+                               f"n_step = max(min({args.budget_factor} * N // n_alive, {args.n_step_cap}), 1)"
                                + (" (the reference's, renderer.py:513)" if (args.budget_factor, args.n_step_cap) == (1, 8) else
                                   " -- sample rows per iteration sized for 288 GB of HBM; the reference's rule is 1 x N rows, <= 8 steps "
                                   "(renderer.py:513): same pixels and per-ray sample counts, timed in 'reference_schedule'")},

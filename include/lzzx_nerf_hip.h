@@ -411,10 +411,43 @@ typedef struct lz_timing lz_timing;   /* opaque: pairs of HIP events */
 int lz_timing_create(uint32_t n_pairs, lz_timing** out);
 int lz_timing_destroy(lz_timing* t);
 int lz_timing_reset(lz_timing* t);
+/* record the begin (which = 0) / end (which = 1) event of the next pair on `stream` */
+int lz_timing_mark(lz_timing* t, int which, lz_stream_t stream);
 /* elapsed ms of every recorded pair (host array); call after synchronising the stream */
 int lz_timing_elapsed_ms(lz_timing* t, float* out_ms, uint32_t capacity, uint32_t* n_pairs);
 /* `timing` (may be NULL): bracket every head launch with an event pair on the launch stream */
 int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterations, lz_timing* timing, lz_stream_t stream);
+
+/* One inference frame as ONE persistent kernel (csrc/lz_frame.hip): near/far + first occupied cell + longest-rays-first queue
+ * (2 small launches), then march -> head -> composite per ray slot with refill from the queue; no per-sample buffers, no host round
+ * trip.  Equals the reference loop (renderer.py:406-570) under the schedule n_step = 1; pixels do not depend on the schedule.
+ * All pointers are device pointers; the caller owns every buffer.  state words after the call (stream order):
+ *   [1] rays that had at least one sample, [3] 1, [5] marched samples, [6] 1, [72] sample rows evaluated by the head (16 per slice)
+ *   -- words 3 / 5 / 6 / 72 as in lz_loop_state / LZ_LOOP_STAT_ROWS. */
+#define LZ_FRAME_STATE_INTS 1024
+typedef struct {
+    lz_head_params head;           /* testing = 1; precision 0 (f32) or 1 (f16) */
+    const float* rays_o;           /* [N,3] */
+    const float* rays_d;           /* [N,3] */
+    const uint8_t* grid;           /* density bitfield */
+    const float* aabb;             /* [6] */
+    float* nears;  float* fars;    /* [N] each, written (near_far_from_aabb) */
+    float* rays_t;                 /* [N] scratch: t of every ray's first occupied cell */
+    int32_t* order;                /* [N] scratch: the queue */
+    int32_t* state;                /* LZ_FRAME_STATE_INTS, zeroed by the call */
+    uint8_t* keys;                 /* [N] scratch */
+    float* weights_sum;  float* depth;  float* image;                     /* [N] [N] [N,3] */
+    float* amb_aud_sum;  float* amb_eye_sum;  float* unc_sum;             /* [N] each */
+    float* out;                    /* [N,3] clamp(image + (1 - weights_sum) * bg, 0, 1), renderer.py:559-561 */
+    const float* bg;               /* [N,3] or NULL -> bg_scalar */
+    uint8_t* out_rgb24;            /* [N,3] or NULL: (out * 255) truncated, TrainerUtil.py:550-555 */
+    int32_t* ray_counts;           /* [N] or NULL: samples per ray */
+    float bg_scalar, bound, dt_gamma, T_thresh, min_near;
+    uint32_t N, max_steps, C, H;
+} lz_frame_fused;
+struct lz_timing;
+/* `timing` (may be NULL): bracket the persistent kernel with one event pair on the launch stream (lz_timing_create) */
+int lz_frame_render(const lz_frame_fused* f, struct lz_timing* timing, lz_stream_t stream);
 
 /* image = clamp(image + (1 - weights_sum) * bg, 0, 1) (renderer.py:559-561); bg: device [N,3] or NULL -> bg_scalar */
 int lz_final_blend(const float* image, const float* weights_sum, const float* bg, float bg_scalar, uint32_t N,

@@ -46,6 +46,15 @@ class Frame(C.Structure):
                 ("sample_budget", u32), ("n_step_cap", u32)]
 
 
+class FrameFused(C.Structure):
+    """mirror of lz_frame_fused (include/lzzx_nerf_hip.h)"""
+    _fields_ = [("head", HeadParams), ("rays_o", vp), ("rays_d", vp), ("grid", vp), ("aabb", vp), ("nears", vp), ("fars", vp), ("rays_t", vp),
+                ("order", vp), ("state", vp), ("keys", vp), ("weights_sum", vp), ("depth", vp), ("image", vp), ("amb_aud_sum", vp),
+                ("amb_eye_sum", vp), ("unc_sum", vp), ("out", vp), ("bg", vp), ("out_rgb24", vp), ("ray_counts", vp),
+                ("bg_scalar", f32), ("bound", f32), ("dt_gamma", f32), ("T_thresh", f32), ("min_near", f32),
+                ("N", u32), ("max_steps", u32), ("C", u32), ("H", u32)]
+
+
 # name -> argtypes, in the order of include/lzzx_nerf_hip.h
 SIGNATURES = {
     "lz_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, i32, i32, vp],
@@ -78,7 +87,9 @@ SIGNATURES = {
     "lz_timing_create": [u32, C.POINTER(vp)],
     "lz_timing_destroy": [vp],
     "lz_timing_reset": [vp],
+    "lz_timing_mark": [vp, i32, vp],
     "lz_timing_elapsed_ms": [vp, C.POINTER(f32), u32, C.POINTER(u32)],
+    "lz_frame_render": [C.POINTER(FrameFused), vp, vp],
     "lz_final_blend": [vp, vp, vp, f32, u32, vp, vp],
     "lz_final_blend_rgb24": [vp, vp, vp, f32, u32, vp, vp, vp],
     "lz_debug_head_clocks": [C.POINTER(C.c_uint64)],

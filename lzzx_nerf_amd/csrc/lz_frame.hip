@@ -1,0 +1,366 @@
+// lz_frame.hip -- one inference frame as ONE persistent kernel: march -> triplane gather -> MLP (MFMA) -> composite per ray, with
+// the per-sample buffers of the reference loop (xyzs, dirs, deltas, sigmas, rgbs, ambient, uncertainty: ~60 B per sample through HBM)
+// gone and ~90 launches per frame (3 per iteration of nerf_triplane/renderer.py:503-548) replaced by 3.
+//
+// What it computes is the reference's inference loop (renderer.py:406-570) under the iteration schedule n_step = 1: every alive ray
+// marches one sample per iteration, the head evaluates it, compositing resumes the ray.  The schedule is a launch-shape heuristic
+// (rays are independent, compositing resumes exactly), so pixels, depth, ambient / uncertainty sums and -- except for rays cut by
+// T_thresh inside a multi-step chunk -- per-ray sample counts equal those of any other schedule; the arithmetic of every step is the
+// operator kernels' (lz_march.h: LzMarch::probe; lz_head_slice.h / lz_head_f16_slice.h; lz_k_composite_rays), bit for bit.
+//
+// MI355X design
+//   * A wave owns 16 RAY SLOTS = the 16 samples of one MFMA B-operand tile.  Per pass: every slot marches its ray to the next
+//     occupied cell (lanes q == 0; the DDA of LzMarch), the 64 lanes evaluate the head for the 16 samples exactly like a slice of
+//     lz_k_triplane_head, lanes q == 0 composite the result into the slot's accumulators.  Ray state (t, far, 8 accumulators, count)
+//     lives in LDS between passes (12 KB per workgroup), not in registers: the head's register budget is unchanged.
+//   * Slots that finish (ray left the box, T < T_thresh, max_steps) are refilled from a global queue with one wave-aggregated atomic,
+//     so a slice never carries exhausted rows: the "ray compaction" of renderer.py:542 is the refill.
+//   * Queue order = longest rays first (counting sort by the estimated sample count (far - t_first) / dt, 256 bins): the rays handed
+//     out last are the short ones, which bounds the tail where slots run empty (list scheduling, LPT).
+//   * lz_k_frame_prepare (one lane per ray) does near/far, marches every ray to its FIRST occupied cell -- rays that never meet
+//     one get their background pixel there and never enter the queue -- and builds the histogram; lz_k_frame_scatter places the
+//     ray ids; lz_k_frame is the persistent kernel: 3 launches + 1 memset per frame, no host round trip, no per-sample HBM traffic
+//     (compulsory: 24 B/ray in, ~50 B/ray out).
+//   * No inter-workgroup communication; a wave leaves when the queue is dry and its slots are empty, so the grid always drains.
+#include "lz_march.h"
+#include "lz_head_slice.h"
+#include "lz_head_f16_slice.h"
+
+#define LZF_WG 1024
+#define LZF_WAVES (LZF_WG / 64)
+#define LZF_BINS 256
+// device state words (LZ_FRAME_STATE_INTS int32, zeroed per frame by lz_frame_render).  Words 3, 5, 6 and 72 sit where the
+// multi-launch loop keeps done / total_samples / iterations / rows (lz_loop_state, LZ_LOOP_STAT_ROWS), so a caller reads both alike.
+#define LZF_Q_HEAD 0      // queue cursor
+#define LZF_Q_SIZE 1      // rays in the queue (those with at least one sample)
+#define LZF_DONE 3        // 1 (the frame is complete in stream order)
+#define LZF_SAMPLES 5     // marched = composited samples
+#define LZF_ITER 6        // 1: one persistent launch
+#define LZF_ROWS 72       // sample rows handed to the head (16 per slice)
+#define LZF_HIST 128      // [256] rays per key
+#define LZF_CURSOR 384    // [256] scatter cursors
+
+struct LzFrameK {
+    const float* rays_o; const float* rays_d; const uint8_t* grid; const float* aabb;
+    float* nears; float* fars; float* rays_t;
+    int* order; int* state; uint8_t* keys;
+    float* weights_sum; float* depth; float* image; float* amb0_sum; float* amb1_sum; float* unc_sum;
+    float* out; const float* bg; uint8_t* out_rgb24; int* ray_counts;
+    float bg_scalar, bound, dt_gamma, T_thresh, min_near;
+    uint32_t N, max_steps, C, H;
+};
+
+__device__ __forceinline__ void lzf_write_pixel(const LzFrameK& F, int ray, float ws, float d, float r, float g, float b, float a0, float a1,
+                                                float u, int cnt) {
+    F.weights_sum[ray] = ws;
+    F.depth[ray] = d;
+    const float rgb[3] = {r, g, b};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const size_t t = (size_t)ray * 3 + c;
+        F.image[t] = rgb[c];
+        const float bgv = F.bg ? F.bg[t] : F.bg_scalar;
+        const float v = rgb[c] + (1.0f - ws) * bgv;              // renderer.py:559, two roundings like lz_k_final_blend
+        const float cl = lz_fminf(lz_fmaxf(v, 0.0f), 1.0f);
+        F.out[t] = cl;
+        if (F.out_rgb24) F.out_rgb24[t] = (uint8_t)(cl * 255.0f);
+    }
+    F.amb0_sum[ray] = a0;
+    F.amb1_sum[ray] = a1;
+    F.unc_sum[ray] = u;
+    if (F.ray_counts) F.ray_counts[ray] = cnt;
+}
+
+// ---- pass 1: near / far, first occupied cell, sort key, histogram -------------------------------------------------------------
+__global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
+    __shared__ int hist[LZF_BINS];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < F.N) {
+        const float* o = F.rays_o + (size_t)n * 3;
+        const float* d = F.rays_d + (size_t)n * 3;
+        float near, far;
+        lz_near_far_ray(o[0], o[1], o[2], d[0], d[1], d[2], F.aabb, F.min_near, near, far);
+        F.nears[n] = near;
+        F.fars[n] = far;
+        LzMarch m;
+        m.init(o, d, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+        float t = near, x, y, z, dt = 0.0f;
+        bool found = false;
+        while (t < far) {
+            if (m.probe(t, x, y, z, dt)) { found = true; break; }
+        }
+        int key = 0;
+        if (found && F.max_steps > 0) {
+            F.rays_t[n] = t;
+            // upper estimate of the samples left on the ray: steps of at least the current dt until far
+            const float est = lz_fminf((far - t) / dt + 1.0f, (float)F.max_steps);
+            key = (int)(est * 255.0f / (float)F.max_steps);
+            key = key < 1 ? 1 : (key > 255 ? 255 : key);
+            atomicAdd(&hist[key], 1);
+        } else {
+            lzf_write_pixel(F, (int)n, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0);   // no sample on this ray: background
+        }
+        F.keys[n] = (uint8_t)key;
+    }
+    __syncthreads();
+    const int h = hist[threadIdx.x];
+    if (h && threadIdx.x > 0) atomicAdd(F.state + LZF_HIST + threadIdx.x, h);
+}
+
+// ---- pass 2: ray ids in descending key order (counting sort; order inside a bin is free -- rays are independent) ---------------
+__global__ void __launch_bounds__(256) lz_k_frame_scatter(LzFrameK F) {
+    __shared__ int start[LZF_BINS];
+    {
+        // start[k] = rays with a larger key (they come first): suffix scan of the 256 bins (key 0 = no sample, not queued)
+        const int h = threadIdx.x > 0 ? F.state[LZF_HIST + threadIdx.x] : 0;
+        start[threadIdx.x] = h;
+        __syncthreads();
+        for (int off = 1; off < LZF_BINS; off <<= 1) {
+            const int v = (threadIdx.x + off < LZF_BINS) ? start[threadIdx.x + off] : 0;
+            __syncthreads();
+            start[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int incl = start[threadIdx.x];      // rays with key >= k
+        __syncthreads();
+        start[threadIdx.x] = incl - h;
+        if (blockIdx.x == 0 && threadIdx.x == 1) { F.state[LZF_Q_SIZE] = incl; F.state[LZF_DONE] = 1; F.state[LZF_ITER] = 1; }   // keys 1..255
+    }
+    __syncthreads();
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    int key = n < F.N ? (int)F.keys[n] : 0;
+    bool pending = key > 0;
+    const int lane = threadIdx.x & 63;
+    while (__ballot(pending)) {          // one atomic per distinct key per wave (neighbouring pixels share keys)
+        const unsigned long long act = __ballot(pending);
+        const int leader = __ffsll((long long)act) - 1;
+        const int k0 = __shfl(key, leader, 64);
+        const unsigned long long same = __ballot(pending && key == k0);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(F.state + LZF_CURSOR + k0, __popcll(same));
+        base = __shfl(base, leader, 64);
+        if (pending && key == k0) {
+            F.order[start[k0] + base + __popcll(same & ((1ull << lane) - 1ull))] = (int)n;
+            pending = false;
+        }
+    }
+}
+
+// ---- pass 3: the persistent kernel --------------------------------------------------------------------------------------------
+// slot state in LDS, per wave [field][16]
+enum { SF_RAY = 0, SF_T, SF_FAR, SF_DT, SF_WS, SF_D, SF_R, SF_G, SF_B, SF_A0, SF_A1, SF_U, SF_CNT, SF_FIELDS };
+
+template <int PREC> struct LzfHead;
+template <> struct LzfHead<0> {
+    using Args = LzHeadArgs; using Ctx = LzHeadCtx; using Out = LzHeadOut;
+    static constexpr int LDS_WORDS = LzHeadLds<false>::FLOATS;
+    __device__ static __forceinline__ void stage(const Args& P, float* lds, int q, Ctx& c) { lz_head_stage<false>(P, lds, LZF_WG, q, c); }
+    template <typename DirFn>
+    __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, DirFn f, Out& o) {
+        lz_head_slice<false>(c, lane, x, y, z, f, o);
+    }
+};
+template <> struct LzfHead<1> {
+    using Args = LzHead16Args; using Ctx = LzHead16Ctx; using Out = LzHead16Out;
+    static constexpr int LDS_WORDS = LZ_HEAD16_LDS_H8 * 4;
+    __device__ static __forceinline__ void stage(const Args& P, float* lds, int, Ctx& c) { lz_head16_stage(P, reinterpret_cast<lz_h8*>(lds), LZF_WG, c); }
+    template <typename DirFn>
+    __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, DirFn f, Out& o) {
+        lz_head16_slice(c, lane, x, y, z, f, o);
+    }
+};
+
+template <int PREC>
+__global__ void __launch_bounds__(LZF_WG, LZF_WG / 256)
+lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
+    using HD = LzfHead<PREC>;
+    constexpr int SLOT_WORDS = LZF_WAVES * SF_FIELDS * 16;
+    __shared__ __align__(16) float lds[HD::LDS_WORDS + SLOT_WORDS + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    typename HD::Ctx ctx;
+    HD::stage(P, lds, q, ctx);
+    float* slot = lds + HD::LDS_WORDS + wave * SF_FIELDS * 16;      // this wave's slots: slot[field * 16 + s]
+    int* sloti = reinterpret_cast<int*>(slot);
+    int* wg_stat = reinterpret_cast<int*>(lds + HD::LDS_WORDS + SLOT_WORDS);   // [0] samples, [1] slices, [2] waves done
+    if (lane < 16) sloti[SF_RAY * 16 + lane] = -1;
+    if (threadIdx.x < 4) wg_stat[threadIdx.x] = 0;
+    __syncthreads();
+    const int n_queue = F.state[LZF_Q_SIZE];
+    LzMarch m;   // the frame-constant part of LzMarch (init() below sets the per-ray part)
+    bool dry = n_queue <= 0;
+    int my_samples = 0, my_slices = 0;
+
+    for (;;) {
+        // ---------------- refill + march: every slot ends with a sample, or empty with the queue dry ----------------
+        int ray = (q == 0) ? sloti[SF_RAY * 16 + s] : -1;
+        bool have = false;
+        float x = 0.0f, y = 0.0f, z = 0.0f;
+        for (int attempt = 0; attempt < 4; attempt++) {
+            const bool need = (q == 0) && ray < 0 && !dry;
+            const unsigned long long mask = __ballot(need);
+            if (mask) {
+                const int leader = __ffsll((long long)mask) - 1, take = __popcll(mask);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(F.state + LZF_Q_HEAD, take);
+                base = __shfl(base, leader, 64);
+                if (need) {
+                    const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (idx < n_queue) {
+                        ray = F.order[idx];
+                        sloti[SF_RAY * 16 + s] = ray;
+                        slot[SF_T * 16 + s] = F.rays_t[ray];
+                        slot[SF_FAR * 16 + s] = F.fars[ray];
+#pragma unroll
+                        for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
+                        sloti[SF_CNT * 16 + s] = 0;
+                    }
+                }
+                if (base + take >= n_queue) dry = true;    // wave-uniform
+            }
+            if (q == 0 && ray >= 0 && !have) {
+                m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+                float t = slot[SF_T * 16 + s], dt = 0.0f;
+                const float far = slot[SF_FAR * 16 + s];
+                while (t < far) {
+                    if (m.probe(t, x, y, z, dt)) { have = true; break; }
+                }
+                if (have) {
+                    slot[SF_T * 16 + s] = t;
+                    slot[SF_DT * 16 + s] = dt;
+                } else {        // the ray left the box (renderer.py: the march writes no row, compositing kills the ray on delta == 0)
+                    lzf_write_pixel(F, ray, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s], slot[SF_B * 16 + s],
+                                    slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s], sloti[SF_CNT * 16 + s]);
+                    my_samples += sloti[SF_CNT * 16 + s];
+                    ray = -1;
+                    sloti[SF_RAY * 16 + s] = -1;
+                    x = y = z = 0.0f;
+                }
+            }
+            if (!__ballot((q == 0) && ray < 0 && !dry)) break;
+        }
+        if (!__ballot(have)) {
+            if (dry) break;     // queue dry and no slot holds a sample: every slot is empty, this wave is done
+            continue;
+        }
+        // ---------------- head: the 16 samples of the slots, exactly one slice of the stand-alone head kernel ----------------
+        const float px = __shfl(x, s, 64), py = __shfl(y, s, 64), pz = __shfl(z, s, 64);
+        typename HD::Out o;
+        HD::slice(ctx, lane, px, py, pz,
+                  [&](float& dx, float& dy, float& dz) {
+                      const int r = sloti[SF_RAY * 16 + s];
+                      const float* d = F.rays_d + (size_t)(r < 0 ? 0 : r) * 3;
+                      dx = d[0]; dy = d[1]; dz = d[2];
+                  }, o);
+        my_slices++;
+        // ---------------- composite (lz_k_composite_rays, n_step = 1): lanes q == 0 ----------------
+        if (have) {
+            const float dt = slot[SF_DT * 16 + s];
+            float ws = slot[SF_WS * 16 + s];
+            const float alpha = 1.0f - lz_expf(-o.sigma * dt);
+            const float T = 1 - ws;
+            const float w = alpha * T;
+            ws += w;
+            const float t = slot[SF_T * 16 + s] + dt;
+            const float d = lz_fmaf(w, t, slot[SF_D * 16 + s]);
+            const float r = lz_fmaf(w, o.rgb[0], slot[SF_R * 16 + s]);
+            const float g = lz_fmaf(w, o.rgb[1], slot[SF_G * 16 + s]);
+            const float b = lz_fmaf(w, o.rgb[2], slot[SF_B * 16 + s]);
+            const float a0 = slot[SF_A0 * 16 + s] + o.ambaud;
+            const float a1 = slot[SF_A1 * 16 + s] + o.eyeatt;
+            const float u = lz_fmaf(w, o.unc, slot[SF_U * 16 + s]);
+            const int cnt = sloti[SF_CNT * 16 + s] + 1;
+            if (T < F.T_thresh || cnt >= (int)F.max_steps) {
+                lzf_write_pixel(F, ray, ws, d, r, g, b, a0, a1, u, cnt);
+                my_samples += cnt;
+                sloti[SF_RAY * 16 + s] = -1;
+            } else {
+                slot[SF_T * 16 + s] = t;
+                slot[SF_WS * 16 + s] = ws; slot[SF_D * 16 + s] = d;
+                slot[SF_R * 16 + s] = r; slot[SF_G * 16 + s] = g; slot[SF_B * 16 + s] = b;
+                slot[SF_A0 * 16 + s] = a0; slot[SF_A1 * 16 + s] = a1; slot[SF_U * 16 + s] = u;
+                sloti[SF_CNT * 16 + s] = cnt;
+            }
+        }
+    }
+    // ---------------- statistics: wave -> workgroup (LDS) -> one pair of global atomics by the last wave out ----------------
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_samples += __shfl_xor(my_samples, off, 64);
+    if (lane == 0) {
+        atomicAdd(&wg_stat[0], my_samples);
+        atomicAdd(&wg_stat[1], my_slices);
+        __threadfence_block();
+        if (atomicAdd(&wg_stat[2], 1) == LZF_WAVES - 1) {
+            const int a = atomicAdd(&wg_stat[0], 0), b = atomicAdd(&wg_stat[1], 0);
+            if (a) atomicAdd(F.state + LZF_SAMPLES, a);
+            if (b) atomicAdd(F.state + LZF_ROWS, 16 * b);
+        }
+    }
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------------------
+static void lzf_level_tables(const lz_head_params* p, float* scale, uint32_t* res) {
+    for (int l = 0; l < 12; l++) {  // gridencoder.cu:125-126 on the host, same libm call as the CPU checker
+        const float sc = exp2f((float)l * p->S) * (float)p->H - 1.0f;
+        scale[l] = sc;
+        res[l] = (uint32_t)ceilf(sc) + 1u;
+    }
+}
+
+extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_stream_t stream) {
+    LZ_REQUIRE(f, LZ_ERR_BAD_ARGUMENT, "frame_render: null");
+    const lz_head_params* p = &f->head;
+    LZ_REQUIRE(f->rays_o && f->rays_d && f->grid && f->aabb && f->nears && f->fars && f->rays_t && f->order && f->state && f->keys &&
+                   f->weights_sum && f->depth && f->image && f->amb_aud_sum && f->amb_eye_sum && f->unc_sum && f->out,
+               LZ_ERR_BAD_ARGUMENT, "frame_render: incomplete lz_frame_fused");
+    LZ_REQUIRE(p->emb_xy && p->emb_yz && p->emb_xz && p->offsets && p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT, "frame_render: incomplete lz_head_params");
+    LZ_REQUIRE(p->testing, LZ_ERR_UNSUPPORTED, "frame_render: inference only (head.testing must be 1)");
+    LZ_REQUIRE(p->precision == 0 || p->precision == 1, LZ_ERR_BAD_ARGUMENT, "frame_render: precision must be 0 (f32) or 1 (f16)");
+    LZ_REQUIRE(f->C >= 1 && f->C <= 8 && f->H > 0, LZ_ERR_BAD_ARGUMENT, "frame_render: cascade must be in [1, 8]");
+    if (f->N == 0) return LZ_OK;
+    hipStream_t st = lz_st(stream);
+    LzFrameK K;
+    K.rays_o = f->rays_o; K.rays_d = f->rays_d; K.grid = f->grid; K.aabb = f->aabb;
+    K.nears = f->nears; K.fars = f->fars; K.rays_t = f->rays_t;
+    K.order = f->order; K.state = f->state; K.keys = f->keys;
+    K.weights_sum = f->weights_sum; K.depth = f->depth; K.image = f->image; K.amb0_sum = f->amb_aud_sum; K.amb1_sum = f->amb_eye_sum;
+    K.unc_sum = f->unc_sum; K.out = f->out; K.bg = f->bg; K.out_rgb24 = f->out_rgb24; K.ray_counts = f->ray_counts;
+    K.bg_scalar = f->bg_scalar; K.bound = f->bound; K.dt_gamma = f->dt_gamma; K.T_thresh = f->T_thresh; K.min_near = f->min_near;
+    K.N = f->N; K.max_steps = f->max_steps; K.C = f->C; K.H = f->H;
+    hipError_t rc = hipMemsetAsync(f->state, 0, LZ_FRAME_STATE_INTS * sizeof(int32_t), st);
+    if (rc != hipSuccess) { lz_set_error("frame_render: memset: %s", hipGetErrorString(rc)); return (int)rc; }
+    const uint32_t nb = lz_div_up(f->N, 256);
+    hipLaunchKernelGGL(lz_k_frame_prepare, dim3(nb), dim3(256), 0, st, K);
+    hipLaunchKernelGGL(lz_k_frame_scatter, dim3(nb), dim3(256), 0, st, K);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    // one workgroup per CU (the weights fill most of its LDS); fewer when there are not enough rays for one slot row per wave
+    uint32_t grid = lz_div_up(f->N, 16 * 4);   // at least 4 waves' worth of slots per workgroup
+    if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu;
+    if (timing) (void)lz_timing_mark(timing, 0, stream);    // the event pair brackets the persistent kernel alone
+    if (p->precision == 1) {
+        LzHead16Args a;
+        a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
+        a.offsets = p->offsets; a.packed = reinterpret_cast<const lz_h8*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code;
+        a.eye = p->eye; a.bound = p->bound;
+        lzf_level_tables(p, a.scale, a.res);
+        hipLaunchKernelGGL((lz_k_frame<1>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
+    } else {
+        LzHeadArgs a;
+        a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
+        a.offsets = p->offsets; a.packed = reinterpret_cast<const float*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code; a.eye = p->eye;
+        a.bound = p->bound; a.testing = 1;
+        lzf_level_tables(p, a.scale, a.res);
+        hipLaunchKernelGGL((lz_k_frame<0>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
+    }
+    if (timing) (void)lz_timing_mark(timing, 1, stream);
+    LZ_CHECK_LAUNCH("frame_render");
+    return LZ_OK;
+}

@@ -23,12 +23,7 @@
 //     matrix pipe), persistent over 512-sample tiles; all packed weights (431 fragments = 110 KB) stay in
 //     LDS for the life of the workgroup.
 //   * `count` (device) bounds the work, so the render loop needs no host round trip.
-#include "lz_common.h"
-#include "lzzx_detmath.h"
-#include "lzzx_sh_eval.h"
-#include "lz_head_gather.h"
-
-#include "lz_head_layers.h"
+#include "lz_head_slice.h"
 
 extern "C" uint32_t lz_head_packed_size(void) { return (uint32_t)LZ_HEAD_PACKED_FLOATS; }
 
@@ -111,7 +106,6 @@ extern "C" int lz_head_pack_weights(const float* aud0, const float* aud1, const 
 }
 
 // ---- the fused head ---------------------------------------------------------------------------------
-#define LZ_T 1             // sample tiles (of 16) per wave pass
 #define LZ_WG 1024         // threads per workgroup (16 waves = 4 per SIMD)
 #define LZ_WG_SAMPLES (LZ_WG / 64 * LZ_T * 16)
 
@@ -124,9 +118,7 @@ __global__ void __launch_bounds__(LZ_WG, LZ_WG / 256)
 lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
                    const int* __restrict__ count, float* __restrict__ sigmas, float* __restrict__ rgbs,
                    float* __restrict__ amb_aud, float* __restrict__ amb_eye, float* __restrict__ unc_out) {
-    constexpr int NFRAG = TRAIN_UNC ? LZ_FRAGS_ALL : LZ_FRAGS_INFER;
-    constexpr int WV = NFRAG * 64, TAB = WV + LZ_WV_FLOATS;
-    __shared__ float wl[TAB + 96];  // packed A fragments, VALU-layer rows, level table (64 words), enc_a (32)
+    __shared__ float wl[LzHeadLds<TRAIN_UNC>::FLOATS];  // packed A fragments, VALU-layer rows, level table (64 words), enc_a (32)
     uint32_t Meff = M;
     if (count) {
         const int c = *count;
@@ -142,39 +134,16 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
     unsigned long long probe_c = 0, probe_w = 0;
     if (probe) { probe_c = clock64(); probe_w = wall_clock64(); }
 
-    // stage weights into LDS (16 B per lane per step, coalesced)
-    {
-        const float4* src = reinterpret_cast<const float4*>(P.packed);
-        float4* dst = reinterpret_cast<float4*>(wl);
-        for (int i = threadIdx.x; i < NFRAG * 16; i += LZ_WG) dst[i] = src[i];
-        if (threadIdx.x < LZ_WV_FLOATS) wl[WV + threadIdx.x] = P.packed[LZ_FRAGS_ALL * 64 + threadIdx.x];
-        // per-level table (indexed per lane in the gather): [0,13) offsets, [16,28) scale, [32,44) resolution
-        int* tab = reinterpret_cast<int*>(wl + TAB);
-        if (threadIdx.x < 13) tab[threadIdx.x] = P.offsets[threadIdx.x];
-        if (threadIdx.x < 12) {
-            wl[TAB + 16 + threadIdx.x] = P.scale[threadIdx.x];
-            tab[32 + threadIdx.x] = (int)P.res[threadIdx.x];
-        }
-        if (threadIdx.x < 32) wl[TAB + 64 + threadIdx.x] = P.enc_a[threadIdx.x];
-        if (threadIdx.x == 0) tab[48] = 0;   // slice queue head (see the tile loop)
-    }
-    __syncthreads();
-    const int* offs = reinterpret_cast<const int*>(wl + TAB);
-    const float* lscale = wl + TAB + 16;
-    const int* lres = offs + 32;
-    const float* lenca = wl + TAB + 64;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int s = lane & 15, q = lane >> 4;
-    const float two_bound = 2.0f * P.bound;
-    const bool has_eye = P.eye != nullptr;
-    const float eye_v = has_eye ? P.eye[0] : 0.0f;
-    const float indq = P.ind_code ? P.ind_code[q] : 0.0f;
+    LzHeadCtx ctx;
+    lz_head_stage<TRAIN_UNC>(P, wl, LZ_WG, q, ctx);
+    __syncthreads();
 
     // Work distribution: the workgroup owns slices [slice_lo, slice_hi); its 16 waves pull 16-sample slices from a queue
     // in LDS (one ds_add_rtn per slice).  The waves that share a SIMD drift apart: some gather (texture-address bound)
     // while another feeds the matrix pipe, instead of all gathering and then all multiplying in lockstep.
-    int* queue = reinterpret_cast<int*>(wl + TAB) + 48;
+    int* queue = reinterpret_cast<int*>(wl + LzHeadLds<TRAIN_UNC>::TAB) + 48;
     for (;;) {
         int slice = 0;
         if (lane == 0) slice = atomicAdd(queue, 1);
@@ -184,202 +153,19 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
             break;
         }
         const uint32_t base = (slice_lo + (uint32_t)slice) * (LZ_T * 16);
-
-        // ---------------- gather: enc_x features f = 4i + q of sample (j, s) -> B operands (lz_head_gather.h) ----------------
-        float encx[LZ_T][9];
-#pragma unroll
-        for (int j = 0; j < LZ_T; j++) {
-            uint32_t m = base + j * 16 + s;
-            if (m >= Meff) m = Meff - 1;  // clamp: computed, never stored
-            lz_head_gather(P.emb, offs, lscale, lres, xyzs, m, q, P.bound, two_bound, encx[j]);
-            __builtin_amdgcn_sched_barrier(0);  // one tile's 36 reads in flight at a time: bounds the register footprint
-        }
-
-        // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
-        float att[LZ_T][8];   // chained layout: [t*4 + r] = feature 16t + 4q + r
-        {
-            lz_f4 acc1[4][LZ_T];
-#pragma unroll
-            for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-                for (int j = 0; j < LZ_T; j++) acc1[ft][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_A1, LZ_T>(wl, lane, encx, acc1);
-            float b2[LZ_T][16];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++)
-#pragma unroll
-                for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
-            lz_f4 acc2[2][LZ_T];
-#pragma unroll
-            for (int ft = 0; ft < 2; ft++)
-#pragma unroll
-                for (int j = 0; j < LZ_T; j++) acc2[ft][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_A2, LZ_T>(wl, lane, b2, acc2);
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++)
-#pragma unroll
-                for (int ft = 0; ft < 2; ft++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) att[j][4 * ft + r] = acc2[ft][j][r];
-        }
-        // ambient_aud = || att ||_2 : sum of squares in the lane-partial order (att is its own weight row), then sqrt
-        float ambaud[LZ_T];
-#pragma unroll
-        for (int j = 0; j < LZ_T; j++) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; k++) acc = lz_fmaf(att[j][k], att[j][k], acc);
-            acc += __shfl_xor(acc, 16, 64);
-            acc += __shfl_xor(acc, 32, 64);
-            ambaud[j] = sqrtf(acc);
-        }
-        // ---------------- eye attention: 36 -> 16 -> 1, sigmoid ----------------
-        float eyeatt[LZ_T];
-#pragma unroll
-        for (int j = 0; j < LZ_T; j++) eyeatt[j] = 0.0f;
-        if (has_eye) {
-            lz_f4 acce[1][LZ_T];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) acce[0][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_E1, LZ_T>(wl, lane, encx, acce);
-            float be[LZ_T][4];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) be[j][r] = lz_relu(acce[0][j][r]);
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) eyeatt[j] = lz_sigmoidf(lz_lane_dot<1>(wl + WV + LZ_WV_E2, q, be[j]));
-        }
-        // ---------------- uncertainty ----------------
-        float uncv[LZ_T];
-        if constexpr (TRAIN_UNC) {
-            lz_f4 accu[2][LZ_T];
-#pragma unroll
-            for (int ft = 0; ft < 2; ft++)
-#pragma unroll
-                for (int j = 0; j < LZ_T; j++) accu[ft][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_U1, LZ_T>(wl, lane, encx, accu);
-            float bu[LZ_T][8];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++)
-#pragma unroll
-                for (int ft = 0; ft < 2; ft++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) bu[j][4 * ft + r] = lz_relu(accu[ft][j][r]);
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) uncv[j] = lz_softplusf(lz_lane_dot<2>(wl + WV + LZ_WV_U2, q, bu[j]));
-        } else {
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) uncv[j] = lz_softplusf(0.0f);   // network.py:243-249, 278
-        }
-        // ---------------- sigma net: [enc_x 36 | enc_a * att 32 | eye * eye_att 1] -> 64 -> 64 -> 65 ----------------
-        float geo[LZ_T][16];
-        float sigma[LZ_T];
-        {
-            float b1[LZ_T][18];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) {
-#pragma unroll
-                for (int i = 0; i < 9; i++) b1[j][i] = encx[j][i];
-#pragma unroll
-                for (int t = 0; t < 2; t++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) b1[j][9 + 4 * t + r] = lenca[16 * t + 4 * q + r] * att[j][4 * t + r];
-                b1[j][17] = (has_eye && q == 0) ? eye_v * eyeatt[j] : 0.0f;
-            }
-            lz_f4 acc1[4][LZ_T];
-#pragma unroll
-            for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-                for (int j = 0; j < LZ_T; j++) acc1[ft][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_S1, LZ_T>(wl, lane, b1, acc1);
-            float b2[LZ_T][16];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++)
-#pragma unroll
-                for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
-            lz_f4 acc2[4][LZ_T];
-#pragma unroll
-            for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-                for (int j = 0; j < LZ_T; j++) acc2[ft][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_S2, LZ_T>(wl, lane, b2, acc2);
-            float b3[LZ_T][16];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++)
-#pragma unroll
-                for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) b3[j][4 * ft + r] = lz_relu(acc2[ft][j][r]);
-            lz_f4 acc3[4][LZ_T];
-#pragma unroll
-            for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-                for (int j = 0; j < LZ_T; j++) acc3[ft][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_S3, LZ_T>(wl, lane, b3, acc3);
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) {
-#pragma unroll
-                for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) geo[j][4 * ft + r] = acc3[ft][j][r];   // geo_feat, no activation (network.py:304)
-                sigma[j] = lz_expf(lz_lane_dot<4>(wl + WV + LZ_WV_SIG, q, b3[j]));     // row 0 of sigma_net.2 on the VALU
-            }
-        }
-        // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
-        float rgb[LZ_T][3];
-        {
-            float b1[LZ_T][21];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) {
-                // SH(4) of the view direction (constant per ray, recomputed per sample like the reference): this lane
-                // keeps components 4i + q
-                uint32_t m = base + j * 16 + s;
-                if (m >= Meff) m = Meff - 1;
-                float o[16];
-                lz_sh_eval(dirs[(size_t)m * 3], dirs[(size_t)m * 3 + 1], dirs[(size_t)m * 3 + 2], 4, o, nullptr, nullptr, nullptr);
-#pragma unroll
-                for (int i = 0; i < 4; i++) b1[j][i] = q == 0 ? o[4 * i] : (q == 1 ? o[4 * i + 1] : (q == 2 ? o[4 * i + 2] : o[4 * i + 3]));
-#pragma unroll
-                for (int k = 0; k < 16; k++) b1[j][4 + k] = geo[j][k];
-                b1[j][20] = indq;
-            }
-            lz_f4 acc1[4][LZ_T];
-#pragma unroll
-            for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-                for (int j = 0; j < LZ_T; j++) acc1[ft][j] = lz_f4{0, 0, 0, 0};
-            lz_layer<LZ_L_C1, LZ_T>(wl, lane, b1, acc1);
-            float b2[LZ_T][16];
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++)
-#pragma unroll
-                for (int ft = 0; ft < 4; ft++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++)
-#pragma unroll
-                for (int c = 0; c < 3; c++)   // colour_net.1 (64 -> 3) on the VALU; network.py:275
-                    rgb[j][c] = lz_sigmoidf(lz_lane_dot<4>(wl + WV + LZ_WV_C2 + 64 * c, q, b2[j])) * 1.002f - 0.001f;
-        }
-        // ---------------- store (lanes q == 0 own sample (j, s)) ----------------
-        if (q == 0) {
-#pragma unroll
-            for (int j = 0; j < LZ_T; j++) {
-                const uint32_t m = base + j * 16 + s;
-                if (m < Meff) {
-                    sigmas[m] = sigma[j];
-                    rgbs[(size_t)m * 3] = rgb[j][0]; rgbs[(size_t)m * 3 + 1] = rgb[j][1]; rgbs[(size_t)m * 3 + 2] = rgb[j][2];
-                    amb_aud[m] = ambaud[j];
-                    if (amb_eye) amb_eye[m] = eyeatt[j];
-                    unc_out[m] = uncv[j];
-                }
-            }
+        uint32_t m = base + s;
+        if (m >= Meff) m = Meff - 1;  // clamp: computed, never stored
+        const float px = xyzs[(size_t)m * 3], py = xyzs[(size_t)m * 3 + 1], pz = xyzs[(size_t)m * 3 + 2];
+        LzHeadOut o;
+        lz_head_slice<TRAIN_UNC>(ctx, lane, px, py, pz,
+                                 [&](float& dx, float& dy, float& dz) { dx = dirs[(size_t)m * 3]; dy = dirs[(size_t)m * 3 + 1]; dz = dirs[(size_t)m * 3 + 2]; }, o);
+        // ---------------- store (lanes q == 0 own sample s) ----------------
+        if (q == 0 && base + s < Meff) {
+            sigmas[m] = o.sigma;
+            rgbs[(size_t)m * 3] = o.rgb[0]; rgbs[(size_t)m * 3 + 1] = o.rgb[1]; rgbs[(size_t)m * 3 + 2] = o.rgb[2];
+            amb_aud[m] = o.ambaud;
+            if (amb_eye) amb_eye[m] = o.eyeatt;
+            unc_out[m] = o.unc;
         }
     }
 }

@@ -156,7 +156,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 
         // =============================== forward (as lz_k_triplane_head<true>) ===============================
         float encx[9];
-        lz_head_gather(P.emb, offs, lscale, lres, xyzs, m, q, P.bound, two_bound, encx);
+        lz_head_gather(P.emb, offs, lscale, lres, xyzs[(size_t)m * 3], xyzs[(size_t)m * 3 + 1], xyzs[(size_t)m * 3 + 2], q, P.bound, two_bound, encx);
         // every per-sample input is loaded here, before the first dump store of the slice: a load issued after stores can only be waited
         // for once those stores have been acknowledged (one counter, in order), which under this kernel's write stream takes microseconds
         const float g_sig = A.g_sigma[row], g_aa = A.g_amb_aud[row], g_ae = A.g_amb_eye ? A.g_amb_eye[row] : 0.0f, g_un = A.g_unc[row];

@@ -18,27 +18,7 @@
 //     (texture-address rate) and the VALU work around them, not by the matrix pipe.
 //   * Same workgroup geometry and work distribution as lz_k_triplane_head (1024 threads, contiguous slice shares, LDS
 //     slice queue); the packed weights are 59 KB of LDS.
-#include <hip/hip_fp16.h>
-
-#include "lz_common.h"
-#include "lzzx_detmath.h"
-#include "lzzx_sh_eval.h"
-#include "lz_head_gather.h"
-
-typedef float lz_f4 __attribute__((ext_vector_type(4)));
-typedef _Float16 lz_h8 __attribute__((ext_vector_type(8)));
-
-enum { H_A1 = 0, H_A2, H_E1, H_E2, H_S1, H_S2, H_S3, H_C1, H_C2, H_COUNT };
-//                               A1 A2 E1 E2 S1 S2 S3 C1 C2
-constexpr int H_KS[H_COUNT] = {  2, 2, 2, 1, 3, 2, 2, 3, 2 };
-constexpr int H_NT[H_COUNT] = {  4, 2, 1, 1, 4, 4, 5, 4, 1 };
-constexpr int h_frag_base(int layer) {
-    int b = 0;
-    for (int i = 0; i < layer; i++) b += H_KS[i] * H_NT[i];
-    return b;
-}
-constexpr int H_FRAGS = h_frag_base(H_COUNT);  // 59
-static_assert(H_FRAGS * 64 * 16 == LZ_HEAD_PACKED_F16_BYTES, "packed size mismatch with the header");
+#include "lz_head_f16_slice.h"
 
 extern "C" uint32_t lz_head_packed_size_f16(void) { return (uint32_t)H_FRAGS * 64u * 16u; }
 
@@ -117,50 +97,14 @@ extern "C" int lz_head_pack_weights_f16(const float* aud0, const float* aud1, co
     LZ_CHECK_LAUNCH("head_pack_weights_f16");
     return LZ_OK;
 }
-
 // ---- the kernel ---------------------------------------------------------------------------------------
 #define H_WG 1024
-
-struct LzHead16Args {
-    const float* emb[3];
-    const int* offsets;
-    const lz_h8* packed;
-    const float* enc_a;
-    const float* ind_code;
-    const float* eye;
-    float bound;
-    float scale[12];
-    uint32_t res[12];
-};
-
-template <int LAYER>
-__device__ __forceinline__ void h_layer(const lz_h8* __restrict__ wl, int lane, const lz_h8 (&b)[H_KS[LAYER]], lz_f4 (&acc)[H_NT[LAYER]]) {
-    constexpr int KS = H_KS[LAYER], NT = H_NT[LAYER];
-    const lz_h8* frag = wl + h_frag_base(LAYER) * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-        for (int ft = 0; ft < NT; ft++) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag[(ks * NT + ft) * 64], b[ks], acc[ft], 0, 0, 0);
-}
-
-__device__ __forceinline__ _Float16 h_relu16(float v) { return (_Float16)(v > 0.0f ? v : 0.0f); }   // relu(half(v)) == half(relu(v))
-
-// two D tiles of a layer -> one B operand of the next (ReLU + round to half = the half output of an autocast Linear + relu)
-__device__ __forceinline__ lz_h8 h_pair(const lz_f4& lo, const lz_f4& hi, bool relu) {
-    lz_h8 b;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        b[r] = relu ? h_relu16(lo[r]) : (_Float16)lo[r];
-        b[4 + r] = relu ? h_relu16(hi[r]) : (_Float16)hi[r];
-    }
-    return b;
-}
 
 __global__ void __launch_bounds__(H_WG, H_WG / 256)
 lz_k_triplane_head_f16(LzHead16Args P, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
                        const int* __restrict__ count, float* __restrict__ sigmas, float* __restrict__ rgbs,
                        float* __restrict__ amb_aud, float* __restrict__ amb_eye, float* __restrict__ unc_out) {
-    __shared__ lz_h8 wl[H_FRAGS * 64 + 24];   // packed A fragments, then 96 words: level table (64), enc_a (32)
+    __shared__ lz_h8 wl[LZ_HEAD16_LDS_H8];   // packed A fragments, then 96 words: level table (64), enc_a (32)
     uint32_t Meff = M;
     if (count) {
         const int c = *count;
@@ -170,32 +114,12 @@ lz_k_triplane_head_f16(LzHead16Args P, const float* __restrict__ xyzs, const flo
     const uint32_t slice_lo = (uint32_t)(((uint64_t)n_slices * blockIdx.x) / gridDim.x);
     const uint32_t slice_hi = (uint32_t)(((uint64_t)n_slices * (blockIdx.x + 1)) / gridDim.x);
     if (slice_lo >= slice_hi) return;
-
-    float* tabf = reinterpret_cast<float*>(wl + H_FRAGS * 64);
-    int* tab = reinterpret_cast<int*>(tabf);
-    {
-        for (int i = threadIdx.x; i < H_FRAGS * 64; i += H_WG) wl[i] = P.packed[i];
-        if (threadIdx.x < 13) tab[threadIdx.x] = P.offsets[threadIdx.x];
-        if (threadIdx.x < 12) {
-            tabf[16 + threadIdx.x] = P.scale[threadIdx.x];
-            tab[32 + threadIdx.x] = (int)P.res[threadIdx.x];
-        }
-        if (threadIdx.x < 32) tabf[64 + threadIdx.x] = (float)(_Float16)P.enc_a[threadIdx.x];   // enc_a is half under autocast
-        if (threadIdx.x == 0) tab[48] = 0;   // slice queue head
-    }
+    LzHead16Ctx ctx;
+    lz_head16_stage(P, wl, H_WG, ctx);
     __syncthreads();
-    const int* offs = tab;
-    const float* lscale = tabf + 16;
-    const int* lres = tab + 32;
-    const float* lenca = tabf + 64;
-
     const int lane = threadIdx.x & 63;
     const int s = lane & 15, q = lane >> 4;
-    const float two_bound = 2.0f * P.bound;
-    const bool has_eye = P.eye != nullptr;
-    const float eye_v = has_eye ? P.eye[0] : 0.0f;
-    const float unc_const = lz_softplusf(0.0f);   // test mode (network.py:243-249, 278)
-    int* queue = tab + 48;
+    int* queue = reinterpret_cast<int*>(wl + H_FRAGS * 64) + 48;
     for (;;) {
         int slice = 0;
         if (lane == 0) slice = atomicAdd(queue, 1);
@@ -204,99 +128,17 @@ lz_k_triplane_head_f16(LzHead16Args P, const float* __restrict__ xyzs, const flo
         const uint32_t base = (slice_lo + (uint32_t)slice) * 16;
         uint32_t m = base + s;
         if (m >= Meff) m = Meff - 1;  // clamp: computed, never stored
-
-        // ---------------- gather (f32, the same code as lz_k_triplane_head: lz_head_gather.h): lane q holds enc_x features 4 i + q
-        float encx[9];
-        lz_head_gather(P.emb, offs, lscale, lres, xyzs, m, q, P.bound, two_bound, encx);
-        // enc_x as two half B operands (slot j of k-step ks <-> i = 8 ks + j); slot (1, q = 0, 1) is filled in for the sigma net
-        lz_h8 bx[2];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { bx[0][j] = (_Float16)encx[j]; bx[1][j] = (_Float16)0.0f; }
-        bx[1][0] = (_Float16)encx[8];
-
-        // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
-        _Float16 att16[8];   // [4 t + r] = feature 16 t + 4 q + r
-        {
-            lz_f4 a1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_A1>(wl, lane, bx, a1);
-            const lz_h8 b2[2] = {h_pair(a1[0], a1[1], true), h_pair(a1[2], a1[3], true)};
-            lz_f4 a2[2] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_A2>(wl, lane, b2, a2);
-#pragma unroll
-            for (int r = 0; r < 4; r++) { att16[r] = (_Float16)a2[0][r]; att16[4 + r] = (_Float16)a2[1][r]; }
-        }
-        // ambient_aud = || att ||_2 in f32 (norm is an autocast-to-f32 op): lane partial over its 8 features, then over q
-        float ss = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; k++) ss = lz_fmaf((float)att16[k], (float)att16[k], ss);
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float ambaud = sqrtf(ss);
-        // ---------------- eye attention: 36 -> 16 -> 1, sigmoid (half) ----------------
-        float eyeatt = 0.0f;
-        if (has_eye) {
-            lz_f4 e1[1] = {lz_f4{0, 0, 0, 0}};
-            h_layer<H_E1>(wl, lane, bx, e1);
-            const lz_f4 z = lz_f4{0, 0, 0, 0};
-            const lz_h8 be[1] = {h_pair(e1[0], z, true)};
-            lz_f4 e2[1] = {lz_f4{0, 0, 0, 0}};
-            h_layer<H_E2>(wl, lane, be, e2);
-            eyeatt = (float)(_Float16)lz_sigmoidf((float)(_Float16)e2[0][0]);   // valid on lanes q == 0
-        }
-        // ---------------- sigma net: [enc_x 36 | enc_a * att 32 | eye * eye_att 1] -> 64 -> 64 -> 65 ----------------
-        lz_h8 geo16[2];
-        float sigma;
-        {
-            lz_h8 b1[3];
-            b1[0] = bx[0];
-            b1[1] = bx[1];
-            b1[1][1] = (has_eye && q == 0) ? (_Float16)(eye_v * eyeatt) : (_Float16)0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; j++) b1[2][j] = (_Float16)(lenca[16 * (j >> 2) + 4 * q + (j & 3)] * (float)att16[j]);
-            lz_f4 s1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_S1>(wl, lane, b1, s1);
-            const lz_h8 b2[2] = {h_pair(s1[0], s1[1], true), h_pair(s1[2], s1[3], true)};
-            lz_f4 s2[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_S2>(wl, lane, b2, s2);
-            const lz_h8 b3[2] = {h_pair(s2[0], s2[1], true), h_pair(s2[2], s2[3], true)};
-            lz_f4 s3[5] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_S3>(wl, lane, b3, s3);
-            geo16[0] = h_pair(s3[0], s3[1], false);   // geo_feat, no activation (network.py:304)
-            geo16[1] = h_pair(s3[2], s3[3], false);
-            sigma = lz_expf((float)(_Float16)s3[4][0]);   // trunc_exp casts its half input to f32; lanes q == 0
-        }
-        // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
-        float rgb[3];
-        {
-            float o[16];
-            lz_sh_eval(dirs[(size_t)m * 3], dirs[(size_t)m * 3 + 1], dirs[(size_t)m * 3 + 2], 4, o, nullptr, nullptr, nullptr);
-            lz_h8 b1[3];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                b1[0][j] = (_Float16)(q == 0 ? o[j] : (q == 1 ? o[4 + j] : (q == 2 ? o[8 + j] : o[12 + j])));   // SH 4 q + j
-                b1[0][4 + j] = (q == 0 && P.ind_code) ? (_Float16)P.ind_code[j] : (_Float16)0.0f;
-            }
-            b1[1] = geo16[0];
-            b1[2] = geo16[1];
-            lz_f4 c1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_C1>(wl, lane, b1, c1);
-            const lz_h8 b2[2] = {h_pair(c1[0], c1[1], true), h_pair(c1[2], c1[3], true)};
-            lz_f4 c2[1] = {lz_f4{0, 0, 0, 0}};
-            h_layer<H_C2>(wl, lane, b2, c2);
-#pragma unroll
-            for (int c = 0; c < 3; c++) {   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
-                const _Float16 sg = (_Float16)lz_sigmoidf((float)(_Float16)c2[0][c]);
-                const _Float16 t1 = (_Float16)((float)sg * 1.002f);
-                rgb[c] = (float)(_Float16)((float)t1 - 0.001f);
-            }
-        }
+        const float px = xyzs[(size_t)m * 3], py = xyzs[(size_t)m * 3 + 1], pz = xyzs[(size_t)m * 3 + 2];
+        LzHead16Out o;
+        lz_head16_slice(ctx, lane, px, py, pz,
+                        [&](float& dx, float& dy, float& dz) { dx = dirs[(size_t)m * 3]; dy = dirs[(size_t)m * 3 + 1]; dz = dirs[(size_t)m * 3 + 2]; }, o);
         // ---------------- store (lanes q == 0 own sample s) ----------------
         if (q == 0 && base + s < Meff) {
-            sigmas[m] = sigma;
-            rgbs[(size_t)m * 3] = rgb[0]; rgbs[(size_t)m * 3 + 1] = rgb[1]; rgbs[(size_t)m * 3 + 2] = rgb[2];
-            amb_aud[m] = ambaud;
-            if (amb_eye) amb_eye[m] = eyeatt;
-            unc_out[m] = unc_const;
+            sigmas[m] = o.sigma;
+            rgbs[(size_t)m * 3] = o.rgb[0]; rgbs[(size_t)m * 3 + 1] = o.rgb[1]; rgbs[(size_t)m * 3 + 2] = o.rgb[2];
+            amb_aud[m] = o.ambaud;
+            if (amb_eye) amb_eye[m] = o.eyeatt;
+            unc_out[m] = o.unc;
         }
     }
 }

@@ -1,0 +1,204 @@
+// lz_head_f16_slice.h -- the f16 fused triplane head (v_mfma_f32_16x16x32_f16, torch-autocast rounding) for ONE 16-sample slice of a
+// wave, shared by the stand-alone kernel (lz_head_f16.hip) and the fused frame kernel (lz_frame.hip).  See lz_head_f16.hip for
+// the rounding sequence it reproduces and the operand layout.
+#ifndef LZ_HEAD_F16_SLICE_H
+#define LZ_HEAD_F16_SLICE_H
+#include <hip/hip_fp16.h>
+
+#include "lz_common.h"
+#include "lzzx_detmath.h"
+#include "lzzx_sh_eval.h"
+#include "lz_head_gather.h"
+
+#ifndef LZ_HEAD_LAYERS_H
+typedef float lz_f4 __attribute__((ext_vector_type(4)));
+#endif
+typedef _Float16 lz_h8 __attribute__((ext_vector_type(8)));
+
+enum { H_A1 = 0, H_A2, H_E1, H_E2, H_S1, H_S2, H_S3, H_C1, H_C2, H_COUNT };
+//                               A1 A2 E1 E2 S1 S2 S3 C1 C2
+constexpr int H_KS[H_COUNT] = {  2, 2, 2, 1, 3, 2, 2, 3, 2 };
+constexpr int H_NT[H_COUNT] = {  4, 2, 1, 1, 4, 4, 5, 4, 1 };
+constexpr int h_frag_base(int layer) {
+    int b = 0;
+    for (int i = 0; i < layer; i++) b += H_KS[i] * H_NT[i];
+    return b;
+}
+constexpr int H_FRAGS = h_frag_base(H_COUNT);  // 59
+static_assert(H_FRAGS * 64 * 16 == LZ_HEAD_PACKED_F16_BYTES, "packed size mismatch with the header");
+
+struct LzHead16Args {
+    const float* emb[3];
+    const int* offsets;
+    const lz_h8* packed;
+    const float* enc_a;
+    const float* ind_code;
+    const float* eye;
+    float bound;
+    float scale[12];
+    uint32_t res[12];
+};
+
+template <int LAYER>
+__device__ __forceinline__ void h_layer(const lz_h8* __restrict__ wl, int lane, const lz_h8 (&b)[H_KS[LAYER]], lz_f4 (&acc)[H_NT[LAYER]]) {
+    constexpr int KS = H_KS[LAYER], NT = H_NT[LAYER];
+    const lz_h8* frag = wl + h_frag_base(LAYER) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int ft = 0; ft < NT; ft++) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag[(ks * NT + ft) * 64], b[ks], acc[ft], 0, 0, 0);
+}
+
+__device__ __forceinline__ _Float16 h_relu16(float v) { return (_Float16)(v > 0.0f ? v : 0.0f); }   // relu(half(v)) == half(relu(v))
+
+// two D tiles of a layer -> one B operand of the next (ReLU + round to half = the half output of an autocast Linear + relu)
+__device__ __forceinline__ lz_h8 h_pair(const lz_f4& lo, const lz_f4& hi, bool relu) {
+    lz_h8 b;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        b[r] = relu ? h_relu16(lo[r]) : (_Float16)lo[r];
+        b[4 + r] = relu ? h_relu16(hi[r]) : (_Float16)hi[r];
+    }
+    return b;
+}
+
+struct LzHead16Ctx {
+    const lz_h8* wl;        // LDS: packed A fragments
+    const int* offs;        // LDS: level offsets [13]
+    const float* lscale;    // LDS: level scale [12]
+    const int* lres;        // LDS: level resolution [12]
+    const float* lenca;     // LDS: enc_a rounded to half [32]
+    const float* emb[3];
+    const float* ind_code;
+    float bound, two_bound, eye_v, unc_const;
+    bool has_eye;
+};
+
+struct LzHead16Out {
+    float sigma, rgb[3], ambaud, eyeatt, unc;   // sigma / eyeatt are valid on lanes q == 0 only
+};
+
+constexpr int LZ_HEAD16_LDS_H8 = H_FRAGS * 64 + 24;   // lz_h8 elements: fragments, then 96 words (level table 64, enc_a 32)
+
+// stage weights + tables into LDS (all threads; caller synchronises afterwards) and fill the context
+__device__ __forceinline__ void lz_head16_stage(const LzHead16Args& P, lz_h8* wl, uint32_t n_threads, LzHead16Ctx& hc) {
+    float* tabf = reinterpret_cast<float*>(wl + H_FRAGS * 64);
+    int* tab = reinterpret_cast<int*>(tabf);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)H_FRAGS * 64; i += n_threads) wl[i] = P.packed[i];
+    if (threadIdx.x < 13) tab[threadIdx.x] = P.offsets[threadIdx.x];
+    if (threadIdx.x < 12) {
+        tabf[16 + threadIdx.x] = P.scale[threadIdx.x];
+        tab[32 + threadIdx.x] = (int)P.res[threadIdx.x];
+    }
+    if (threadIdx.x < 32) tabf[64 + threadIdx.x] = (float)(_Float16)P.enc_a[threadIdx.x];   // enc_a is half under autocast
+    if (threadIdx.x == 0) tab[48] = 0;   // slice queue head of the stand-alone kernel
+    hc.wl = wl;
+    hc.offs = tab;
+    hc.lscale = tabf + 16;
+    hc.lres = tab + 32;
+    hc.lenca = tabf + 64;
+    hc.emb[0] = P.emb[0]; hc.emb[1] = P.emb[1]; hc.emb[2] = P.emb[2];
+    hc.ind_code = P.ind_code;
+    hc.bound = P.bound;
+    hc.two_bound = 2.0f * P.bound;
+    hc.has_eye = P.eye != nullptr;
+    hc.eye_v = hc.has_eye ? P.eye[0] : 0.0f;
+    hc.unc_const = lz_softplusf(0.0f);   // test mode (network.py:243-249, 278)
+}
+
+template <typename DirFn>
+__device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane, float px, float py, float pz, DirFn dirfn, LzHead16Out& out) {
+    const int q = lane >> 4;
+    // ---------------- gather (f32, the same code as lz_k_triplane_head: lz_head_gather.h): lane q holds enc_x features 4 i + q
+    float encx[9];
+    lz_head_gather(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx);
+    // enc_x as two half B operands (slot j of k-step ks <-> i = 8 ks + j); slot (1, q = 0, 1) is filled in for the sigma net
+    lz_h8 bx[2];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { bx[0][j] = (_Float16)encx[j]; bx[1][j] = (_Float16)0.0f; }
+    bx[1][0] = (_Float16)encx[8];
+
+    // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
+    _Float16 att16[8];   // [4 t + r] = feature 16 t + 4 q + r
+    {
+        lz_f4 a1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
+        h_layer<H_A1>(hc.wl, lane, bx, a1);
+        const lz_h8 b2[2] = {h_pair(a1[0], a1[1], true), h_pair(a1[2], a1[3], true)};
+        lz_f4 a2[2] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
+        h_layer<H_A2>(hc.wl, lane, b2, a2);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { att16[r] = (_Float16)a2[0][r]; att16[4 + r] = (_Float16)a2[1][r]; }
+    }
+    // ambient_aud = || att ||_2 in f32 (norm is an autocast-to-f32 op): lane partial over its 8 features, then over q
+    float ss = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ss = lz_fmaf((float)att16[k], (float)att16[k], ss);
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float ambaud = sqrtf(ss);
+    // ---------------- eye attention: 36 -> 16 -> 1, sigmoid (half) ----------------
+    float eyeatt = 0.0f;
+    if (hc.has_eye) {
+        lz_f4 e1[1] = {lz_f4{0, 0, 0, 0}};
+        h_layer<H_E1>(hc.wl, lane, bx, e1);
+        const lz_f4 z = lz_f4{0, 0, 0, 0};
+        const lz_h8 be[1] = {h_pair(e1[0], z, true)};
+        lz_f4 e2[1] = {lz_f4{0, 0, 0, 0}};
+        h_layer<H_E2>(hc.wl, lane, be, e2);
+        eyeatt = (float)(_Float16)lz_sigmoidf((float)(_Float16)e2[0][0]);   // valid on lanes q == 0
+    }
+    // ---------------- sigma net: [enc_x 36 | enc_a * att 32 | eye * eye_att 1] -> 64 -> 64 -> 65 ----------------
+    lz_h8 geo16[2];
+    float sigma;
+    {
+        lz_h8 b1[3];
+        b1[0] = bx[0];
+        b1[1] = bx[1];
+        b1[1][1] = (hc.has_eye && q == 0) ? (_Float16)(hc.eye_v * eyeatt) : (_Float16)0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) b1[2][j] = (_Float16)(hc.lenca[16 * (j >> 2) + 4 * q + (j & 3)] * (float)att16[j]);
+        lz_f4 s1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
+        h_layer<H_S1>(hc.wl, lane, b1, s1);
+        const lz_h8 b2[2] = {h_pair(s1[0], s1[1], true), h_pair(s1[2], s1[3], true)};
+        lz_f4 s2[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
+        h_layer<H_S2>(hc.wl, lane, b2, s2);
+        const lz_h8 b3[2] = {h_pair(s2[0], s2[1], true), h_pair(s2[2], s2[3], true)};
+        lz_f4 s3[5] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
+        h_layer<H_S3>(hc.wl, lane, b3, s3);
+        geo16[0] = h_pair(s3[0], s3[1], false);   // geo_feat, no activation (network.py:304)
+        geo16[1] = h_pair(s3[2], s3[3], false);
+        sigma = lz_expf((float)(_Float16)s3[4][0]);   // trunc_exp casts its half input to f32; lanes q == 0
+    }
+    // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
+    float rgb[3];
+    {
+        float o[16];
+        float ddx, ddy, ddz;
+        dirfn(ddx, ddy, ddz);
+        lz_sh_eval(ddx, ddy, ddz, 4, o, nullptr, nullptr, nullptr);
+        lz_h8 b1[3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            b1[0][j] = (_Float16)(q == 0 ? o[j] : (q == 1 ? o[4 + j] : (q == 2 ? o[8 + j] : o[12 + j])));   // SH 4 q + j
+            b1[0][4 + j] = (q == 0 && hc.ind_code) ? (_Float16)hc.ind_code[j] : (_Float16)0.0f;
+        }
+        b1[1] = geo16[0];
+        b1[2] = geo16[1];
+        lz_f4 c1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
+        h_layer<H_C1>(hc.wl, lane, b1, c1);
+        const lz_h8 b2[2] = {h_pair(c1[0], c1[1], true), h_pair(c1[2], c1[3], true)};
+        lz_f4 c2[1] = {lz_f4{0, 0, 0, 0}};
+        h_layer<H_C2>(hc.wl, lane, b2, c2);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
+            const _Float16 sg = (_Float16)lz_sigmoidf((float)(_Float16)c2[0][c]);
+            const _Float16 t1 = (_Float16)((float)sg * 1.002f);
+            rgb[c] = (float)(_Float16)((float)t1 - 0.001f);
+        }
+    }    out.sigma = sigma;
+    out.rgb[0] = rgb[0]; out.rgb[1] = rgb[1]; out.rgb[2] = rgb[2];
+    out.ambaud = ambaud;
+    out.eyeatt = eyeatt;
+    out.unc = hc.unc_const;
+}
+#endif

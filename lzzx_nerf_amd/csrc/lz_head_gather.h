@@ -8,9 +8,9 @@
 #include "lz_common.h"
 #include "lzzx_detmath.h"
 
-// offs / lscale / lres: the per-level table in LDS ([0,13) offsets, scale, resolution); emb: the three planes' tables
+// offs / lscale / lres: the per-level table in LDS ([0,13) offsets, scale, resolution); emb: the three planes' tables; (px, py, pz): the sample
 __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], const int* __restrict__ offs, const float* __restrict__ lscale,
-                                               const int* __restrict__ lres, const float* __restrict__ xyzs, uint32_t m, int q, float bound,
+                                               const int* __restrict__ lres, float px, float py, float pz, int q, float bound,
                                                float two_bound, float (&encx)[9]) {
     // the three grid levels this lane touches (level = 4 m + q), gridencoder.cu:124-126; rebuilt per slice from LDS so that they
     // do not occupy registers during the matrix phase
@@ -26,7 +26,6 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
         lv_stride[mrec] = (uint32_t)lres[level] + 1u;
         lv_dense[mrec] = lv_stride[mrec] <= lv_hs[mrec] && lv_stride[mrec] * lv_stride[mrec] <= lv_hs[mrec];
     }
-    const float px = xyzs[(size_t)m * 3], py = xyzs[(size_t)m * 3 + 1], pz = xyzs[(size_t)m * 3 + 2];
     const float x01 = (px + bound) / two_bound, y01 = (py + bound) / two_bound, z01 = (pz + bound) / two_bound;
     // Branch-free: out-of-range coordinates are clamped for ADDRESSING only and the feature is zeroed by a select
     // (gridencoder.cu:98-122), so all 36 gathers of a sample are independent loads.  Two passes so that the 36 table reads are IN

@@ -1,0 +1,255 @@
+// lz_head_slice.h -- the f32 fused triplane head for ONE 16-sample slice of a wave (v_mfma_f32_16x16x4_f32), shared by the stand-alone
+// head kernel (lz_head.hip: lz_k_triplane_head) and the fused frame kernel (lz_frame.hip: lz_k_frame), so that both evaluate
+// NeRFNetwork.forward (nerf_triplane/network.py:252-311) with the same instruction sequence, bit for bit.  Lane (s = lane & 15,
+// q = lane >> 4) owns sample s and a quarter of its features; see lz_head.hip for the layer chaining and the summation orders.
+#ifndef LZ_HEAD_SLICE_H
+#define LZ_HEAD_SLICE_H
+#include "lz_common.h"
+#include "lzzx_detmath.h"
+#include "lzzx_sh_eval.h"
+#include "lz_head_gather.h"
+#include "lz_head_layers.h"
+
+#define LZ_T 1             // sample tiles (of 16) per wave pass
+
+// per-workgroup context: the packed weights and small tables staged in LDS (lz_head_stage), per-launch constants
+struct LzHeadCtx {
+    const float* wl;        // LDS: packed A fragments, then the VALU-layer rows
+    const int* offs;        // LDS: level offsets [13]
+    const float* lscale;    // LDS: level scale [12]
+    const int* lres;        // LDS: level resolution [12]
+    const float* lenca;     // LDS: enc_a [32]
+    const float* emb[3];    // the three planes' tables (global)
+    float bound, two_bound, eye_v, indq;
+    bool has_eye;
+};
+
+struct LzHeadOut {
+    float sigma, rgb[3], ambaud, eyeatt, unc;   // every lane of a sample ends with the same bits
+};
+
+// LDS floats the stage needs: fragments + VALU rows + 96 words (level table 64, enc_a 32)
+template <bool TRAIN_UNC>
+struct LzHeadLds {
+    static constexpr int NFRAG = TRAIN_UNC ? LZ_FRAGS_ALL : LZ_FRAGS_INFER;
+    static constexpr int WV = NFRAG * 64, TAB = WV + LZ_WV_FLOATS, FLOATS = TAB + 96;
+};
+
+// stage weights + tables into LDS (all threads of the workgroup; caller synchronises afterwards) and fill the context
+template <bool TRAIN_UNC>
+__device__ __forceinline__ void lz_head_stage(const LzHeadArgs& P, float* wl, uint32_t n_threads, int q, LzHeadCtx& hc) {
+    using L = LzHeadLds<TRAIN_UNC>;
+    const float4* src = reinterpret_cast<const float4*>(P.packed);
+    float4* dst = reinterpret_cast<float4*>(wl);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)L::NFRAG * 16; i += n_threads) dst[i] = src[i];   // 16 B per lane per step, coalesced
+    if (threadIdx.x < LZ_WV_FLOATS) wl[L::WV + threadIdx.x] = P.packed[LZ_FRAGS_ALL * 64 + threadIdx.x];
+    // per-level table (indexed per lane in the gather): [0,13) offsets, [16,28) scale, [32,44) resolution
+    int* tab = reinterpret_cast<int*>(wl + L::TAB);
+    if (threadIdx.x < 13) tab[threadIdx.x] = P.offsets[threadIdx.x];
+    if (threadIdx.x < 12) {
+        wl[L::TAB + 16 + threadIdx.x] = P.scale[threadIdx.x];
+        tab[32 + threadIdx.x] = (int)P.res[threadIdx.x];
+    }
+    if (threadIdx.x < 32) wl[L::TAB + 64 + threadIdx.x] = P.enc_a[threadIdx.x];
+    if (threadIdx.x == 0) tab[48] = 0;   // slice queue head of the stand-alone kernel
+    hc.wl = wl;
+    hc.offs = reinterpret_cast<const int*>(wl + L::TAB);
+    hc.lscale = wl + L::TAB + 16;
+    hc.lres = hc.offs + 32;
+    hc.lenca = wl + L::TAB + 64;
+    hc.emb[0] = P.emb[0]; hc.emb[1] = P.emb[1]; hc.emb[2] = P.emb[2];
+    hc.bound = P.bound;
+    hc.two_bound = 2.0f * P.bound;
+    hc.has_eye = P.eye != nullptr;
+    hc.eye_v = hc.has_eye ? P.eye[0] : 0.0f;
+    hc.indq = P.ind_code ? P.ind_code[q] : 0.0f;
+}
+
+// one slice: (px, py, pz) = this lane's sample position, dirfn(dx, dy, dz) yields its view direction when the colour net needs it
+template <bool TRAIN_UNC, typename DirFn>
+__device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, float px, float py, float pz, DirFn dirfn, LzHeadOut& out) {
+    constexpr int WV = LzHeadLds<TRAIN_UNC>::WV;
+    const int q = lane >> 4;
+    // ---------------- gather: enc_x features f = 4i + q of sample s -> B operands (lz_head_gather.h) ----------------
+    float encx[LZ_T][9];
+    lz_head_gather(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx[0]);
+    __builtin_amdgcn_sched_barrier(0);  // the tile's 36 reads in flight at a time: bounds the register footprint
+
+    // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
+    float att[LZ_T][8];   // chained layout: [t*4 + r] = feature 16t + 4q + r
+    {
+        lz_f4 acc1[4][LZ_T];
+#pragma unroll
+        for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) acc1[ft][j] = lz_f4{0, 0, 0, 0};
+        lz_layer<LZ_L_A1, LZ_T>(hc.wl, lane, encx, acc1);
+        float b2[LZ_T][16];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
+        lz_f4 acc2[2][LZ_T];
+#pragma unroll
+        for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) acc2[ft][j] = lz_f4{0, 0, 0, 0};
+        lz_layer<LZ_L_A2, LZ_T>(hc.wl, lane, b2, acc2);
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) att[j][4 * ft + r] = acc2[ft][j][r];
+    }
+    // ambient_aud = || att ||_2 : sum of squares in the lane-partial order (att is its own weight row), then sqrt
+    float ambaud[LZ_T];
+#pragma unroll
+    for (int j = 0; j < LZ_T; j++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc = lz_fmaf(att[j][k], att[j][k], acc);
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        ambaud[j] = sqrtf(acc);
+    }
+    // ---------------- eye attention: 36 -> 16 -> 1, sigmoid ----------------
+    float eyeatt[LZ_T];
+#pragma unroll
+    for (int j = 0; j < LZ_T; j++) eyeatt[j] = 0.0f;
+    if (hc.has_eye) {
+        lz_f4 acce[1][LZ_T];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++) acce[0][j] = lz_f4{0, 0, 0, 0};
+        lz_layer<LZ_L_E1, LZ_T>(hc.wl, lane, encx, acce);
+        float be[LZ_T][4];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) be[j][r] = lz_relu(acce[0][j][r]);
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++) eyeatt[j] = lz_sigmoidf(lz_lane_dot<1>(hc.wl + WV + LZ_WV_E2, q, be[j]));
+    }
+    // ---------------- uncertainty ----------------
+    float uncv[LZ_T];
+    if constexpr (TRAIN_UNC) {
+        lz_f4 accu[2][LZ_T];
+#pragma unroll
+        for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) accu[ft][j] = lz_f4{0, 0, 0, 0};
+        lz_layer<LZ_L_U1, LZ_T>(hc.wl, lane, encx, accu);
+        float bu[LZ_T][8];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) bu[j][4 * ft + r] = lz_relu(accu[ft][j][r]);
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++) uncv[j] = lz_softplusf(lz_lane_dot<2>(hc.wl + WV + LZ_WV_U2, q, bu[j]));
+    } else {
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++) uncv[j] = lz_softplusf(0.0f);   // network.py:243-249, 278
+    }
+    // ---------------- sigma net: [enc_x 36 | enc_a * att 32 | eye * eye_att 1] -> 64 -> 64 -> 65 ----------------
+    float geo[LZ_T][16];
+    float sigma[LZ_T];
+    {
+        float b1[LZ_T][18];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) b1[j][i] = encx[j][i];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) b1[j][9 + 4 * t + r] = hc.lenca[16 * t + 4 * q + r] * att[j][4 * t + r];
+            b1[j][17] = (hc.has_eye && q == 0) ? hc.eye_v * eyeatt[j] : 0.0f;
+        }
+        lz_f4 acc1[4][LZ_T];
+#pragma unroll
+        for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) acc1[ft][j] = lz_f4{0, 0, 0, 0};
+        lz_layer<LZ_L_S1, LZ_T>(hc.wl, lane, b1, acc1);
+        float b2[LZ_T][16];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
+        lz_f4 acc2[4][LZ_T];
+#pragma unroll
+        for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) acc2[ft][j] = lz_f4{0, 0, 0, 0};
+        lz_layer<LZ_L_S2, LZ_T>(hc.wl, lane, b2, acc2);
+        float b3[LZ_T][16];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) b3[j][4 * ft + r] = lz_relu(acc2[ft][j][r]);
+        lz_f4 acc3[4][LZ_T];
+#pragma unroll
+        for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) acc3[ft][j] = lz_f4{0, 0, 0, 0};
+        lz_layer<LZ_L_S3, LZ_T>(hc.wl, lane, b3, acc3);
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) geo[j][4 * ft + r] = acc3[ft][j][r];   // geo_feat, no activation (network.py:304)
+            sigma[j] = lz_expf(lz_lane_dot<4>(hc.wl + WV + LZ_WV_SIG, q, b3[j]));     // row 0 of sigma_net.2 on the VALU
+        }
+    }
+    // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
+    float rgb[LZ_T][3];
+    {
+        float b1[LZ_T][21];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++) {
+            // SH(4) of the view direction (constant per ray, recomputed per sample like the reference): this lane
+            // keeps components 4i + q
+            float ddx, ddy, ddz;
+            dirfn(ddx, ddy, ddz);
+            float o[16];
+            lz_sh_eval(ddx, ddy, ddz, 4, o, nullptr, nullptr, nullptr);
+#pragma unroll
+            for (int i = 0; i < 4; i++) b1[j][i] = q == 0 ? o[4 * i] : (q == 1 ? o[4 * i + 1] : (q == 2 ? o[4 * i + 2] : o[4 * i + 3]));
+#pragma unroll
+            for (int k = 0; k < 16; k++) b1[j][4 + k] = geo[j][k];
+            b1[j][20] = hc.indq;
+        }
+        lz_f4 acc1[4][LZ_T];
+#pragma unroll
+        for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++) acc1[ft][j] = lz_f4{0, 0, 0, 0};
+        lz_layer<LZ_L_C1, LZ_T>(hc.wl, lane, b1, acc1);
+        float b2[LZ_T][16];
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)   // colour_net.1 (64 -> 3) on the VALU; network.py:275
+                rgb[j][c] = lz_sigmoidf(lz_lane_dot<4>(hc.wl + WV + LZ_WV_C2 + 64 * c, q, b2[j])) * 1.002f - 0.001f;
+    }    out.sigma = sigma[0];
+    out.rgb[0] = rgb[0][0]; out.rgb[1] = rgb[0][1]; out.rgb[2] = rgb[0][2];
+    out.ambaud = ambaud[0];
+    out.eyeatt = eyeatt[0];
+    out.unc = uncv[0];
+}
+#endif

@@ -15,43 +15,7 @@
 //     frame needs no host synchronisation (the reference's `rays_alive[rays_alive >= 0]`, renderer.py:542,
 //     costs one device->host sync per iteration: 38 % of its loop time).
 //   * all kernels launch on the caller's stream.
-#include "lz_common.h"
-#include "lzzx_detmath.h"
-#include <float.h>
-#include <math.h>
-
-#define LZ_SQRT3F 1.7320508075688772f
-#define LZ_RPIF 0.3183098861837907f
-
-// ------------------------------------------------------------------------------------------------
-// helpers (raymarching.cu:42-81)
-// ------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ uint32_t lz_expand_bits(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
-__host__ __device__ __forceinline__ uint32_t lz_morton3(uint32_t x, uint32_t y, uint32_t z) {
-    return lz_expand_bits(x) | (lz_expand_bits(y) << 1) | (lz_expand_bits(z) << 2);
-}
-__host__ __device__ __forceinline__ uint32_t lz_morton3_inv(uint32_t x) {
-    x = x & 0x49249249u;
-    x = (x | (x >> 2)) & 0xc30c30c3u;
-    x = (x | (x >> 4)) & 0x0f00f00fu;
-    x = (x | (x >> 8)) & 0xff0000ffu;
-    x = (x | (x >> 16)) & 0x0000ffffu;
-    return x;
-}
-__device__ __forceinline__ int lz_mip_from_pos(float x, float y, float z, float max_cascade) {
-    const float mx = lz_fmaxf(lz_fabsf(x), lz_fmaxf(lz_fabsf(y), lz_fabsf(z)));
-    return (int)lz_fminf(max_cascade - 1, lz_fmaxf(0, (float)lz_frexp_exp(mx)));
-}
-__device__ __forceinline__ int lz_mip_from_dt(float dt, float H, float max_cascade) {
-    const float mx = (float)((double)(dt * H) * 0.5);
-    return (int)lz_fminf(max_cascade - 1, lz_fmaxf(0, (float)lz_frexp_exp(mx)));
-}
+#include "lz_march.h"
 
 // ------------------------------------------------------------------------------------------------
 // ray generation (nerf_triplane/utils.py:226-312): B poses x N pixels.  `inds` (pixel = row * W + col, shared by the batch like the
@@ -117,23 +81,8 @@ lz_k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d
               float min_near, float* __restrict__ nears, float* __restrict__ fars) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const float ox = rays_o[(size_t)n * 3], oy = rays_o[(size_t)n * 3 + 1], oz = rays_o[(size_t)n * 3 + 2];
-    const float rdx = 1 / rays_d[(size_t)n * 3], rdy = 1 / rays_d[(size_t)n * 3 + 1], rdz = 1 / rays_d[(size_t)n * 3 + 2];
-    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
-    if (near > far) { const float c = near; near = far; far = c; }
-    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
-    if (near_y > far_y) { const float c = near_y; near_y = far_y; far_y = c; }
-    if (near > far_y || near_y > far) { nears[n] = fars[n] = FLT_MAX; return; }
-    if (near_y > near) near = near_y;
-    if (far_y < far) far = far_y;
-    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
-    if (near_z > far_z) { const float c = near_z; near_z = far_z; far_z = c; }
-    if (near > far_z || near_z > far) { nears[n] = fars[n] = FLT_MAX; return; }
-    if (near_z > near) near = near_z;
-    if (far_z < far) far = far_z;
-    if (near < min_near) near = min_near;
-    nears[n] = near;
-    fars[n] = far;
+    lz_near_far_ray(rays_o[(size_t)n * 3], rays_o[(size_t)n * 3 + 1], rays_o[(size_t)n * 3 + 2], rays_d[(size_t)n * 3], rays_d[(size_t)n * 3 + 1],
+                    rays_d[(size_t)n * 3 + 2], aabb, min_near, nears[n], fars[n]);
 }
 
 __global__ void __launch_bounds__(256)
@@ -471,54 +420,6 @@ extern "C" int lz_density_grid_update(const float* sigmas, float density_scale, 
 // ------------------------------------------------------------------------------------------------
 // marching
 // ------------------------------------------------------------------------------------------------
-struct LzMarch {
-    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
-    float bound, dt_gamma, dt_min, dt_max, rH, H3, fC, fH;
-    uint32_t H;
-    const uint8_t* grid;
-
-    __device__ __forceinline__ void init(const float* o, const float* d, float bound_, float dt_gamma_, uint32_t max_steps,
-                                         uint32_t C, uint32_t H_, const uint8_t* grid_) {
-        ox = o[0]; oy = o[1]; oz = o[2];
-        dx = d[0]; dy = d[1]; dz = d[2];
-        rdx = 1 / dx; rdy = 1 / dy; rdz = 1 / dz;
-        bound = bound_; dt_gamma = dt_gamma_;
-        rH = 1 / (float)H_;
-        H3 = (float)(H_ * H_ * H_);
-        H = H_; fC = (float)C; fH = (float)H_; grid = grid_;
-        dt_max = 2 * LZ_SQRT3F * (float)(1 << (C - 1)) / (float)H_;
-        dt_min = lz_fminf(dt_max, 2 * LZ_SQRT3F / (float)max_steps);
-    }
-
-    // 1: cell occupied (x, y, z, dt describe the sample, caller advances t by dt); 0: t advanced past the empty cell
-    __device__ __forceinline__ int probe(float& t, float& x, float& y, float& z, float& dt) const {
-        const float tt0 = t;
-        x = lz_clampf(lz_fmaf(tt0, dx, ox), -bound, bound);
-        y = lz_clampf(lz_fmaf(tt0, dy, oy), -bound, bound);
-        z = lz_clampf(lz_fmaf(tt0, dz, oz), -bound, bound);
-        dt = lz_clampf(tt0 * dt_gamma, dt_min, dt_max);
-        const int lp = lz_mip_from_pos(x, y, z, fC), ld = lz_mip_from_dt(dt, fH, fC);
-        const int level = lp > ld ? lp : ld;
-        const float mip_bound = lz_fminf(lz_scalbnf(1.0f, level), bound);
-        const float mip_rbound = 1 / mip_bound;
-        const float hm1 = (float)(H - 1);
-        const int nx = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
-        const int ny = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
-        const int nz = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
-        const uint32_t index = (uint32_t)((float)level * H3 + (float)lz_morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-        const int occ = grid[index / 8] & (1 << (index % 8));
-        if (occ) return 1;
-        const float tx = lz_fmaf(lz_fmaf(((float)nx + 0.5f + 0.5f * lz_signf(dx)) * rH, 2.0f, -1.0f), mip_bound, -x) * rdx;
-        const float ty = lz_fmaf(lz_fmaf(((float)ny + 0.5f + 0.5f * lz_signf(dy)) * rH, 2.0f, -1.0f), mip_bound, -y) * rdy;
-        const float tz = lz_fmaf(lz_fmaf(((float)nz + 0.5f + 0.5f * lz_signf(dz)) * rH, 2.0f, -1.0f), mip_bound, -z) * rdz;
-        const float tt = tt0 + lz_fmaxf(0.0f, lz_fminf(tx, lz_fminf(ty, tz)));
-        float tc = tt0;
-        do { tc += lz_clampf(tc * dt_gamma, dt_min, dt_max); } while (tc < tt);
-        t = tc;
-        return 0;
-    }
-};
-
 // pass 1: count occupied steps per ray (raymarching.cu:394-441)
 __global__ void __launch_bounds__(256)
 lz_k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,

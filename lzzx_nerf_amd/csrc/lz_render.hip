@@ -49,6 +49,17 @@ extern "C" int lz_timing_reset(lz_timing* t) {
     return LZ_OK;
 }
 
+// record the begin (which = 0) / end (which = 1) event of the next pair on `stream`: callers that bracket something other than the
+// loop's head launches (the fused frame kernel) use the same lz_timing object
+extern "C" int lz_timing_mark(lz_timing* t, int which, lz_stream_t stream) {
+    LZ_REQUIRE(t, LZ_ERR_BAD_ARGUMENT, "timing_mark: null");
+    if ((size_t)(t->used + 1) * 2 > t->ev.size()) return LZ_OK;   // full: further pairs are dropped
+    hipError_t rc = hipEventRecord(t->ev[2 * t->used + (which ? 1 : 0)], lz_st(stream));
+    if (rc != hipSuccess) { lz_set_error("timing_mark: %s", hipGetErrorString(rc)); return (int)rc; }
+    if (which) t->used++;
+    return LZ_OK;
+}
+
 // elapsed time of every recorded pair, in ms; call after the stream has been synchronised.  Returns the pair count.
 extern "C" int lz_timing_elapsed_ms(lz_timing* t, float* out_ms, uint32_t capacity, uint32_t* n_pairs) {
     LZ_REQUIRE(t && out_ms && n_pairs, LZ_ERR_BAD_ARGUMENT, "timing_elapsed_ms: null argument");

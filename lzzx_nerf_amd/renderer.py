@@ -58,7 +58,13 @@ class TriplaneRenderer:
     """
 
     def __init__(self, head: FusedTriplaneHead, density_bitfield, bound=1.0, cascade=None, grid_size=128, aabb=None,
-                 min_near=0.05, density_scale=1, budget_factor=1, n_step_cap=8):
+                 min_near=0.05, density_scale=1, budget_factor=1, n_step_cap=8, mode="loop"):
+        """mode "loop": the reference's iteration structure, 3 launches per iteration (march, head, composite), schedule
+        (budget_factor, n_step_cap).  mode "fused": the whole frame as one persistent kernel (csrc/lz_frame.hip) -- the loop under
+        the schedule n_step = 1 with on-the-fly refill of finished ray slots; same pixels, depth and sums, bit for bit."""
+        if mode not in ("loop", "fused"):
+            raise ValueError("mode must be 'loop' or 'fused'")
+        self.mode = mode
         import math
         self.head = head
         self.bound = float(bound)
@@ -158,7 +164,7 @@ class TriplaneRenderer:
         rays_o = rays_o.reshape(-1, 3).float().contiguous()
         rays_d = rays_d.reshape(-1, 3).float().contiguous()
         N = rays_o.shape[0]
-        if N > MAX_RAYS_PER_PASS:
+        if N > MAX_RAYS_PER_PASS and self.mode != "fused":
             # rays are independent: larger batches are rendered in passes of <= 2^20 rays (the device loop scans at most 4096
             # workgroup counts per iteration) and concatenated; pixels do not depend on the split
             outs = []
@@ -175,6 +181,8 @@ class TriplaneRenderer:
             res["state"][72] = st[:, 72].sum()
             res["state"][6] = st[:, 6].max()
             return res
+        if self.mode == "fused":
+            return self._render_fused(rays_o, rays_d, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg_color, count_samples, rgb24)
         b = self._buffers(N, rays_o.device)
         self._rays_o, self._rays_d = rays_o, rays_d
         call("lz_near_far_from_aabb", ptr(rays_o), ptr(rays_d), ptr(self.aabb), N, self.min_near, ptr(b.nears), ptr(b.fars), stream())
@@ -231,4 +239,52 @@ class TriplaneRenderer:
             res["ray_counts"] = b.ray_counts
         if rgb24:
             res["image_rgb24"] = b.out_rgb24
+        return res
+
+    # ---- the whole frame as one persistent kernel (csrc/lz_frame.hip) ----
+    def _fused_buffers(self, N, device):
+        fb = getattr(self, "_fbuf", None)
+        if fb is None or fb["N"] != N or fb["device"] != device:
+            f = dict(dtype=torch.float32, device=device)
+            fb = dict(N=N, device=device, nears=torch.empty(N, **f), fars=torch.empty(N, **f), rays_t=torch.empty(N, **f),
+                      order=torch.empty(N, dtype=torch.int32, device=device), state=torch.zeros(1024, dtype=torch.int32, device=device),
+                      keys=torch.empty(N, dtype=torch.uint8, device=device), weights_sum=torch.empty(N, **f), depth=torch.empty(N, **f),
+                      image=torch.empty(N, 3, **f), amb_aud_sum=torch.empty(N, **f), amb_eye_sum=torch.empty(N, **f), unc_sum=torch.empty(N, **f),
+                      out=torch.empty(N, 3, **f), out_rgb24=None, ray_counts=None)
+            self._fbuf = fb
+        return fb
+
+    def _render_fused(self, rays_o, rays_d, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg_color, count_samples, rgb24):
+        N, dev = rays_o.shape[0], rays_o.device
+        b = self._fused_buffers(N, dev)
+        h = self.head
+        enc_a = enc_a.reshape(-1).float().contiguous()
+        ind_code = None if ind_code is None else ind_code.reshape(-1).float().contiguous()
+        eye = None if eye is None else eye.reshape(-1).float().contiguous()
+        bg = None
+        if torch.is_tensor(bg_color):
+            bg = bg_color.to(dev, torch.float32).expand(N, 3).contiguous()
+        if rgb24 and b["out_rgb24"] is None:
+            b["out_rgb24"] = torch.empty(N, 3, dtype=torch.uint8, device=dev)
+        if count_samples and b["ray_counts"] is None:
+            b["ray_counts"] = torch.zeros(N, dtype=torch.int32, device=dev)
+        f = _lib.FrameFused()
+        f.head = h._params(enc_a, ind_code, eye, True)
+        p = lambda t: None if t is None else t.data_ptr()
+        f.rays_o, f.rays_d, f.grid, f.aabb = p(rays_o), p(rays_d), p(self.bitfield), p(self.aabb)
+        for k in ("nears", "fars", "rays_t", "order", "state", "keys", "weights_sum", "depth", "image", "amb_aud_sum", "amb_eye_sum", "unc_sum", "out"):
+            setattr(f, k, p(b[k]))
+        f.bg, f.out_rgb24 = p(bg), p(b["out_rgb24"]) if rgb24 else None
+        f.ray_counts = p(b["ray_counts"]) if count_samples else None
+        f.bg_scalar = 1.0 if bg is not None else float(bg_color)
+        f.bound, f.dt_gamma, f.T_thresh, f.min_near = self.bound, float(dt_gamma), float(T_thresh), self.min_near
+        f.N, f.max_steps, f.C, f.H = N, int(max_steps), int(self.cascade), int(self.grid_size)
+        call("lz_frame_render", C.byref(f), self._timing, stream())   # timing: one event pair around the persistent kernel
+        self._keep = (enc_a, ind_code, eye, bg, rays_o, rays_d)
+        res = dict(image=b["out"], image_raw=b["image"], weights_sum=b["weights_sum"], depth=b["depth"], amb_aud_sum=b["amb_aud_sum"],
+                   amb_eye_sum=b["amb_eye_sum"], uncertainty_sum=b["unc_sum"], state=b["state"], nears=b["nears"], fars=b["fars"])
+        if count_samples:
+            res["ray_counts"] = b["ray_counts"]
+        if rgb24:
+            res["image_rgb24"] = b["out_rgb24"]
         return res

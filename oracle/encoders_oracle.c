@@ -152,3 +152,8 @@ void lzo_vec_unary(int op, const float* x, float* y, size_t n) {
         y[i] = r;
     }
 }
+
+/* test-infrastructure knob: size of the OpenMP teams of this library (bench.py's cpu_baseline sets it to the host's CPU quota) */
+#include <omp.h>
+void lzo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int lzo_get_max_threads(void) { return omp_get_max_threads(); }

@@ -42,6 +42,29 @@ def lib():
     return _lib
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands each job a share of
+    its host: 256 CPUs in the mask, a quota of 16)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, (q + p // 2) // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def set_threads(n):
+    lib().lzo_set_threads(C.c_int(int(n)))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

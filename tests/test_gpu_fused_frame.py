@@ -1,0 +1,109 @@
+"""The whole frame as one persistent kernel (csrc/lz_frame.hip, TriplaneRenderer(mode="fused")) against the multi-launch loop and the
+CPU checker.  The fused kernel is the reference loop (renderer.py:406-570) under the schedule n_step = 1, so against the loop /
+checker run with (budget_factor, n_step_cap) = (1, 1) EVERYTHING is bit-identical, per-ray sample counts included; against any other
+schedule the pixels and sums are (counts too unless T_thresh cuts a ray inside a chunk)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ellipsoid_bitfield, synthetic_camera
+from oracle.head import TriplaneSpec
+from oracle.render import render_inference
+
+pytestmark = pytest.mark.gpu
+KEYS = ("image", "image_raw", "weights_sum", "depth", "amb_aud_sum", "amb_eye_sum", "uncertainty_sum", "nears", "fars")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def setup(params, golden, H, W, scene, precision="f32"):
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.utils import frame_rays
+    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in params.items()}, bound=1.0, precision=precision)
+    bits = np.full(128 ** 3 // 8, 255, np.uint8) if scene == "ones" else ellipsoid_bitfield()[0]
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = frame_rays(dev(pose), intr, H, W)
+    cond = (dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]))
+    return head, bits, ro, rd, cond
+
+
+def both(head, bits, ro, rd, cond, loop_schedule=(1, 1), **kw):
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    fused = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused").render(ro, rd, *cond, count_samples=True, **kw)
+    fused = {k: v.clone() for k, v in fused.items()}
+    loop = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=loop_schedule[0], n_step_cap=loop_schedule[1]).render(
+        ro, rd, *cond, count_samples=True, **kw)
+    return fused, loop
+
+
+@pytest.mark.parametrize("scene,H,W,kw", [
+    ("ellipsoid", 64, 64, dict(max_steps=64)),
+    ("ones", 48, 40, dict(max_steps=96)),
+    ("ones", 40, 40, dict(max_steps=16, dt_gamma=0.0)),                 # max_steps binds: every ray is cut at 16 samples
+    ("ellipsoid", 64, 64, dict(max_steps=64, T_thresh=0.6)),            # T_thresh terminates rays early
+])
+def test_fused_frame_bit_exact_vs_loop_and_checker(params, golden, scene, H, W, kw):
+    head, bits, ro, rd, cond = setup(params, golden, H, W, scene)
+    fused, loop = both(head, bits, ro, rd, cond, **kw)
+    for k in KEYS:
+        assert torch.equal(fused[k], loop[k]), k
+    assert torch.equal(fused["ray_counts"], loop["ray_counts"])
+    assert int(fused["state"][5]) == int(loop["state"][5]) == int(fused["ray_counts"].sum())
+    assert int(fused["state"][3]) == 1 and int(fused["state"][72]) >= int(fused["state"][5])
+    st = {}
+    ref = render_inference(TriplaneSpec(1.0), params, ro.cpu().numpy(), rd.cpu().numpy(), bits, golden["net_enc_a"], golden["net_ind"],
+                           golden["net_eye"], stats=st, budget_factor=1, n_step_cap=1, **kw)
+    assert np.array_equal(fused["image"].cpu().numpy(), ref["image"])
+    assert np.array_equal(fused["depth"].cpu().numpy(), ref["depth"])
+    assert np.array_equal(fused["ray_counts"].cpu().numpy().astype(np.int64), st["samples_per_ray"])
+    if kw.get("T_thresh", 0) > 0.1:
+        assert int((fused["weights_sum"] > 0.4).sum()) > 0      # the threshold did cut rays
+    if kw.get("max_steps") == 16:
+        assert int(fused["ray_counts"].max()) == 16
+
+
+def test_fused_frame_equals_other_schedules_on_the_bench_frame(params, golden):
+    """512 x 512, max_steps 192, all-ones occupancy: pixels, sums and (no ray is cut by T_thresh here) sample counts equal the
+    headline schedule (4, 4) of the multi-launch loop"""
+    head, bits, ro, rd, cond = setup(params, golden, 512, 512, "ones")
+    fused, loop = both(head, bits, ro, rd, cond, loop_schedule=(4, 4), max_steps=192)
+    for k in KEYS:
+        assert torch.equal(fused[k], loop[k]), k
+    assert torch.equal(fused["ray_counts"], loop["ray_counts"])
+    assert int(fused["state"][5]) == 23928228
+    rows = int(fused["state"][72])
+    assert rows < 1.08 * 23928228          # refill keeps the slices full: < 8 % of the rows the head evaluates are empty slots
+
+
+def test_fused_frame_f16_equals_loop_f16(params, golden):
+    head, bits, ro, rd, cond = setup(params, golden, 96, 96, "ellipsoid", precision="f16")
+    fused, loop = both(head, bits, ro, rd, cond, max_steps=64)
+    for k in KEYS:
+        assert torch.equal(fused[k], loop[k]), k
+    assert torch.equal(fused["ray_counts"], loop["ray_counts"])
+
+
+def test_fused_frame_edge_cases(params, golden):
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    head, bits, ro, rd, cond = setup(params, golden, 32, 32, "ellipsoid")
+    r = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
+    # every ray misses the box: background everywhere, nothing queued
+    up = torch.zeros_like(rd)
+    up[:, 1] = 1.0
+    up[:, 0] = 1e-3
+    up[:, 2] = 1e-3
+    out = r.render(ro + torch.tensor([0.0, 5.0, 0.0], device="cuda"), up, *cond, max_steps=32, count_samples=True)
+    assert float(out["image"].min()) == 1.0 and int(out["state"][5]) == 0 and int(out["state"][1]) == 0
+    assert int(out["ray_counts"].sum()) == 0 and float(out["weights_sum"].abs().max()) == 0.0
+    # 5 rays, a per-ray background, RGB24 hand-off
+    bg = torch.rand(5, 3, device="cuda")
+    sel = torch.tensor([0, 500, 528, 700, 1023], device="cuda")
+    o5 = r.render(ro[sel], rd[sel], *cond, max_steps=32, bg_color=bg, rgb24=True)
+    loop = TriplaneRenderer(head, dev(bits), bound=1.0).render(ro[sel], rd[sel], *cond, max_steps=32, bg_color=bg, rgb24=True)
+    assert torch.equal(o5["image"], loop["image"]) and torch.equal(o5["image_rgb24"], loop["image_rgb24"])
+    # determinism across runs (the queue order inside a key bin is free; results are not)
+    a = r.render(ro, rd, *cond, max_steps=32)["image"].clone()
+    b = r.render(ro, rd, *cond, max_steps=32)["image"].clone()
+    assert torch.equal(a, b)
