@@ -172,7 +172,7 @@ class TriplaneTrainNet(torch.nn.Module):
         return sigma, rgb, att.norm(dim=-1), eye_att.abs().sum(-1), unc
 
 
-def train_bench(args, device, P, golden, bits, rank=0, world=1):
+def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
     """BASELINE cfg3: one training step (fwd + bwd + Adam) on `--train-rays` random rays of the 512x512 frame through the
     operator API as the reference's run_cuda arranges it (renderer.py:279-304).  The MLP GEMMs are torch/rocBLAS here;
     everything else is this repo's HIP kernels.  Reported beside the headline line, never instead of it."""
@@ -185,7 +185,7 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1):
     pose, intr = synthetic_camera(H, W)
     ro, rd = frame_rays(dev(pose), intr, H, W)
     g = torch.Generator(device=device).manual_seed(0)
-    n_rays = min(args.train_rays, H * W)
+    n_rays = min(n_rays or args.train_rays, H * W)
     sel = torch.randperm(H * W, device=device, generator=g)[:n_rays]
     target = torch.rand(n_rays, 3, device=device, generator=g)
     lo, hi = D.shard_bounds(n_rays, rank, world)   # data parallel over the sampled rays (world == 1: everything)
@@ -202,12 +202,20 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1):
     bitfield = dev(bits)
     ctr = torch.zeros(2, dtype=torch.int32, device=device)
     n_samples = [0]
+    # The reference sizes the sample buffers from a running average of the step counter once it has one (mean_count > 0,
+    # renderer.py:814-818 -> raymarching.py:221-228): no D2H copy in the step.  Only while mean_count <= 0 (the first steps) or with
+    # force_all_rays does its wrapper trim by counter[0].item().  The first warm-up step below is that start-up case and yields the
+    # count; every later step, the timed ones included, runs the steady state (noise perturbs t0 by less than one step, so the
+    # count of a step stays within the 128-row padding of the first one's plus a margin).
+    mean_count = [-1]
 
     def step():
         nears, fars = R.near_far_from_aabb(ro, rd, aabb, 0.05)
         ctr.zero_()
-        xyzs, dirs, deltas, rays = R.march_rays_train(ro, rd, 1.0, bitfield, 1, 128, nears, fars, ctr, -1, True, 128, True, 1 / 256,
-                                                      args.max_steps)
+        xyzs, dirs, deltas, rays = R.march_rays_train(ro, rd, 1.0, bitfield, 1, 128, nears, fars, ctr, mean_count[0], True, 128,
+                                                      mean_count[0] <= 0, 1 / 256, args.max_steps)
+        if mean_count[0] <= 0:
+            mean_count[0] = int(xyzs.shape[0]) + n_rays // 64   # margin: a perturbed ray gains or loses at most one sample
         sigma, rgb, a0, a1, unc = net(xyzs, dirs, enc_a, ind, eye)
         if args.train_mlp == "fused":
             a0, a1, unc = a0[:, 0], a1[:, 0], unc[:, 0]
@@ -221,19 +229,21 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1):
             loss.backward()
             bucket.all_reduce()
         opt.step()
-        n_samples[0] = xyzs.shape[0]
         return loss
 
-    for _ in range(max(args.warmup, 1)):
+    k_steps = args.steps if n_rays <= 65536 else max(3, args.steps // 3)
+    for _ in range(max(args.warmup, 2)):
         step()
     torch.cuda.synchronize()
+    overflow = int(ctr[0].item()) > mean_count[0]     # rays dropped because the buffer was too small (raymarching.cu:457)? must be False
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(k_steps):
         loss = step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / k_steps
+    n_samples[0] = int(ctr[0].item())      # samples of the last step (after the timed region)
     if world > 1:
         red = torch.tensor([dt, float(n_samples[0])], dtype=torch.float64, device=device)
         mx = red.clone()
@@ -244,7 +254,8 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1):
                             f"({bucket.flat.numel() * 4 / 1e6:.2f} MB) per step" if world > 1 else "single GPU",
                 workload=f"cfg3: {n_rays} random rays of a {H}x{W} frame, max_steps {args.max_steps}, occupancy={args.scene}, "
                          "march_rays_train -> head (see 'mlp') -> composite_rays_train_triplane -> MSE -> backward (weight gradients + grid "
-                         "scatter-add) -> Adam", rays=n_rays, samples_per_step=int(n_samples[0]),
+                         "scatter-add) -> Adam; sample buffers sized by mean_count like the reference's steady state (no D2H copy in the step)",
+                rays=n_rays, samples_per_step=int(n_samples[0]), steps=k_steps, sample_buffer_overflow=overflow,
                 ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
                 loss=float(loss.detach()), dtype="f32", mlp={"fused": "fused head forward + backward kernels (csrc/lz_head.hip, lz_head_bwd.hip)", "lz": "csrc/lz_linear.hip (MFMA f32)",
                      "torch": "torch/rocBLAS"}[args.train_mlp])
@@ -271,6 +282,7 @@ def parse_args():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
                     help="f16 = the reference's opt.fp16 / autocast arithmetic on the f16 matrix cores (not bit-exact vs the f32 checker)")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-only", action="store_true", help="time only the cfg3 training step (tools/profile_train.sh) and print it")
     ap.add_argument("--train-rays", type=int, default=65536)
     ap.add_argument("--train-dp", action="store_true",
                     help="N > 1 only: also time the cfg3 training step data-parallel over ray shards (strong scaling of one step, "
@@ -454,21 +466,37 @@ PMC_SUMMARY = "r2_final_pmc_summary.json"   # written by tools/profile_bench.sh 
 F16_SLICE_MFMAS = 59    # v_mfma_f32_16x16x32_f16 per 16-row slice of lz_k_triplane_head_f16
 
 
-def f16_head_roofline(samples, rows, steps, head_total_ms, n_launch, launches_with_work, dt):
-    """roofline object of the f16 head.  Its matrix work is 7 % of the f32 kernel's (59 MFMAs x 16 cycles per 16-row slice), so the dense
-    f16 MFMA peak is not what bounds it; DESIGN 4.1b derives the bound from the PMC passes (profiles/r2_f16_head_pmc_summary.json):
-    the per-sample VALU + table-gather instruction stream.  `frac` is priced against the f16 MFMA peak only as the formal figure of the
-    contract; `bound_detail` names the real limiter and `samples_per_s` is the number to watch."""
+def f16_head_roofline(samples, rows, steps, head_total_ms, n_launch, launches_with_work, dt, fused=True):
+    """roofline object of the f16 head / fused f16 frame kernel.  Its matrix work is 7 % of the f32 kernel's (59 MFMAs x 16 cycles per
+    16-row slice), so the dense f16 MFMA peak does not bound it.  The PMC passes (profiles/r2_f16_head_pmc_summary.json, rocprofv3
+    --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_MFMA_MOPS_F16 over this same command) show what does: vector-instruction ISSUE.  A wave64 VALU
+    instruction occupies its SIMD's issue port for 4 cycles and an MFMA for 8 of its 16 (MI355X_MICROARCH.md, cycle constants), and
+    4 x (SQ_INSTS_VALU - N_mfma) + 8 x N_mfma per SIMD equals the elapsed cycles of the kernel: the port is saturated.  So the bound
+    reported here is that instruction stream at the nominal 2.4 GHz; `frac` = achieved / that."""
     t = head_total_ms * 1e-3
-    achieved = FLOP_PER_SAMPLE * samples * steps / t / 1e12
-    return dict(bound="mfma", achieved=round(achieved, 3), peak=2500.0, unit="TFLOP/s", frac=round(achieved / 2500.0, 5), traffic=None,
-                kernel="lz_k_triplane_head_f16", avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5),
-                avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5), launches=n_launch, launches_with_work=launches_with_work,
-                head_time_share=round(t / dt, 4), head_ms_per_step=round(head_total_ms / steps, 4), rows_per_frame=rows,
-                samples_per_s=round(samples * steps / t, 1),
-                matrix_pipe_busy_frac=round(F16_SLICE_MFMAS * 16 * (rows / 16) * steps / (t * 2.4e9 * 1024), 4),
-                bound_detail="VALU issue + table gathers (144 per sample): 59 MFMAs x 16 cycles per 16-row slice keep the matrix pipe "
-                             "busy a few % of the time (matrix_pipe_busy_frac, at the nominal 2.4 GHz x 1024 SIMDs); see DESIGN 4.1b")
+    sps = samples * steps / t
+    r = dict(bound="valu-issue", achieved=round(sps / 1e9, 4), peak=None, unit="Gsample/s", frac=None, traffic=None,
+             kernel="lz_k_frame<1> (march + f16 head + composite, one persistent launch per frame)" if fused else "lz_k_triplane_head_f16",
+             avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5), avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5),
+             launches=n_launch, head_time_share=round(t / dt, 4), head_ms_per_step=round(head_total_ms / steps, 4), rows_per_frame=rows,
+             samples_per_s=round(sps, 1),
+             mfma_frac_of_dense_f16_peak=round(FLOP_PER_SAMPLE * sps / 1e12 / 2500.0, 5),
+             matrix_pipe_busy_frac=round(F16_SLICE_MFMAS * 16 * (rows / 16) * steps / (t * 2.4e9 * 1024), 4))
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_f16_head_pmc_summary.json")))
+        k = "lz_k_frame<1>" if fused else "lz_k_triplane_head_f16"
+        n_mfma = pmc["SQ_INSTS_VALU_MFMA_MOPS_F16"][k]["avg_per_launch"] / 32.0       # MOPS counts 512-FLOP units: 32 per 16x16x32 MFMA
+        slices = n_mfma / F16_SLICE_MFMAS
+        valu = pmc["SQ_INSTS_VALU"][k]["avg_per_launch"] - n_mfma
+        cyc = (4.0 * valu + 8.0 * n_mfma) / slices                                      # issue-port cycles per 16-row slice
+        peak = 1024 * 2.4e9 / cyc * 16 * (samples / max(rows, 1))                        # samples/s the chip's 1024 SIMDs can issue at 2.4 GHz
+        r.update(peak=round(peak / 1e9, 4), frac=round(sps / peak, 4), valu_insts_per_slice=round(valu / slices, 1),
+                 issue_cycles_per_slice=round(cyc, 1), vmem_reads_per_slice=round(pmc["SQ_INSTS_VMEM_RD"][k]["avg_per_launch"] / slices, 1),
+                 lds_insts_per_slice=round(pmc["SQ_INSTS_LDS"][k]["avg_per_launch"] / slices, 1),
+                 pmc="profiles/r2_f16_head_pmc_summary.json")
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        r["note"] = "PMC summary absent: VALU-issue bound not priced"
+    return r
 
 
 def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, image, samples_per_frame, make_job):
@@ -551,7 +579,7 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
                        reference_schedule_value=leg8["value"], reference_schedule_ms_per_step=leg8["ms_per_step"],
                        reference_schedule_image_equal=bool(torch.equal(img16, img16b)),
                        roofline=f16_head_roofline(int(s16[5]), int(s16[72]), args.steps, hms16, int(s16[6]) * args.steps, int(s16[6]) * args.steps,
-                                                  leg["ms_per_step"] * 1e-3 * args.steps))
+                                                  leg["ms_per_step"] * 1e-3 * args.steps, fused=args.mode == "fused"))
             result["fp16_head"] = leg
         except Exception as exc:
             err("fp16_head", exc)
@@ -628,8 +656,12 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
     if not args.no_train:
         try:
             result["train_step"] = train_bench(args, device, P, golden, bits)
+            torch.cuda.empty_cache()
+            # BASELINE cfg3's second size: every ray of the 512 x 512 frame (N = 262 144; 24 M samples, 63 GB of per-sample records)
+            result["train_step_full_frame"] = train_bench(args, device, P, golden, bits, n_rays=H * W)
+            torch.cuda.empty_cache()
         except Exception as exc:   # an optional leg must never take the headline line down
-            result.setdefault("leg_errors", {})["train_step"] = repr(exc)
+            err("train_step", exc)
     log("leg: if not args.no_occupancy and args.precision == 'f32':")
     if not args.no_occupancy and args.precision == "f32":
         try:
@@ -761,6 +793,9 @@ def main():
         return FrameJob(r, H, W, orbit_pose(k), intr, (enc_a, ind, eye), args.max_steps, rank, world, shard, tiles, args.gather, device, shard_of)
 
     log(f"rank {rank}/{world}: setup done")
+    if args.train_only:
+        print(json.dumps({"train_step": train_bench(args, device, P, golden, bits, rank, world)}))
+        return
     # ---- headline ----
     job = make_job(args.shard, args.tiles, shard_of=args.shard_of)
     dt, head_ms, out, tiles = timed(job, args.steps, args.warmup, world, device)
@@ -836,7 +871,7 @@ def main():
     if world > 1:
         roofline["note"] = "rank 0's head launches over rank 0's samples"
     if args.precision == "f16":
-        roofline = f16_head_roofline(my_samples, my_rows, args.steps, head_total_ms, n_launch, launches_with_work, dt)
+        roofline = f16_head_roofline(my_samples, my_rows, args.steps, head_total_ms, n_launch, launches_with_work, dt, fused=args.mode == "fused")
     pmc_path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
     if os.path.exists(pmc_path) and args.precision == "f32":
         # HBM-side traffic of the head per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /

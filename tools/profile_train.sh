@@ -6,7 +6,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -- python3 $REPO/bench.py --train --steps 3 --warmup 1 --no-cpu-baseline --no-grid-roofline --no-fat-schedule --no-fp16-leg --no-occupancy --no-dense192 > $OUT/prof_train_bench.json 2> $OUT/prof_train.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -- python3 $REPO/bench.py --train-only --steps 12 --warmup 2 > $OUT/prof_train_bench.json 2> $OUT/prof_train.err
 cd $REPO
 find $OUT/prof_train -name "*kernel_stats.csv" -exec cp {} $OUT/train_kernel_stats.csv \;
 find $OUT/prof_train -name "*.db" -delete
