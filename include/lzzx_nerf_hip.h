@@ -444,6 +444,8 @@ typedef struct {
     int32_t* ray_counts;           /* [N] or NULL: samples per ray */
     float bg_scalar, bound, dt_gamma, T_thresh, min_near;
     uint32_t N, max_steps, C, H;
+    uint32_t steps_per_pass;       /* samples a ray marches per pass = the n_step of the schedule it equals: 0 = auto (1 for large
+                                      frames; 2..16 when there are too few rays to fill the chip), or 1, 2, 4, 8, 16 */
 } lz_frame_fused;
 struct lz_timing;
 /* `timing` (may be NULL): bracket the persistent kernel with one event pair on the launch stream (lz_timing_create) */

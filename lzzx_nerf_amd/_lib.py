@@ -52,7 +52,7 @@ class FrameFused(C.Structure):
                 ("order", vp), ("state", vp), ("keys", vp), ("weights_sum", vp), ("depth", vp), ("image", vp), ("amb_aud_sum", vp),
                 ("amb_eye_sum", vp), ("unc_sum", vp), ("out", vp), ("bg", vp), ("out_rgb24", vp), ("ray_counts", vp),
                 ("bg_scalar", f32), ("bound", f32), ("dt_gamma", f32), ("T_thresh", f32), ("min_near", f32),
-                ("N", u32), ("max_steps", u32), ("C", u32), ("H", u32)]
+                ("N", u32), ("max_steps", u32), ("C", u32), ("H", u32), ("steps_per_pass", u32)]
 
 
 # name -> argtypes, in the order of include/lzzx_nerf_hip.h

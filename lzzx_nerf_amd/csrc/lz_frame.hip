@@ -150,7 +150,9 @@ __global__ void __launch_bounds__(256) lz_k_frame_scatter(LzFrameK F) {
 
 // ---- pass 3: the persistent kernel --------------------------------------------------------------------------------------------
 // slot state in LDS, per wave [field][16]
-enum { SF_RAY = 0, SF_T, SF_FAR, SF_DT, SF_WS, SF_D, SF_R, SF_G, SF_B, SF_A0, SF_A1, SF_U, SF_CNT, SF_FIELDS };
+enum { SF_RAY = 0, SF_T, SF_FAR, SF_DT, SF_WS, SF_D, SF_R, SF_G, SF_B, SF_A0, SF_A1, SF_U, SF_CNT, SF_FIELDS,
+       // S > 1 only: per-SAMPLE staging (march -> head, head -> composite) and the per-ray pass counter
+       SF_X = SF_FIELDS, SF_Y, SF_Z, SF_TS, SF_OSIG, SF_OR, SF_OG, SF_OB, SF_OA0, SF_OA1, SF_OU, SF_IT, SF_FIELDS_MULTI };
 
 template <int PREC> struct LzfHead;
 template <> struct LzfHead<0> {
@@ -172,17 +174,23 @@ template <> struct LzfHead<1> {
     }
 };
 
-template <int PREC>
+// S = samples one ray marches per pass (1, 2, 4, 8 or 16; a slice holds 16 / S rays).  S = 1 is the layout described at the top of the file.
+// With few rays a wave would own too few of them to keep the matrix pipe busy for the ~100 dependent passes a ray needs, so the host
+// raises S until there are enough 16-sample rows in flight: the loop under the schedule n_step = S (the rows behind a ray's last sample
+// in its last pass are the only waste).  Samples of a pass are staged per slot in LDS: the group leader (lane j == 0 of a ray's S
+// slots) marches and composites, every slot's lanes evaluate the head.
+template <int PREC, int S>
 __global__ void __launch_bounds__(LZF_WG, LZF_WG / 256)
 lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     using HD = LzfHead<PREC>;
-    constexpr int SLOT_WORDS = LZF_WAVES * SF_FIELDS * 16;
+    constexpr int NF = S == 1 ? (int)SF_FIELDS : (int)SF_FIELDS_MULTI;
+    constexpr int SLOT_WORDS = LZF_WAVES * NF * 16;
     __shared__ __align__(16) float lds[HD::LDS_WORDS + SLOT_WORDS + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
     typename HD::Ctx ctx;
     HD::stage(P, lds, q, ctx);
-    float* slot = lds + HD::LDS_WORDS + wave * SF_FIELDS * 16;      // this wave's slots: slot[field * 16 + s]
+    float* slot = lds + HD::LDS_WORDS + wave * NF * 16;      // this wave's slots: slot[field * 16 + s]
     int* sloti = reinterpret_cast<int*>(slot);
     int* wg_stat = reinterpret_cast<int*>(lds + HD::LDS_WORDS + SLOT_WORDS);   // [0] samples, [1] slices, [2] waves done
     if (lane < 16) sloti[SF_RAY * 16 + lane] = -1;
@@ -193,95 +201,214 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     bool dry = n_queue <= 0;
     int my_samples = 0, my_slices = 0;
 
-    for (;;) {
-        // ---------------- refill + march: every slot ends with a sample, or empty with the queue dry ----------------
-        int ray = (q == 0) ? sloti[SF_RAY * 16 + s] : -1;
-        bool have = false;
-        float x = 0.0f, y = 0.0f, z = 0.0f;
-        for (int attempt = 0; attempt < 4; attempt++) {
-            const bool need = (q == 0) && ray < 0 && !dry;
-            const unsigned long long mask = __ballot(need);
-            if (mask) {
-                const int leader = __ffsll((long long)mask) - 1, take = __popcll(mask);
-                int base = 0;
-                if (lane == leader) base = atomicAdd(F.state + LZF_Q_HEAD, take);
-                base = __shfl(base, leader, 64);
-                if (need) {
-                    const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (idx < n_queue) {
-                        ray = F.order[idx];
-                        sloti[SF_RAY * 16 + s] = ray;
-                        slot[SF_T * 16 + s] = F.rays_t[ray];
-                        slot[SF_FAR * 16 + s] = F.fars[ray];
+    if constexpr (S > 1) {
+        const int j = s % S, lead = s - j;              // slot s = step j of the ray whose state sits at slot `lead`
+        const int max_passes = ((int)F.max_steps + S - 1) / S;
+        for (;;) {
+            // ---------------- refill + march (group leaders): up to S samples per ray into the staging fields ----------------
+            const bool leader = (q == 0) && j == 0;
+            int ray = leader ? sloti[SF_RAY * 16 + s] : -1;
+            int kk = 0;                                  // samples marched this pass (leaders)
+            for (int attempt = 0; attempt < 4; attempt++) {
+                const bool need = leader && ray < 0 && !dry;
+                const unsigned long long mask = __ballot(need);
+                if (mask) {
+                    const int first = __ffsll((long long)mask) - 1, take = __popcll(mask);
+                    int base = 0;
+                    if (lane == first) base = atomicAdd(F.state + LZF_Q_HEAD, take);
+                    base = __shfl(base, first, 64);
+                    if (need) {
+                        const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (idx < n_queue) {
+                            ray = F.order[idx];
+                            sloti[SF_RAY * 16 + s] = ray;
+                            slot[SF_T * 16 + s] = F.rays_t[ray];
+                            slot[SF_FAR * 16 + s] = F.fars[ray];
 #pragma unroll
-                        for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
-                        sloti[SF_CNT * 16 + s] = 0;
+                            for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
+                            sloti[SF_CNT * 16 + s] = 0;
+                            sloti[SF_IT * 16 + s] = 0;
+                        }
+                    }
+                    if (base + take >= n_queue) dry = true;
+                }
+                if (leader && ray >= 0 && kk == 0) {
+                    m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+                    float t = slot[SF_T * 16 + s];
+                    const float far = slot[SF_FAR * 16 + s];
+                    while (t < far && kk < S) {
+                        float x, y, z, dt;
+                        if (m.probe(t, x, y, z, dt)) {
+                            const int sl = s + kk;
+                            slot[SF_X * 16 + sl] = x; slot[SF_Y * 16 + sl] = y; slot[SF_Z * 16 + sl] = z;
+                            slot[SF_DT * 16 + sl] = dt;
+                            t += dt;
+                            slot[SF_TS * 16 + sl] = t;
+                            kk++;
+                        }
+                    }
+                    if (kk == 0) {     // the ray left the box without another sample
+                        lzf_write_pixel(F, ray, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s],
+                                        slot[SF_B * 16 + s], slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s], sloti[SF_CNT * 16 + s]);
+                        my_samples += sloti[SF_CNT * 16 + s];
+                        ray = -1;
+                        sloti[SF_RAY * 16 + s] = -1;
                     }
                 }
-                if (base + take >= n_queue) dry = true;    // wave-uniform
+                if (!__ballot(leader && ray < 0 && !dry)) break;
             }
-            if (q == 0 && ray >= 0 && !have) {
-                m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
-                float t = slot[SF_T * 16 + s], dt = 0.0f;
-                const float far = slot[SF_FAR * 16 + s];
-                while (t < far) {
-                    if (m.probe(t, x, y, z, dt)) { have = true; break; }
+            if (leader) sloti[SF_IT * 16 + s] = (sloti[SF_IT * 16 + s] & 0xffff) | (kk << 16);   // low half: passes done, high half: samples of this pass
+            if (!__ballot(kk > 0)) {
+                if (dry) break;
+                continue;
+            }
+            // ---------------- head: slot s evaluates sample j of its ray when the leader staged one ----------------
+            const int lkk = sloti[SF_IT * 16 + lead] >> 16;
+            const bool live = sloti[SF_RAY * 16 + lead] >= 0 && j < lkk;
+            const float px = live ? slot[SF_X * 16 + s] : 0.0f, py = live ? slot[SF_Y * 16 + s] : 0.0f, pz = live ? slot[SF_Z * 16 + s] : 0.0f;
+            typename HD::Out o;
+            HD::slice(ctx, lane, px, py, pz,
+                      [&](float& dx, float& dy, float& dz) {
+                          const int r = sloti[SF_RAY * 16 + lead];
+                          const float* d = F.rays_d + (size_t)(r < 0 ? 0 : r) * 3;
+                          dx = d[0]; dy = d[1]; dz = d[2];
+                      }, o);
+            my_slices++;
+            if (q == 0) {
+                slot[SF_OSIG * 16 + s] = o.sigma;
+                slot[SF_OR * 16 + s] = o.rgb[0]; slot[SF_OG * 16 + s] = o.rgb[1]; slot[SF_OB * 16 + s] = o.rgb[2];
+                slot[SF_OA0 * 16 + s] = o.ambaud; slot[SF_OA1 * 16 + s] = o.eyeatt; slot[SF_OU * 16 + s] = o.unc;
+            }
+            // ---------------- composite (lz_k_composite_rays, n_step = S): the leader walks its ray's staged samples ----------------
+            if (leader && kk > 0) {
+                float ws = slot[SF_WS * 16 + s], d = slot[SF_D * 16 + s], r = slot[SF_R * 16 + s], g = slot[SF_G * 16 + s], b = slot[SF_B * 16 + s];
+                float a0 = slot[SF_A0 * 16 + s], a1 = slot[SF_A1 * 16 + s], u = slot[SF_U * 16 + s], t = slot[SF_T * 16 + s];
+                int step = 0;
+                while (step < kk) {
+                    const int sl = s + step;
+                    const float alpha = 1.0f - lz_expf(-slot[SF_OSIG * 16 + sl] * slot[SF_DT * 16 + sl]);
+                    const float T = 1 - ws;
+                    const float w = alpha * T;
+                    ws += w;
+                    t = slot[SF_TS * 16 + sl];
+                    d = lz_fmaf(w, t, d);
+                    r = lz_fmaf(w, slot[SF_OR * 16 + sl], r);
+                    g = lz_fmaf(w, slot[SF_OG * 16 + sl], g);
+                    b = lz_fmaf(w, slot[SF_OB * 16 + sl], b);
+                    a0 = a0 + slot[SF_OA0 * 16 + sl];
+                    a1 = a1 + slot[SF_OA1 * 16 + sl];
+                    u = lz_fmaf(w, slot[SF_OU * 16 + sl], u);
+                    if (T < F.T_thresh) break;
+                    step++;
                 }
-                if (have) {
-                    slot[SF_T * 16 + s] = t;
-                    slot[SF_DT * 16 + s] = dt;
-                } else {        // the ray left the box (renderer.py: the march writes no row, compositing kills the ray on delta == 0)
-                    lzf_write_pixel(F, ray, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s], slot[SF_B * 16 + s],
-                                    slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s], sloti[SF_CNT * 16 + s]);
-                    my_samples += sloti[SF_CNT * 16 + s];
-                    ray = -1;
+                const int cnt = sloti[SF_CNT * 16 + s] + kk;                 // marched samples (renderer semantics: the chunk was marched)
+                const int passes = (sloti[SF_IT * 16 + s] & 0xffff) + 1;
+                const bool survives = step == kk && kk == S;                 // composited the whole chunk and the chunk was full
+                if (!survives || passes >= max_passes) {
+                    lzf_write_pixel(F, ray, ws, d, r, g, b, a0, a1, u, cnt);
+                    my_samples += cnt;
                     sloti[SF_RAY * 16 + s] = -1;
-                    x = y = z = 0.0f;
+                } else {
+                    slot[SF_T * 16 + s] = t;
+                    slot[SF_WS * 16 + s] = ws; slot[SF_D * 16 + s] = d;
+                    slot[SF_R * 16 + s] = r; slot[SF_G * 16 + s] = g; slot[SF_B * 16 + s] = b;
+                    slot[SF_A0 * 16 + s] = a0; slot[SF_A1 * 16 + s] = a1; slot[SF_U * 16 + s] = u;
+                    sloti[SF_CNT * 16 + s] = cnt;
+                    sloti[SF_IT * 16 + s] = passes;
                 }
             }
-            if (!__ballot((q == 0) && ray < 0 && !dry)) break;
         }
-        if (!__ballot(have)) {
-            if (dry) break;     // queue dry and no slot holds a sample: every slot is empty, this wave is done
-            continue;
-        }
-        // ---------------- head: the 16 samples of the slots, exactly one slice of the stand-alone head kernel ----------------
-        const float px = __shfl(x, s, 64), py = __shfl(y, s, 64), pz = __shfl(z, s, 64);
-        typename HD::Out o;
-        HD::slice(ctx, lane, px, py, pz,
-                  [&](float& dx, float& dy, float& dz) {
-                      const int r = sloti[SF_RAY * 16 + s];
-                      const float* d = F.rays_d + (size_t)(r < 0 ? 0 : r) * 3;
-                      dx = d[0]; dy = d[1]; dz = d[2];
-                  }, o);
-        my_slices++;
-        // ---------------- composite (lz_k_composite_rays, n_step = 1): lanes q == 0 ----------------
-        if (have) {
-            const float dt = slot[SF_DT * 16 + s];
-            float ws = slot[SF_WS * 16 + s];
-            const float alpha = 1.0f - lz_expf(-o.sigma * dt);
-            const float T = 1 - ws;
-            const float w = alpha * T;
-            ws += w;
-            const float t = slot[SF_T * 16 + s] + dt;
-            const float d = lz_fmaf(w, t, slot[SF_D * 16 + s]);
-            const float r = lz_fmaf(w, o.rgb[0], slot[SF_R * 16 + s]);
-            const float g = lz_fmaf(w, o.rgb[1], slot[SF_G * 16 + s]);
-            const float b = lz_fmaf(w, o.rgb[2], slot[SF_B * 16 + s]);
-            const float a0 = slot[SF_A0 * 16 + s] + o.ambaud;
-            const float a1 = slot[SF_A1 * 16 + s] + o.eyeatt;
-            const float u = lz_fmaf(w, o.unc, slot[SF_U * 16 + s]);
-            const int cnt = sloti[SF_CNT * 16 + s] + 1;
-            if (T < F.T_thresh || cnt >= (int)F.max_steps) {
-                lzf_write_pixel(F, ray, ws, d, r, g, b, a0, a1, u, cnt);
-                my_samples += cnt;
-                sloti[SF_RAY * 16 + s] = -1;
-            } else {
-                slot[SF_T * 16 + s] = t;
-                slot[SF_WS * 16 + s] = ws; slot[SF_D * 16 + s] = d;
-                slot[SF_R * 16 + s] = r; slot[SF_G * 16 + s] = g; slot[SF_B * 16 + s] = b;
-                slot[SF_A0 * 16 + s] = a0; slot[SF_A1 * 16 + s] = a1; slot[SF_U * 16 + s] = u;
-                sloti[SF_CNT * 16 + s] = cnt;
+    } else {
+        for (;;) {
+            // ---------------- refill + march: every slot ends with a sample, or empty with the queue dry ----------------
+            int ray = (q == 0) ? sloti[SF_RAY * 16 + s] : -1;
+            bool have = false;
+            float x = 0.0f, y = 0.0f, z = 0.0f;
+            for (int attempt = 0; attempt < 4; attempt++) {
+                const bool need = (q == 0) && ray < 0 && !dry;
+                const unsigned long long mask = __ballot(need);
+                if (mask) {
+                    const int leader = __ffsll((long long)mask) - 1, take = __popcll(mask);
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(F.state + LZF_Q_HEAD, take);
+                    base = __shfl(base, leader, 64);
+                    if (need) {
+                        const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (idx < n_queue) {
+                            ray = F.order[idx];
+                            sloti[SF_RAY * 16 + s] = ray;
+                            slot[SF_T * 16 + s] = F.rays_t[ray];
+                            slot[SF_FAR * 16 + s] = F.fars[ray];
+    #pragma unroll
+                            for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
+                            sloti[SF_CNT * 16 + s] = 0;
+                        }
+                    }
+                    if (base + take >= n_queue) dry = true;    // wave-uniform
+                }
+                if (q == 0 && ray >= 0 && !have) {
+                    m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+                    float t = slot[SF_T * 16 + s], dt = 0.0f;
+                    const float far = slot[SF_FAR * 16 + s];
+                    while (t < far) {
+                        if (m.probe(t, x, y, z, dt)) { have = true; break; }
+                    }
+                    if (have) {
+                        slot[SF_T * 16 + s] = t;
+                        slot[SF_DT * 16 + s] = dt;
+                    } else {        // the ray left the box (renderer.py: the march writes no row, compositing kills the ray on delta == 0)
+                        lzf_write_pixel(F, ray, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s], slot[SF_B * 16 + s],
+                                        slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s], sloti[SF_CNT * 16 + s]);
+                        my_samples += sloti[SF_CNT * 16 + s];
+                        ray = -1;
+                        sloti[SF_RAY * 16 + s] = -1;
+                        x = y = z = 0.0f;
+                    }
+                }
+                if (!__ballot((q == 0) && ray < 0 && !dry)) break;
+            }
+            if (!__ballot(have)) {
+                if (dry) break;     // queue dry and no slot holds a sample: every slot is empty, this wave is done
+                continue;
+            }
+            // ---------------- head: the 16 samples of the slots, exactly one slice of the stand-alone head kernel ----------------
+            const float px = __shfl(x, s, 64), py = __shfl(y, s, 64), pz = __shfl(z, s, 64);
+            typename HD::Out o;
+            HD::slice(ctx, lane, px, py, pz,
+                      [&](float& dx, float& dy, float& dz) {
+                          const int r = sloti[SF_RAY * 16 + s];
+                          const float* d = F.rays_d + (size_t)(r < 0 ? 0 : r) * 3;
+                          dx = d[0]; dy = d[1]; dz = d[2];
+                      }, o);
+            my_slices++;
+            // ---------------- composite (lz_k_composite_rays, n_step = 1): lanes q == 0 ----------------
+            if (have) {
+                const float dt = slot[SF_DT * 16 + s];
+                float ws = slot[SF_WS * 16 + s];
+                const float alpha = 1.0f - lz_expf(-o.sigma * dt);
+                const float T = 1 - ws;
+                const float w = alpha * T;
+                ws += w;
+                const float t = slot[SF_T * 16 + s] + dt;
+                const float d = lz_fmaf(w, t, slot[SF_D * 16 + s]);
+                const float r = lz_fmaf(w, o.rgb[0], slot[SF_R * 16 + s]);
+                const float g = lz_fmaf(w, o.rgb[1], slot[SF_G * 16 + s]);
+                const float b = lz_fmaf(w, o.rgb[2], slot[SF_B * 16 + s]);
+                const float a0 = slot[SF_A0 * 16 + s] + o.ambaud;
+                const float a1 = slot[SF_A1 * 16 + s] + o.eyeatt;
+                const float u = lz_fmaf(w, o.unc, slot[SF_U * 16 + s]);
+                const int cnt = sloti[SF_CNT * 16 + s] + 1;
+                if (T < F.T_thresh || cnt >= (int)F.max_steps) {
+                    lzf_write_pixel(F, ray, ws, d, r, g, b, a0, a1, u, cnt);
+                    my_samples += cnt;
+                    sloti[SF_RAY * 16 + s] = -1;
+                } else {
+                    slot[SF_T * 16 + s] = t;
+                    slot[SF_WS * 16 + s] = ws; slot[SF_D * 16 + s] = d;
+                    slot[SF_R * 16 + s] = r; slot[SF_G * 16 + s] = g; slot[SF_B * 16 + s] = b;
+                    slot[SF_A0 * 16 + s] = a0; slot[SF_A1 * 16 + s] = a1; slot[SF_U * 16 + s] = u;
+                    sloti[SF_CNT * 16 + s] = cnt;
+                }
             }
         }
     }
@@ -344,22 +471,41 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     // one workgroup per CU (the weights fill most of its LDS); fewer when there are not enough rays for one slot row per wave
     uint32_t grid = lz_div_up(f->N, 16 * 4);   // at least 4 waves' worth of slots per workgroup
     if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu;
+    // samples per ray and pass: 1 when there are enough rays to give every wave of the chip 16 of them twice over; doubled until the
+    // 16-sample rows in flight (N * S / 16) reach that number otherwise (f->steps_per_pass overrides: 1, 2, 4, 8 or 16)
+    uint32_t S = f->steps_per_pass;
+    if (S == 0) {
+        S = 1;
+        while (S < 16 && (uint64_t)f->N * S < (uint64_t)n_cu * LZF_WAVES * 16 * 2) S *= 2;
+    }
+    LZ_REQUIRE(S == 1 || S == 2 || S == 4 || S == 8 || S == 16, LZ_ERR_BAD_ARGUMENT, "frame_render: steps_per_pass must be 0 (auto), 1, 2, 4, 8 or 16");
     if (timing) (void)lz_timing_mark(timing, 0, stream);    // the event pair brackets the persistent kernel alone
+#define LZF_LAUNCH(PREC, SS) hipLaunchKernelGGL((lz_k_frame<PREC, SS>), dim3(grid), dim3(LZF_WG), 0, st, a, K)
+#define LZF_SWITCH(PREC)                                                        \
+    switch (S) {                                                                \
+        case 1: LZF_LAUNCH(PREC, 1); break;                                     \
+        case 2: LZF_LAUNCH(PREC, 2); break;                                     \
+        case 4: LZF_LAUNCH(PREC, 4); break;                                     \
+        case 8: LZF_LAUNCH(PREC, 8); break;                                     \
+        default: LZF_LAUNCH(PREC, 16); break;                                   \
+    }
     if (p->precision == 1) {
         LzHead16Args a;
         a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
         a.offsets = p->offsets; a.packed = reinterpret_cast<const lz_h8*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code;
         a.eye = p->eye; a.bound = p->bound;
         lzf_level_tables(p, a.scale, a.res);
-        hipLaunchKernelGGL((lz_k_frame<1>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
+        LZF_SWITCH(1)
     } else {
         LzHeadArgs a;
         a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
         a.offsets = p->offsets; a.packed = reinterpret_cast<const float*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code; a.eye = p->eye;
         a.bound = p->bound; a.testing = 1;
         lzf_level_tables(p, a.scale, a.res);
-        hipLaunchKernelGGL((lz_k_frame<0>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
+        LZF_SWITCH(0)
     }
+#undef LZF_SWITCH
+#undef LZF_LAUNCH
     if (timing) (void)lz_timing_mark(timing, 1, stream);
     LZ_CHECK_LAUNCH("frame_render");
     return LZ_OK;

@@ -65,6 +65,7 @@ class TriplaneRenderer:
         if mode not in ("loop", "fused"):
             raise ValueError("mode must be 'loop' or 'fused'")
         self.mode = mode
+        self.steps_per_pass = 0    # fused mode: samples per ray and pass (0 = auto by ray count; 1, 2, 4, 8, 16 = the schedule n_step it equals)
         import math
         self.head = head
         self.bound = float(bound)
@@ -279,6 +280,7 @@ class TriplaneRenderer:
         f.bg_scalar = 1.0 if bg is not None else float(bg_color)
         f.bound, f.dt_gamma, f.T_thresh, f.min_near = self.bound, float(dt_gamma), float(T_thresh), self.min_near
         f.N, f.max_steps, f.C, f.H = N, int(max_steps), int(self.cascade), int(self.grid_size)
+        f.steps_per_pass = int(self.steps_per_pass)
         call("lz_frame_render", C.byref(f), self._timing, stream())   # timing: one event pair around the persistent kernel
         self._keep = (enc_a, ind_code, eye, bg, rays_o, rays_d)
         res = dict(image=b["out"], image_raw=b["image"], weights_sum=b["weights_sum"], depth=b["depth"], amb_aud_sum=b["amb_aud_sum"],

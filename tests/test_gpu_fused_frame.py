@@ -29,9 +29,11 @@ def setup(params, golden, H, W, scene, precision="f32"):
     return head, bits, ro, rd, cond
 
 
-def both(head, bits, ro, rd, cond, loop_schedule=(1, 1), **kw):
+def both(head, bits, ro, rd, cond, loop_schedule=(1, 1), steps_per_pass=1, **kw):
     from lzzx_nerf_amd.renderer import TriplaneRenderer
-    fused = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused").render(ro, rd, *cond, count_samples=True, **kw)
+    fr = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
+    fr.steps_per_pass = steps_per_pass
+    fused = fr.render(ro, rd, *cond, count_samples=True, **kw)
     fused = {k: v.clone() for k, v in fused.items()}
     loop = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=loop_schedule[0], n_step_cap=loop_schedule[1]).render(
         ro, rd, *cond, count_samples=True, **kw)
@@ -107,3 +109,34 @@ def test_fused_frame_edge_cases(params, golden):
     a = r.render(ro, rd, *cond, max_steps=32)["image"].clone()
     b = r.render(ro, rd, *cond, max_steps=32)["image"].clone()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("S", [2, 4, 8, 16])
+@pytest.mark.parametrize("scene,kw", [("ellipsoid", dict(max_steps=64)), ("ones", dict(max_steps=50, T_thresh=0.5)), ("ones", dict(max_steps=19, dt_gamma=0.0))])
+def test_fused_frame_multi_step_equals_schedule_s(params, golden, S, scene, kw):
+    """steps_per_pass = S (what the host picks for small ray counts) is the loop under n_step = S: bit-identical to the multi-launch
+    loop and to the checker run with (budget_factor, n_step_cap) = (S, S), counts of T_thresh-cut rays and the max_steps rounding included"""
+    head, bits, ro, rd, cond = setup(params, golden, 40, 48, scene)
+    fused, loop = both(head, bits, ro, rd, cond, loop_schedule=(S, S), steps_per_pass=S, **kw)
+    for k in KEYS:
+        assert torch.equal(fused[k], loop[k]), k
+    assert torch.equal(fused["ray_counts"], loop["ray_counts"])
+    assert int(fused["state"][5]) == int(fused["ray_counts"].sum()) == int(loop["state"][5])
+    st = {}
+    ref = render_inference(TriplaneSpec(1.0), params, ro.cpu().numpy(), rd.cpu().numpy(), bits, golden["net_enc_a"], golden["net_ind"],
+                           golden["net_eye"], stats=st, budget_factor=S, n_step_cap=S, **kw)
+    assert np.array_equal(fused["image"].cpu().numpy(), ref["image"])
+    assert np.array_equal(fused["ray_counts"].cpu().numpy().astype(np.int64), st["samples_per_ray"])
+
+
+def test_fused_frame_auto_steps_per_pass_keeps_pixels(params, golden):
+    """a 1/8 tile of the bench frame (32 768 rays: the host picks S = 4) renders the same pixels as the frame rendered whole (S = 1)"""
+    from lzzx_nerf_amd import dist as D
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    head, bits, ro, rd, cond = setup(params, golden, 512, 512, "ones")
+    r = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
+    full = r.render(ro, rd, *cond, max_steps=192)["image"].clone()
+    px = D.tile_pixels(512, 512, 3, 8, "interleaved", "cuda")
+    tile = r.render(ro[px].contiguous(), rd[px].contiguous(), *cond, max_steps=192)
+    assert torch.equal(tile["image"], full[px])
+    assert int(tile["state"][72]) < 1.08 * int(tile["state"][5])      # rows wasted behind the last sample of a ray: < 8 %
