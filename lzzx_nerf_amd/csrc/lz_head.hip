@@ -19,9 +19,10 @@
 //   * First-layer operands come straight from the gathers: the 4 lanes that share a sample split its 36
 //     (plane, level) features (feature f = 4i + q), so the bilinear lookups are spread over all 64 lanes
 //     and land directly in B-operand position.
-//   * One 512-thread workgroup per CU (8 waves = 2 per SIMD: one can gather while the other feeds the
-//     matrix pipe), persistent over 512-sample tiles; all packed weights (431 fragments = 110 KB) stay in
-//     LDS for the life of the workgroup.
+//   * One 1024-thread workgroup per CU (16 waves = 4 per SIMD: some gather while another feeds the matrix pipe), persistent
+//     over a contiguous share of the launch's 16-sample slices, which its waves pull from a queue in LDS; the packed
+//     inference weights (361 fragments + the VALU-layer rows = 94 KB) stay in LDS for the life of the workgroup.
+//   * The body of a slice lives in lz_head_slice.h, shared with the fused frame kernel (lz_frame.hip).
 //   * `count` (device) bounds the work, so the render loop needs no host round trip.
 #include "lz_head_slice.h"
 
