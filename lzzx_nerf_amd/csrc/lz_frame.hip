@@ -110,12 +110,15 @@ __global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
 }
 
 // ---- pass 2: ray ids in descending key order (counting sort; order inside a bin is free -- rays are independent) ---------------
+// Per workgroup: a local histogram in LDS gives every ray its rank among the workgroup's rays of the same key (one LDS atomic each),
+// ONE global atomic per non-empty key reserves the workgroup's range in that bin, all of them in flight together.
 __global__ void __launch_bounds__(256) lz_k_frame_scatter(LzFrameK F) {
-    __shared__ int start[LZF_BINS];
+    __shared__ int start[LZF_BINS], lcount[LZF_BINS], lbase[LZF_BINS];
     {
         // start[k] = rays with a larger key (they come first): suffix scan of the 256 bins (key 0 = no sample, not queued)
         const int h = threadIdx.x > 0 ? F.state[LZF_HIST + threadIdx.x] : 0;
         start[threadIdx.x] = h;
+        lcount[threadIdx.x] = 0;
         __syncthreads();
         for (int off = 1; off < LZF_BINS; off <<= 1) {
             const int v = (threadIdx.x + off < LZF_BINS) ? start[threadIdx.x + off] : 0;
@@ -130,37 +133,47 @@ __global__ void __launch_bounds__(256) lz_k_frame_scatter(LzFrameK F) {
     }
     __syncthreads();
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    int key = n < F.N ? (int)F.keys[n] : 0;
-    bool pending = key > 0;
-    const int lane = threadIdx.x & 63;
-    while (__ballot(pending)) {          // one atomic per distinct key per wave (neighbouring pixels share keys)
-        const unsigned long long act = __ballot(pending);
-        const int leader = __ffsll((long long)act) - 1;
-        const int k0 = __shfl(key, leader, 64);
-        const unsigned long long same = __ballot(pending && key == k0);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(F.state + LZF_CURSOR + k0, __popcll(same));
-        base = __shfl(base, leader, 64);
-        if (pending && key == k0) {
-            F.order[start[k0] + base + __popcll(same & ((1ull << lane) - 1ull))] = (int)n;
-            pending = false;
-        }
-    }
+    const int key = n < F.N ? (int)F.keys[n] : 0;
+    const int lrank = key > 0 ? atomicAdd(&lcount[key], 1) : 0;
+    __syncthreads();
+    const int c = lcount[threadIdx.x];
+    if (c > 0 && threadIdx.x > 0) lbase[threadIdx.x] = atomicAdd(F.state + LZF_CURSOR + threadIdx.x, c);
+    __syncthreads();
+    if (key > 0) F.order[start[key] + lbase[key] + lrank] = (int)n;
 }
 
 // ---- pass 3: the persistent kernel --------------------------------------------------------------------------------------------
 // slot state in LDS, per wave [field][16]
-enum { SF_RAY = 0, SF_T, SF_FAR, SF_DT, SF_WS, SF_D, SF_R, SF_G, SF_B, SF_A0, SF_A1, SF_U, SF_CNT, SF_FIELDS,
+enum { SF_RAY = 0, SF_T, SF_FAR, SF_DT, SF_WS, SF_D, SF_R, SF_G, SF_B, SF_A0, SF_A1, SF_U, SF_CNT,
+       SF_SH,                       // 16 fields: SH(4) of the ray's direction, evaluated once per ray at refill (the head needs it per sample)
+       SF_FIELDS = SF_SH + 16,
        // S > 1 only: per-SAMPLE staging (march -> head, head -> composite) and the per-ray pass counter
        SF_X = SF_FIELDS, SF_Y, SF_Z, SF_TS, SF_OSIG, SF_OR, SF_OG, SF_OB, SF_OA0, SF_OA1, SF_OU, SF_IT, SF_FIELDS_MULTI };
+
+// SH(4) of the slot's ray from LDS: component k of the ray whose state sits at slot `ls`
+struct LzShFromSlot {
+    const float* slot;
+    int ls;
+    __device__ __forceinline__ void prepare() const {}
+    __device__ __forceinline__ float comp_iq(int i, int q) const { return slot[(SF_SH + 4 * i + q) * 16 + ls]; }
+    __device__ __forceinline__ float comp_qj(int q, int j) const { return slot[(SF_SH + 4 * q + j) * 16 + ls]; }
+};
+// evaluated by the lane that takes the ray (the same lz_sh_eval call on the same direction as the stand-alone head makes per sample)
+__device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* slot, int s) {
+    const float* d = F.rays_d + (size_t)ray * 3;
+    float o[16];
+    lz_sh_eval(d[0], d[1], d[2], 4, o, nullptr, nullptr, nullptr);
+#pragma unroll
+    for (int k = 0; k < 16; k++) slot[(SF_SH + k) * 16 + s] = o[k];
+}
 
 template <int PREC> struct LzfHead;
 template <> struct LzfHead<0> {
     using Args = LzHeadArgs; using Ctx = LzHeadCtx; using Out = LzHeadOut;
     static constexpr int LDS_WORDS = LzHeadLds<false>::FLOATS;
     __device__ static __forceinline__ void stage(const Args& P, float* lds, int q, Ctx& c) { lz_head_stage<false>(P, lds, LZF_WG, q, c); }
-    template <typename DirFn>
-    __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, DirFn f, Out& o) {
+    template <typename ShFn>
+    __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
         lz_head_slice<false>(c, lane, x, y, z, f, o);
     }
 };
@@ -168,8 +181,8 @@ template <> struct LzfHead<1> {
     using Args = LzHead16Args; using Ctx = LzHead16Ctx; using Out = LzHead16Out;
     static constexpr int LDS_WORDS = LZ_HEAD16_LDS_H8 * 4;
     __device__ static __forceinline__ void stage(const Args& P, float* lds, int, Ctx& c) { lz_head16_stage(P, reinterpret_cast<lz_h8*>(lds), LZF_WG, c); }
-    template <typename DirFn>
-    __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, DirFn f, Out& o) {
+    template <typename ShFn>
+    __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
         lz_head16_slice(c, lane, x, y, z, f, o);
     }
 };
@@ -228,6 +241,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
                             sloti[SF_CNT * 16 + s] = 0;
                             sloti[SF_IT * 16 + s] = 0;
+                            lzf_store_sh(F, ray, slot, s);
                         }
                     }
                     if (base + take >= n_queue) dry = true;
@@ -267,12 +281,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
             const bool live = sloti[SF_RAY * 16 + lead] >= 0 && j < lkk;
             const float px = live ? slot[SF_X * 16 + s] : 0.0f, py = live ? slot[SF_Y * 16 + s] : 0.0f, pz = live ? slot[SF_Z * 16 + s] : 0.0f;
             typename HD::Out o;
-            HD::slice(ctx, lane, px, py, pz,
-                      [&](float& dx, float& dy, float& dz) {
-                          const int r = sloti[SF_RAY * 16 + lead];
-                          const float* d = F.rays_d + (size_t)(r < 0 ? 0 : r) * 3;
-                          dx = d[0]; dy = d[1]; dz = d[2];
-                      }, o);
+            HD::slice(ctx, lane, px, py, pz, LzShFromSlot{slot, lead}, o);
             my_slices++;
             if (q == 0) {
                 slot[SF_OSIG * 16 + s] = o.sigma;
@@ -342,6 +351,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     #pragma unroll
                             for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
                             sloti[SF_CNT * 16 + s] = 0;
+                            lzf_store_sh(F, ray, slot, s);
                         }
                     }
                     if (base + take >= n_queue) dry = true;    // wave-uniform
@@ -374,12 +384,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
             // ---------------- head: the 16 samples of the slots, exactly one slice of the stand-alone head kernel ----------------
             const float px = __shfl(x, s, 64), py = __shfl(y, s, 64), pz = __shfl(z, s, 64);
             typename HD::Out o;
-            HD::slice(ctx, lane, px, py, pz,
-                      [&](float& dx, float& dy, float& dz) {
-                          const int r = sloti[SF_RAY * 16 + s];
-                          const float* d = F.rays_d + (size_t)(r < 0 ? 0 : r) * 3;
-                          dx = d[0]; dy = d[1]; dz = d[2];
-                      }, o);
+            HD::slice(ctx, lane, px, py, pz, LzShFromSlot{slot, s}, o);
             my_slices++;
             // ---------------- composite (lz_k_composite_rays, n_step = 1): lanes q == 0 ----------------
             if (have) {

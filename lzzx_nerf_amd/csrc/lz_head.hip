@@ -159,7 +159,7 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
         const float px = xyzs[(size_t)m * 3], py = xyzs[(size_t)m * 3 + 1], pz = xyzs[(size_t)m * 3 + 2];
         LzHeadOut o;
         lz_head_slice<TRAIN_UNC>(ctx, lane, px, py, pz,
-                                 [&](float& dx, float& dy, float& dz) { dx = dirs[(size_t)m * 3]; dy = dirs[(size_t)m * 3 + 1]; dz = dirs[(size_t)m * 3 + 2]; }, o);
+                                 lz_sh_from_dir([&](float& dx, float& dy, float& dz) { dx = dirs[(size_t)m * 3]; dy = dirs[(size_t)m * 3 + 1]; dz = dirs[(size_t)m * 3 + 2]; }), o);
         // ---------------- store (lanes q == 0 own sample s) ----------------
         if (q == 0 && base + s < Meff) {
             sigmas[m] = o.sigma;

@@ -131,7 +131,7 @@ lz_k_triplane_head_f16(LzHead16Args P, const float* __restrict__ xyzs, const flo
         const float px = xyzs[(size_t)m * 3], py = xyzs[(size_t)m * 3 + 1], pz = xyzs[(size_t)m * 3 + 2];
         LzHead16Out o;
         lz_head16_slice(ctx, lane, px, py, pz,
-                        [&](float& dx, float& dy, float& dz) { dx = dirs[(size_t)m * 3]; dy = dirs[(size_t)m * 3 + 1]; dz = dirs[(size_t)m * 3 + 2]; }, o);
+                        lz_sh_from_dir([&](float& dx, float& dy, float& dz) { dx = dirs[(size_t)m * 3]; dy = dirs[(size_t)m * 3 + 1]; dz = dirs[(size_t)m * 3 + 2]; }), o);
         // ---------------- store (lanes q == 0 own sample s) ----------------
         if (q == 0 && base + s < Meff) {
             sigmas[m] = o.sigma;

@@ -9,6 +9,7 @@
 #include "lzzx_detmath.h"
 #include "lzzx_sh_eval.h"
 #include "lz_head_gather.h"
+#include "lz_head_slice.h"   // LzShFromDir
 
 #ifndef LZ_HEAD_LAYERS_H
 typedef float lz_f4 __attribute__((ext_vector_type(4)));
@@ -106,8 +107,8 @@ __device__ __forceinline__ void lz_head16_stage(const LzHead16Args& P, lz_h8* wl
     hc.unc_const = lz_softplusf(0.0f);   // test mode (network.py:243-249, 278)
 }
 
-template <typename DirFn>
-__device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane, float px, float py, float pz, DirFn dirfn, LzHead16Out& out) {
+template <typename ShFn>   // SH(4) source: LzShFromDir (lz_head_slice.h) or the frame kernel's per-ray LDS copy
+__device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane, float px, float py, float pz, ShFn shfn, LzHead16Out& out) {
     const int q = lane >> 4;
     // ---------------- gather (f32, the same code as lz_k_triplane_head: lz_head_gather.h): lane q holds enc_x features 4 i + q
     float encx[9];
@@ -172,14 +173,11 @@ __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane,
     // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
     float rgb[3];
     {
-        float o[16];
-        float ddx, ddy, ddz;
-        dirfn(ddx, ddy, ddz);
-        lz_sh_eval(ddx, ddy, ddz, 4, o, nullptr, nullptr, nullptr);
+        shfn.prepare();
         lz_h8 b1[3];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            b1[0][j] = (_Float16)(q == 0 ? o[j] : (q == 1 ? o[4 + j] : (q == 2 ? o[8 + j] : o[12 + j])));   // SH 4 q + j
+            b1[0][j] = (_Float16)shfn.comp_qj(q, j);   // SH 4 q + j
             b1[0][4 + j] = (q == 0 && hc.ind_code) ? (_Float16)hc.ind_code[j] : (_Float16)0.0f;
         }
         b1[1] = geo16[0];

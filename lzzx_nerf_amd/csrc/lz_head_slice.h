@@ -65,9 +65,31 @@ __device__ __forceinline__ void lz_head_stage(const LzHeadArgs& P, float* wl, ui
     hc.indq = P.ind_code ? P.ind_code[q] : 0.0f;
 }
 
-// one slice: (px, py, pz) = this lane's sample position, dirfn(dx, dy, dz) yields its view direction when the colour net needs it
-template <bool TRAIN_UNC, typename DirFn>
-__device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, float px, float py, float pz, DirFn dirfn, LzHeadOut& out) {
+// SH(4) source that evaluates the polynomials from a direction fetched on demand (the stand-alone kernels: dirs are per sample)
+template <typename DirFn>
+struct LzShFromDir {
+    DirFn dirfn;
+    float o[16];
+    __device__ __forceinline__ explicit LzShFromDir(DirFn f) : dirfn(f) {}
+    __device__ __forceinline__ void prepare() {
+        float dx, dy, dz;
+        dirfn(dx, dy, dz);
+        lz_sh_eval(dx, dy, dz, 4, o, nullptr, nullptr, nullptr);
+    }
+    __device__ __forceinline__ float comp_iq(int i, int q) const {    // component 4 i + q (i compile-time after unrolling)
+        return q == 0 ? o[4 * i] : (q == 1 ? o[4 * i + 1] : (q == 2 ? o[4 * i + 2] : o[4 * i + 3]));
+    }
+    __device__ __forceinline__ float comp_qj(int q, int j) const {    // component 4 q + j
+        return q == 0 ? o[j] : (q == 1 ? o[4 + j] : (q == 2 ? o[8 + j] : o[12 + j]));
+    }
+};
+template <typename DirFn>
+__device__ __forceinline__ LzShFromDir<DirFn> lz_sh_from_dir(DirFn f) { return LzShFromDir<DirFn>(f); }
+
+// one slice: (px, py, pz) = this lane's sample position; shfn supplies SH(4) of its view direction when the colour net needs it
+// (LzShFromDir: evaluated here from the direction, like the reference per sample; the fused frame kernel reads it per ray from LDS)
+template <bool TRAIN_UNC, typename ShFn>
+__device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, float px, float py, float pz, ShFn shfn, LzHeadOut& out) {
     constexpr int WV = LzHeadLds<TRAIN_UNC>::WV;
     const int q = lane >> 4;
     // ---------------- gather: enc_x features f = 4i + q of sample s -> B operands (lz_head_gather.h) ----------------
@@ -218,12 +240,9 @@ __device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, flo
         for (int j = 0; j < LZ_T; j++) {
             // SH(4) of the view direction (constant per ray, recomputed per sample like the reference): this lane
             // keeps components 4i + q
-            float ddx, ddy, ddz;
-            dirfn(ddx, ddy, ddz);
-            float o[16];
-            lz_sh_eval(ddx, ddy, ddz, 4, o, nullptr, nullptr, nullptr);
+            shfn.prepare();
 #pragma unroll
-            for (int i = 0; i < 4; i++) b1[j][i] = q == 0 ? o[4 * i] : (q == 1 ? o[4 * i + 1] : (q == 2 ? o[4 * i + 2] : o[4 * i + 3]));
+            for (int i = 0; i < 4; i++) b1[j][i] = shfn.comp_iq(i, q);     // SH component 4 i + q
 #pragma unroll
             for (int k = 0; k < 16; k++) b1[j][4 + k] = geo[j][k];
             b1[j][20] = hc.indq;
