@@ -304,6 +304,7 @@ def parse_args():
     ap.add_argument("--mode", default="fused", choices=["fused", "loop"],
                     help="fused: the frame as one persistent kernel (csrc/lz_frame.hip; the loop under the schedule n_step = 1, same pixels); "
                          "loop: march / head / composite launches per iteration under --budget-factor / --n-step-cap")
+    ap.add_argument("--steps-per-pass", type=int, default=0, help="fused mode: samples per ray and pass (0 = auto by ray count)")
     ap.add_argument("--no-side-legs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true",
@@ -786,6 +787,7 @@ def main():
     def make_job(shard, tiles, budget_factor=None, n_step_cap=None, h=None, shard_of=0, mode=None):
         r = TriplaneRenderer(h or head, bits_dev, bound=1.0, budget_factor=budget_factor or args.budget_factor,
                              n_step_cap=n_step_cap or args.n_step_cap, mode=mode or args.mode)
+        r.steps_per_pass = args.steps_per_pass
         k = rank if (world > 1 and shard == "clip") else 0     # clip mode: frame `rank` of the clip, with its own audio feature
         enc_a = enc_a0
         if k > 0:

@@ -140,3 +140,17 @@ def test_fused_frame_auto_steps_per_pass_keeps_pixels(params, golden):
     tile = r.render(ro[px].contiguous(), rd[px].contiguous(), *cond, max_steps=192)
     assert torch.equal(tile["image"], full[px])
     assert int(tile["state"][72]) < 1.08 * int(tile["state"][5])      # rows wasted behind the last sample of a ray: < 8 %
+
+
+def test_cfg5_1024_ellipsoid_f16_fused_equals_loop(params, golden):
+    """BASELINE cfg5 at full size: 1024 x 1024 rays, ellipsoid occupancy (2.9 % of the cells: empty-space skipping + compaction),
+    f16 MLP on the matrix cores -- the fused frame equals the multi-launch loop under the reference's schedule, pixel for pixel and
+    count for count (no ray of this scene is cut by T_thresh), and most rays never enter the queue"""
+    head, bits, ro, rd, cond = setup(params, golden, 1024, 1024, "ellipsoid", precision="f16")
+    fused, loop = both(head, bits, ro, rd, cond, loop_schedule=(1, 8), max_steps=192)
+    for k in KEYS:
+        assert torch.equal(fused[k], loop[k]), k
+    assert torch.equal(fused["ray_counts"], loop["ray_counts"])
+    n_hit = int(fused["state"][1])
+    assert 0.05 * 1024 * 1024 < n_hit < 0.5 * 1024 * 1024           # only the rays that meet the ellipsoid are queued
+    assert int((fused["ray_counts"] > 0).sum()) == n_hit
