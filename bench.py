@@ -90,11 +90,22 @@ def grid_roofline(device):
             ("triplane_plane_D2_L12_C1_f32", tri, 8 + 12 * 4 * 4 + 48, 1 << 24, "fwd"),
             ("hashgrid_D3_L16_C2_f32", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23, "fwd"),
             ("hashgrid_D3_L16_C2_f32_ray_ordered", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23, "fwd_rays"),
+            ("hashgrid_D3_L16_C2_f32_march_order", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23, "fwd_march"),
             ("hashgrid_D3_L16_C2_f16", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 2 + 64, 1 << 23, "fwd16"),
             ("triplane_plane_D2_L12_C1_f32_backward", tri, 8 + 48 + 12 * 4 * 4 * 2, 1 << 22, "bwd")):
         enc = GridEncoder(**kw).to(device)
         enc.embeddings.data.uniform_(-1, 1, generator=g)
-        if mode == "fwd_rays":   # BASELINE cfg2 as march_rays hands it to the encoder: 256 x 256 rays x 128 samples, ray-major
+        if mode == "fwd_march":   # BASELINE cfg2 as the INFERENCE loop hands it to the encoder (renderer.py:513-521): per iteration every
+            # alive ray contributes n_step = 8 consecutive samples, rays in pixel order -> [iteration][ray][8 steps]; 16 iterations of the
+            # 256 x 256 frame = 2^23 samples (all rays kept alive: the densest case)
+            from lzzx_nerf_amd.synthetic import synthetic_camera
+            from lzzx_nerf_amd.utils import frame_rays
+            pose, intr = synthetic_camera(256, 256)
+            ro, rd = frame_rays(torch.from_numpy(pose).to(device), intr, 256, 256)
+            t = torch.linspace(2.35, 4.35, 128, device=device).view(16, 1, 8)                       # [iteration, 1, step]
+            p = ro[None, :, None, :] + rd[None, :, None, :] * t[..., None]                        # [16, rays, 8, 3]
+            x = ((p.clamp(-1, 1) + 1) / 2).reshape(-1, 3).contiguous()
+        elif mode == "fwd_rays":   # march_rays_train order: 256 x 256 rays x 128 consecutive samples, ray-major
             from lzzx_nerf_amd.synthetic import synthetic_camera
             from lzzx_nerf_amd.utils import frame_rays
             pose, intr = synthetic_camera(256, 256)
