@@ -166,3 +166,79 @@ def test_pipeline_smooth_lips_blends_audio_code_across_frames(params, golden):
     frame.reset()
     out = frame.render(dev(ro), dev(rd), auds.cuda(), eye=dev(golden["net_eye"]), ind_code=dev(golden["net_ind"]), max_steps=32)
     assert np.array_equal(out["enc_a"].cpu().numpy(), own)                          # a new clip starts from its own code
+
+
+def test_torso_trains_through_the_operator_path():
+    """forward_torso as an autograd graph over the operators (lzzx_nerf_amd.torso_train.TorsoTrainNet): the forward agrees with the
+    one-launch inference kernel on the same state dict, and every gradient (MLP weights, tiled-grid table, anchor points) with a
+    float64 torch model of the same math -- the reference trains exactly this graph (network.py:170-205, get_params :318-330)"""
+    from lzzx_nerf_amd.torso import FusedTorso
+    from lzzx_nerf_amd.torso_train import TorsoTrainNet
+    sd = _torso_state(8, seed=3)
+    net = TorsoTrainNet(ind_dim_torso=8).cuda()
+    missing = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not missing.unexpected_keys and set(missing.missing_keys) <= {"torso_encoder.offsets"} or not missing.missing_keys
+    rng = np.random.default_rng(9)
+    N = 3000
+    x = torch.from_numpy(rng.uniform(-1, 1, (N, 2)).astype(F32)).cuda()
+    pose = np.eye(4, dtype=F32)
+    pose[:3, 3] = [0.05, -0.02, 3.3]
+    poses = torch.from_numpy(pose[None]).cuda()
+    c = torch.from_numpy((rng.normal(size=(1, 8)) * 0.1).astype(F32)).cuda()
+    target = torch.from_numpy(rng.uniform(0, 1, (N, 4)).astype(F32)).cuda()
+    alpha, color, dx = net(x, poses, c)
+    fused = FusedTorso({k: torch.from_numpy(v) for k, v in sd.items()})
+    a_f, c_f, d_f = fused(x, poses, c)
+    assert float((alpha - a_f).abs().max()) < 2e-5 and float((color - c_f).abs().max()) < 2e-5 and float((dx - d_f).abs().max()) < 2e-5
+    loss = ((torch.cat([alpha, color], -1) - target) ** 2).mean() + 1e-2 * (dx ** 2).mean()
+    loss.backward()
+    grads = {k: p.grad.detach().double().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    assert {"torso_net.net.0.weight", "torso_deform_net.net.2.weight", "torso_encoder.embeddings", "anchor_points"} <= set(grads)
+
+    # float64 model of the same graph in plain torch (dense bilinear interpolation of the tiled grid written out)
+    P = {k: torch.from_numpy(v).double().requires_grad_(v.dtype == F32) for k, v in sd.items() if k != "torso_encoder.offsets"}
+    offs = sd["torso_encoder.offsets"].astype(np.int64)
+
+    def freq(v, deg):
+        outs = [v]
+        for k in range(deg):
+            outs += [torch.sin(v * 2.0 ** k), torch.cos(v * 2.0 ** k)]
+        return torch.cat(outs, -1)
+
+    def tiled_grid(u01):
+        feats = []
+        S = np.log2(2048 / 16) / 15
+        for l in range(16):
+            scale = float(np.float32(np.exp2(np.float32(l) * np.float32(S)) * np.float32(16) - np.float32(1)))
+            res = int(np.ceil(scale)) + 1
+            size = int(offs[l + 1] - offs[l])
+            pos = u01 * scale + 0.5
+            g0 = torch.floor(pos).detach()
+            fr = pos - g0
+            g0 = g0.long()
+            acc = 0
+            for cx in (0, 1):
+                for cy in (0, 1):
+                    ix, iy = g0[:, 0] + cx, g0[:, 1] + cy
+                    idx = (ix + iy * (res + 1)) % size                     # tiled: wrap the dense index (gridencoder.cu:54-72)
+                    w = (fr[:, 0] if cx else 1 - fr[:, 0]) * (fr[:, 1] if cy else 1 - fr[:, 1])
+                    acc = acc + w[:, None] * P["torso_encoder.embeddings"][offs[l] + idx]
+            feats.append(acc)
+        return torch.cat(feats, -1)
+
+    xd = x.double().cpu() * 0.8
+    wrapped = P["anchor_points"][None] @ torch.from_numpy(pose[None]).double().permute(0, 2, 1).inverse()
+    wrapped = (wrapped[:, :, :2] / wrapped[:, :, 3, None] / wrapped[:, :, 2, None]).view(1, -1)
+    h = torch.cat([freq(xd, 8), freq(wrapped, 3).repeat(N, 1), c.double().cpu().repeat(N, 1)], -1)
+    mlp = lambda v, name: torch.relu(torch.relu(v @ P[f"{name}.net.0.weight"].T) @ P[f"{name}.net.1.weight"].T) @ P[f"{name}.net.2.weight"].T
+    dxd = mlp(h, "torso_deform_net")
+    xx = (xd + dxd).clamp(-1, 1)
+    hh = mlp(torch.cat([tiled_grid((xx + 1) / 2), h], -1), "torso_net")
+    out = torch.sigmoid(hh) * 1.002 - 0.001
+    ref_loss = ((out - target.double().cpu()) ** 2).mean() + 1e-2 * (dxd ** 2).mean()
+    ref_loss.backward()
+    assert float(loss) == pytest.approx(float(ref_loss), rel=1e-5)
+    for k, g in grads.items():
+        r = P[k].grad
+        scale = float(r.abs().max())
+        assert scale > 0 and float((g - r).abs().max()) <= 2e-3 * scale, (k, float((g - r).abs().max()), scale)
