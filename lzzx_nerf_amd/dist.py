@@ -119,7 +119,11 @@ class TileGatherer:
     def wait(self):
         """make the current stream wait for every collective issued so far"""
         if self.comm is not None:
-            torch.cuda.current_stream().wait_stream(self.comm)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self.comm)
+            for o in self.out:       # the gathered buffers were allocated on the side stream: tell the allocator this stream reads them
+                if o is not None:
+                    o.record_stream(cur)
 
 
 class ShardedFrame:

@@ -5,6 +5,8 @@ Mirror of the reference's `MLP` (/root/reference/nerf_triplane/network.py:73-94)
 shapes (K, N <= 84 over millions of samples) those spend 3/4 of a training step.  Here every layer is ONE kernel forward
 (ReLU fused) and two backward (data gradient with the ReLU mask fused; weight gradient reduced over the samples in-kernel).
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -45,7 +47,13 @@ class _lz_linear(Function):
             dx = dx.view(ctx.in_shape)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(w)
-            call("lz_linear_grad_w", ptr(dy2), N, ptr(y), ptr(x2), K, ptr(dw), K, M, K, N, stream())
+            # the kernel keeps <= 24 accumulator tiles of 16 x 16 and <= 96 input columns per launch: wider layers (the torso net's
+            # 116-column input) go in column blocks -- dW[:, k0:k1] only needs X[:, k0:k1] (leading dimensions stay K)
+            kb = min(96, (24 // ((N + 15) // 16)) * 16)
+            for k0 in range(0, K, kb):
+                k1 = min(K, k0 + kb)
+                call("lz_linear_grad_w", ptr(dy2), N, ptr(y), C.c_void_p(x2.data_ptr() + 4 * k0), K, C.c_void_p(dw.data_ptr() + 4 * k0), K, M,
+                     k1 - k0, N, stream())
         return dx, dw, None
 
 
