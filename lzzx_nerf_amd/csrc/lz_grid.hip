@@ -22,6 +22,7 @@
 #include "lzzx_detmath.h"
 #include <hip/hip_fp16.h>
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #define LZ_MAX_LEVELS 32
@@ -398,6 +399,56 @@ lz_k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
                 } while (old != assumed);
             }
         }
+    }
+}
+
+// Scatter-add for tables too big for LDS (cfg2: 4 MB per level), f32.  Scattered float atomics retire at the memory side per LINE
+// touched (~2e10 lane-adds/s when every lane of an instruction hits its own line, a sixteenth of the contiguous rate).  So the lanes
+// are arranged to share lines: lane = (sample, x bit of the corner, channel) -- the x and x+1 corners of a cell are adjacent entries
+// on dense levels and sit in the same 128-byte line on hashed ones (prime_x = 1) -- and an instruction covers one (y, z, ...) corner
+// combination of 64 / (2 C) samples: 2 C lanes per line instead of one.  Levels are the slow launch dimension (one 4 MB gradient
+// level L2-resident at a time).  Same terms as the plain kernel; the order of the atomics is free in both.
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256)
+lz_k_grid_backward_xc(const float* __restrict__ grad, const float* __restrict__ inputs, const int* __restrict__ offsets,
+                      float* __restrict__ grad_grid, uint32_t B, uint32_t L, LzGridLevels lv, uint32_t gridtype, bool align_corners,
+                      bool sample_major) {
+    constexpr uint32_t LPS = 2 * C;                     // lanes per sample
+    const uint32_t level = blockIdx.y;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t / LPS, sub = t - b * LPS, xb = sub / C, ch = sub - xb * C;
+    if (b >= B) return;
+    float x[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        if (x[d] < 0 || x[d] > 1) return;
+    }
+    const uint32_t off0 = (uint32_t)offsets[level], hs = (uint32_t)offsets[level + 1] - off0;
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.res[level];
+    float* gg = grad_grid + (size_t)off0 * C;
+    const float g = grad[(sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C) + ch];
+    float pos[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = lz_fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+    }
+#pragma unroll
+    for (uint32_t h = 0; h < (1u << (D - 1)); h++) {
+        const uint32_t idx = (h << 1) | xb;
+        float w = 1.0f;
+        uint32_t pl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+            else { w *= pos[d]; pl[d] = pg[d] + 1; }
+        }
+        const uint32_t index = lz_grid_index<D>(C, gridtype, align_corners, hs, resolution, pl);
+        lz_atomic_add(gg + index + ch, w * g);
     }
 }
 
@@ -1157,6 +1208,14 @@ static void lz_grid_bwd_launch(const T* grad, const float* inputs, const int* of
     if constexpr (sizeof(T) == 4 && D <= 3 && C <= 2) {
         if (resident) {  // level tables fit LDS: private fixed-point accumulation, see lz_k_grid_backward_lds_fx
             lz_grid_bwd_lds_launch<D, C>(grad, inputs, offsets, gemb, B, L, lv, gridtype, ac, sm, st);
+            done = true;
+        }
+    }
+    if constexpr (sizeof(T) == 4 && C <= 2 && D >= 2) {
+        static const bool plain = getenv("LZ_GRID_BWD_PLAIN") != nullptr;   // diagnostic: the one-lane-per-(sample, level) kernel
+        if (!done && !plain && B >= 4096) {  // big tables: lanes share lines (lz_k_grid_backward_xc)
+            hipLaunchKernelGGL((lz_k_grid_backward_xc<D, C>), dim3(lz_div_up((uint64_t)B * 2 * C, 256), L, 1), block, 0, st, grad, inputs, offsets,
+                               gemb, B, L, lv, gridtype, ac, sm);
             done = true;
         }
     }
