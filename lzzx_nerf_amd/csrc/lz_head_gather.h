@@ -26,7 +26,17 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
         lv_stride[mrec] = (uint32_t)lres[level] + 1u;
         lv_dense[mrec] = lv_stride[mrec] <= lv_hs[mrec] && lv_stride[mrec] * lv_stride[mrec] <= lv_hs[mrec];
     }
-    const float x01 = (px + bound) / two_bound, y01 = (py + bound) / two_bound, z01 = (pz + bound) / two_bound;
+    // (x + bound) / (2 bound), grid.py:143.  When 2 bound is a power of two (bound 1, 2, 4 ...: every scene of the reference) the
+    // division equals the multiplication by its exact reciprocal bit for bit, and an IEEE division is ~11 VALU instructions
+    const uint32_t tb_bits = __float_as_uint(two_bound);
+    const bool pow2 = (tb_bits & 0x007fffffu) == 0u && tb_bits > 0x00800000u && tb_bits < 0x7f000000u;   // wave-uniform
+    float x01, y01, z01;
+    if (pow2) {
+        const float inv = __uint_as_float(0x7f000000u - tb_bits);    // 2^-k for two_bound = 2^k
+        x01 = (px + bound) * inv; y01 = (py + bound) * inv; z01 = (pz + bound) * inv;
+    } else {
+        x01 = (px + bound) / two_bound; y01 = (py + bound) / two_bound; z01 = (pz + bound) / two_bound;
+    }
     // Branch-free: out-of-range coordinates are clamped for ADDRESSING only and the feature is zeroed by a select
     // (gridencoder.cu:98-122), so all 36 gathers of a sample are independent loads.  Two passes so that the 36 table reads are IN
     // FLIGHT TOGETHER (one L2 round trip per slice instead of one per read): pass 1 computes fractions + table indices and issues
