@@ -29,6 +29,7 @@
 #define LZF_WG 1024
 #define LZF_WAVES (LZF_WG / 64)
 #define LZF_BINS 256
+#define LZF_MARCH_PROBES 6   // cells a slot may cross per march attempt (S = 1)
 // device state words (LZ_FRAME_STATE_INTS int32, zeroed per frame by lz_frame_render).  Words 3, 5, 6 and 72 sit where the
 // multi-launch loop keeps done / total_samples / iterations / rows (lz_loop_state, LZ_LOOP_STAT_ROWS), so a caller reads both alike.
 #define LZF_Q_HEAD 0      // queue cursor
@@ -360,12 +361,19 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                     m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
                     float t = slot[SF_T * 16 + s], dt = 0.0f;
                     const float far = slot[SF_FAR * 16 + s];
-                    while (t < far) {
+                    // at most LZF_MARCH_PROBES cells per attempt: a ray crossing empty space (behind the object, between two blobs) keeps
+                    // its slot idle for a few passes instead of stalling the 15 other slots of the wave for the whole crossing
+                    int probes = 0;
+                    while (t < far && probes < LZF_MARCH_PROBES) {
                         if (m.probe(t, x, y, z, dt)) { have = true; break; }
+                        probes++;
                     }
                     if (have) {
                         slot[SF_T * 16 + s] = t;
                         slot[SF_DT * 16 + s] = dt;
+                    } else if (t < far) {   // still in empty space: resume from here in the next pass
+                        slot[SF_T * 16 + s] = t;
+                        x = y = z = 0.0f;
                     } else {        // the ray left the box (renderer.py: the march writes no row, compositing kills the ray on delta == 0)
                         lzf_write_pixel(F, ray, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s], slot[SF_B * 16 + s],
                                         slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s], sloti[SF_CNT * 16 + s]);
@@ -378,8 +386,8 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 if (!__ballot((q == 0) && ray < 0 && !dry)) break;
             }
             if (!__ballot(have)) {
-                if (dry) break;     // queue dry and no slot holds a sample: every slot is empty, this wave is done
-                continue;
+                if (dry && !__ballot((q == 0) && ray >= 0)) break;     // queue dry and every slot empty: this wave is done
+                continue;                                             // slots still crossing empty space (or waiting for a refill)
             }
             // ---------------- head: the 16 samples of the slots, exactly one slice of the stand-alone head kernel ----------------
             const float px = __shfl(x, s, 64), py = __shfl(y, s, 64), pz = __shfl(z, s, 64);
