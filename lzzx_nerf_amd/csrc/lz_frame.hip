@@ -29,7 +29,7 @@
 #define LZF_WG 1024
 #define LZF_WAVES (LZF_WG / 64)
 #define LZF_BINS 256
-#define LZF_MARCH_PROBES 6   // cells a slot may cross per march attempt (S = 1)
+#define LZF_MARCH_PROBES 2   // empty cells a slot may cross per march attempt (S = 1); measured on cfg5 (f16 / f32 ms): 1 -> 1.80 / 4.30, 2 -> 1.82 / 4.29, 3 -> 1.83 / 4.34, 6 -> 1.84 / 4.38, 12 -> 1.96 / 4.49, unbounded -> 2.39 / 4.81
 // device state words (LZ_FRAME_STATE_INTS int32, zeroed per frame by lz_frame_render).  Words 3, 5, 6 and 72 sit where the
 // multi-launch loop keeps done / total_samples / iterations / rows (lz_loop_state, LZ_LOOP_STAT_ROWS), so a caller reads both alike.
 #define LZF_Q_HEAD 0      // queue cursor
@@ -361,7 +361,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                     m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
                     float t = slot[SF_T * 16 + s], dt = 0.0f;
                     const float far = slot[SF_FAR * 16 + s];
-                    // at most LZF_MARCH_PROBES cells per attempt: a ray crossing empty space (behind the object, between two blobs) keeps
+                    // at most LZF_MARCH_PROBES empty cells per attempt: a ray crossing empty space (behind the object, between two blobs) keeps
                     // its slot idle for a few passes instead of stalling the 15 other slots of the wave for the whole crossing
                     int probes = 0;
                     while (t < far && probes < LZF_MARCH_PROBES) {
