@@ -895,7 +895,8 @@ def main():
             k = "lz_k_frame<0, 1>" if args.mode == "fused" else "lz_k_triplane_head<false>"
             roofline["traffic"] = round((2 * pmc["FETCH_SIZE"][k]["avg_per_launch"] + pmc["WRITE_SIZE"][k]["avg_per_launch"]) * 1024)
             roofline["traffic_unit"] = f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, averaged over all launches of profiles/{PMC_SUMMARY})"
-            roofline["algorithmic_bytes_per_launch"] = (round(92 * job.n_rays) if args.mode == "fused" else   # 24 B/ray in, ~68 B/ray out
+            # fused: 24 B/ray in + ~68 B/ray out, plus the packed weights every workgroup stages into its LDS once (256 x 94 KB)
+            roofline["algorithmic_bytes_per_launch"] = (round(92 * job.n_rays + min(256, (job.n_rays + 63) // 64) * 94080) if args.mode == "fused" else
                                                         round(52 * my_rows * args.steps / max(n_launch, 1)))
         except (KeyError, ValueError):
             pass
