@@ -488,7 +488,7 @@ def f16_head_roofline(samples, rows, steps, head_total_ms, n_launch, launches_wi
     t = head_total_ms * 1e-3
     sps = samples * steps / t
     r = dict(bound="valu-issue", achieved=round(sps / 1e9, 4), peak=None, unit="Gsample/s", frac=None, traffic=None,
-             kernel="lz_k_frame<1, S> (march + f16 head + composite, one persistent launch per frame)" if fused else "lz_k_triplane_head_f16",
+             kernel="lz_k_frame<1, S, ROWS> (march + f16 head + composite, one persistent launch per frame)" if fused else "lz_k_triplane_head_f16",
              avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5), avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5),
              launches=n_launch, head_time_share=round(t / dt, 4), head_ms_per_step=round(head_total_ms / steps, 4), rows_per_frame=rows,
              samples_per_s=round(sps, 1),
@@ -496,7 +496,7 @@ def f16_head_roofline(samples, rows, steps, head_total_ms, n_launch, launches_wi
              matrix_pipe_busy_frac=round(F16_SLICE_MFMAS * 16 * (rows / 16) * steps / (t * 2.4e9 * 1024), 4))
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_f16_head_pmc_summary.json")))
-        k = "lz_k_frame<1, 1>" if fused else "lz_k_triplane_head_f16"
+        k = "lz_k_frame<1, 1, 2>" if fused else "lz_k_triplane_head_f16"
         n_mfma = pmc["SQ_INSTS_VALU_MFMA_MOPS_F16"][k]["avg_per_launch"] / 32.0       # MOPS counts 512-FLOP units: 32 per 16x16x32 MFMA
         slices = n_mfma / F16_SLICE_MFMAS
         valu = pmc["SQ_INSTS_VALU"][k]["avg_per_launch"] - n_mfma
@@ -873,7 +873,7 @@ def main():
     achieved_tflops = FLOP_PER_SAMPLE * my_samples * args.steps / (head_total_ms * 1e-3) / 1e12
     roofline = dict(bound="mfma", achieved=round(achieved_tflops, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                    kernel="lz_k_frame<0, S> (march + head + composite, one persistent launch per frame)" if args.mode == "fused" else "lz_k_triplane_head<false>",
+                    kernel="lz_k_frame<0, S, 1> (march + head + composite, one persistent launch per frame)" if args.mode == "fused" else "lz_k_triplane_head<false>",
                     avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5),
                     avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5), launches=n_launch,
                     launches_with_work=launches_with_work, flop_per_sample=FLOP_PER_SAMPLE,
@@ -892,7 +892,7 @@ def main():
         # for gfx950 (128-B requests tallied at 64 B).  bench.py cannot collect counters itself; null when the summary is absent.
         try:
             pmc = json.load(open(pmc_path))
-            k = "lz_k_frame<0, 1>" if args.mode == "fused" else "lz_k_triplane_head<false>"
+            k = "lz_k_frame<0, 1, 1>" if args.mode == "fused" else "lz_k_triplane_head<false>"
             roofline["traffic"] = round((2 * pmc["FETCH_SIZE"][k]["avg_per_launch"] + pmc["WRITE_SIZE"][k]["avg_per_launch"]) * 1024)
             roofline["traffic_unit"] = f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, averaged over all launches of profiles/{PMC_SUMMARY})"
             # fused: 24 B/ray in + ~68 B/ray out, plus the packed weights every workgroup stages into its LDS once (256 x 94 KB)

@@ -22,6 +22,8 @@
 //     ray ids; lz_k_frame is the persistent kernel: 3 launches + 1 memset per frame, no host round trip, no per-sample HBM traffic
 //     (compulsory: 24 B/ray in, ~50 B/ray out).
 //   * No inter-workgroup communication; a wave leaves when the queue is dry and its slots are empty, so the grid always drains.
+#include <stdlib.h>
+
 #include "lz_march.h"
 #include "lz_head_slice.h"
 #include "lz_head_f16_slice.h"
@@ -151,21 +153,21 @@ enum { SF_RAY = 0, SF_T, SF_FAR, SF_DT, SF_WS, SF_D, SF_R, SF_G, SF_B, SF_A0, SF
        // S > 1 only: per-SAMPLE staging (march -> head, head -> composite) and the per-ray pass counter
        SF_X = SF_FIELDS, SF_Y, SF_Z, SF_TS, SF_OSIG, SF_OR, SF_OG, SF_OB, SF_OA0, SF_OA1, SF_OU, SF_IT, SF_FIELDS_MULTI };
 
-// SH(4) of the slot's ray from LDS: component k of the ray whose state sits at slot `ls`
+// SH(4) of the slot's ray from LDS: component k of the ray whose state sits at slot `ls` (fields are `ns` slots wide)
 struct LzShFromSlot {
     const float* slot;
-    int ls;
+    int ls, ns;
     __device__ __forceinline__ void prepare() const {}
-    __device__ __forceinline__ float comp_iq(int i, int q) const { return slot[(SF_SH + 4 * i + q) * 16 + ls]; }
-    __device__ __forceinline__ float comp_qj(int q, int j) const { return slot[(SF_SH + 4 * q + j) * 16 + ls]; }
+    __device__ __forceinline__ float comp_iq(int i, int q) const { return slot[(SF_SH + 4 * i + q) * ns + ls]; }
+    __device__ __forceinline__ float comp_qj(int q, int j) const { return slot[(SF_SH + 4 * q + j) * ns + ls]; }
 };
 // evaluated by the lane that takes the ray (the same lz_sh_eval call on the same direction as the stand-alone head makes per sample)
-__device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* slot, int s) {
+__device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* slot, int s, int ns) {
     const float* d = F.rays_d + (size_t)ray * 3;
     float o[16];
     lz_sh_eval(d[0], d[1], d[2], 4, o, nullptr, nullptr, nullptr);
 #pragma unroll
-    for (int k = 0; k < 16; k++) slot[(SF_SH + k) * 16 + s] = o[k];
+    for (int k = 0; k < 16; k++) slot[(SF_SH + k) * ns + s] = o[k];
 }
 
 template <int PREC> struct LzfHead;
@@ -193,21 +195,23 @@ template <> struct LzfHead<1> {
 // raises S until there are enough 16-sample rows in flight: the loop under the schedule n_step = S (the rows behind a ray's last sample
 // in its last pass are the only waste).  Samples of a pass are staged per slot in LDS: the group leader (lane j == 0 of a ray's S
 // slots) marches and composites, every slot's lanes evaluate the head.
-template <int PREC, int S>
+template <int PREC, int S, int ROWS>
 __global__ void __launch_bounds__(LZF_WG, LZF_WG / 256)
 lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     using HD = LzfHead<PREC>;
-    constexpr int NF = S == 1 ? (int)SF_FIELDS : (int)SF_FIELDS_MULTI;
-    constexpr int SLOT_WORDS = LZF_WAVES * NF * 16;
+    static_assert(ROWS == 1 || S == 1, "several slot rows per wave only with one sample per ray and pass");
+    constexpr int NS = 16 * ROWS;                                   // ray slots per wave
+    constexpr int NF = (S == 1 && ROWS == 1) ? (int)SF_FIELDS : (int)SF_FIELDS_MULTI;
+    constexpr int SLOT_WORDS = LZF_WAVES * NF * NS;
     __shared__ __align__(16) float lds[HD::LDS_WORDS + SLOT_WORDS + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
     typename HD::Ctx ctx;
     HD::stage(P, lds, q, ctx);
-    float* slot = lds + HD::LDS_WORDS + wave * NF * 16;      // this wave's slots: slot[field * 16 + s]
+    float* slot = lds + HD::LDS_WORDS + wave * NF * NS;      // this wave's slots: slot[field * 16 + s]
     int* sloti = reinterpret_cast<int*>(slot);
     int* wg_stat = reinterpret_cast<int*>(lds + HD::LDS_WORDS + SLOT_WORDS);   // [0] samples, [1] slices, [2] waves done
-    if (lane < 16) sloti[SF_RAY * 16 + lane] = -1;
+    if (lane < NS) sloti[SF_RAY * NS + lane] = -1;
     if (threadIdx.x < 4) wg_stat[threadIdx.x] = 0;
     __syncthreads();
     const int n_queue = F.state[LZF_Q_SIZE];
@@ -242,7 +246,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
                             sloti[SF_CNT * 16 + s] = 0;
                             sloti[SF_IT * 16 + s] = 0;
-                            lzf_store_sh(F, ray, slot, s);
+                            lzf_store_sh(F, ray, slot, s, 16);
                         }
                     }
                     if (base + take >= n_queue) dry = true;
@@ -282,7 +286,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
             const bool live = sloti[SF_RAY * 16 + lead] >= 0 && j < lkk;
             const float px = live ? slot[SF_X * 16 + s] : 0.0f, py = live ? slot[SF_Y * 16 + s] : 0.0f, pz = live ? slot[SF_Z * 16 + s] : 0.0f;
             typename HD::Out o;
-            HD::slice(ctx, lane, px, py, pz, LzShFromSlot{slot, lead}, o);
+            HD::slice(ctx, lane, px, py, pz, LzShFromSlot{slot, lead, 16}, o);
             my_slices++;
             if (q == 0) {
                 slot[SF_OSIG * 16 + s] = o.sigma;
@@ -329,13 +333,18 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
             }
         }
     } else {
+        // S = 1.  ROWS slot rows per wave (NS = 16 ROWS slots, slot l lives on lane l): the march, the refill and the compositing run
+        // ONCE for all NS slots, the head runs once per row of 16.  ROWS = 2 is for the f16 head, which is bound by vector-instruction
+        // issue: the sections that use 16 of 64 lanes are then shared by two slices (outputs of a row wait for the compositing in LDS).
+        const bool slot_lane = lane < NS;
+        const int sl = lane;                       // this lane's slot (slot lanes only)
         for (;;) {
-            // ---------------- refill + march: every slot ends with a sample, or empty with the queue dry ----------------
-            int ray = (q == 0) ? sloti[SF_RAY * 16 + s] : -1;
+            // ---------------- refill + march: every slot ends with a sample, crossing empty space, or empty with the queue dry ----------------
+            int ray = slot_lane ? sloti[SF_RAY * NS + sl] : -1;
             bool have = false;
             float x = 0.0f, y = 0.0f, z = 0.0f;
             for (int attempt = 0; attempt < 4; attempt++) {
-                const bool need = (q == 0) && ray < 0 && !dry;
+                const bool need = slot_lane && ray < 0 && !dry;
                 const unsigned long long mask = __ballot(need);
                 if (mask) {
                     const int leader = __ffsll((long long)mask) - 1, take = __popcll(mask);
@@ -346,81 +355,99 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                         const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
                         if (idx < n_queue) {
                             ray = F.order[idx];
-                            sloti[SF_RAY * 16 + s] = ray;
-                            slot[SF_T * 16 + s] = F.rays_t[ray];
-                            slot[SF_FAR * 16 + s] = F.fars[ray];
-    #pragma unroll
-                            for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
-                            sloti[SF_CNT * 16 + s] = 0;
-                            lzf_store_sh(F, ray, slot, s);
+                            sloti[SF_RAY * NS + sl] = ray;
+                            slot[SF_T * NS + sl] = F.rays_t[ray];
+                            slot[SF_FAR * NS + sl] = F.fars[ray];
+#pragma unroll
+                            for (int f = SF_WS; f <= SF_U; f++) slot[f * NS + sl] = 0.0f;
+                            sloti[SF_CNT * NS + sl] = 0;
+                            lzf_store_sh(F, ray, slot, sl, NS);
                         }
                     }
                     if (base + take >= n_queue) dry = true;    // wave-uniform
                 }
-                if (q == 0 && ray >= 0 && !have) {
+                if (slot_lane && ray >= 0 && !have) {
                     m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
-                    float t = slot[SF_T * 16 + s], dt = 0.0f;
-                    const float far = slot[SF_FAR * 16 + s];
+                    float t = slot[SF_T * NS + sl], dt = 0.0f;
+                    const float far = slot[SF_FAR * NS + sl];
                     // at most LZF_MARCH_PROBES empty cells per attempt: a ray crossing empty space (behind the object, between two blobs) keeps
-                    // its slot idle for a few passes instead of stalling the 15 other slots of the wave for the whole crossing
+                    // its slot idle for a few passes instead of stalling the other slots of the wave for the whole crossing
                     int probes = 0;
                     while (t < far && probes < LZF_MARCH_PROBES) {
                         if (m.probe(t, x, y, z, dt)) { have = true; break; }
                         probes++;
                     }
                     if (have) {
-                        slot[SF_T * 16 + s] = t;
-                        slot[SF_DT * 16 + s] = dt;
+                        slot[SF_T * NS + sl] = t;
+                        slot[SF_DT * NS + sl] = dt;
                     } else if (t < far) {   // still in empty space: resume from here in the next pass
-                        slot[SF_T * 16 + s] = t;
+                        slot[SF_T * NS + sl] = t;
                         x = y = z = 0.0f;
                     } else {        // the ray left the box (renderer.py: the march writes no row, compositing kills the ray on delta == 0)
-                        lzf_write_pixel(F, ray, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s], slot[SF_B * 16 + s],
-                                        slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s], sloti[SF_CNT * 16 + s]);
-                        my_samples += sloti[SF_CNT * 16 + s];
+                        lzf_write_pixel(F, ray, slot[SF_WS * NS + sl], slot[SF_D * NS + sl], slot[SF_R * NS + sl], slot[SF_G * NS + sl],
+                                        slot[SF_B * NS + sl], slot[SF_A0 * NS + sl], slot[SF_A1 * NS + sl], slot[SF_U * NS + sl], sloti[SF_CNT * NS + sl]);
+                        my_samples += sloti[SF_CNT * NS + sl];
                         ray = -1;
-                        sloti[SF_RAY * 16 + s] = -1;
+                        sloti[SF_RAY * NS + sl] = -1;
                         x = y = z = 0.0f;
                     }
                 }
-                if (!__ballot((q == 0) && ray < 0 && !dry)) break;
+                if (!__ballot(slot_lane && ray < 0 && !dry)) break;
             }
-            if (!__ballot(have)) {
-                if (dry && !__ballot((q == 0) && ray >= 0)) break;     // queue dry and every slot empty: this wave is done
+            const unsigned long long have_mask = __ballot(have);
+            if (!have_mask) {
+                if (dry && !__ballot(slot_lane && ray >= 0)) break;     // queue dry and every slot empty: this wave is done
                 continue;                                             // slots still crossing empty space (or waiting for a refill)
             }
-            // ---------------- head: the 16 samples of the slots, exactly one slice of the stand-alone head kernel ----------------
-            const float px = __shfl(x, s, 64), py = __shfl(y, s, 64), pz = __shfl(z, s, 64);
+            // ---------------- head: one slice per row of 16 slots, exactly a slice of the stand-alone head kernel ----------------
             typename HD::Out o;
-            HD::slice(ctx, lane, px, py, pz, LzShFromSlot{slot, s}, o);
-            my_slices++;
-            // ---------------- composite (lz_k_composite_rays, n_step = 1): lanes q == 0 ----------------
+#pragma unroll 1
+            for (int row = 0; row < ROWS; row++) {
+                if (ROWS > 1 && !((have_mask >> (16 * row)) & 0xffffull)) continue;   // no sample in this row
+                const int rs = 16 * row + s;                   // the slot whose sample this lane works on
+                const float px = __shfl(x, rs, 64), py = __shfl(y, rs, 64), pz = __shfl(z, rs, 64);
+                HD::slice(ctx, lane, px, py, pz, LzShFromSlot{slot, rs, NS}, o);
+                my_slices++;
+                if (ROWS > 1 && q == 0) {   // park the row's outputs for the compositing below (lanes q == 0 hold valid bits in both heads)
+                    slot[SF_OSIG * NS + rs] = o.sigma;
+                    slot[SF_OR * NS + rs] = o.rgb[0]; slot[SF_OG * NS + rs] = o.rgb[1]; slot[SF_OB * NS + rs] = o.rgb[2];
+                    slot[SF_OA0 * NS + rs] = o.ambaud; slot[SF_OA1 * NS + rs] = o.eyeatt; slot[SF_OU * NS + rs] = o.unc;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();     // the parked outputs are read by other lanes of this wave: keep the LDS order
+            // ---------------- composite (lz_k_composite_rays, n_step = 1): the slot lanes ----------------
             if (have) {
-                const float dt = slot[SF_DT * 16 + s];
-                float ws = slot[SF_WS * 16 + s];
-                const float alpha = 1.0f - lz_expf(-o.sigma * dt);
+                float sg = o.sigma, c0 = o.rgb[0], c1 = o.rgb[1], c2 = o.rgb[2], am0 = o.ambaud, am1 = o.eyeatt, un = o.unc;
+                if (ROWS > 1) {
+                    sg = slot[SF_OSIG * NS + sl];
+                    c0 = slot[SF_OR * NS + sl]; c1 = slot[SF_OG * NS + sl]; c2 = slot[SF_OB * NS + sl];
+                    am0 = slot[SF_OA0 * NS + sl]; am1 = slot[SF_OA1 * NS + sl]; un = slot[SF_OU * NS + sl];
+                }
+                const float dt = slot[SF_DT * NS + sl];
+                float ws = slot[SF_WS * NS + sl];
+                const float alpha = 1.0f - lz_expf(-sg * dt);
                 const float T = 1 - ws;
                 const float w = alpha * T;
                 ws += w;
-                const float t = slot[SF_T * 16 + s] + dt;
-                const float d = lz_fmaf(w, t, slot[SF_D * 16 + s]);
-                const float r = lz_fmaf(w, o.rgb[0], slot[SF_R * 16 + s]);
-                const float g = lz_fmaf(w, o.rgb[1], slot[SF_G * 16 + s]);
-                const float b = lz_fmaf(w, o.rgb[2], slot[SF_B * 16 + s]);
-                const float a0 = slot[SF_A0 * 16 + s] + o.ambaud;
-                const float a1 = slot[SF_A1 * 16 + s] + o.eyeatt;
-                const float u = lz_fmaf(w, o.unc, slot[SF_U * 16 + s]);
-                const int cnt = sloti[SF_CNT * 16 + s] + 1;
+                const float t = slot[SF_T * NS + sl] + dt;
+                const float d = lz_fmaf(w, t, slot[SF_D * NS + sl]);
+                const float r = lz_fmaf(w, c0, slot[SF_R * NS + sl]);
+                const float g = lz_fmaf(w, c1, slot[SF_G * NS + sl]);
+                const float b = lz_fmaf(w, c2, slot[SF_B * NS + sl]);
+                const float a0 = slot[SF_A0 * NS + sl] + am0;
+                const float a1 = slot[SF_A1 * NS + sl] + am1;
+                const float u = lz_fmaf(w, un, slot[SF_U * NS + sl]);
+                const int cnt = sloti[SF_CNT * NS + sl] + 1;
                 if (T < F.T_thresh || cnt >= (int)F.max_steps) {
                     lzf_write_pixel(F, ray, ws, d, r, g, b, a0, a1, u, cnt);
                     my_samples += cnt;
-                    sloti[SF_RAY * 16 + s] = -1;
+                    sloti[SF_RAY * NS + sl] = -1;
                 } else {
-                    slot[SF_T * 16 + s] = t;
-                    slot[SF_WS * 16 + s] = ws; slot[SF_D * 16 + s] = d;
-                    slot[SF_R * 16 + s] = r; slot[SF_G * 16 + s] = g; slot[SF_B * 16 + s] = b;
-                    slot[SF_A0 * 16 + s] = a0; slot[SF_A1 * 16 + s] = a1; slot[SF_U * 16 + s] = u;
-                    sloti[SF_CNT * 16 + s] = cnt;
+                    slot[SF_T * NS + sl] = t;
+                    slot[SF_WS * NS + sl] = ws; slot[SF_D * NS + sl] = d;
+                    slot[SF_R * NS + sl] = r; slot[SF_G * NS + sl] = g; slot[SF_B * NS + sl] = b;
+                    slot[SF_A0 * NS + sl] = a0; slot[SF_A1 * NS + sl] = a1; slot[SF_U * NS + sl] = u;
+                    sloti[SF_CNT * NS + sl] = cnt;
                 }
             }
         }
@@ -493,7 +520,7 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     }
     LZ_REQUIRE(S == 1 || S == 2 || S == 4 || S == 8 || S == 16, LZ_ERR_BAD_ARGUMENT, "frame_render: steps_per_pass must be 0 (auto), 1, 2, 4, 8 or 16");
     if (timing) (void)lz_timing_mark(timing, 0, stream);    // the event pair brackets the persistent kernel alone
-#define LZF_LAUNCH(PREC, SS) hipLaunchKernelGGL((lz_k_frame<PREC, SS>), dim3(grid), dim3(LZF_WG), 0, st, a, K)
+#define LZF_LAUNCH(PREC, SS) hipLaunchKernelGGL((lz_k_frame<PREC, SS, 1>), dim3(grid), dim3(LZF_WG), 0, st, a, K)
 #define LZF_SWITCH(PREC)                                                        \
     switch (S) {                                                                \
         case 1: LZF_LAUNCH(PREC, 1); break;                                     \
@@ -508,7 +535,12 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
         a.offsets = p->offsets; a.packed = reinterpret_cast<const lz_h8*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code;
         a.eye = p->eye; a.bound = p->bound;
         lzf_level_tables(p, a.scale, a.res);
-        LZF_SWITCH(1)
+        static const bool one_row = getenv("LZ_FRAME_ONE_ROW") != nullptr;   // diagnostic: the 16-slot layout for the f16 head too
+        if (S == 1 && !one_row && (uint64_t)f->N >= (uint64_t)n_cu * LZF_WAVES * 32) {   // two slot rows per wave (f16: VALU-issue bound)
+            hipLaunchKernelGGL((lz_k_frame<1, 1, 2>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
+        } else {
+            LZF_SWITCH(1)
+        }
     } else {
         LzHeadArgs a;
         a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
