@@ -37,7 +37,7 @@ __device__ __forceinline__ int lz_mip_from_pos(float x, float y, float z, float 
     return (int)lz_fminf(max_cascade - 1, lz_fmaxf(0, (float)lz_frexp_exp(mx)));
 }
 __device__ __forceinline__ int lz_mip_from_dt(float dt, float H, float max_cascade) {
-    const float mx = (float)((double)(dt * H) * 0.5);
+    const float mx = (dt * H) * 0.5f;   // raymarching.cu:50 narrows (double)(dt * H) * 0.5: halving a float is exact in either type
     return (int)lz_fminf(max_cascade - 1, lz_fmaxf(0, (float)lz_frexp_exp(mx)));
 }
 
@@ -67,8 +67,9 @@ __device__ __forceinline__ void lz_near_far_ray(float ox, float oy, float oz, fl
 // ------------------------------------------------------------------------------------------------
 struct LzMarch {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
-    float bound, dt_gamma, dt_min, dt_max, rH, H3, fC, fH;
+    float bound, rbound, dt_gamma, dt_min, dt_max, rH, H3, fC, fH, halfH;
     uint32_t H;
+    bool pow2H;
     const uint8_t* grid;
 
     __device__ __forceinline__ void init(const float* o, const float* d, float bound_, float dt_gamma_, uint32_t max_steps,
@@ -76,10 +77,12 @@ struct LzMarch {
         ox = o[0]; oy = o[1]; oz = o[2];
         dx = d[0]; dy = d[1]; dz = d[2];
         rdx = 1 / dx; rdy = 1 / dy; rdz = 1 / dz;
-        bound = bound_; dt_gamma = dt_gamma_;
+        bound = bound_; rbound = 1 / bound_; dt_gamma = dt_gamma_;
         rH = 1 / (float)H_;
         H3 = (float)(H_ * H_ * H_);
         H = H_; fC = (float)C; fH = (float)H_; grid = grid_;
+        pow2H = (H_ & (H_ - 1u)) == 0u && H_ >= 2u;
+        halfH = 0.5f * (float)H_;
         dt_max = 2 * LZ_SQRT3F * (float)(1 << (C - 1)) / (float)H_;
         dt_min = lz_fminf(dt_max, 2 * LZ_SQRT3F / (float)max_steps);
     }
@@ -93,12 +96,24 @@ struct LzMarch {
         dt = lz_clampf(tt0 * dt_gamma, dt_min, dt_max);
         const int lp = lz_mip_from_pos(x, y, z, fC), ld = lz_mip_from_dt(dt, fH, fC);
         const int level = lp > ld ? lp : ld;
-        const float mip_bound = lz_fminf(lz_scalbnf(1.0f, level), bound);
-        const float mip_rbound = 1 / mip_bound;
+        const float lb = lz_scalbnf(1.0f, level);
+        const float mip_bound = lz_fminf(lb, bound);
+        // 1 / mip_bound without a division per probe: the reciprocal of 2^level is exact, the one of `bound` is hoisted to init()
+        const float mip_rbound = (lb <= bound) ? lz_scalbnf(1.0f, -level) : rbound;
         const float hm1 = (float)(H - 1);
-        const int nx = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
-        const int ny = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
-        const int nz = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+        // raymarching.cu:415-417 evaluates 0.5 * (x * mip_rbound + 1) * H in double and narrows.  For a power-of-two H (the reference
+        // hard-codes 128, renderer.py:94) the two multiplications are exact in float as well, so both evaluations give the same bits
+        // and the f64 pipe (half rate, plus four conversions per axis) stays out of the march; any other H takes the double path.
+        int nx, ny, nz;
+        if (pow2H) {
+            nx = (int)lz_clampf(lz_fmaf(x, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
+            ny = (int)lz_clampf(lz_fmaf(y, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
+            nz = (int)lz_clampf(lz_fmaf(z, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
+        } else {
+            nx = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+            ny = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+            nz = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+        }
         const uint32_t index = (uint32_t)((float)level * H3 + (float)lz_morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
         const int occ = grid[index / 8] & (1 << (index % 8));
         if (occ) return 1;
