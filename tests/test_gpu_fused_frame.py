@@ -154,3 +154,54 @@ def test_cfg5_1024_ellipsoid_f16_fused_equals_loop(params, golden):
     n_hit = int(fused["state"][1])
     assert 0.05 * 1024 * 1024 < n_hit < 0.5 * 1024 * 1024           # only the rays that meet the ellipsoid are queued
     assert int((fused["ray_counts"] > 0).sum()) == n_hit
+
+
+@pytest.mark.parametrize("S", [1, 4])
+def test_fused_frame_two_cascades(golden, S):
+    """bound 2 (cascade 2: mip level from position / step size, dt_max = 2 sqrt(3) 2 / 128, 128^3 cells per cascade): the fused frame,
+    the multi-launch loop and the checker agree bit for bit on a scene with cells in both cascades"""
+    from conftest import make_params
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.utils import frame_rays
+    from oracle import oracle as O
+    bound = 2.0
+    spec = TriplaneSpec(bound)
+    P = make_params(golden)
+    rng = np.random.default_rng(21)
+    for n in ("xy", "yz", "xz"):
+        P[f"encoder_{n}.embeddings"] = rng.uniform(-1, 1, (spec.n_params, 1)).astype(np.float32)
+        P[f"encoder_{n}.offsets"] = spec.offsets.astype(np.int32)
+    # occupancy: a ball of radius 0.6 (cascade 0 cells) and a shell 1.2 < r < 1.6 (cascade 1 cells), Morton-ordered per cascade
+    c = np.arange(128, dtype=np.int32)
+    X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+    idx = O.morton3D(coords)
+    grid = np.zeros((2, 128 ** 3), np.float32)
+    for cas, half in ((0, 1.0), (1, 2.0)):
+        xyz = (coords.astype(np.float32) + 0.5) / 128 * 2 * half - half
+        r = np.sqrt((xyz ** 2).sum(1))
+        grid[cas, idx] = ((r < 0.6) if cas == 0 else ((r > 1.2) & (r < 1.6))).astype(np.float32)
+    bits = O.packbits(grid, 0.5)
+    H = W = 56
+    pose, intr = synthetic_camera(H, W)
+    pose = pose.copy()
+    pose[2, 3] = -5.0
+    intr = [intr[0] * 0.5, intr[1] * 0.5, intr[2], intr[3]]             # wider field of view: rays cross both cascades
+    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in P.items()}, bound=bound)
+    ro, rd = frame_rays(dev(pose), intr, H, W)
+    cond = (dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]))
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    fr = TriplaneRenderer(head, dev(bits), bound=bound, mode="fused")
+    fr.steps_per_pass = S
+    fused = {k: v.clone() for k, v in fr.render(ro, rd, *cond, max_steps=96, count_samples=True).items()}
+    loop = TriplaneRenderer(head, dev(bits), bound=bound, budget_factor=S, n_step_cap=S).render(ro, rd, *cond, max_steps=96, count_samples=True)
+    for k in KEYS:
+        assert torch.equal(fused[k], loop[k]), k
+    assert torch.equal(fused["ray_counts"], loop["ray_counts"])
+    st = {}
+    ref = render_inference(spec, P, ro.cpu().numpy(), rd.cpu().numpy(), bits, golden["net_enc_a"], golden["net_ind"], golden["net_eye"],
+                           cascade=2, max_steps=96, stats=st, budget_factor=S, n_step_cap=S)
+    assert np.array_equal(fused["image"].cpu().numpy(), ref["image"])
+    assert np.array_equal(fused["ray_counts"].cpu().numpy().astype(np.int64), st["samples_per_ray"])
+    cnt = st["samples_per_ray"]
+    assert cnt.max() > 20 and (cnt == 0).any()        # rays through the shell and the ball, and rays that miss everything
