@@ -115,17 +115,76 @@ int lz_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, 
                   const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                   const float* noises, lz_stream_t stream);
 
-/* Compositing.  One entry per direction; the reference's five channel variants
+/* Compositing, the reference's 13 entry points under their own names and argument order (raymarching.h:16-38) + the stream.
+ * Each is a thin wrapper over the three descriptor-driven entries further down (`*_v`), which is what the Python operators call. */
+int lz_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* ambient, const float* deltas, const int32_t* rays,
+                                    uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* ambient_sum, float* depth,
+                                    float* image, lz_stream_t stream);                                           /* raymarching.h:16 */
+int lz_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_ambient_sum, const float* grad_image,
+                                     const float* sigmas, const float* rgbs, const float* ambient, const float* deltas,
+                                     const int32_t* rays, const float* weights_sum, const float* ambient_sum, const float* image,
+                                     uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas, float* grad_rgbs,
+                                     float* grad_ambient, lz_stream_t stream);                                   /* raymarching.h:17 */
+int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t, const float* sigmas,
+                      const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image,
+                      lz_stream_t stream);                                                                       /* raymarching.h:20 */
+int lz_composite_rays_ambient(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                              const float* sigmas, const float* rgbs, const float* deltas, const float* ambients, float* weights,
+                              float* depth, float* image, float* ambient_sum, lz_stream_t stream);               /* raymarching.h:21 */
+int lz_composite_rays_train_sigma_forward(const float* sigmas, const float* rgbs, const float* ambient, const float* deltas,
+                                          const int32_t* rays, uint32_t M, uint32_t N, float T_thresh, float* weights_sum,
+                                          float* ambient_sum, float* depth, float* image, lz_stream_t stream);   /* raymarching.h:24 */
+int lz_composite_rays_train_sigma_backward(const float* grad_weights_sum, const float* grad_ambient_sum, const float* grad_image,
+                                           const float* sigmas, const float* rgbs, const float* ambient, const float* deltas,
+                                           const int32_t* rays, const float* weights_sum, const float* ambient_sum,
+                                           const float* image, uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas,
+                                           float* grad_rgbs, float* grad_ambient, lz_stream_t stream);           /* raymarching.h:25 */
+int lz_composite_rays_ambient_sigma(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                                    const float* sigmas, const float* rgbs, const float* deltas, const float* ambients,
+                                    float* weights, float* depth, float* image, float* ambient_sum, lz_stream_t stream);   /* :27 */
+int lz_composite_rays_train_uncertainty_forward(const float* sigmas, const float* rgbs, const float* ambient, const float* uncertainty,
+                                                const float* deltas, const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
+                                                float* weights_sum, float* ambient_sum, float* uncertainty_sum, float* depth,
+                                                float* image, lz_stream_t stream);                               /* raymarching.h:31 */
+int lz_composite_rays_train_uncertainty_backward(const float* grad_weights_sum, const float* grad_ambient_sum,
+                                                 const float* grad_uncertainty_sum, const float* grad_image, const float* sigmas,
+                                                 const float* rgbs, const float* ambient, const float* uncertainty, const float* deltas,
+                                                 const int32_t* rays, const float* weights_sum, const float* ambient_sum,
+                                                 const float* uncertainty_sum, const float* image, uint32_t M, uint32_t N,
+                                                 float T_thresh, float* grad_sigmas, float* grad_rgbs, float* grad_ambient,
+                                                 float* grad_uncertainty, lz_stream_t stream);                   /* raymarching.h:32 */
+int lz_composite_rays_uncertainty(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                                  const float* sigmas, const float* rgbs, const float* deltas, const float* ambients,
+                                  const float* uncertainties, float* weights, float* depth, float* image, float* ambient_sum,
+                                  float* uncertainty_sum, lz_stream_t stream);                                   /* raymarching.h:33 */
+int lz_composite_rays_train_triplane_forward(const float* sigmas, const float* rgbs, const float* amb_aud, const float* amb_eye,
+                                             const float* uncertainty, const float* deltas, const int32_t* rays, uint32_t M,
+                                             uint32_t N, float T_thresh, float* weights_sum, float* amb_aud_sum, float* amb_eye_sum,
+                                             float* uncertainty_sum, float* depth, float* image, lz_stream_t stream);    /* :36 */
+int lz_composite_rays_train_triplane_backward(const float* grad_weights_sum, const float* grad_amb_aud_sum, const float* grad_amb_eye_sum,
+                                              const float* grad_uncertainty_sum, const float* grad_image, const float* sigmas,
+                                              const float* rgbs, const float* amb_aud, const float* amb_eye, const float* uncertainty,
+                                              const float* deltas, const int32_t* rays, const float* weights_sum,
+                                              const float* amb_aud_sum, const float* amb_eye_sum, const float* uncertainty_sum,
+                                              const float* image, uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas,
+                                              float* grad_rgbs, float* grad_amb_aud, float* grad_amb_eye, float* grad_uncertainty,
+                                              lz_stream_t stream);                                               /* raymarching.h:37 */
+int lz_composite_rays_triplane(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                               const float* sigmas, const float* rgbs, const float* deltas, const float* ambs_aud,
+                               const float* ambs_eye, const float* uncertainties, float* weights, float* depth, float* image,
+                               float* amb_aud_sum, float* amb_eye_sum, float* uncertainty_sum, lz_stream_t stream);      /* :38 */
+
+/* The same compositing with the channel variant as data: one entry per direction; the reference's five channel variants
  *   plain (raymarching.h:16-17,20)  ambient (:21)  sigma (:24-27)  uncertainty (:31-33)  triplane (:36-38)
  * are selected by (n_amb, amb_weighted, has_unc) = plain (0,0,0) [inference only], ambient (1,0,0),
  * sigma (1,1,0), uncertainty (1,0,1), triplane (2,0,1).  Unused channel pointers may be NULL. */
-int lz_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* amb0, const float* amb1,
+int lz_composite_train_forward_v(const float* sigmas, const float* rgbs, const float* amb0, const float* amb1,
                                     const float* unc, const float* deltas, const int32_t* rays, uint32_t M, uint32_t N,
                                     float T_thresh, int n_amb, int amb_weighted, int has_unc, float* weights_sum,
                                     float* amb0_sum, float* amb1_sum, float* unc_sum, float* depth, float* image,
                                     lz_stream_t stream);
 /* grad_* outputs pre-zeroed by the caller (raymarching.py:332-334, 649-653) */
-int lz_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_amb0_sum, const float* grad_amb1_sum,
+int lz_composite_train_backward_v(const float* grad_weights_sum, const float* grad_amb0_sum, const float* grad_amb1_sum,
                                      const float* grad_unc_sum, const float* grad_image, const float* sigmas,
                                      const float* rgbs, const float* amb0, const float* amb1, const float* unc,
                                      const float* deltas, const int32_t* rays, const float* weights_sum,
@@ -134,7 +193,7 @@ int lz_composite_rays_train_backward(const float* grad_weights_sum, const float*
                                      float* grad_sigmas, float* grad_rgbs, float* grad_amb0, float* grad_amb1,
                                      float* grad_unc, lz_stream_t stream);
 /* in place on rays_alive, rays_t and the per-ray accumulators */
-int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+int lz_composite_rays_v(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
                       const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,
                       const float* unc, int n_amb, int amb_weighted, int has_unc, float* weights_sum, float* depth,
                       float* image, float* amb0_sum, float* amb1_sum, float* unc_sum, lz_stream_t stream);

@@ -73,9 +73,23 @@ SIGNATURES = {
     "lz_march_rays_train": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_march_rays_train_backward": [vp, vp, vp, vp, u32, u32, vp, vp, vp],
     "lz_march_rays": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
-    "lz_composite_rays_train_forward": [vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
-    "lz_composite_rays_train_backward": [vp] * 16 + [u32, u32, f32, i32, i32, i32] + [vp] * 6,
-    "lz_composite_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "lz_composite_train_forward_v": [vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "lz_composite_train_backward_v": [vp] * 16 + [u32, u32, f32, i32, i32, i32] + [vp] * 6,
+    "lz_composite_rays_v": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    # the reference's 13 compositing entry points by name (thin wrappers over the three *_v entries above)
+    "lz_composite_rays_train_forward": [vp] * 5 + [u32, u32, f32] + [vp] * 5,
+    "lz_composite_rays_train_backward": [vp] * 11 + [u32, u32, f32] + [vp] * 4,
+    "lz_composite_rays": [u32, u32, f32] + [vp] * 9,
+    "lz_composite_rays_ambient": [u32, u32, f32] + [vp] * 11,
+    "lz_composite_rays_train_sigma_forward": [vp] * 5 + [u32, u32, f32] + [vp] * 5,
+    "lz_composite_rays_train_sigma_backward": [vp] * 11 + [u32, u32, f32] + [vp] * 4,
+    "lz_composite_rays_ambient_sigma": [u32, u32, f32] + [vp] * 11,
+    "lz_composite_rays_train_uncertainty_forward": [vp] * 6 + [u32, u32, f32] + [vp] * 6,
+    "lz_composite_rays_train_uncertainty_backward": [vp] * 14 + [u32, u32, f32] + [vp] * 5,
+    "lz_composite_rays_uncertainty": [u32, u32, f32] + [vp] * 13,
+    "lz_composite_rays_train_triplane_forward": [vp] * 7 + [u32, u32, f32] + [vp] * 7,
+    "lz_composite_rays_train_triplane_backward": [vp] * 17 + [u32, u32, f32] + [vp] * 6,
+    "lz_composite_rays_triplane": [u32, u32, f32] + [vp] * 15,
     "lz_get_rays": [vp, f32, f32, f32, f32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp],
     "lz_bg_coords": [u32, u32, vp, vp],
     "lz_head_pack_weights": [vp] * 11 + [i32, i32, vp, vp],

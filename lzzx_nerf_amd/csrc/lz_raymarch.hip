@@ -980,7 +980,7 @@ lz_k_composite_rays(uint32_t n_alive_h, uint32_t n_step_h, const lz_loop_state* 
         else { lz_set_error("composite: unsupported channel variant (%d,%d,%d)", n_amb, aw, hu); return LZ_ERR_UNSUPPORTED; } \
     } while (0)
 
-extern "C" int lz_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* amb0, const float* amb1,
+extern "C" int lz_composite_train_forward_v(const float* sigmas, const float* rgbs, const float* amb0, const float* amb1,
                                                const float* unc, const float* deltas, const int32_t* rays, uint32_t M, uint32_t N,
                                                float T_thresh, int n_amb, int amb_weighted, int has_unc, float* weights_sum,
                                                float* amb0_sum, float* amb1_sum, float* unc_sum, float* depth, float* image,
@@ -995,7 +995,7 @@ extern "C" int lz_composite_rays_train_forward(const float* sigmas, const float*
     return LZ_OK;
 }
 
-extern "C" int lz_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_amb0_sum, const float* grad_amb1_sum,
+extern "C" int lz_composite_train_backward_v(const float* grad_weights_sum, const float* grad_amb0_sum, const float* grad_amb1_sum,
                                                 const float* grad_unc_sum, const float* grad_image, const float* sigmas,
                                                 const float* rgbs, const float* amb0, const float* amb1, const float* unc,
                                                 const float* deltas, const int32_t* rays, const float* weights_sum,
@@ -1014,7 +1014,7 @@ extern "C" int lz_composite_rays_train_backward(const float* grad_weights_sum, c
     return LZ_OK;
 }
 
-extern "C" int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+extern "C" int lz_composite_rays_v(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
                                  const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,
                                  const float* unc, int n_amb, int amb_weighted, int has_unc, float* weights_sum, float* depth,
                                  float* image, float* amb0_sum, float* amb1_sum, float* unc_sum, lz_stream_t stream) {
@@ -1026,6 +1026,100 @@ extern "C" int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thre
 #undef CALL
     LZ_CHECK_LAUNCH("composite_rays");
     return LZ_OK;
+}
+
+// ---- the reference's 13 compositing entry points by name (raymarching.h:16-38): thin wrappers over the descriptor-driven ones ----
+#define LZ_TRAIN_FWD(NAME, NA, AW)                                                                                                   \
+    extern "C" int NAME(const float* sigmas, const float* rgbs, const float* ambient, const float* deltas, const int32_t* rays,     \
+                        uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* ambient_sum, float* depth, float* image, \
+                        lz_stream_t stream) {                                                                                        \
+        return lz_composite_train_forward_v(sigmas, rgbs, ambient, nullptr, nullptr, deltas, rays, M, N, T_thresh, NA, AW, 0, weights_sum, \
+                                            ambient_sum, nullptr, nullptr, depth, image, stream);                                    \
+    }
+#define LZ_TRAIN_BWD(NAME, NA, AW)                                                                                                   \
+    extern "C" int NAME(const float* grad_weights_sum, const float* grad_ambient_sum, const float* grad_image, const float* sigmas, \
+                        const float* rgbs, const float* ambient, const float* deltas, const int32_t* rays, const float* weights_sum, \
+                        const float* ambient_sum, const float* image, uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas,    \
+                        float* grad_rgbs, float* grad_ambient, lz_stream_t stream) {                                                 \
+        return lz_composite_train_backward_v(grad_weights_sum, grad_ambient_sum, nullptr, nullptr, grad_image, sigmas, rgbs, ambient, \
+                                             nullptr, nullptr, deltas, rays, weights_sum, ambient_sum, nullptr, image, M, N, T_thresh, \
+                                             NA, AW, 0, grad_sigmas, grad_rgbs, grad_ambient, nullptr, nullptr, stream);             \
+    }
+#define LZ_INFER_AMB(NAME, AW)                                                                                                       \
+    extern "C" int NAME(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t, const float* sigmas,  \
+                        const float* rgbs, const float* deltas, const float* ambients, float* weights, float* depth, float* image,   \
+                        float* ambient_sum, lz_stream_t stream) {                                                                    \
+        return lz_composite_rays_v(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, ambients, nullptr, nullptr, 1, AW, \
+                                   0, weights, depth, image, ambient_sum, nullptr, nullptr, stream);                                 \
+    }
+LZ_TRAIN_FWD(lz_composite_rays_train_forward, 1, 0)
+LZ_TRAIN_BWD(lz_composite_rays_train_backward, 1, 0)
+LZ_TRAIN_FWD(lz_composite_rays_train_sigma_forward, 1, 1)
+LZ_TRAIN_BWD(lz_composite_rays_train_sigma_backward, 1, 1)
+LZ_INFER_AMB(lz_composite_rays_ambient, 0)
+LZ_INFER_AMB(lz_composite_rays_ambient_sigma, 1)
+#undef LZ_TRAIN_FWD
+#undef LZ_TRAIN_BWD
+#undef LZ_INFER_AMB
+
+extern "C" int lz_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t, const float* sigmas,
+                                 const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image, lz_stream_t stream) {
+    return lz_composite_rays_v(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, nullptr, nullptr, nullptr, 0, 0, 0, weights_sum,
+                               depth, image, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int lz_composite_rays_train_uncertainty_forward(const float* sigmas, const float* rgbs, const float* ambient, const float* uncertainty,
+                                                           const float* deltas, const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
+                                                           float* weights_sum, float* ambient_sum, float* uncertainty_sum, float* depth,
+                                                           float* image, lz_stream_t stream) {
+    return lz_composite_train_forward_v(sigmas, rgbs, ambient, nullptr, uncertainty, deltas, rays, M, N, T_thresh, 1, 0, 1, weights_sum, ambient_sum,
+                                        nullptr, uncertainty_sum, depth, image, stream);
+}
+extern "C" int lz_composite_rays_train_uncertainty_backward(const float* grad_weights_sum, const float* grad_ambient_sum,
+                                                            const float* grad_uncertainty_sum, const float* grad_image, const float* sigmas,
+                                                            const float* rgbs, const float* ambient, const float* uncertainty,
+                                                            const float* deltas, const int32_t* rays, const float* weights_sum,
+                                                            const float* ambient_sum, const float* uncertainty_sum, const float* image,
+                                                            uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas, float* grad_rgbs,
+                                                            float* grad_ambient, float* grad_uncertainty, lz_stream_t stream) {
+    return lz_composite_train_backward_v(grad_weights_sum, grad_ambient_sum, nullptr, grad_uncertainty_sum, grad_image, sigmas, rgbs, ambient, nullptr,
+                                         uncertainty, deltas, rays, weights_sum, ambient_sum, uncertainty_sum, image, M, N, T_thresh, 1, 0, 1,
+                                         grad_sigmas, grad_rgbs, grad_ambient, nullptr, grad_uncertainty, stream);
+}
+extern "C" int lz_composite_rays_uncertainty(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                                             const float* sigmas, const float* rgbs, const float* deltas, const float* ambients,
+                                             const float* uncertainties, float* weights, float* depth, float* image, float* ambient_sum,
+                                             float* uncertainty_sum, lz_stream_t stream) {
+    return lz_composite_rays_v(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, ambients, nullptr, uncertainties, 1, 0, 1, weights,
+                               depth, image, ambient_sum, nullptr, uncertainty_sum, stream);
+}
+extern "C" int lz_composite_rays_train_triplane_forward(const float* sigmas, const float* rgbs, const float* amb_aud, const float* amb_eye,
+                                                        const float* uncertainty, const float* deltas, const int32_t* rays, uint32_t M,
+                                                        uint32_t N, float T_thresh, float* weights_sum, float* amb_aud_sum,
+                                                        float* amb_eye_sum, float* uncertainty_sum, float* depth, float* image,
+                                                        lz_stream_t stream) {
+    return lz_composite_train_forward_v(sigmas, rgbs, amb_aud, amb_eye, uncertainty, deltas, rays, M, N, T_thresh, 2, 0, 1, weights_sum, amb_aud_sum,
+                                        amb_eye_sum, uncertainty_sum, depth, image, stream);
+}
+extern "C" int lz_composite_rays_train_triplane_backward(const float* grad_weights_sum, const float* grad_amb_aud_sum,
+                                                         const float* grad_amb_eye_sum, const float* grad_uncertainty_sum,
+                                                         const float* grad_image, const float* sigmas, const float* rgbs,
+                                                         const float* amb_aud, const float* amb_eye, const float* uncertainty,
+                                                         const float* deltas, const int32_t* rays, const float* weights_sum,
+                                                         const float* amb_aud_sum, const float* amb_eye_sum, const float* uncertainty_sum,
+                                                         const float* image, uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas,
+                                                         float* grad_rgbs, float* grad_amb_aud, float* grad_amb_eye,
+                                                         float* grad_uncertainty, lz_stream_t stream) {
+    (void)amb_eye_sum;   // the ambient sums are unweighted: their gradient is constant on the visited samples (raymarching.cu:2088-2089)
+    return lz_composite_train_backward_v(grad_weights_sum, grad_amb_aud_sum, grad_amb_eye_sum, grad_uncertainty_sum, grad_image, sigmas, rgbs, amb_aud,
+                                         amb_eye, uncertainty, deltas, rays, weights_sum, amb_aud_sum, uncertainty_sum, image, M, N, T_thresh, 2, 0, 1,
+                                         grad_sigmas, grad_rgbs, grad_amb_aud, grad_amb_eye, grad_uncertainty, stream);
+}
+extern "C" int lz_composite_rays_triplane(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                                          const float* sigmas, const float* rgbs, const float* deltas, const float* ambs_aud,
+                                          const float* ambs_eye, const float* uncertainties, float* weights, float* depth, float* image,
+                                          float* amb_aud_sum, float* amb_eye_sum, float* uncertainty_sum, lz_stream_t stream) {
+    return lz_composite_rays_v(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, ambs_aud, ambs_eye, uncertainties, 2, 0, 1, weights,
+                               depth, image, amb_aud_sum, amb_eye_sum, uncertainty_sum, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -176,7 +176,7 @@ def _composite_train_fwd(variant, sigmas, rgbs, amb0, amb1, unc, deltas, rays, T
     a0s = torch.empty(N, **kw) if na > 0 else None
     a1s = torch.empty(N, **kw) if na > 1 else None
     us = torch.empty(N, **kw) if hu else None
-    call("lz_composite_rays_train_forward", ptr(sigmas), ptr(rgbs), ptr(amb0), ptr(amb1), ptr(unc), ptr(deltas), ptr(rays), M, N,
+    call("lz_composite_train_forward_v", ptr(sigmas), ptr(rgbs), ptr(amb0), ptr(amb1), ptr(unc), ptr(deltas), ptr(rays), M, N,
          float(T_thresh), na, aw, hu, ptr(weights_sum), ptr(a0s), ptr(a1s), ptr(us), ptr(depth), ptr(image), stream())
     return weights_sum, a0s, a1s, us, depth, image
 
@@ -189,7 +189,7 @@ def _composite_train_bwd(variant, g_ws, g_a0, g_a1, g_u, g_img, sigmas, rgbs, am
     ga0 = torch.zeros_like(amb0) if na > 0 else None
     ga1 = torch.zeros_like(amb1) if na > 1 else None
     gu = torch.zeros_like(unc) if hu else None
-    call("lz_composite_rays_train_backward", ptr(g_ws), ptr(g_a0), ptr(g_a1), ptr(g_u), ptr(g_img), ptr(sigmas), ptr(rgbs), ptr(amb0),
+    call("lz_composite_train_backward_v", ptr(g_ws), ptr(g_a0), ptr(g_a1), ptr(g_u), ptr(g_img), ptr(sigmas), ptr(rgbs), ptr(amb0),
          ptr(amb1), ptr(unc), ptr(deltas), ptr(rays), ptr(weights_sum), ptr(a0s), ptr(us), ptr(image), M, N, float(T_thresh), na, aw, hu,
          ptr(grad_sigmas), ptr(grad_rgbs), ptr(ga0), ptr(ga1), ptr(gu), stream())
     return grad_sigmas, grad_rgbs, ga0, ga1, gu
@@ -310,7 +310,7 @@ def _composite_infer(variant, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs,
     na, aw, hu = variant
     cont = lambda t: None if t is None else t.contiguous()
     sigmas, rgbs, deltas, amb0, amb1, unc = [cont(t) for t in (sigmas, rgbs, deltas, amb0, amb1, unc)]   # all alive until the launch
-    call("lz_composite_rays", int(n_alive), int(n_step), float(T_thresh), ptr(rays_alive), ptr(rays_t), ptr(sigmas), ptr(rgbs),
+    call("lz_composite_rays_v", int(n_alive), int(n_step), float(T_thresh), ptr(rays_alive), ptr(rays_t), ptr(sigmas), ptr(rgbs),
          ptr(deltas), ptr(amb0), ptr(amb1), ptr(unc), na, aw, hu, ptr(weights_sum), ptr(depth), ptr(image),
          ptr(a0s), ptr(a1s), ptr(us), stream())
 

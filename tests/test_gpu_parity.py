@@ -895,3 +895,54 @@ def test_full_size_grid_linearity_and_layouts():
     call("lz_grid_encode_forward", ptr(x), ptr(e1), ptr(enc.offsets), ptr(lm), B, 3, 2, 16, float(np.float32(np.log2(enc.per_level_scale))),
          16, None, 0, 0, 0, 0, stream())
     assert torch.equal(lm.permute(1, 0, 2).reshape(B, 32), f1)
+
+
+def test_composite_reference_named_entry_points():
+    """the C ABI exports the reference's 13 compositing functions under their own names and argument order (raymarching.h:16-38);
+    they must give what the descriptor-driven entries behind the Python operators give"""
+    from lzzx_nerf_amd import raymarching as R
+    from lzzx_nerf_amd._util import call, ptr, stream
+    g = torch.Generator(device="cuda").manual_seed(7)
+    N, S = 300, 6
+    M = N * S
+    rnd = lambda *s: torch.rand(*s, device="cuda", generator=g)
+    sig, rgb, a0, a1, un = rnd(M) * 3, rnd(M, 3), rnd(M), rnd(M), rnd(M)
+    deltas = torch.stack([torch.full((M,), 0.02, device="cuda"), torch.arange(M, device="cuda").float() * 0.02 + 1], 1).contiguous()
+    rays = torch.stack([torch.arange(N, device="cuda"), torch.arange(N, device="cuda") * S, torch.full((N,), S, device="cuda")], 1).int().contiguous()
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    # train forward / backward, triplane variant
+    ws, aas, aes, us, dep, img = R.composite_rays_train_triplane(sig, rgb, a0, a1, un, deltas, rays, 1e-4)
+    o = [z(N), z(N), z(N), z(N), z(N), z(N, 3)]
+    call("lz_composite_rays_train_triplane_forward", ptr(sig), ptr(rgb), ptr(a0), ptr(a1), ptr(un), ptr(deltas), ptr(rays), M, N, 1e-4,
+         *[ptr(t) for t in o], stream())
+    for a, b in zip((ws, aas, aes, us, dep, img), o):
+        assert torch.equal(a, b)
+    gws, gaa, gae, gu, gim = rnd(N), rnd(N), rnd(N), rnd(N), rnd(N, 3)
+    ref = R._composite_train_bwd((2, 0, 1), gws, gaa, gae, gu, gim, sig, rgb, a0, a1, un, deltas, rays, ws, aas, us, img, 1e-4)
+    go = [z(M), z(M, 3), z(M), z(M), z(M)]
+    call("lz_composite_rays_train_triplane_backward", ptr(gws), ptr(gaa), ptr(gae), ptr(gu), ptr(gim), ptr(sig), ptr(rgb), ptr(a0), ptr(a1), ptr(un),
+         ptr(deltas), ptr(rays), ptr(ws), ptr(aas), ptr(aes), ptr(us), ptr(img), M, N, 1e-4, *[ptr(t) for t in go], stream())
+    for a, b in zip(ref, go):
+        assert torch.equal(a, b)
+    # sigma-weighted ambient variant, forward
+    ws2, as2, dep2, img2 = R.composite_rays_train_sigma(sig, rgb, a0, deltas, rays, 1e-4)
+    o2 = [z(N), z(N), z(N), z(N, 3)]
+    call("lz_composite_rays_train_sigma_forward", ptr(sig), ptr(rgb), ptr(a0), ptr(deltas), ptr(rays), M, N, 1e-4, *[ptr(t) for t in o2], stream())
+    for a, b in zip((ws2, as2, dep2, img2), o2):
+        assert torch.equal(a, b)
+    # inference: triplane and plain
+    n_alive, n_step = N, S
+    mk = lambda: (torch.arange(N, device="cuda").int(), torch.ones(N, device="cuda"), z(N), z(N), z(N, 3), z(N), z(N), z(N))
+    al, rt, w_, d_, im_, s0, s1, s2 = mk()
+    R.composite_rays_triplane(n_alive, n_step, al, rt, sig, rgb, deltas, a0, a1, un, w_, d_, im_, s0, s1, s2, 1e-2)
+    al2, rt2, w2, d2, im2, t0, t1, t2 = mk()
+    call("lz_composite_rays_triplane", n_alive, n_step, 1e-2, ptr(al2), ptr(rt2), ptr(sig), ptr(rgb), ptr(deltas), ptr(a0), ptr(a1), ptr(un), ptr(w2),
+         ptr(d2), ptr(im2), ptr(t0), ptr(t1), ptr(t2), stream())
+    for a, b in zip((al, rt, w_, d_, im_, s0, s1, s2), (al2, rt2, w2, d2, im2, t0, t1, t2)):
+        assert torch.equal(a, b)
+    al, rt, w_, d_, im_, *_ = mk()
+    R.composite_rays(n_alive, n_step, al, rt, sig, rgb, deltas, w_, d_, im_, 1e-2)
+    al2, rt2, w2, d2, im2, *_ = mk()
+    call("lz_composite_rays", n_alive, n_step, 1e-2, ptr(al2), ptr(rt2), ptr(sig), ptr(rgb), ptr(deltas), ptr(w2), ptr(d2), ptr(im2), stream())
+    for a, b in zip((al, rt, w_, d_, im_), (al2, rt2, w2, d2, im2)):
+        assert torch.equal(a, b)
