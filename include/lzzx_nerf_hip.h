@@ -370,6 +370,30 @@ typedef struct {
 int lz_triplane_head_backward(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M, const float* g_sigma,
                               const float* g_rgb, const float* g_amb_aud, const float* g_amb_eye, const float* g_unc,
                               const lz_head_bwd_out* out, lz_stream_t stream);
+/* The same step without the recompute (lz_head_rec.hip): the forward records, the backward starts from the record.
+ * lz_triplane_head_forward_record = lz_triplane_head_forward in training mode (same bits in the five outputs) that also writes the X
+ * columns of rec [M, LZ_BWD_REC] (LZ_BWD_X_*: what the recomputing backward wrote itself) and one state row per sample:
+ *   state  [M, LZ_FWD_STATE] (16-byte aligned), columns in the lane layout of the kernels (feature 16 t + 4 q + r at 16 t + 4 q + r):
+ *            LZ_ST_ATT [32] aud_ch_att_net output   LZ_ST_C1 [64] input of color_net.1   LZ_ST_U1 [32] input of unc_net.1
+ *            LZ_ST_E1  [16] input of eye_att_net.1 (unwritten without an eye input)
+ *            LZ_ST_MK  [16] four words per q: ReLU masks aud.0 | sigma.0 << 16, sigma.1 | color.0 << 16, unc.0 | eye.0 << 8, and one
+ *                           scalar (q = 0 ||att||, 1 eye_att, 2 unc pre-activation, 3 sigma)
+ *            LZ_ST_CLR [4]  the three colour pre-activations
+ * lz_triplane_head_backward_recorded takes that state instead of (xyzs, dirs): no gather, no forward matrix work (380 instead of 759
+ * MFMAs per 16 samples); it fills the G columns of the same rec, denc and small exactly as lz_triplane_head_backward does (same
+ * values, same summation order).  The price is memory held from forward to backward: 2 624 + 704 bytes per sample. */
+#define LZ_FWD_STATE 176   /* 164 used; rows padded to a multiple of 64 bytes so that every 64-byte store segment covers whole sectors */
+#define LZ_ST_ATT 0
+#define LZ_ST_C1 32
+#define LZ_ST_U1 96
+#define LZ_ST_E1 128
+#define LZ_ST_MK 144
+#define LZ_ST_CLR 160
+int lz_triplane_head_forward_record(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M, float* sigmas, float* rgbs,
+                                    float* amb_aud, float* amb_eye, float* unc, float* rec, float* state, lz_stream_t stream);
+int lz_triplane_head_backward_recorded(const lz_head_params* p, const float* state, uint32_t M, const float* g_sigma, const float* g_rgb,
+                                       const float* g_amb_aud, const float* g_amb_eye, const float* g_unc, const lz_head_bwd_out* out,
+                                       lz_stream_t stream);
 /* Weight gradients of the wide layers from the records, in ONE pass over them (five waves per workgroup, each owning the
  * accumulator tiles of one product; partial tiles per workgroup in `workspace`, summed by a second small launch: no atomics).
  * Outputs are overwritten, row-major [N, K]: dW_x3 [112,36] = aud_ch_att_net.0 (rows 0..63) | eye_att_net.0 (64..79) | unc_net.0

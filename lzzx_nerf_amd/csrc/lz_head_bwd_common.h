@@ -1,0 +1,70 @@
+// lz_head_bwd_common.h -- pieces shared by the two backward kernels of the fused head (lz_head_bwd.hip: activations recomputed;
+// lz_head_rec.hip: activations recorded by the forward): the transposed-fragment layer, record stores, ReLU masks.
+#ifndef LZ_HEAD_BWD_COMMON_H
+#define LZ_HEAD_BWD_COMMON_H
+#include "lz_head_layers.h"
+
+#define LZ_BWD_WG 512
+
+struct LzHeadBwdArgs {
+    LzHeadArgs fwd;
+    const float *g_sigma, *g_rgb, *g_amb_aud, *g_amb_eye, *g_unc;     // upstream gradients [M], [M,3], [M], [M], [M]
+    lz_head_bwd_out o;
+};
+
+// dX = W^T dY on the matrix cores from the FORWARD fragments of `LAYER` (see the header comment for the address map)
+template <int LAYER>
+__device__ __forceinline__ void lz_layer_bwd(const float* __restrict__ wl, int lane, const float (&dy)[4 * LZ_NT[LAYER]], float (&dx)[LZ_KS[LAYER]]) {
+    constexpr int KS = LZ_KS[LAYER], NT = LZ_NT[LAYER], KT = (KS + 3) / 4;
+    const int m = lane & 15, q = lane >> 4;
+    const float* base = wl + lz_frag_base(LAYER) * 64 + 4 * q + 16 * (m >> 2);
+    // One 16-byte LDS read feeds four MFMAs (128 cycles); the read of step i + 1 is issued BEFORE the MFMAs of step i and the
+    // scheduling barrier keeps it there, so its latency (4-way bank conflict included) hides under them.
+    auto frag = [&](int i) -> lz_f4 {   // raw read (rows past KS are clamped to row 0 and zeroed at use)
+        const int kt = i / NT, ft = i - kt * NT;
+        const int ks = 4 * kt + (m & 3);
+        return *reinterpret_cast<const lz_f4*>(base + (size_t)(ks < KS ? ks : 0) * NT * 64 + ft * 64);
+    };
+    lz_f4 a_cur = frag(0);
+    lz_f4 acc = lz_f4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < KT * NT; i++) {
+        const int kt = i / NT, ft = i - kt * NT;
+        lz_f4 a_nxt = a_cur;
+        if (i + 1 < KT * NT) a_nxt = frag(i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ft == 0) acc = lz_f4{0, 0, 0, 0};
+        const bool ok = 4 * kt + (m & 3) < KS;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? a_cur[r] : 0.0f, dy[4 * ft + r], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ft == NT - 1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (4 * kt + r < KS) dx[4 * kt + r] = acc[r];
+        }
+        a_cur = a_nxt;
+    }
+}
+
+// chained-layout vector v[4 t + r] = feature 16 t + 4 q + r -> record columns col0 + feature; `recq` = this sample's record + 4 q, so every
+// store is (one per-slice address) + (an immediate offset): one dwordx4 per tile (records and slots are 16-byte aligned)
+template <int NTILE>
+__device__ __forceinline__ void lz_dump_chained(float* __restrict__ recq, int col0, const float (&v)[4 * NTILE]) {
+    typedef float lz_v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int t = 0; t < NTILE; t++) {
+        lz_v4 w = {v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
+        __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(recq + col0 + 16 * t));   // streamed: read back once by the weight-gradient pass
+    }
+}
+
+template <int N>
+__device__ __forceinline__ uint32_t lz_mask_pos(const float (&v)[N]) {
+    uint32_t mk = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) mk |= (v[k] > 0.0f) ? (1u << k) : 0u;
+    return mk;
+}
+
+#endif

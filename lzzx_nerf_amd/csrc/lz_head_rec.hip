@@ -1,0 +1,549 @@
+// lz_head_rec.hip -- the fused triplane head for TRAINING without the recompute: a forward that records what the backward needs,
+// and a backward that starts from that record (NeRFNetwork.forward, nerf_triplane/network.py:252-311, training mode).
+//
+// lz_head_bwd.hip recomputes the forward inside the backward kernel: 379 of its 759 MFMAs per 16-sample slice, on a kernel that is
+// bound by the matrix pipe.  Here the forward kernel (the same instruction sequence as lz_k_triplane_head<true>, so the five outputs
+// have the same bits) also writes
+//   * the X half of the per-sample record (the wide layers' inputs, which the weight-gradient pass reads: the recomputing backward
+//     wrote exactly these columns itself), and
+//   * a state row per sample (LZ_FWD_STATE floats): att, the inputs of the three skinny output layers, the ReLU masks as bits and
+//     seven scalars (||att||, eye_att, the pre-activations of unc / sigma / rgb),
+// and the backward kernel reads the state row instead of xyz / dirs / the tables: no gather, no SH, no forward matrix work.  The
+// arithmetic of every gradient is unchanged (same values, same order), only where the forward values come from.
+#include "lz_head_bwd_common.h"
+#include "lz_head_gather.h"
+#include "lz_head_slice.h"
+#include "lzzx_sh_eval.h"
+
+typedef float lz_v4 __attribute__((ext_vector_type(4)));
+
+#ifndef LZ_FREC_WG
+#define LZ_FREC_WG 768   // forward: 143 VGPRs -> three waves per SIMD
+#endif
+
+__device__ __forceinline__ uint32_t lz_fbits(float v) { return __float_as_uint(v); }
+
+// ------------------------------------------------------------------------------------------------
+// forward, recording
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(LZ_FREC_WG, 1)
+lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
+                               float* __restrict__ sigmas, float* __restrict__ rgbs, float* __restrict__ amb_aud,
+                               float* __restrict__ amb_eye, float* __restrict__ unc_out, float* __restrict__ rec, float* __restrict__ st) {
+    __shared__ float wl[LzHeadLds<true>::FLOATS];
+    const uint32_t n_slices = (M + 15) / 16;
+    const uint32_t slice_lo = (uint32_t)(((uint64_t)n_slices * blockIdx.x) / gridDim.x);
+    const uint32_t slice_hi = (uint32_t)(((uint64_t)n_slices * (blockIdx.x + 1)) / gridDim.x);
+    if (slice_lo >= slice_hi) return;
+    const int lane = threadIdx.x & 63;
+    const int s = lane & 15, q = lane >> 4;
+    LzHeadCtx hc;
+    lz_head_stage<true>(P, wl, LZ_FREC_WG, q, hc);
+    __syncthreads();
+    const float* wv = wl + LzHeadLds<true>::WV;
+    int* queue = reinterpret_cast<int*>(wl + LzHeadLds<true>::TAB) + 48;
+    for (int w = threadIdx.x >> 8; w > 0; w--) {   // see lz_k_triplane_head_backward: the waves that share a SIMD start a part of a slice apart
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+    }
+    // The position / direction of slice n + 1 are requested at the top of slice n, before its stores: a load issued behind stores can
+    // only be waited for once those stores are acknowledged (one in-order counter), and the gather needs the position first.
+    auto grab = [&]() -> int {
+        int sl = 0;
+        if (lane == 0) sl = atomicAdd(queue, 1);
+        return __builtin_amdgcn_readfirstlane(sl);
+    };
+    auto row_of = [&](int sl) -> uint32_t {
+        const uint32_t b = (slice_lo + (uint32_t)sl) * 16 + s;
+        return b < M ? b : M - 1;
+    };
+    int slice = grab();
+    float px = 0.0f, py = 0.0f, pz = 0.0f, dir0 = 0.0f, dir1 = 0.0f, dir2 = 0.0f;
+    if (slice_lo + (uint32_t)slice < slice_hi) {
+        const size_t r0 = row_of(slice);
+        px = xyzs[r0 * 3]; py = xyzs[r0 * 3 + 1]; pz = xyzs[r0 * 3 + 2];
+        dir0 = dirs[r0 * 3]; dir1 = dirs[r0 * 3 + 1]; dir2 = dirs[r0 * 3 + 2];
+    }
+    for (;;) {
+        if (slice_lo + (uint32_t)slice >= slice_hi) break;
+        const uint32_t base = (slice_lo + (uint32_t)slice) * 16;
+        const bool valid = base + s < M;
+        const uint32_t m = valid ? base + s : M - 1;   // clamped rows are computed, never stored
+        const size_t row = m;
+        float* rec1 = rec + row * LZ_BWD_REC + q;
+        float* recq = rec1 + 3 * q;
+        float* stq = st + row * LZ_FWD_STATE + 4 * q;
+
+        float encx[9];
+        lz_head_gather(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx);
+        const float cd0 = dir0, cd1 = dir1, cd2 = dir2;
+        const int next = grab();
+        if (slice_lo + (uint32_t)next < slice_hi) {
+            const size_t r1 = row_of(next);
+            px = xyzs[r1 * 3]; py = xyzs[r1 * 3 + 1]; pz = xyzs[r1 * 3 + 2];
+            dir0 = dirs[r1 * 3]; dir1 = dirs[r1 * 3 + 1]; dir2 = dirs[r1 * 3 + 2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float bx[1][9] = {{encx[0], encx[1], encx[2], encx[3], encx[4], encx[5], encx[6], encx[7], encx[8]}};
+        // audio channel attention
+        float att[8];
+        uint32_t mk_a1;
+        {
+            lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
+            lz_layer<LZ_L_A1, 1>(wl, lane, bx, acc1);
+            float a1[1][16];
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) a1[0][4 * ft + r] = lz_relu(acc1[ft][0][r]);
+            mk_a1 = lz_mask_pos(a1[0]);
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_A1, a1[0]);
+            lz_f4 acc2[2][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
+            lz_layer<LZ_L_A2, 1>(wl, lane, a1, acc2);
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) att[4 * ft + r] = acc2[ft][0][r];
+        }
+        if (valid) lz_dump_chained<2>(stq, LZ_ST_ATT, att);
+        float norm;
+        {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc = lz_fmaf(att[k], att[k], acc);
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            norm = sqrtf(acc);
+        }
+        // eye attention
+        float eyeatt = 0.0f;
+        uint32_t mk_e1 = 0;
+        if (hc.has_eye) {
+            lz_f4 acce[1][1] = {{lz_f4{0, 0, 0, 0}}};
+            lz_layer<LZ_L_E1, 1>(wl, lane, bx, acce);
+            float e1[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) e1[r] = lz_relu(acce[0][0][r]);
+            mk_e1 = lz_mask_pos(e1);
+            if (valid) lz_dump_chained<1>(stq, LZ_ST_E1, e1);
+            eyeatt = lz_sigmoidf(lz_lane_dot<1>(wv + LZ_WV_E2, q, e1));
+        }
+        // uncertainty
+        float upre;
+        uint32_t mk_u1;
+        {
+            lz_f4 accu[2][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
+            lz_layer<LZ_L_U1, 1>(wl, lane, bx, accu);
+            float u1[8];
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) u1[4 * ft + r] = lz_relu(accu[ft][0][r]);
+            mk_u1 = lz_mask_pos(u1);
+            if (valid) lz_dump_chained<2>(stq, LZ_ST_U1, u1);
+            upre = lz_lane_dot<2>(wv + LZ_WV_U2, q, u1);
+        }
+        // sigma net
+        float spre;
+        uint32_t mk_s1, mk_s2;
+        float geo[1][16];
+        {
+            float b1[1][18];
+#pragma unroll
+            for (int i = 0; i < 9; i++) b1[0][i] = encx[i];
+            float encw[8];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) encw[4 * t + r] = hc.lenca[16 * t + 4 * q + r] * att[4 * t + r];
+#pragma unroll
+            for (int k = 0; k < 8; k++) b1[0][9 + k] = encw[k];
+            b1[0][17] = (hc.has_eye && q == 0) ? hc.eye_v * eyeatt : 0.0f;
+            if (valid) {   // sigma_net.0 input [enc_x 36 | enc_a * att 32 | eye * eye_att 1]
+#pragma unroll
+                for (int i = 0; i < 9; i++) rec1[LZ_BWD_X_SIG0 + 4 * i] = encx[i];
+                lz_dump_chained<2>(recq, LZ_BWD_X_SIG0 + 36, encw);
+                if (q == 0) rec1[LZ_BWD_X_SIG0 + 68] = b1[0][17];
+            }
+            lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
+            lz_layer<LZ_L_S1, 1>(wl, lane, b1, acc1);
+            float s1[1][16];
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s1[0][4 * ft + r] = lz_relu(acc1[ft][0][r]);
+            mk_s1 = lz_mask_pos(s1[0]);
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_S1, s1[0]);
+            lz_f4 acc2[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
+            lz_layer<LZ_L_S2, 1>(wl, lane, s1, acc2);
+            float s2[1][16];
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s2[0][4 * ft + r] = lz_relu(acc2[ft][0][r]);
+            mk_s2 = lz_mask_pos(s2[0]);
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_S2C, s2[0]);
+            lz_f4 acc3[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
+            lz_layer<LZ_L_S3, 1>(wl, lane, s2, acc3);
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) geo[0][4 * ft + r] = acc3[ft][0][r];
+            spre = lz_lane_dot<4>(wv + LZ_WV_SIG, q, s2[0]);
+        }
+        // colour net
+        float cpre[3];
+        uint32_t mk_c1;
+        {
+            float o[16];
+            lz_sh_eval(cd0, cd1, cd2, 4, o, nullptr, nullptr, nullptr);
+            float b1[1][21];
+#pragma unroll
+            for (int i = 0; i < 4; i++) b1[0][i] = q == 0 ? o[4 * i] : (q == 1 ? o[4 * i + 1] : (q == 2 ? o[4 * i + 2] : o[4 * i + 3]));
+#pragma unroll
+            for (int k = 0; k < 16; k++) b1[0][4 + k] = geo[0][k];
+            b1[0][20] = hc.indq;
+            if (valid) {   // colour_net.0 input [SH 16 | geo 64 | ind 4]; geo = s2 . Wg^T is not stored (lz_head_bwd.hip)
+#pragma unroll
+                for (int i = 0; i < 4; i++) rec1[LZ_BWD_X_S2C + 64 + 4 * i] = b1[0][i];
+                rec1[LZ_BWD_X_S2C + 80] = hc.indq;
+            }
+            lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
+            lz_layer<LZ_L_C1, 1>(wl, lane, b1, acc1);
+            float c1[16];
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) c1[4 * ft + r] = lz_relu(acc1[ft][0][r]);
+            mk_c1 = lz_mask_pos(c1);
+            if (valid) lz_dump_chained<4>(stq, LZ_ST_C1, c1);
+#pragma unroll
+            for (int c = 0; c < 3; c++) cpre[c] = lz_lane_dot<4>(wv + LZ_WV_C2 + 64 * c, q, c1);
+        }
+        const float sigma = lz_expf(spre);
+        if (valid) {
+            // masks + one scalar per lane: q = 0 ||att||, 1 eye_att, 2 unc pre-activation, 3 sigma
+            const float sc = q == 0 ? norm : (q == 1 ? eyeatt : (q == 2 ? upre : sigma));
+            lz_v4 w = {__uint_as_float(mk_a1 | (mk_s1 << 16)), __uint_as_float(mk_s2 | (mk_c1 << 16)), __uint_as_float(mk_u1 | (mk_e1 << 8)), sc};
+            __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(stq + LZ_ST_MK));
+            if (q == 0) {
+                lz_v4 cw = {cpre[0], cpre[1], cpre[2], 0.0f};
+                __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(st + row * LZ_FWD_STATE + LZ_ST_CLR));
+                sigmas[m] = sigma;
+                amb_aud[m] = norm;
+                if (amb_eye) amb_eye[m] = eyeatt;
+                unc_out[m] = lz_softplusf(upre);
+            }
+            if (q < 3) {
+                const float cv = q == 0 ? cpre[0] : (q == 1 ? cpre[1] : cpre[2]);
+                rgbs[(size_t)m * 3 + q] = lz_sigmoidf(cv) * 1.002f - 0.001f;
+            }
+        }
+        slice = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward from the recorded state
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(LZ_BWD_WG, LZ_BWD_WG / 256)
+lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, uint32_t M) {
+    constexpr int NFRAG = LZ_FRAGS_ALL;
+    constexpr int WV = NFRAG * 64, TAB = WV + LZ_WV_FLOATS;
+    __shared__ float wl[TAB + 96];
+    const LzHeadArgs& P = A.fwd;
+    const lz_head_bwd_out& O = A.o;
+    const uint32_t n_slices = (M + 15) / 16;
+    const uint32_t slice_lo = (uint32_t)(((uint64_t)n_slices * blockIdx.x) / gridDim.x);
+    const uint32_t slice_hi = (uint32_t)(((uint64_t)n_slices * (blockIdx.x + 1)) / gridDim.x);
+    if (slice_lo >= slice_hi) return;
+    {
+        const float4* src = reinterpret_cast<const float4*>(P.packed);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = threadIdx.x; i < NFRAG * 16; i += LZ_BWD_WG) dst[i] = src[i];
+        if (threadIdx.x < LZ_WV_FLOATS) wl[WV + threadIdx.x] = P.packed[LZ_FRAGS_ALL * 64 + threadIdx.x];
+        if (threadIdx.x < 32) wl[TAB + 64 + threadIdx.x] = P.enc_a[threadIdx.x];
+        if (threadIdx.x == 0) reinterpret_cast<int*>(wl + TAB)[48] = 0;
+    }
+    __syncthreads();
+    const float* lenca = wl + TAB + 64;
+    const float* wv = wl + WV;
+    const int lane = threadIdx.x & 63;
+    const int s = lane & 15, q = lane >> 4;
+    const bool has_eye = P.eye != nullptr;
+    const float eye_v = has_eye ? P.eye[0] : 0.0f;
+    int* queue = reinterpret_cast<int*>(wl + TAB) + 48;
+    if ((threadIdx.x >> 6) >= 4) {
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+    }
+    float acc_enca[8], acc_ind = 0.0f;   // d(enc_a)[16 t + 4 q + r], d(ind_code)[q], summed over this lane's samples
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc_enca[k] = 0.0f;
+    float acc_e2[4], acc_u2[8], acc_c2[3][16];   // weight gradients of the skinny output layers (lz_head_bwd.hip)
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc_e2[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc_u2[k] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc_c2[c][k] = 0.0f;
+
+    for (;;) {
+        int slice = 0;
+        if (lane == 0) slice = atomicAdd(queue, 1);
+        slice = __builtin_amdgcn_readfirstlane(slice);
+        if (slice_lo + (uint32_t)slice >= slice_hi) break;
+        const uint32_t base = (slice_lo + (uint32_t)slice) * 16;
+        const bool valid = base + s < M;
+        const uint32_t m = valid ? base + s : M - 1;
+        const size_t row = m;
+        float* rec1 = O.rec + row * LZ_BWD_REC + q;
+        float* recq = rec1 + 3 * q;
+        float* dencq = O.denc + (size_t)q * M + row;
+        const float* strow = st + row * LZ_FWD_STATE;
+        const float* stq = strow + 4 * q;
+
+        // ---- everything this slice reads, before its first store (one counter orders loads behind earlier stores) ----
+        auto ld4 = [](const float* p) -> lz_v4 { return __builtin_nontemporal_load(reinterpret_cast<const lz_v4*>(p)); };
+        const lz_v4 l_att0 = ld4(stq + LZ_ST_ATT), l_att1 = ld4(stq + LZ_ST_ATT + 16);
+        const lz_v4 l_c0 = ld4(stq + LZ_ST_C1), l_c1 = ld4(stq + LZ_ST_C1 + 16), l_c2 = ld4(stq + LZ_ST_C1 + 32), l_c3 = ld4(stq + LZ_ST_C1 + 48);
+        const lz_v4 l_u0 = ld4(stq + LZ_ST_U1), l_u1 = ld4(stq + LZ_ST_U1 + 16);
+        lz_v4 l_e = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (has_eye) l_e = ld4(stq + LZ_ST_E1);
+        const lz_v4 l_mk = ld4(stq + LZ_ST_MK);
+        const lz_v4 l_clr = ld4(strow + LZ_ST_CLR);
+        const float g_sig = A.g_sigma[row], g_aa = A.g_amb_aud[row], g_ae = A.g_amb_eye ? A.g_amb_eye[row] : 0.0f, g_un = A.g_unc[row];
+        const float g_r0 = A.g_rgb[row * 3], g_r1 = A.g_rgb[row * 3 + 1], g_r2 = A.g_rgb[row * 3 + 2];
+        __builtin_amdgcn_sched_barrier(0);
+        const float att[8] = {l_att0[0], l_att0[1], l_att0[2], l_att0[3], l_att1[0], l_att1[1], l_att1[2], l_att1[3]};
+        const float c1[16] = {l_c0[0], l_c0[1], l_c0[2], l_c0[3], l_c1[0], l_c1[1], l_c1[2], l_c1[3],
+                              l_c2[0], l_c2[1], l_c2[2], l_c2[3], l_c3[0], l_c3[1], l_c3[2], l_c3[3]};
+        const float u1[8] = {l_u0[0], l_u0[1], l_u0[2], l_u0[3], l_u1[0], l_u1[1], l_u1[2], l_u1[3]};
+        const float e1[4] = {l_e[0], l_e[1], l_e[2], l_e[3]};
+        const uint32_t w0 = lz_fbits(l_mk[0]), w1 = lz_fbits(l_mk[1]), w2 = lz_fbits(l_mk[2]);
+        const uint32_t mk_a1 = w0 & 0xffffu, mk_s1 = w0 >> 16, mk_s2 = w1 & 0xffffu, mk_c1 = w1 >> 16, mk_u1 = w2 & 0xffu, mk_e1 = (w2 >> 8) & 0xfu;
+        // the four scalars sit one per q lane of the sample
+        const float norm = __shfl(l_mk[3], s, 64), eyeatt = __shfl(l_mk[3], s + 16, 64), upre = __shfl(l_mk[3], s + 32, 64),
+                    sigma = __shfl(l_mk[3], s + 48, 64);
+
+        // uncertainty / colour heads: d loss / d pre-activation, and the skinny layers' weight gradients
+        const float du = g_un * lz_sigmoidf(upre);
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc_u2[k] = lz_fmaf(du, u1[k], acc_u2[k]);
+        }
+        float dc[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float sg = lz_sigmoidf(l_clr[c]);
+            dc[c] = (c == 0 ? g_r0 : (c == 1 ? g_r1 : g_r2)) * 1.002f * sg * (1.0f - sg);
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc_c2[c][k] = lz_fmaf(dc[c], c1[k], acc_c2[c][k]);
+            }
+        }
+
+        float dgeo[16];
+        float dind;
+        {
+            float dc1[16];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int f = 16 * t + 4 * q + r, k = 4 * t + r;
+                    float v = wv[LZ_WV_C2 + f] * dc[0];
+                    v = lz_fmaf(wv[LZ_WV_C2 + 64 + f], dc[1], v);
+                    v = lz_fmaf(wv[LZ_WV_C2 + 128 + f], dc[2], v);
+                    dc1[k] = ((mk_c1 >> k) & 1u) ? v : 0.0f;
+                }
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_C1H, dc1);
+            float dxc[21];
+            lz_layer_bwd<LZ_L_C1>(wl, lane, dc1, dxc);
+#pragma unroll
+            for (int k = 0; k < 16; k++) dgeo[k] = dxc[4 + k];
+            dind = dxc[20];
+        }
+        if (valid) acc_ind += dind;
+        const float dh0 = g_sig * sigma;
+        if (valid) {
+            if (q == 0) rec1[LZ_BWD_G_C1H + 64] = dh0;
+        }
+        float dencx[9], dencw[8], determ;
+        {
+            float ds2[16];
+            lz_layer_bwd<LZ_L_S3>(wl, lane, dgeo, ds2);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = 4 * t + r;
+                    const float v = lz_fmaf(wv[LZ_WV_SIG + 16 * t + 4 * q + r], dh0, ds2[k]);
+                    ds2[k] = ((mk_s2 >> k) & 1u) ? v : 0.0f;
+                }
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_S2, ds2);
+            float ds1[16];
+            lz_layer_bwd<LZ_L_S2>(wl, lane, ds2, ds1);
+#pragma unroll
+            for (int k = 0; k < 16; k++) ds1[k] = ((mk_s1 >> k) & 1u) ? ds1[k] : 0.0f;
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_S1, ds1);
+            float dxs[18];
+            lz_layer_bwd<LZ_L_S1>(wl, lane, ds1, dxs);
+#pragma unroll
+            for (int i = 0; i < 9; i++) dencx[i] = dxs[i];
+#pragma unroll
+            for (int k = 0; k < 8; k++) dencw[k] = dxs[9 + k];
+            determ = dxs[17];   // meaningful on lanes q == 0
+        }
+        float datt[8];
+        {
+            const float inv = norm > 0.0f ? g_aa / norm : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = 4 * t + r;
+                    datt[k] = lz_fmaf(lenca[16 * t + 4 * q + r], dencw[k], inv * att[k]);
+                    if (valid) acc_enca[k] = lz_fmaf(att[k], dencw[k], acc_enca[k]);
+                }
+            if (valid) lz_dump_chained<2>(recq, LZ_BWD_G_ATT, datt);
+        }
+        if (has_eye) {
+            const float det0 = __shfl(determ, s, 64);   // from lane (s, q = 0)
+            const float deye = lz_fmaf(eye_v, det0, g_ae);
+            const float de2 = deye * eyeatt * (1.0f - eyeatt);
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc_e2[r] = lz_fmaf(de2, e1[r], acc_e2[r]);
+            }
+            float de1[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) de1[r] = ((mk_e1 >> r) & 1u) ? wv[LZ_WV_E2 + 4 * q + r] * de2 : 0.0f;
+            if (valid) lz_dump_chained<1>(recq, LZ_BWD_G_X + 64, de1);
+            float dxe[9];
+            lz_layer_bwd<LZ_L_E1>(wl, lane, de1, dxe);
+#pragma unroll
+            for (int i = 0; i < 9; i++) dencx[i] += dxe[i];
+        } else if (valid) {
+            const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            lz_dump_chained<1>(recq, LZ_BWD_G_X + 64, zero);
+        }
+        {
+            float da1[16];
+            lz_layer_bwd<LZ_L_A2>(wl, lane, datt, da1);
+#pragma unroll
+            for (int k = 0; k < 16; k++) da1[k] = ((mk_a1 >> k) & 1u) ? da1[k] : 0.0f;
+            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_X, da1);
+            float dxa[9];
+            lz_layer_bwd<LZ_L_A1>(wl, lane, da1, dxa);
+#pragma unroll
+            for (int i = 0; i < 9; i++) dencx[i] += dxa[i];
+        }
+        {
+            float du1[8];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = 4 * t + r;
+                    du1[k] = ((mk_u1 >> k) & 1u) ? wv[LZ_WV_U2 + 16 * t + 4 * q + r] * du : 0.0f;
+                }
+            if (valid) lz_dump_chained<2>(recq, LZ_BWD_G_X + 80, du1);
+        }
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) dencq[(size_t)(4 * i) * M] = dencx[i];   // [3 planes][12 levels][M], level-major; feature 4 i + q
+        }
+    }
+    // per-lane sums -> 16 sample lanes -> the workgroup's waves in LDS -> one atomic per value (layout of lz_head_bwd_out.small)
+    constexpr int NRED = 32 + 4 + 16 + 32 + 192;
+    __syncthreads();
+    float* red = wl;
+    float* mine = red + (threadIdx.x >> 6) * NRED;
+    auto put = [&](float v, int slot) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (s == 0) mine[slot] = v;
+    };
+#pragma unroll
+    for (int k = 0; k < 8; k++) put(acc_enca[k], 16 * (k >> 2) + 4 * q + (k & 3));
+    put(acc_ind, 32 + q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) put(acc_e2[k], 36 + 4 * q + k);
+#pragma unroll
+    for (int k = 0; k < 8; k++) put(acc_u2[k], 52 + 16 * (k >> 2) + 4 * q + (k & 3));
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) put(acc_c2[c][k], 84 + 64 * c + 16 * (k >> 2) + 4 * q + (k & 3));
+    __syncthreads();
+    if (threadIdx.x < NRED) {
+        float v = 0.0f;
+        for (int w = 0; w < LZ_BWD_WG / 64; w++) v += red[w * NRED + threadIdx.x];
+        if (v != 0.0f) atomicAdd(O.small + threadIdx.x, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+static void lz_fill_head_args(const lz_head_params* p, LzHeadArgs& a) {
+    a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
+    a.offsets = p->offsets; a.packed = reinterpret_cast<const float*>(p->packed); a.enc_a = p->enc_a;
+    a.ind_code = p->ind_code; a.eye = p->eye; a.bound = p->bound; a.testing = 0;
+    for (int l = 0; l < 12; l++) {
+        const float sc = exp2f((float)l * p->S) * (float)p->H - 1.0f;
+        a.scale[l] = sc;
+        a.res[l] = (uint32_t)ceilf(sc) + 1u;
+    }
+}
+
+static uint32_t lz_rec_grid(uint32_t M, uint32_t wg) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const uint32_t want = lz_div_up(lz_div_up(M, 16), wg / 64);
+    return want < (uint32_t)n_cu ? want : (uint32_t)n_cu;
+}
+
+extern "C" int lz_triplane_head_forward_record(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M, float* sigmas,
+                                               float* rgbs, float* amb_aud, float* amb_eye, float* unc, float* rec, float* state,
+                                               lz_stream_t stream) {
+    LZ_REQUIRE(p && xyzs && dirs && sigmas && rgbs && amb_aud && unc && rec && state, LZ_ERR_BAD_ARGUMENT, "triplane_head_forward_record: null tensor");
+    LZ_REQUIRE(p->emb_xy && p->emb_yz && p->emb_xz && p->offsets && p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT,
+               "triplane_head_forward_record: incomplete lz_head_params");
+    LZ_REQUIRE(p->precision == 0 && !p->testing, LZ_ERR_UNSUPPORTED, "triplane_head_forward_record: f32 training mode only");
+    LZ_REQUIRE((((uintptr_t)rec | (uintptr_t)state) & 15u) == 0, LZ_ERR_BAD_ARGUMENT, "triplane_head_forward_record: rec / state must be 16-byte aligned");
+    if (M == 0) return LZ_OK;
+    LzHeadArgs a;
+    lz_fill_head_args(p, a);
+    hipLaunchKernelGGL(lz_k_triplane_head_forward_rec, dim3(lz_rec_grid(M, LZ_FREC_WG)), dim3(LZ_FREC_WG), 0, lz_st(stream), a, xyzs, dirs, M, sigmas, rgbs,
+                       amb_aud, amb_eye, unc, rec, state);
+    LZ_CHECK_LAUNCH("triplane_head_forward_record");
+    return LZ_OK;
+}
+
+extern "C" int lz_triplane_head_backward_recorded(const lz_head_params* p, const float* state, uint32_t M, const float* g_sigma,
+                                                  const float* g_rgb, const float* g_amb_aud, const float* g_amb_eye, const float* g_unc,
+                                                  const lz_head_bwd_out* out, lz_stream_t stream) {
+    LZ_REQUIRE(p && state && g_sigma && g_rgb && g_amb_aud && g_unc && out, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded: null tensor");
+    LZ_REQUIRE(p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded: incomplete lz_head_params");
+    LZ_REQUIRE(p->precision == 0 && !p->testing, LZ_ERR_UNSUPPORTED, "triplane_head_backward_recorded: f32 training mode only");
+    const lz_head_bwd_out& o = *out;
+    LZ_REQUIRE(o.denc && o.small && o.rec, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded: incomplete lz_head_bwd_out");
+    LZ_REQUIRE((((uintptr_t)o.rec | (uintptr_t)state) & 15u) == 0, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded: rec / state must be 16-byte aligned");
+    if (M == 0) return LZ_OK;
+    LzHeadBwdArgs a;
+    lz_fill_head_args(p, a.fwd);
+    a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_amb_aud = g_amb_aud; a.g_amb_eye = g_amb_eye; a.g_unc = g_unc;
+    a.o = o;
+    hipLaunchKernelGGL(lz_k_triplane_head_backward_rec, dim3(lz_rec_grid(M, LZ_BWD_WG)), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M);
+    LZ_CHECK_LAUNCH("triplane_head_backward_recorded");
+    return LZ_OK;
+}

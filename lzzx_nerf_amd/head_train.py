@@ -1,6 +1,9 @@
-"""Fused triplane head for TRAINING: forward = `lz_k_triplane_head<true>` (one kernel), backward = `lz_triplane_head_backward`
-(one kernel for the whole data-gradient chain, activations recomputed) + `lz_linear_grad_w` per layer + the LDS grid backward per
-plane.  A drop-in for the per-sample part of `NeRFNetwork.forward` in training mode (/root/reference/nerf_triplane/network.py:252-311):
+"""Fused triplane head for TRAINING: forward = one kernel, backward = one kernel for the whole data-gradient chain + one pass over
+the per-sample records for the weight gradients + the LDS grid backward per plane.  Two arrangements of the same arithmetic:
+`record=True` (default) -- the forward (`lz_triplane_head_forward_record`) writes the layer inputs and a state row per sample, the
+backward (`lz_triplane_head_backward_recorded`) starts from them; `record=False` -- the forward is `lz_triplane_head_forward`, the
+backward (`lz_triplane_head_backward`) recomputes the activations from (xyzs, dirs): no activation memory held between the two
+(3.3 KB per sample in record mode), twice the matrix work in the backward.  A drop-in for the per-sample part of `NeRFNetwork.forward` in training mode (/root/reference/nerf_triplane/network.py:252-311):
 same parameters, same state-dict keys, same five outputs.
 
     net = FusedTriplaneTrainHead(state_dict, bound=1.0)
@@ -19,6 +22,7 @@ from .gridencoder import GridEncoder
 from .linear import MLP
 
 _REC = 656   # floats per sample record of lz_triplane_head_backward (LZ_BWD_REC; slot columns: include/lzzx_nerf_hip.h LZ_BWD_*)
+_STATE = 176   # floats per sample state row of lz_triplane_head_forward_record (LZ_FWD_STATE)
 _ORDER = ["aud0", "aud1", "eye0", "eye1", "sig0", "sig1", "sig2", "col0", "col1", "unc0", "unc1"]
 
 
@@ -42,7 +46,13 @@ class _FusedHeadTrain(Function):
         p = mod._params(emb, enc_a_f, ind_f, eye_f)
         kw = dict(dtype=torch.float32, device=dev)
         sig, rgb, aa, ae, un = torch.empty(M, **kw), torch.empty(M, 3, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw)
-        if M > 0:   # an empty batch (every ray missed the box) has empty outputs and zero gradients
+        ctx.rec = ctx.state = None
+        if M > 0 and mod.record:
+            # held until the backward consumes them (not through save_for_backward: nothing else may alias or modify them)
+            ctx.rec, ctx.state = torch.empty(M, _REC, **kw), torch.empty(M, _STATE, **kw)
+            call("lz_triplane_head_forward_record", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un),
+                 ptr(ctx.rec), ptr(ctx.state), stream())
+        elif M > 0:   # an empty batch (every ray missed the box) has empty outputs and zero gradients
             call("lz_triplane_head_forward", C.byref(p), ptr(xyzs), ptr(dirs), M, None, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un), stream())
         # save_for_backward (not attributes): autograd then detects an in-place update of a weight / table between forward and
         # backward (detach() shares the version counter), and the tensors are released with the graph
@@ -73,7 +83,8 @@ class _FusedHeadTrain(Function):
             return (None, None, None, g_enc_a, g_ind, None) + tuple(torch.zeros_like(t) for t in emb) + tuple(torch.zeros_like(t) for t in w)
         z = lambda g, shape: (torch.zeros(shape, **kw) if g is None else g.float().contiguous())
         g_sig, g_rgb, g_aa, g_ae, g_un = z(g_sig, (M,)), z(g_rgb, (M, 3)), z(g_aa, (M, 1)), z(g_ae, (M, 1)), z(g_un, (M, 1))
-        rec = torch.empty(M, _REC, **kw)            # one record per sample: every layer input / output gradient the reductions need
+        # one record per sample: every layer input / output gradient the reductions need (the X half is there already in record mode)
+        rec = ctx.rec if ctx.rec is not None else torch.empty(M, _REC, **kw)
         denc = torch.empty(3, 12, M, **kw)          # level-major: the grid backward reads one level at a time
         small = torch.zeros(32 + 4 + 16 + 32 + 192, **kw)   # d_enc_a | d_ind | dW of the three skinny output layers (reduced in the kernel)
         d_enc_a, d_ind, dw_e2, dw_u2, dw_c2 = small[:32], small[32:36], small[36:52], small[52:84], small[84:]
@@ -82,8 +93,13 @@ class _FusedHeadTrain(Function):
         # `mod.packed` is shared by every forward of this module: re-pack from the weights THIS forward saw
         call("lz_head_pack_weights", *[ptr(t) for t in w], int(mod.has_eye), int(mod.has_ind), ptr(mod.packed), stream())
         p = mod._params(emb, enc_a_f, ind_f, eye_f)
-        call("lz_triplane_head_backward", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
-             C.byref(o), stream())
+        if ctx.state is not None:
+            call("lz_triplane_head_backward_recorded", C.byref(p), ptr(ctx.state), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
+                 C.byref(o), stream())
+            ctx.state = None
+        else:
+            call("lz_triplane_head_backward", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
+                 C.byref(o), stream())
         # weight gradients of the wide layers: ONE pass over the records (the skinny ones came out of the backward kernel)
         k_sig0, k_col0 = w[4].shape[1], w[7].shape[1]   # 68 without the eye column, 80 without an individual code
         shapes = dict(x3=(112, 36), aud1=(32, 64), sig0=(64, k_sig0), sig1=(64, 64), c1h=(65, 84))
@@ -92,6 +108,7 @@ class _FusedHeadTrain(Function):
             mod._gw_ws = torch.empty(_lib.load().lz_triplane_head_grad_w_workspace() // 4, **kw)
         call("lz_triplane_head_grad_w", ptr(rec), M, k_sig0, *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")],
              ptr(mod._gw_ws), stream())
+        ctx.rec = None
         # geo = s2 . Wg^T and d geo = G_c1 . Wc[:, geo] never left the kernel: both weight gradients follow from R = sum G_c1^T s2
         x3, c1h = red["x3"], red["c1h"]
         R, w_sig2, w_col0 = c1h[:64, :64], w[6], w[7]
@@ -115,9 +132,10 @@ class _FusedHeadTrain(Function):
 
 
 class FusedTriplaneTrainHead(nn.Module):
-    def __init__(self, state_dict=None, bound=1.0, exp_eye=True, ind_dim=4):
+    def __init__(self, state_dict=None, bound=1.0, exp_eye=True, ind_dim=4, record=True):
         super().__init__()
         self.bound = float(bound)
+        self.record = bool(record)
         mk = lambda: GridEncoder(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
                                  desired_resolution=512 * bound)
         self.encoder_xy, self.encoder_yz, self.encoder_xz = mk(), mk(), mk()                       # network.py:131-133

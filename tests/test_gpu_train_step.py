@@ -470,3 +470,44 @@ def test_fused_train_head_tiny_batches(params, golden, M):
         assert torch.equal(a, b)
     for a, b in zip(g_s, g_p):
         assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5 * (float(b.abs().max()) + 1e-12) + 1e-12
+
+
+@pytest.mark.parametrize("exp_eye,ind_dim", [(True, 4), (False, 0)])
+def test_fused_train_head_record_equals_recompute(params, golden, exp_eye, ind_dim):
+    """record=True (forward writes the layer inputs and a state row, backward starts from them) against record=False (backward
+    recomputes the forward): same outputs bit for bit, the wide layers' weight gradients bit for bit (the per-sample records are the
+    same and their reduction is deterministic), everything that ends in float atomics to 1e-5 of its largest entry"""
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    rng = np.random.default_rng(11)
+    p = dict(params)
+    p["sigma_net.net.0.weight"] = np.ascontiguousarray(params["sigma_net.net.0.weight"][:, :68 + int(exp_eye)])
+    p["color_net.net.0.weight"] = np.ascontiguousarray(params["color_net.net.0.weight"][:, :80 + ind_dim])
+    M = 16 * 700 + 5
+    xyz = torch.from_numpy(rng.uniform(-1, 1, (M, 3)).astype(np.float32)).cuda()
+    d = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)), dim=-1).cuda()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    gout = [torch.from_numpy(rng.normal(size=sh).astype(np.float32)).cuda() for sh in ((M,), (M, 3), (M, 1), (M, 1), (M, 1))]
+    res = []
+    for record in (True, False):
+        net = FusedTriplaneTrainHead(p, bound=1.0, exp_eye=exp_eye, ind_dim=ind_dim, record=record).cuda()
+        enc_a = dev(golden["net_enc_a"]).requires_grad_(True)
+        eye = dev(golden["net_eye"]) if exp_eye else None
+        ind = dev(golden["net_ind"]).requires_grad_(True) if ind_dim else None
+        outs = net(xyz, d, enc_a, ind, eye)
+        torch.autograd.backward([o for o, g in zip(outs, gout) if o.requires_grad], [g for o, g in zip(outs, gout) if o.requires_grad])
+        grads = {k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+        grads["enc_a"] = enc_a.grad
+        if ind is not None:
+            grads["ind"] = ind.grad
+        res.append(([o.detach() for o in outs], grads))
+    (o1, g1), (o2, g2) = res
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    assert g1.keys() == g2.keys()
+    exact = ("aud_ch_att_net.net.0.weight", "aud_ch_att_net.net.1.weight", "sigma_net.net.0.weight", "sigma_net.net.1.weight", "unc_net.net.0.weight")
+    for k in g1:
+        if k in exact:
+            assert torch.equal(g1[k], g2[k]), k
+        else:
+            scale = float(g2[k].abs().max()) + 1e-30
+            assert float((g1[k] - g2[k]).abs().max()) / scale < 1e-5, k
