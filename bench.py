@@ -203,7 +203,7 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
     ro, rd, target = ro[sel[lo:hi]].contiguous(), rd[sel[lo:hi]].contiguous(), target[lo:hi].contiguous()
     if args.train_mlp == "fused":   # one kernel forward, one kernel for the backward data chain (lzzx_nerf_amd/head_train.py)
         from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
-        net = FusedTriplaneTrainHead(P, bound=1.0, record=not args.train_recompute).to(device)
+        net = FusedTriplaneTrainHead(P, bound=1.0, record=not args.train_recompute, record_dtype=args.train_records).to(device)
     else:
         net = TriplaneTrainNet(P, device, mlp=args.train_mlp)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-15, fused=True)
@@ -268,7 +268,7 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
                          "scatter-add) -> Adam; sample buffers sized by mean_count like the reference's steady state (no D2H copy in the step)",
                 rays=n_rays, samples_per_step=int(n_samples[0]), steps=k_steps, sample_buffer_overflow=overflow,
                 ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
-                loss=float(loss.detach()), dtype="f32", mlp={"fused": "fused head forward + backward kernels, " + ("activations recomputed in the backward (csrc/lz_head.hip, lz_head_bwd.hip)" if args.train_recompute else "forward records, backward starts from the record (csrc/lz_head_rec.hip)"), "lz": "csrc/lz_linear.hip (MFMA f32)",
+                loss=float(loss.detach()), dtype="f32" if args.train_records == "f32" or args.train_mlp != "fused" else "f32 compute, f16 weight-gradient operands", mlp={"fused": "fused head forward + backward kernels, " + ("activations recomputed in the backward (csrc/lz_head.hip, lz_head_bwd.hip)" if args.train_recompute else "forward records, backward starts from the record (csrc/lz_head_rec.hip), " + args.train_records + " records"), "lz": "csrc/lz_linear.hip (MFMA f32)",
                      "torch": "torch/rocBLAS"}[args.train_mlp])
 
 
@@ -295,6 +295,9 @@ def parse_args():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-only", action="store_true", help="time only the cfg3 training step (tools/profile_train.sh) and print it")
     ap.add_argument("--train-rays", type=int, default=65536)
+    ap.add_argument("--train-records", default="f32", choices=["f32", "f16"],
+                    help="fused training head: precision of the per-sample records the weight gradients are reduced from (f16 = the operand "
+                         "rounding of the reference's autocast dW GEMMs; forward, data gradient and accumulation stay f32)")
     ap.add_argument("--train-recompute", action="store_true",
                     help="fused training head with record=False: the backward recomputes the forward instead of reading what it recorded")
     ap.add_argument("--train-dp", action="store_true",

@@ -389,11 +389,38 @@ int lz_triplane_head_backward(const lz_head_params* p, const float* xyzs, const 
 #define LZ_ST_E1 128
 #define LZ_ST_MK 144
 #define LZ_ST_CLR 160
+/* record_f16 = 1: the operands of the weight-gradient products are kept in half precision (rounded to nearest even), which is what the
+ * reference's autocast mode feeds its dW GEMMs (opt.fp16: TrainerUtil.py:103, 865-870, with its GradScaler in front); the data-gradient
+ * chain and the accumulation stay f32.  rec then holds LZ_BWD_REC16 halves per sample (1 408 bytes instead of 2 624): 16-column tiles
+ * interleaved in pairs -- dword j of pair g = {tile 2 g column j, tile 2 g + 1 column j} -- first tile of every slot LZ_R16_*:
+ *   X_A1 4 tiles | X_SIG0 6: {enc_x feature 8 (j % 4) + 4 p + j / 4 at tile p column j | feature 32 + q at column 4 q, eye term at
+ *   column 1 | enc_a * att 2 tiles | pad} | X_S1 4 | X_S2C 6: {s2 4 | SH component 4 (j % 4) + j / 4 at column j | ind_code[q] at
+ *   column 4 q} | G_X 8: {aud.0 4 | eye.0 | unc.0 2 | pad} | G_ATT 2 | G_S1 4 | G_S2 4 | G_C1H 6: {color.0 4 | d h0 at column 0 | pad}
+ * and the state row is LZ_FWD_STATE16 dwords: att f32 [32] | c1 2 pairs | u1 1 pair | e1 (low halves) | masks + scalars | colours. */
+#define LZ_BWD_REC16 704
+#define LZ_R16_X_A1 0
+#define LZ_R16_X_SIG0 4
+#define LZ_R16_X_S1 10
+#define LZ_R16_X_S2C 14
+#define LZ_R16_G_X 20
+#define LZ_R16_G_ATT 28
+#define LZ_R16_G_S1 30
+#define LZ_R16_G_S2 34
+#define LZ_R16_G_C1H 38
+#define LZ_FWD_STATE16 128
+#define LZ_S16_C1 32
+#define LZ_S16_U1 64
+#define LZ_S16_E1 80
+#define LZ_S16_MK 96
+#define LZ_S16_CLR 112
 int lz_triplane_head_forward_record(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M, float* sigmas, float* rgbs,
-                                    float* amb_aud, float* amb_eye, float* unc, float* rec, float* state, lz_stream_t stream);
+                                    float* amb_aud, float* amb_eye, float* unc, void* rec, float* state, int record_f16, lz_stream_t stream);
 int lz_triplane_head_backward_recorded(const lz_head_params* p, const float* state, uint32_t M, const float* g_sigma, const float* g_rgb,
                                        const float* g_amb_aud, const float* g_amb_eye, const float* g_unc, const lz_head_bwd_out* out,
-                                       lz_stream_t stream);
+                                       int record_f16, lz_stream_t stream);
+/* inputs of the three table scatters of a training step in one launch: out [3, M, 2] = (x, y) | (y, z) | (x, z) of xyzs [M, 3], each mapped
+ * (v + bound) / (2 bound) exactly as the fused forward maps it (grid.py:143; network.py:208-223 for the plane order) */
+int lz_triplane_plane_coords(const float* xyzs, uint32_t M, float bound, float* out, lz_stream_t stream);
 /* Weight gradients of the wide layers from the records, in ONE pass over them (five waves per workgroup, each owning the
  * accumulator tiles of one product; partial tiles per workgroup in `workspace`, summed by a second small launch: no atomics).
  * Outputs are overwritten, row-major [N, K]: dW_x3 [112,36] = aud_ch_att_net.0 (rows 0..63) | eye_att_net.0 (64..79) | unc_net.0
@@ -405,6 +432,10 @@ int lz_triplane_head_backward_recorded(const lz_head_params* p, const float* sta
 size_t lz_triplane_head_grad_w_workspace(void);
 int lz_triplane_head_grad_w(const float* rec, uint32_t M, uint32_t k_sig0, float* dW_x3, float* dW_aud1, float* dW_sig0,
                             float* dW_sig1, float* dW_c1h, void* workspace, lz_stream_t stream);
+/* the same pass over f16 records (LZ_BWD_REC16 halves per sample, see lz_triplane_head_forward_record): operands converted to f32 at
+ * use, f32 accumulation, same outputs */
+int lz_triplane_head_grad_w_f16(const void* rec16, uint32_t M, uint32_t k_sig0, float* dW_x3, float* dW_aud1, float* dW_sig0,
+                                float* dW_sig1, float* dW_c1h, void* workspace, lz_stream_t stream);
 
 /* Device-resident inference loop (renderer.py:495-548): no host synchronisation inside the frame, 3 launches per iteration:
  *     lz_loop_march -> lz_triplane_head_forward(count = state words + LZ_LOOP_NEXT + 2) -> lz_loop_composite.

@@ -118,8 +118,10 @@ SIGNATURES = {
     "lz_density_grid_update": [vp, f32, f32, f32, u32, u32, vp, vp, vp, vp, vp],
     "lz_linear_forward": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, i32, vp],
     "lz_linear_grad_w": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, vp],
-    "lz_triplane_head_forward_record": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp],
-    "lz_triplane_head_backward_recorded": [C.POINTER(HeadParams), vp, u32, vp, vp, vp, vp, vp, C.POINTER(HeadBwdOut), vp],
+    "lz_triplane_head_forward_record": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "lz_triplane_head_backward_recorded": [C.POINTER(HeadParams), vp, u32, vp, vp, vp, vp, vp, C.POINTER(HeadBwdOut), i32, vp],
+    "lz_triplane_plane_coords": [vp, u32, f32, vp, vp],
+    "lz_triplane_head_grad_w_f16": [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp],
     "lz_triplane_head_grad_w": [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp],
 }
 PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),

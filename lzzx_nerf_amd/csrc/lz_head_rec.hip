@@ -23,9 +23,38 @@ typedef float lz_v4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t lz_fbits(float v) { return __float_as_uint(v); }
 
+// ---- f16 records (LZ_BWD_REC16 halves per sample; include/lzzx_nerf_hip.h LZ_R16_*): 16-column tiles interleaved in pairs, dword j of
+// pair g = {tile 2 g column j, tile 2 g + 1 column j}.  Lane (s, q) holds columns 4 q + r of a tile in registers r = 0..3, so one
+// dwordx4 store per lane covers its share of a pair (64 bytes per sample), values rounded to nearest even.
+typedef _Float16 lz_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lz_pack_h2(float lo, float hi) {
+    const lz_h2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(float, v);
+}
+// rowq = this sample's f16 row (as dwords) + 4 q; `pair` = tile / 2
+__device__ __forceinline__ void lz_dump_pair(float* __restrict__ rowq, int pair, float l0, float l1, float l2, float l3, float h0, float h1,
+                                             float h2, float h3) {
+    lz_v4 w = {lz_pack_h2(l0, h0), lz_pack_h2(l1, h1), lz_pack_h2(l2, h2), lz_pack_h2(l3, h3)};
+    __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(rowq + 16 * pair));
+}
+// tiles t0, t0 + 1 of a chained-layout vector -> pair
+template <int N>
+__device__ __forceinline__ void lz_dump_pair_chained(float* __restrict__ rowq, int pair, const float (&v)[N], int t0) {
+    lz_dump_pair(rowq, pair, v[4 * t0], v[4 * t0 + 1], v[4 * t0 + 2], v[4 * t0 + 3], v[4 * t0 + 4], v[4 * t0 + 5], v[4 * t0 + 6], v[4 * t0 + 7]);
+}
+__device__ __forceinline__ void lz_unpack_pair(const lz_v4& w, float* lo4, float* hi4) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t u = __float_as_uint(w[r]);
+        lo4[r] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu));
+        hi4[r] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward, recording
 // ------------------------------------------------------------------------------------------------
+template <bool H16>
 __global__ void __launch_bounds__(LZ_FREC_WG, 1)
 lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
                                float* __restrict__ sigmas, float* __restrict__ rgbs, float* __restrict__ amb_aud,
@@ -70,9 +99,10 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
         const bool valid = base + s < M;
         const uint32_t m = valid ? base + s : M - 1;   // clamped rows are computed, never stored
         const size_t row = m;
-        float* rec1 = rec + row * LZ_BWD_REC + q;
+        float* rec1 = rec + row * (H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC) + q;   // f16: rows counted in dwords
         float* recq = rec1 + 3 * q;
-        float* stq = st + row * LZ_FWD_STATE + 4 * q;
+        float* strow = st + row * (H16 ? LZ_FWD_STATE16 : LZ_FWD_STATE);
+        float* stq = strow + 4 * q;
 
         float encx[9];
         lz_head_gather(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx);
@@ -97,7 +127,14 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) a1[0][4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_a1 = lz_mask_pos(a1[0]);
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_A1, a1[0]);
+            if (valid) {
+                if constexpr (H16) {
+                    lz_dump_pair_chained(recq, LZ_R16_X_A1 / 2, a1[0], 0);
+                    lz_dump_pair_chained(recq, LZ_R16_X_A1 / 2 + 1, a1[0], 2);
+                } else {
+                    lz_dump_chained<4>(recq, LZ_BWD_X_A1, a1[0]);
+                }
+            }
             lz_f4 acc2[2][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_A2, 1>(wl, lane, a1, acc2);
 #pragma unroll
@@ -105,7 +142,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) att[4 * ft + r] = acc2[ft][0][r];
         }
-        if (valid) lz_dump_chained<2>(stq, LZ_ST_ATT, att);
+        if (valid) lz_dump_chained<2>(stq, LZ_ST_ATT, att);   // f32 in both layouts: the data gradient uses it
         float norm;
         {
             float acc = 0.0f;
@@ -125,7 +162,10 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
             for (int r = 0; r < 4; r++) e1[r] = lz_relu(acce[0][0][r]);
             mk_e1 = lz_mask_pos(e1);
-            if (valid) lz_dump_chained<1>(stq, LZ_ST_E1, e1);
+            if (valid) {
+                if constexpr (H16) lz_dump_pair(stq, LZ_S16_E1 / 16, e1[0], e1[1], e1[2], e1[3], 0.0f, 0.0f, 0.0f, 0.0f);
+                else lz_dump_chained<1>(stq, LZ_ST_E1, e1);
+            }
             eyeatt = lz_sigmoidf(lz_lane_dot<1>(wv + LZ_WV_E2, q, e1));
         }
         // uncertainty
@@ -140,7 +180,10 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) u1[4 * ft + r] = lz_relu(accu[ft][0][r]);
             mk_u1 = lz_mask_pos(u1);
-            if (valid) lz_dump_chained<2>(stq, LZ_ST_U1, u1);
+            if (valid) {
+                if constexpr (H16) lz_dump_pair_chained(stq, LZ_S16_U1 / 16, u1, 0);
+                else lz_dump_chained<2>(stq, LZ_ST_U1, u1);
+            }
             upre = lz_lane_dot<2>(wv + LZ_WV_U2, q, u1);
         }
         // sigma net
@@ -160,10 +203,18 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             for (int k = 0; k < 8; k++) b1[0][9 + k] = encw[k];
             b1[0][17] = (hc.has_eye && q == 0) ? hc.eye_v * eyeatt : 0.0f;
             if (valid) {   // sigma_net.0 input [enc_x 36 | enc_a * att 32 | eye * eye_att 1]
+                if constexpr (H16) {
+                    // tiles 0, 1: enc_x features 4 i + q, i < 8 (half 2 r + p of the lane's eight = i); tile 2: feature 32 + q at column
+                    // 4 q, the eye term at column 1; tiles 3, 4: enc_a * att; tile 5: padding
+                    lz_dump_pair(recq, LZ_R16_X_SIG0 / 2, encx[0], encx[2], encx[4], encx[6], encx[1], encx[3], encx[5], encx[7]);
+                    lz_dump_pair(recq, LZ_R16_X_SIG0 / 2 + 1, encx[8], b1[0][17], 0.0f, 0.0f, encw[0], encw[1], encw[2], encw[3]);
+                    lz_dump_pair(recq, LZ_R16_X_SIG0 / 2 + 2, encw[4], encw[5], encw[6], encw[7], 0.0f, 0.0f, 0.0f, 0.0f);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 9; i++) rec1[LZ_BWD_X_SIG0 + 4 * i] = encx[i];
-                lz_dump_chained<2>(recq, LZ_BWD_X_SIG0 + 36, encw);
-                if (q == 0) rec1[LZ_BWD_X_SIG0 + 68] = b1[0][17];
+                    for (int i = 0; i < 9; i++) rec1[LZ_BWD_X_SIG0 + 4 * i] = encx[i];
+                    lz_dump_chained<2>(recq, LZ_BWD_X_SIG0 + 36, encw);
+                    if (q == 0) rec1[LZ_BWD_X_SIG0 + 68] = b1[0][17];
+                }
             }
             lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_S1, 1>(wl, lane, b1, acc1);
@@ -173,7 +224,14 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) s1[0][4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_s1 = lz_mask_pos(s1[0]);
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_S1, s1[0]);
+            if (valid) {
+                if constexpr (H16) {
+                    lz_dump_pair_chained(recq, LZ_R16_X_S1 / 2, s1[0], 0);
+                    lz_dump_pair_chained(recq, LZ_R16_X_S1 / 2 + 1, s1[0], 2);
+                } else {
+                    lz_dump_chained<4>(recq, LZ_BWD_X_S1, s1[0]);
+                }
+            }
             lz_f4 acc2[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_S2, 1>(wl, lane, s1, acc2);
             float s2[1][16];
@@ -182,7 +240,14 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) s2[0][4 * ft + r] = lz_relu(acc2[ft][0][r]);
             mk_s2 = lz_mask_pos(s2[0]);
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_S2C, s2[0]);
+            if (valid) {
+                if constexpr (H16) {
+                    lz_dump_pair_chained(recq, LZ_R16_X_S2C / 2, s2[0], 0);
+                    lz_dump_pair_chained(recq, LZ_R16_X_S2C / 2 + 1, s2[0], 2);
+                } else {
+                    lz_dump_chained<4>(recq, LZ_BWD_X_S2C, s2[0]);
+                }
+            }
             lz_f4 acc3[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_S3, 1>(wl, lane, s2, acc3);
 #pragma unroll
@@ -204,9 +269,13 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             for (int k = 0; k < 16; k++) b1[0][4 + k] = geo[0][k];
             b1[0][20] = hc.indq;
             if (valid) {   // colour_net.0 input [SH 16 | geo 64 | ind 4]; geo = s2 . Wg^T is not stored (lz_head_bwd.hip)
+                if constexpr (H16) {   // tile 4: SH component 4 r + q at column 4 q + r; tile 5: ind_code[q] at column 4 q
+                    lz_dump_pair(recq, LZ_R16_X_S2C / 2 + 2, b1[0][0], b1[0][1], b1[0][2], b1[0][3], hc.indq, 0.0f, 0.0f, 0.0f);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) rec1[LZ_BWD_X_S2C + 64 + 4 * i] = b1[0][i];
-                rec1[LZ_BWD_X_S2C + 80] = hc.indq;
+                    for (int i = 0; i < 4; i++) rec1[LZ_BWD_X_S2C + 64 + 4 * i] = b1[0][i];
+                    rec1[LZ_BWD_X_S2C + 80] = hc.indq;
+                }
             }
             lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_C1, 1>(wl, lane, b1, acc1);
@@ -216,7 +285,14 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) c1[4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_c1 = lz_mask_pos(c1);
-            if (valid) lz_dump_chained<4>(stq, LZ_ST_C1, c1);
+            if (valid) {
+                if constexpr (H16) {
+                    lz_dump_pair_chained(stq, LZ_S16_C1 / 16, c1, 0);
+                    lz_dump_pair_chained(stq, LZ_S16_C1 / 16 + 1, c1, 2);
+                } else {
+                    lz_dump_chained<4>(stq, LZ_ST_C1, c1);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 3; c++) cpre[c] = lz_lane_dot<4>(wv + LZ_WV_C2 + 64 * c, q, c1);
         }
@@ -225,10 +301,10 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             // masks + one scalar per lane: q = 0 ||att||, 1 eye_att, 2 unc pre-activation, 3 sigma
             const float sc = q == 0 ? norm : (q == 1 ? eyeatt : (q == 2 ? upre : sigma));
             lz_v4 w = {__uint_as_float(mk_a1 | (mk_s1 << 16)), __uint_as_float(mk_s2 | (mk_c1 << 16)), __uint_as_float(mk_u1 | (mk_e1 << 8)), sc};
-            __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(stq + LZ_ST_MK));
+            __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(stq + (H16 ? LZ_S16_MK : LZ_ST_MK)));
             if (q == 0) {
                 lz_v4 cw = {cpre[0], cpre[1], cpre[2], 0.0f};
-                __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(st + row * LZ_FWD_STATE + LZ_ST_CLR));
+                __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(strow + (H16 ? LZ_S16_CLR : LZ_ST_CLR)));
                 sigmas[m] = sigma;
                 amb_aud[m] = norm;
                 if (amb_eye) amb_eye[m] = eyeatt;
@@ -246,6 +322,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 // ------------------------------------------------------------------------------------------------
 // backward from the recorded state
 // ------------------------------------------------------------------------------------------------
+template <bool H16>
 __global__ void __launch_bounds__(LZ_BWD_WG, LZ_BWD_WG / 256)
 lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, uint32_t M) {
     constexpr int NFRAG = LZ_FRAGS_ALL;
@@ -299,29 +376,46 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         const bool valid = base + s < M;
         const uint32_t m = valid ? base + s : M - 1;
         const size_t row = m;
-        float* rec1 = O.rec + row * LZ_BWD_REC + q;
+        float* rec1 = O.rec + row * (H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC) + q;   // f16: rows counted in dwords
         float* recq = rec1 + 3 * q;
         float* dencq = O.denc + (size_t)q * M + row;
-        const float* strow = st + row * LZ_FWD_STATE;
+        const float* strow = st + row * (H16 ? LZ_FWD_STATE16 : LZ_FWD_STATE);
         const float* stq = strow + 4 * q;
 
         // ---- everything this slice reads, before its first store (one counter orders loads behind earlier stores) ----
         auto ld4 = [](const float* p) -> lz_v4 { return __builtin_nontemporal_load(reinterpret_cast<const lz_v4*>(p)); };
         const lz_v4 l_att0 = ld4(stq + LZ_ST_ATT), l_att1 = ld4(stq + LZ_ST_ATT + 16);
-        const lz_v4 l_c0 = ld4(stq + LZ_ST_C1), l_c1 = ld4(stq + LZ_ST_C1 + 16), l_c2 = ld4(stq + LZ_ST_C1 + 32), l_c3 = ld4(stq + LZ_ST_C1 + 48);
-        const lz_v4 l_u0 = ld4(stq + LZ_ST_U1), l_u1 = ld4(stq + LZ_ST_U1 + 16);
-        lz_v4 l_e = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (has_eye) l_e = ld4(stq + LZ_ST_E1);
-        const lz_v4 l_mk = ld4(stq + LZ_ST_MK);
-        const lz_v4 l_clr = ld4(strow + LZ_ST_CLR);
+        lz_v4 l_c0, l_c1, l_c2 = {0.0f, 0.0f, 0.0f, 0.0f}, l_c3 = l_c2, l_u0, l_u1 = l_c2, l_e = l_c2;
+        if constexpr (H16) {
+            l_c0 = ld4(stq + LZ_S16_C1); l_c1 = ld4(stq + LZ_S16_C1 + 16);
+            l_u0 = ld4(stq + LZ_S16_U1);
+            if (has_eye) l_e = ld4(stq + LZ_S16_E1);
+        } else {
+            l_c0 = ld4(stq + LZ_ST_C1); l_c1 = ld4(stq + LZ_ST_C1 + 16); l_c2 = ld4(stq + LZ_ST_C1 + 32); l_c3 = ld4(stq + LZ_ST_C1 + 48);
+            l_u0 = ld4(stq + LZ_ST_U1); l_u1 = ld4(stq + LZ_ST_U1 + 16);
+            if (has_eye) l_e = ld4(stq + LZ_ST_E1);
+        }
+        const lz_v4 l_mk = ld4(stq + (H16 ? LZ_S16_MK : LZ_ST_MK));
+        const lz_v4 l_clr = ld4(strow + (H16 ? LZ_S16_CLR : LZ_ST_CLR));
         const float g_sig = A.g_sigma[row], g_aa = A.g_amb_aud[row], g_ae = A.g_amb_eye ? A.g_amb_eye[row] : 0.0f, g_un = A.g_unc[row];
         const float g_r0 = A.g_rgb[row * 3], g_r1 = A.g_rgb[row * 3 + 1], g_r2 = A.g_rgb[row * 3 + 2];
         __builtin_amdgcn_sched_barrier(0);
         const float att[8] = {l_att0[0], l_att0[1], l_att0[2], l_att0[3], l_att1[0], l_att1[1], l_att1[2], l_att1[3]};
-        const float c1[16] = {l_c0[0], l_c0[1], l_c0[2], l_c0[3], l_c1[0], l_c1[1], l_c1[2], l_c1[3],
-                              l_c2[0], l_c2[1], l_c2[2], l_c2[3], l_c3[0], l_c3[1], l_c3[2], l_c3[3]};
-        const float u1[8] = {l_u0[0], l_u0[1], l_u0[2], l_u0[3], l_u1[0], l_u1[1], l_u1[2], l_u1[3]};
-        const float e1[4] = {l_e[0], l_e[1], l_e[2], l_e[3]};
+        float c1[16], u1[8], e1[4];
+        if constexpr (H16) {
+            lz_unpack_pair(l_c0, c1, c1 + 4);
+            lz_unpack_pair(l_c1, c1 + 8, c1 + 12);
+            lz_unpack_pair(l_u0, u1, u1 + 4);
+            float pad[4];
+            lz_unpack_pair(l_e, e1, pad);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                c1[r] = l_c0[r]; c1[4 + r] = l_c1[r]; c1[8 + r] = l_c2[r]; c1[12 + r] = l_c3[r];
+                u1[r] = l_u0[r]; u1[4 + r] = l_u1[r];
+                e1[r] = l_e[r];
+            }
+        }
         const uint32_t w0 = lz_fbits(l_mk[0]), w1 = lz_fbits(l_mk[1]), w2 = lz_fbits(l_mk[2]);
         const uint32_t mk_a1 = w0 & 0xffffu, mk_s1 = w0 >> 16, mk_s2 = w1 & 0xffffu, mk_c1 = w1 >> 16, mk_u1 = w2 & 0xffu, mk_e1 = (w2 >> 8) & 0xfu;
         // the four scalars sit one per q lane of the sample
@@ -359,7 +453,14 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     v = lz_fmaf(wv[LZ_WV_C2 + 128 + f], dc[2], v);
                     dc1[k] = ((mk_c1 >> k) & 1u) ? v : 0.0f;
                 }
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_C1H, dc1);
+            if (valid) {
+                if constexpr (H16) {
+                    lz_dump_pair_chained(recq, LZ_R16_G_C1H / 2, dc1, 0);
+                    lz_dump_pair_chained(recq, LZ_R16_G_C1H / 2 + 1, dc1, 2);
+                } else {
+                    lz_dump_chained<4>(recq, LZ_BWD_G_C1H, dc1);
+                }
+            }
             float dxc[21];
             lz_layer_bwd<LZ_L_C1>(wl, lane, dc1, dxc);
 #pragma unroll
@@ -368,8 +469,9 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         }
         if (valid) acc_ind += dind;
         const float dh0 = g_sig * sigma;
-        if (valid) {
-            if (q == 0) rec1[LZ_BWD_G_C1H + 64] = dh0;
+        if (valid && q == 0) {
+            if constexpr (H16) lz_dump_pair(recq, LZ_R16_G_C1H / 2 + 2, dh0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);   // tile 4, column 0
+            else rec1[LZ_BWD_G_C1H + 64] = dh0;
         }
         float dencx[9], dencw[8], determ;
         {
@@ -383,12 +485,26 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     const float v = lz_fmaf(wv[LZ_WV_SIG + 16 * t + 4 * q + r], dh0, ds2[k]);
                     ds2[k] = ((mk_s2 >> k) & 1u) ? v : 0.0f;
                 }
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_S2, ds2);
+            if (valid) {
+                if constexpr (H16) {
+                    lz_dump_pair_chained(recq, LZ_R16_G_S2 / 2, ds2, 0);
+                    lz_dump_pair_chained(recq, LZ_R16_G_S2 / 2 + 1, ds2, 2);
+                } else {
+                    lz_dump_chained<4>(recq, LZ_BWD_G_S2, ds2);
+                }
+            }
             float ds1[16];
             lz_layer_bwd<LZ_L_S2>(wl, lane, ds2, ds1);
 #pragma unroll
             for (int k = 0; k < 16; k++) ds1[k] = ((mk_s1 >> k) & 1u) ? ds1[k] : 0.0f;
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_S1, ds1);
+            if (valid) {
+                if constexpr (H16) {
+                    lz_dump_pair_chained(recq, LZ_R16_G_S1 / 2, ds1, 0);
+                    lz_dump_pair_chained(recq, LZ_R16_G_S1 / 2 + 1, ds1, 2);
+                } else {
+                    lz_dump_chained<4>(recq, LZ_BWD_G_S1, ds1);
+                }
+            }
             float dxs[18];
             lz_layer_bwd<LZ_L_S1>(wl, lane, ds1, dxs);
 #pragma unroll
@@ -408,8 +524,21 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     datt[k] = lz_fmaf(lenca[16 * t + 4 * q + r], dencw[k], inv * att[k]);
                     if (valid) acc_enca[k] = lz_fmaf(att[k], dencw[k], acc_enca[k]);
                 }
-            if (valid) lz_dump_chained<2>(recq, LZ_BWD_G_ATT, datt);
+            if (valid) {
+                if constexpr (H16) lz_dump_pair_chained(recq, LZ_R16_G_ATT / 2, datt, 0);
+                else lz_dump_chained<2>(recq, LZ_BWD_G_ATT, datt);
+            }
         }
+        // uncertainty: unc = softplus(u); its input is detached (network.py:241-249): weight gradients only
+        float du1[8];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = 4 * t + r;
+                du1[k] = ((mk_u1 >> k) & 1u) ? wv[LZ_WV_U2 + 16 * t + 4 * q + r] * du : 0.0f;
+            }
+        float de1[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // stays zero without an eye input: the stacked reduction over G_x reads these columns
         if (has_eye) {
             const float det0 = __shfl(determ, s, 64);   // from lane (s, q = 0)
             const float deye = lz_fmaf(eye_v, det0, g_ae);
@@ -418,39 +547,39 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc_e2[r] = lz_fmaf(de2, e1[r], acc_e2[r]);
             }
-            float de1[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) de1[r] = ((mk_e1 >> r) & 1u) ? wv[LZ_WV_E2 + 4 * q + r] * de2 : 0.0f;
-            if (valid) lz_dump_chained<1>(recq, LZ_BWD_G_X + 64, de1);
             float dxe[9];
             lz_layer_bwd<LZ_L_E1>(wl, lane, de1, dxe);
 #pragma unroll
             for (int i = 0; i < 9; i++) dencx[i] += dxe[i];
-        } else if (valid) {
-            const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            lz_dump_chained<1>(recq, LZ_BWD_G_X + 64, zero);
+        }
+        if (valid) {   // G_X = [aud_ch_att_net.0 64 | eye_att_net.0 16 | unc_net.0 32]: the last three tiles
+            if constexpr (H16) {
+                lz_dump_pair(recq, LZ_R16_G_X / 2 + 2, de1[0], de1[1], de1[2], de1[3], du1[0], du1[1], du1[2], du1[3]);
+                lz_dump_pair(recq, LZ_R16_G_X / 2 + 3, du1[4], du1[5], du1[6], du1[7], 0.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                lz_dump_chained<1>(recq, LZ_BWD_G_X + 64, de1);
+                lz_dump_chained<2>(recq, LZ_BWD_G_X + 80, du1);
+            }
         }
         {
             float da1[16];
             lz_layer_bwd<LZ_L_A2>(wl, lane, datt, da1);
 #pragma unroll
             for (int k = 0; k < 16; k++) da1[k] = ((mk_a1 >> k) & 1u) ? da1[k] : 0.0f;
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_X, da1);
+            if (valid) {
+                if constexpr (H16) {
+                    lz_dump_pair_chained(recq, LZ_R16_G_X / 2, da1, 0);
+                    lz_dump_pair_chained(recq, LZ_R16_G_X / 2 + 1, da1, 2);
+                } else {
+                    lz_dump_chained<4>(recq, LZ_BWD_G_X, da1);
+                }
+            }
             float dxa[9];
             lz_layer_bwd<LZ_L_A1>(wl, lane, da1, dxa);
 #pragma unroll
             for (int i = 0; i < 9; i++) dencx[i] += dxa[i];
-        }
-        {
-            float du1[8];
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int k = 4 * t + r;
-                    du1[k] = ((mk_u1 >> k) & 1u) ? wv[LZ_WV_U2 + 16 * t + 4 * q + r] * du : 0.0f;
-                }
-            if (valid) lz_dump_chained<2>(recq, LZ_BWD_G_X + 80, du1);
         }
         if (valid) {
 #pragma unroll
@@ -487,6 +616,38 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 }
 
 // ------------------------------------------------------------------------------------------------
+// plane coordinates of the three table scatters: [3][M][2] = ((x, y) | (y, z) | (x, z)) mapped like the forward (lz_head_gather.h)
+// ------------------------------------------------------------------------------------------------
+__global__ void lz_k_plane_coords(const float* __restrict__ xyzs, uint32_t M, float bound, float* __restrict__ out) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float two_bound = 2.0f * bound;
+    const uint32_t tb_bits = __float_as_uint(two_bound);
+    const bool pow2 = (tb_bits & 0x007fffffu) == 0u && tb_bits > 0x00800000u && tb_bits < 0x7f000000u;
+    const float px = xyzs[(size_t)m * 3], py = xyzs[(size_t)m * 3 + 1], pz = xyzs[(size_t)m * 3 + 2];
+    float x01, y01, z01;
+    if (pow2) {
+        const float inv = __uint_as_float(0x7f000000u - tb_bits);
+        x01 = (px + bound) * inv; y01 = (py + bound) * inv; z01 = (pz + bound) * inv;
+    } else {
+        x01 = (px + bound) / two_bound; y01 = (py + bound) / two_bound; z01 = (pz + bound) / two_bound;
+    }
+    float2* o = reinterpret_cast<float2*>(out);
+    o[m] = make_float2(x01, y01);
+    o[(size_t)M + m] = make_float2(y01, z01);
+    o[2 * (size_t)M + m] = make_float2(x01, z01);
+}
+
+extern "C" int lz_triplane_plane_coords(const float* xyzs, uint32_t M, float bound, float* out, lz_stream_t stream) {
+    LZ_REQUIRE(M == 0 || (xyzs && out), LZ_ERR_BAD_ARGUMENT, "triplane_plane_coords: null tensor");
+    LZ_REQUIRE(((uintptr_t)out & 7u) == 0, LZ_ERR_BAD_ARGUMENT, "triplane_plane_coords: out must be 8-byte aligned");
+    if (M == 0) return LZ_OK;
+    hipLaunchKernelGGL(lz_k_plane_coords, dim3(lz_div_up(M, 256)), dim3(256), 0, lz_st(stream), xyzs, M, bound, out);
+    LZ_CHECK_LAUNCH("triplane_plane_coords");
+    return LZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
 static void lz_fill_head_args(const lz_head_params* p, LzHeadArgs& a) {
@@ -513,8 +674,9 @@ static uint32_t lz_rec_grid(uint32_t M, uint32_t wg) {
 }
 
 extern "C" int lz_triplane_head_forward_record(const lz_head_params* p, const float* xyzs, const float* dirs, uint32_t M, float* sigmas,
-                                               float* rgbs, float* amb_aud, float* amb_eye, float* unc, float* rec, float* state,
-                                               lz_stream_t stream) {
+                                               float* rgbs, float* amb_aud, float* amb_eye, float* unc, void* rec_v, float* state,
+                                               int record_f16, lz_stream_t stream) {
+    float* rec = static_cast<float*>(rec_v);
     LZ_REQUIRE(p && xyzs && dirs && sigmas && rgbs && amb_aud && unc && rec && state, LZ_ERR_BAD_ARGUMENT, "triplane_head_forward_record: null tensor");
     LZ_REQUIRE(p->emb_xy && p->emb_yz && p->emb_xz && p->offsets && p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT,
                "triplane_head_forward_record: incomplete lz_head_params");
@@ -523,15 +685,19 @@ extern "C" int lz_triplane_head_forward_record(const lz_head_params* p, const fl
     if (M == 0) return LZ_OK;
     LzHeadArgs a;
     lz_fill_head_args(p, a);
-    hipLaunchKernelGGL(lz_k_triplane_head_forward_rec, dim3(lz_rec_grid(M, LZ_FREC_WG)), dim3(LZ_FREC_WG), 0, lz_st(stream), a, xyzs, dirs, M, sigmas, rgbs,
-                       amb_aud, amb_eye, unc, rec, state);
+    if (record_f16)
+        hipLaunchKernelGGL(lz_k_triplane_head_forward_rec<true>, dim3(lz_rec_grid(M, LZ_FREC_WG)), dim3(LZ_FREC_WG), 0, lz_st(stream), a, xyzs, dirs, M,
+                           sigmas, rgbs, amb_aud, amb_eye, unc, rec, state);
+    else
+        hipLaunchKernelGGL(lz_k_triplane_head_forward_rec<false>, dim3(lz_rec_grid(M, LZ_FREC_WG)), dim3(LZ_FREC_WG), 0, lz_st(stream), a, xyzs, dirs, M,
+                           sigmas, rgbs, amb_aud, amb_eye, unc, rec, state);
     LZ_CHECK_LAUNCH("triplane_head_forward_record");
     return LZ_OK;
 }
 
 extern "C" int lz_triplane_head_backward_recorded(const lz_head_params* p, const float* state, uint32_t M, const float* g_sigma,
                                                   const float* g_rgb, const float* g_amb_aud, const float* g_amb_eye, const float* g_unc,
-                                                  const lz_head_bwd_out* out, lz_stream_t stream) {
+                                                  const lz_head_bwd_out* out, int record_f16, lz_stream_t stream) {
     LZ_REQUIRE(p && state && g_sigma && g_rgb && g_amb_aud && g_unc && out, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded: null tensor");
     LZ_REQUIRE(p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded: incomplete lz_head_params");
     LZ_REQUIRE(p->precision == 0 && !p->testing, LZ_ERR_UNSUPPORTED, "triplane_head_backward_recorded: f32 training mode only");
@@ -543,7 +709,10 @@ extern "C" int lz_triplane_head_backward_recorded(const lz_head_params* p, const
     lz_fill_head_args(p, a.fwd);
     a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_amb_aud = g_amb_aud; a.g_amb_eye = g_amb_eye; a.g_unc = g_unc;
     a.o = o;
-    hipLaunchKernelGGL(lz_k_triplane_head_backward_rec, dim3(lz_rec_grid(M, LZ_BWD_WG)), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M);
+    if (record_f16)
+        hipLaunchKernelGGL(lz_k_triplane_head_backward_rec<true>, dim3(lz_rec_grid(M, LZ_BWD_WG)), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M);
+    else
+        hipLaunchKernelGGL(lz_k_triplane_head_backward_rec<false>, dim3(lz_rec_grid(M, LZ_BWD_WG)), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M);
     LZ_CHECK_LAUNCH("triplane_head_backward_recorded");
     return LZ_OK;
 }

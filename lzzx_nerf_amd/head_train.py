@@ -3,7 +3,7 @@ the per-sample records for the weight gradients + the LDS grid backward per plan
 `record=True` (default) -- the forward (`lz_triplane_head_forward_record`) writes the layer inputs and a state row per sample, the
 backward (`lz_triplane_head_backward_recorded`) starts from them; `record=False` -- the forward is `lz_triplane_head_forward`, the
 backward (`lz_triplane_head_backward`) recomputes the activations from (xyzs, dirs): no activation memory held between the two
-(3.3 KB per sample in record mode), twice the matrix work in the backward.  A drop-in for the per-sample part of `NeRFNetwork.forward` in training mode (/root/reference/nerf_triplane/network.py:252-311):
+(3.3 KB per sample in record mode, 1.9 KB with record_dtype="f16"), twice the matrix work in the backward.  A drop-in for the per-sample part of `NeRFNetwork.forward` in training mode (/root/reference/nerf_triplane/network.py:252-311):
 same parameters, same state-dict keys, same five outputs.
 
     net = FusedTriplaneTrainHead(state_dict, bound=1.0)
@@ -23,6 +23,7 @@ from .linear import MLP
 
 _REC = 656   # floats per sample record of lz_triplane_head_backward (LZ_BWD_REC; slot columns: include/lzzx_nerf_hip.h LZ_BWD_*)
 _STATE = 176   # floats per sample state row of lz_triplane_head_forward_record (LZ_FWD_STATE)
+_REC16, _STATE16 = 704, 128   # record_dtype="f16": halves per record (LZ_BWD_REC16), dwords per state row (LZ_FWD_STATE16)
 _ORDER = ["aud0", "aud1", "eye0", "eye1", "sig0", "sig1", "sig2", "col0", "col1", "unc0", "unc1"]
 
 
@@ -49,9 +50,12 @@ class _FusedHeadTrain(Function):
         ctx.rec = ctx.state = None
         if M > 0 and mod.record:
             # held until the backward consumes them (not through save_for_backward: nothing else may alias or modify them)
-            ctx.rec, ctx.state = torch.empty(M, _REC, **kw), torch.empty(M, _STATE, **kw)
+            if mod.record_f16:
+                ctx.rec, ctx.state = torch.empty(M, _REC16, dtype=torch.float16, device=dev), torch.empty(M, _STATE16, **kw)
+            else:
+                ctx.rec, ctx.state = torch.empty(M, _REC, **kw), torch.empty(M, _STATE, **kw)
             call("lz_triplane_head_forward_record", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un),
-                 ptr(ctx.rec), ptr(ctx.state), stream())
+                 ptr(ctx.rec), ptr(ctx.state), int(mod.record_f16), stream())
         elif M > 0:   # an empty batch (every ray missed the box) has empty outputs and zero gradients
             call("lz_triplane_head_forward", C.byref(p), ptr(xyzs), ptr(dirs), M, None, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un), stream())
         # save_for_backward (not attributes): autograd then detects an in-place update of a weight / table between forward and
@@ -95,7 +99,7 @@ class _FusedHeadTrain(Function):
         p = mod._params(emb, enc_a_f, ind_f, eye_f)
         if ctx.state is not None:
             call("lz_triplane_head_backward_recorded", C.byref(p), ptr(ctx.state), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
-                 C.byref(o), stream())
+                 C.byref(o), int(mod.record_f16), stream())
             ctx.state = None
         else:
             call("lz_triplane_head_backward", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
@@ -106,8 +110,8 @@ class _FusedHeadTrain(Function):
         red = {n: torch.empty(sh, **kw) for n, sh in shapes.items()}
         if mod._gw_ws is None or mod._gw_ws.device != dev:
             mod._gw_ws = torch.empty(_lib.load().lz_triplane_head_grad_w_workspace() // 4, **kw)
-        call("lz_triplane_head_grad_w", ptr(rec), M, k_sig0, *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")],
-             ptr(mod._gw_ws), stream())
+        call("lz_triplane_head_grad_w_f16" if rec.dtype == torch.float16 else "lz_triplane_head_grad_w", ptr(rec), M, k_sig0,
+             *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")], ptr(mod._gw_ws), stream())
         ctx.rec = None
         # geo = s2 . Wg^T and d geo = G_c1 . Wc[:, geo] never left the kernel: both weight gradients follow from R = sum G_c1^T s2
         x3, c1h = red["x3"], red["c1h"]
@@ -118,11 +122,12 @@ class _FusedHeadTrain(Function):
                    sig2=d_sig2, col0=d_col0, eye1=dw_e2.view(1, 16), unc1=dw_u2.view(1, 32), col1=dw_c2.view(3, 64))
         dws = {n: dws[n].reshape(wt.shape) for n, wt in zip(_ORDER, w)}
         # table gradients: LDS-accumulated scatter per plane, inputs mapped exactly like the forward ((x + bound) / (2 bound))
+        x01 = torch.empty(3, M, 2, **kw)
+        call("lz_triplane_plane_coords", ptr(xyzs), M, mod.bound, ptr(x01), stream())
         demb = []
-        for cols, e, g in zip(((0, 1), (1, 2), (0, 2)), emb, denc):
-            x01 = ((xyzs[:, list(cols)] + mod.bound) / (2 * mod.bound)).contiguous()
+        for c, e, g in zip(x01, emb, denc):
             ge = torch.zeros_like(e)
-            call("lz_grid_encode_backward", ptr(g), ptr(x01), ptr(e), ptr(mod.offsets), ptr(ge), M, 2, 1, 12, mod.S, mod.H, None, None, 0, 0,
+            call("lz_grid_encode_backward", ptr(g), ptr(c), ptr(e), ptr(mod.offsets), ptr(ge), M, 2, 1, 12, mod.S, mod.H, None, None, 0, 0,
                  0, 3 if M >= 16384 else 0, stream())
             demb.append(ge)
         enc_a_shape, ind_shape = ctx.shapes
@@ -132,10 +137,18 @@ class _FusedHeadTrain(Function):
 
 
 class FusedTriplaneTrainHead(nn.Module):
-    def __init__(self, state_dict=None, bound=1.0, exp_eye=True, ind_dim=4, record=True):
+    def __init__(self, state_dict=None, bound=1.0, exp_eye=True, ind_dim=4, record=True, record_dtype="f32"):
         super().__init__()
+        if record_dtype not in ("f32", "f16"):
+            raise ValueError("record_dtype must be 'f32' or 'f16'")
+        if record_dtype == "f16" and not record:
+            raise ValueError("record_dtype='f16' needs record=True (the recomputing backward writes f32 records)")
         self.bound = float(bound)
         self.record = bool(record)
+        # "f16": the operands of the weight-gradient products (layer inputs and output gradients) are rounded to half on their way
+        # through memory, as the reference's autocast mode does for its dW GEMMs (TrainerUtil.py:103, 865-870); forward, data gradient
+        # and accumulation stay f32.  Upstream gradients should come through a GradScaler like there (small ones flush to zero in half).
+        self.record_f16 = record_dtype == "f16"
         mk = lambda: GridEncoder(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
                                  desired_resolution=512 * bound)
         self.encoder_xy, self.encoder_yz, self.encoder_xz = mk(), mk(), mk()                       # network.py:131-133

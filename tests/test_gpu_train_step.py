@@ -511,3 +511,46 @@ def test_fused_train_head_record_equals_recompute(params, golden, exp_eye, ind_d
         else:
             scale = float(g2[k].abs().max()) + 1e-30
             assert float((g1[k] - g2[k]).abs().max()) / scale < 1e-5, k
+
+
+@pytest.mark.parametrize("exp_eye,ind_dim", [(True, 4), (False, 0)])
+def test_fused_train_head_f16_records(params, golden, exp_eye, ind_dim):
+    """record_dtype="f16": the operands of the weight-gradient products go through memory in half (the reference's autocast dW GEMMs
+    see the same rounding), everything else is f32.  Outputs and the data gradients (tables, enc_a, ind_code) equal the f32-record run
+    (bit for bit / to atomic order); the weight gradients to 1e-3 of their largest entry (per-term rounding 2^-11, summed over M)."""
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    rng = np.random.default_rng(12)
+    p = dict(params)
+    p["sigma_net.net.0.weight"] = np.ascontiguousarray(params["sigma_net.net.0.weight"][:, :68 + int(exp_eye)])
+    p["color_net.net.0.weight"] = np.ascontiguousarray(params["color_net.net.0.weight"][:, :80 + ind_dim])
+    for n in ("xy", "yz", "xz"):   # the fixture's tables are at their initial scale (1e-4): half-precision records want trained-size features
+        p[f"encoder_{n}.embeddings"] = params[f"encoder_{n}.embeddings"] * np.float32(100.0)
+    M = 16 * 900 + 3
+    xyz = torch.from_numpy(rng.uniform(-1, 1, (M, 3)).astype(np.float32)).cuda()
+    d = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)), dim=-1).cuda()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    gout = [torch.from_numpy(rng.normal(size=sh).astype(np.float32)).cuda() for sh in ((M,), (M, 3), (M, 1), (M, 1), (M, 1))]
+    res = []
+    for dt in ("f32", "f16"):
+        net = FusedTriplaneTrainHead(p, bound=1.0, exp_eye=exp_eye, ind_dim=ind_dim, record_dtype=dt).cuda()
+        enc_a = dev(golden["net_enc_a"]).requires_grad_(True)
+        eye = dev(golden["net_eye"]) if exp_eye else None
+        ind = dev(golden["net_ind"]).requires_grad_(True) if ind_dim else None
+        outs = net(xyz, d, enc_a, ind, eye)
+        torch.autograd.backward([o for o, g in zip(outs, gout) if o.requires_grad], [g for o, g in zip(outs, gout) if o.requires_grad])
+        grads = {k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+        grads["enc_a"] = enc_a.grad
+        if ind is not None:
+            grads["ind"] = ind.grad
+        res.append(([o.detach() for o in outs], grads))
+    (o1, g1), (o2, g2) = res
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    assert g1.keys() == g2.keys()
+    for k in g1:
+        data_path = k.startswith("encoder_") or k in ("enc_a", "ind")
+        scale = float(g1[k].abs().max()) + 1e-30
+        err = float((g1[k] - g2[k]).abs().max()) / scale
+        assert err < (1e-5 if data_path else 1e-3), (k, err)
+        if not data_path and (exp_eye or not k.startswith("eye_att_net")):
+            assert float(g2[k].abs().max()) > 0, k

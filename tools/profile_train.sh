@@ -1,14 +1,16 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the cfg3 training step (bench.py --train) on the GPU box
+# rocprofv3 kernel trace of the cfg3 training step (bench.py --train-only) on the GPU box; extra arguments go to bench.py,
+# e.g. tools/profile_train.sh --train-records f16; TAG names the output (default train)
 set -e
 export TMPDIR=/tmp
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
+TAG=${TAG:-train}
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -- python3 $REPO/bench.py --train-only --steps 12 --warmup 2 > $OUT/prof_train_bench.json 2> $OUT/prof_train.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $REPO/bench.py --train-only --steps 12 --warmup 2 "$@" > $OUT/prof_${TAG}_bench.json 2> $OUT/prof_$TAG.err
 cd $REPO
-find $OUT/prof_train -name "*kernel_stats.csv" -exec cp {} $OUT/train_kernel_stats.csv \;
-find $OUT/prof_train -name "*.db" -delete
-find $OUT/prof_train -name "*kernel_trace.csv" -delete
-cut -c1-160 $OUT/train_kernel_stats.csv | head -40
+find $OUT/prof_$TAG -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
+find $OUT/prof_$TAG -name "*.db" -delete
+find $OUT/prof_$TAG -name "*kernel_trace.csv" -delete
+cut -c1-160 $OUT/${TAG}_kernel_stats.csv | head -40
