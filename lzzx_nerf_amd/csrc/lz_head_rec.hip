@@ -97,7 +97,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
         if (slice_lo + (uint32_t)slice >= slice_hi) break;
         const uint32_t base = (slice_lo + (uint32_t)slice) * 16;
         const bool valid = base + s < M;
-        const uint32_t m = valid ? base + s : M - 1;   // clamped rows are computed, never stored
+        const uint32_t m = valid ? base + s : M - 1;   // clamped lanes repeat the last row: the same values are stored again
         const size_t row = m;
         float* rec1 = rec + row * (H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC) + q;   // f16: rows counted in dwords
         float* recq = rec1 + 3 * q;
@@ -127,7 +127,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) a1[0][4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_a1 = lz_mask_pos(a1[0]);
-            if (valid) {
+            {
                 if constexpr (H16) {
                     lz_dump_pair_chained(recq, LZ_R16_X_A1 / 2, a1[0], 0);
                     lz_dump_pair_chained(recq, LZ_R16_X_A1 / 2 + 1, a1[0], 2);
@@ -142,7 +142,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) att[4 * ft + r] = acc2[ft][0][r];
         }
-        if (valid) lz_dump_chained<2>(stq, LZ_ST_ATT, att);   // f32 in both layouts: the data gradient uses it
+        lz_dump_chained<2>(stq, LZ_ST_ATT, att);   // f32 in both layouts: the data gradient uses it
         float norm;
         {
             float acc = 0.0f;
@@ -162,7 +162,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
             for (int r = 0; r < 4; r++) e1[r] = lz_relu(acce[0][0][r]);
             mk_e1 = lz_mask_pos(e1);
-            if (valid) {
+            {
                 if constexpr (H16) lz_dump_pair(stq, LZ_S16_E1 / 16, e1[0], e1[1], e1[2], e1[3], 0.0f, 0.0f, 0.0f, 0.0f);
                 else lz_dump_chained<1>(stq, LZ_ST_E1, e1);
             }
@@ -180,7 +180,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) u1[4 * ft + r] = lz_relu(accu[ft][0][r]);
             mk_u1 = lz_mask_pos(u1);
-            if (valid) {
+            {
                 if constexpr (H16) lz_dump_pair_chained(stq, LZ_S16_U1 / 16, u1, 0);
                 else lz_dump_chained<2>(stq, LZ_ST_U1, u1);
             }
@@ -202,7 +202,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
             for (int k = 0; k < 8; k++) b1[0][9 + k] = encw[k];
             b1[0][17] = (hc.has_eye && q == 0) ? hc.eye_v * eyeatt : 0.0f;
-            if (valid) {   // sigma_net.0 input [enc_x 36 | enc_a * att 32 | eye * eye_att 1]
+            {   // sigma_net.0 input [enc_x 36 | enc_a * att 32 | eye * eye_att 1]
                 if constexpr (H16) {
                     // tiles 0, 1: enc_x features 4 i + q, i < 8 (half 2 r + p of the lane's eight = i); tile 2: feature 32 + q at column
                     // 4 q, the eye term at column 1; tiles 3, 4: enc_a * att; tile 5: padding
@@ -213,7 +213,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                     for (int i = 0; i < 9; i++) rec1[LZ_BWD_X_SIG0 + 4 * i] = encx[i];
                     lz_dump_chained<2>(recq, LZ_BWD_X_SIG0 + 36, encw);
-                    if (q == 0) rec1[LZ_BWD_X_SIG0 + 68] = b1[0][17];
+                    rec1[LZ_BWD_X_SIG0 + 68] = b1[0][17];   // lanes q > 0 write zeros into the padding columns 69..71
                 }
             }
             lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
@@ -224,7 +224,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) s1[0][4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_s1 = lz_mask_pos(s1[0]);
-            if (valid) {
+            {
                 if constexpr (H16) {
                     lz_dump_pair_chained(recq, LZ_R16_X_S1 / 2, s1[0], 0);
                     lz_dump_pair_chained(recq, LZ_R16_X_S1 / 2 + 1, s1[0], 2);
@@ -240,7 +240,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) s2[0][4 * ft + r] = lz_relu(acc2[ft][0][r]);
             mk_s2 = lz_mask_pos(s2[0]);
-            if (valid) {
+            {
                 if constexpr (H16) {
                     lz_dump_pair_chained(recq, LZ_R16_X_S2C / 2, s2[0], 0);
                     lz_dump_pair_chained(recq, LZ_R16_X_S2C / 2 + 1, s2[0], 2);
@@ -268,7 +268,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
             for (int k = 0; k < 16; k++) b1[0][4 + k] = geo[0][k];
             b1[0][20] = hc.indq;
-            if (valid) {   // colour_net.0 input [SH 16 | geo 64 | ind 4]; geo = s2 . Wg^T is not stored (lz_head_bwd.hip)
+            {   // colour_net.0 input [SH 16 | geo 64 | ind 4]; geo = s2 . Wg^T is not stored (lz_head_bwd.hip)
                 if constexpr (H16) {   // tile 4: SH component 4 r + q at column 4 q + r; tile 5: ind_code[q] at column 4 q
                     lz_dump_pair(recq, LZ_R16_X_S2C / 2 + 2, b1[0][0], b1[0][1], b1[0][2], b1[0][3], hc.indq, 0.0f, 0.0f, 0.0f);
                 } else {
@@ -285,7 +285,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) c1[4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_c1 = lz_mask_pos(c1);
-            if (valid) {
+            {
                 if constexpr (H16) {
                     lz_dump_pair_chained(stq, LZ_S16_C1 / 16, c1, 0);
                     lz_dump_pair_chained(stq, LZ_S16_C1 / 16 + 1, c1, 2);
@@ -297,23 +297,21 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             for (int c = 0; c < 3; c++) cpre[c] = lz_lane_dot<4>(wv + LZ_WV_C2 + 64 * c, q, c1);
         }
         const float sigma = lz_expf(spre);
-        if (valid) {
+        {
             // masks + one scalar per lane: q = 0 ||att||, 1 eye_att, 2 unc pre-activation, 3 sigma
             const float sc = q == 0 ? norm : (q == 1 ? eyeatt : (q == 2 ? upre : sigma));
             lz_v4 w = {__uint_as_float(mk_a1 | (mk_s1 << 16)), __uint_as_float(mk_s2 | (mk_c1 << 16)), __uint_as_float(mk_u1 | (mk_e1 << 8)), sc};
             __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(stq + (H16 ? LZ_S16_MK : LZ_ST_MK)));
-            if (q == 0) {
-                lz_v4 cw = {cpre[0], cpre[1], cpre[2], 0.0f};
-                __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(strow + (H16 ? LZ_S16_CLR : LZ_ST_CLR)));
-                sigmas[m] = sigma;
-                amb_aud[m] = norm;
-                if (amb_eye) amb_eye[m] = eyeatt;
-                unc_out[m] = lz_softplusf(upre);
-            }
-            if (q < 3) {
-                const float cv = q == 0 ? cpre[0] : (q == 1 ? cpre[1] : cpre[2]);
-                rgbs[(size_t)m * 3 + q] = lz_sigmoidf(cv) * 1.002f - 0.001f;
-            }
+            // the four lanes of a sample hold the same bits: all of them store (same address, same value), no lane-dependent branch
+            lz_v4 cw = {cpre[0], cpre[1], cpre[2], 0.0f};
+            __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(strow + (H16 ? LZ_S16_CLR : LZ_ST_CLR)));
+            sigmas[m] = sigma;
+            amb_aud[m] = norm;
+            if (amb_eye) amb_eye[m] = eyeatt;
+            unc_out[m] = lz_softplusf(upre);
+            const int qc = q < 2 ? q : 2;
+            const float cv = q == 0 ? cpre[0] : (q == 1 ? cpre[1] : cpre[2]);
+            rgbs[(size_t)m * 3 + qc] = lz_sigmoidf(cv) * 1.002f - 0.001f;
         }
         slice = next;
     }
@@ -367,39 +365,63 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
         for (int k = 0; k < 16; k++) acc_c2[c][k] = 0.0f;
 
+    // Everything a slice reads (its state row and upstream gradients) is requested one slice ahead, at the top of the previous slice and
+    // before that slice's stores: one in-order counter covers loads and stores, so a load issued behind the record stores could only be
+    // waited for once those were acknowledged.  The last prefetch of a workgroup reads a clamped row and is dropped.
+    struct In {
+        lz_v4 att0, att1, c0, c1, c2, c3, u0, u1, e, mk, clr;
+        float g_sig, g_aa, g_ae, g_un, g_r0, g_r1, g_r2;
+    };
+    auto ld4 = [](const float* p) -> lz_v4 { return __builtin_nontemporal_load(reinterpret_cast<const lz_v4*>(p)); };
+    auto grab = [&]() -> int {
+        int sl = 0;
+        if (lane == 0) sl = atomicAdd(queue, 1);
+        return __builtin_amdgcn_readfirstlane(sl);
+    };
+    auto fetch = [&](int sl) -> In {
+        uint32_t gs = slice_lo + (uint32_t)sl;
+        if (gs >= slice_hi) gs = slice_hi - 1;
+        const uint32_t b = gs * 16 + s;
+        const size_t row = b < M ? b : M - 1;
+        const float* strow = st + row * (H16 ? LZ_FWD_STATE16 : LZ_FWD_STATE);
+        const float* stq = strow + 4 * q;
+        In in;
+        const lz_v4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        in.att0 = ld4(stq + LZ_ST_ATT); in.att1 = ld4(stq + LZ_ST_ATT + 16);
+        in.c2 = z; in.c3 = z; in.u1 = z; in.e = z;
+        if constexpr (H16) {
+            in.c0 = ld4(stq + LZ_S16_C1); in.c1 = ld4(stq + LZ_S16_C1 + 16);
+            in.u0 = ld4(stq + LZ_S16_U1);
+            if (has_eye) in.e = ld4(stq + LZ_S16_E1);
+        } else {
+            in.c0 = ld4(stq + LZ_ST_C1); in.c1 = ld4(stq + LZ_ST_C1 + 16); in.c2 = ld4(stq + LZ_ST_C1 + 32); in.c3 = ld4(stq + LZ_ST_C1 + 48);
+            in.u0 = ld4(stq + LZ_ST_U1); in.u1 = ld4(stq + LZ_ST_U1 + 16);
+            if (has_eye) in.e = ld4(stq + LZ_ST_E1);
+        }
+        in.mk = ld4(stq + (H16 ? LZ_S16_MK : LZ_ST_MK));
+        in.clr = ld4(strow + (H16 ? LZ_S16_CLR : LZ_ST_CLR));
+        in.g_sig = A.g_sigma[row]; in.g_aa = A.g_amb_aud[row]; in.g_ae = A.g_amb_eye ? A.g_amb_eye[row] : 0.0f; in.g_un = A.g_unc[row];
+        in.g_r0 = A.g_rgb[row * 3]; in.g_r1 = A.g_rgb[row * 3 + 1]; in.g_r2 = A.g_rgb[row * 3 + 2];
+        return in;
+    };
+    int slice = grab();
+    In nx = fetch(slice);
     for (;;) {
-        int slice = 0;
-        if (lane == 0) slice = atomicAdd(queue, 1);
-        slice = __builtin_amdgcn_readfirstlane(slice);
         if (slice_lo + (uint32_t)slice >= slice_hi) break;
         const uint32_t base = (slice_lo + (uint32_t)slice) * 16;
         const bool valid = base + s < M;
-        const uint32_t m = valid ? base + s : M - 1;
+        const uint32_t m = valid ? base + s : M - 1;   // clamped lanes repeat the last row: same values stored again, nothing accumulated
         const size_t row = m;
         float* rec1 = O.rec + row * (H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC) + q;   // f16: rows counted in dwords
         float* recq = rec1 + 3 * q;
         float* dencq = O.denc + (size_t)q * M + row;
-        const float* strow = st + row * (H16 ? LZ_FWD_STATE16 : LZ_FWD_STATE);
-        const float* stq = strow + 4 * q;
-
-        // ---- everything this slice reads, before its first store (one counter orders loads behind earlier stores) ----
-        auto ld4 = [](const float* p) -> lz_v4 { return __builtin_nontemporal_load(reinterpret_cast<const lz_v4*>(p)); };
-        const lz_v4 l_att0 = ld4(stq + LZ_ST_ATT), l_att1 = ld4(stq + LZ_ST_ATT + 16);
-        lz_v4 l_c0, l_c1, l_c2 = {0.0f, 0.0f, 0.0f, 0.0f}, l_c3 = l_c2, l_u0, l_u1 = l_c2, l_e = l_c2;
-        if constexpr (H16) {
-            l_c0 = ld4(stq + LZ_S16_C1); l_c1 = ld4(stq + LZ_S16_C1 + 16);
-            l_u0 = ld4(stq + LZ_S16_U1);
-            if (has_eye) l_e = ld4(stq + LZ_S16_E1);
-        } else {
-            l_c0 = ld4(stq + LZ_ST_C1); l_c1 = ld4(stq + LZ_ST_C1 + 16); l_c2 = ld4(stq + LZ_ST_C1 + 32); l_c3 = ld4(stq + LZ_ST_C1 + 48);
-            l_u0 = ld4(stq + LZ_ST_U1); l_u1 = ld4(stq + LZ_ST_U1 + 16);
-            if (has_eye) l_e = ld4(stq + LZ_ST_E1);
-        }
-        const lz_v4 l_mk = ld4(stq + (H16 ? LZ_S16_MK : LZ_ST_MK));
-        const lz_v4 l_clr = ld4(strow + (H16 ? LZ_S16_CLR : LZ_ST_CLR));
-        const float g_sig = A.g_sigma[row], g_aa = A.g_amb_aud[row], g_ae = A.g_amb_eye ? A.g_amb_eye[row] : 0.0f, g_un = A.g_unc[row];
-        const float g_r0 = A.g_rgb[row * 3], g_r1 = A.g_rgb[row * 3 + 1], g_r2 = A.g_rgb[row * 3 + 2];
+        const In in = nx;
+        const int next = grab();
+        nx = fetch(next);
         __builtin_amdgcn_sched_barrier(0);
+        const lz_v4 l_att0 = in.att0, l_att1 = in.att1, l_c0 = in.c0, l_c1 = in.c1, l_c2 = in.c2, l_c3 = in.c3, l_u0 = in.u0, l_u1 = in.u1,
+                    l_e = in.e, l_mk = in.mk, l_clr = in.clr;
+        const float g_sig = in.g_sig, g_aa = in.g_aa, g_ae = in.g_ae, g_un = in.g_un, g_r0 = in.g_r0, g_r1 = in.g_r1, g_r2 = in.g_r2;
         const float att[8] = {l_att0[0], l_att0[1], l_att0[2], l_att0[3], l_att1[0], l_att1[1], l_att1[2], l_att1[3]};
         float c1[16], u1[8], e1[4];
         if constexpr (H16) {
@@ -453,7 +475,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     v = lz_fmaf(wv[LZ_WV_C2 + 128 + f], dc[2], v);
                     dc1[k] = ((mk_c1 >> k) & 1u) ? v : 0.0f;
                 }
-            if (valid) {
+            {
                 if constexpr (H16) {
                     lz_dump_pair_chained(recq, LZ_R16_G_C1H / 2, dc1, 0);
                     lz_dump_pair_chained(recq, LZ_R16_G_C1H / 2 + 1, dc1, 2);
@@ -469,7 +491,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         }
         if (valid) acc_ind += dind;
         const float dh0 = g_sig * sigma;
-        if (valid && q == 0) {
+        {   // every q lane writes: columns 1..3 (f32) / 4 q (f16) of this tile are padding rows of dW
             if constexpr (H16) lz_dump_pair(recq, LZ_R16_G_C1H / 2 + 2, dh0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);   // tile 4, column 0
             else rec1[LZ_BWD_G_C1H + 64] = dh0;
         }
@@ -485,7 +507,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     const float v = lz_fmaf(wv[LZ_WV_SIG + 16 * t + 4 * q + r], dh0, ds2[k]);
                     ds2[k] = ((mk_s2 >> k) & 1u) ? v : 0.0f;
                 }
-            if (valid) {
+            {
                 if constexpr (H16) {
                     lz_dump_pair_chained(recq, LZ_R16_G_S2 / 2, ds2, 0);
                     lz_dump_pair_chained(recq, LZ_R16_G_S2 / 2 + 1, ds2, 2);
@@ -497,7 +519,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             lz_layer_bwd<LZ_L_S2>(wl, lane, ds2, ds1);
 #pragma unroll
             for (int k = 0; k < 16; k++) ds1[k] = ((mk_s1 >> k) & 1u) ? ds1[k] : 0.0f;
-            if (valid) {
+            {
                 if constexpr (H16) {
                     lz_dump_pair_chained(recq, LZ_R16_G_S1 / 2, ds1, 0);
                     lz_dump_pair_chained(recq, LZ_R16_G_S1 / 2 + 1, ds1, 2);
@@ -524,7 +546,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     datt[k] = lz_fmaf(lenca[16 * t + 4 * q + r], dencw[k], inv * att[k]);
                     if (valid) acc_enca[k] = lz_fmaf(att[k], dencw[k], acc_enca[k]);
                 }
-            if (valid) {
+            {
                 if constexpr (H16) lz_dump_pair_chained(recq, LZ_R16_G_ATT / 2, datt, 0);
                 else lz_dump_chained<2>(recq, LZ_BWD_G_ATT, datt);
             }
@@ -554,7 +576,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
             for (int i = 0; i < 9; i++) dencx[i] += dxe[i];
         }
-        if (valid) {   // G_X = [aud_ch_att_net.0 64 | eye_att_net.0 16 | unc_net.0 32]: the last three tiles
+        {   // G_X = [aud_ch_att_net.0 64 | eye_att_net.0 16 | unc_net.0 32]: the last three tiles
             if constexpr (H16) {
                 lz_dump_pair(recq, LZ_R16_G_X / 2 + 2, de1[0], de1[1], de1[2], de1[3], du1[0], du1[1], du1[2], du1[3]);
                 lz_dump_pair(recq, LZ_R16_G_X / 2 + 3, du1[4], du1[5], du1[6], du1[7], 0.0f, 0.0f, 0.0f, 0.0f);
@@ -568,7 +590,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             lz_layer_bwd<LZ_L_A2>(wl, lane, datt, da1);
 #pragma unroll
             for (int k = 0; k < 16; k++) da1[k] = ((mk_a1 >> k) & 1u) ? da1[k] : 0.0f;
-            if (valid) {
+            {
                 if constexpr (H16) {
                     lz_dump_pair_chained(recq, LZ_R16_G_X / 2, da1, 0);
                     lz_dump_pair_chained(recq, LZ_R16_G_X / 2 + 1, da1, 2);
@@ -581,10 +603,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
             for (int i = 0; i < 9; i++) dencx[i] += dxa[i];
         }
-        if (valid) {
+        {
 #pragma unroll
             for (int i = 0; i < 9; i++) dencq[(size_t)(4 * i) * M] = dencx[i];   // [3 planes][12 levels][M], level-major; feature 4 i + q
         }
+        slice = next;
     }
     // per-lane sums -> 16 sample lanes -> the workgroup's waves in LDS -> one atomic per value (layout of lz_head_bwd_out.small)
     constexpr int NRED = 32 + 4 + 16 + 32 + 192;
