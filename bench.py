@@ -674,7 +674,14 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
         try:
             result["train_step"] = train_bench(args, device, P, golden, bits)
             torch.cuda.empty_cache()
-            # BASELINE cfg3's second size: every ray of the 512 x 512 frame (N = 262 144; 24 M samples, 63 GB of per-sample records)
+            if args.train_mlp == "fused" and not args.train_recompute and args.train_records == "f32":
+                # the same step with the weight-gradient operands in half (what the reference's autocast mode feeds its dW GEMMs)
+                import copy
+                a16 = copy.copy(args)
+                a16.train_records = "f16"
+                result["train_step_f16_records"] = train_bench(a16, device, P, golden, bits)
+                torch.cuda.empty_cache()
+            # BASELINE cfg3's second size: every ray of the 512 x 512 frame (N = 262 144; 24 M samples, 80 GB of per-sample records + state)
             result["train_step_full_frame"] = train_bench(args, device, P, golden, bits, n_rays=H * W)
             torch.cuda.empty_cache()
         except Exception as exc:   # an optional leg must never take the headline line down
