@@ -203,7 +203,7 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
     ro, rd, target = ro[sel[lo:hi]].contiguous(), rd[sel[lo:hi]].contiguous(), target[lo:hi].contiguous()
     if args.train_mlp == "fused":   # one kernel forward, one kernel for the backward data chain (lzzx_nerf_amd/head_train.py)
         from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
-        net = FusedTriplaneTrainHead(P, bound=1.0, record=not args.train_recompute, record_dtype=args.train_records).to(device)
+        net = FusedTriplaneTrainHead(P, bound=1.0, record=not args.train_recompute, record_dtype=args.train_records, forward_dtype=args.train_forward).to(device)
     else:
         net = TriplaneTrainNet(P, device, mlp=args.train_mlp)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-15, fused=True)
@@ -268,7 +268,7 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
                          "scatter-add) -> Adam; sample buffers sized by mean_count like the reference's steady state (no D2H copy in the step)",
                 rays=n_rays, samples_per_step=int(n_samples[0]), steps=k_steps, sample_buffer_overflow=overflow,
                 ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
-                loss=float(loss.detach()), dtype="f32" if args.train_records == "f32" or args.train_mlp != "fused" else "f32 compute, f16 weight-gradient operands", mlp={"fused": "fused head forward + backward kernels, " + ("activations recomputed in the backward (csrc/lz_head.hip, lz_head_bwd.hip)" if args.train_recompute else "forward records, backward starts from the record (csrc/lz_head_rec.hip), " + args.train_records + " records"), "lz": "csrc/lz_linear.hip (MFMA f32)",
+                loss=float(loss.detach()), dtype=("f32" if args.train_records == "f32" and args.train_forward == "f32" or args.train_mlp != "fused" else ("f16 forward (autocast arithmetic), f32 data gradient, f16 weight-gradient operands" if args.train_forward == "f16" else "f32 compute, f16 weight-gradient operands")), mlp={"fused": "fused head forward + backward kernels, " + ("activations recomputed in the backward (csrc/lz_head.hip, lz_head_bwd.hip)" if args.train_recompute else "forward records, backward starts from the record (csrc/lz_head_rec.hip" + (", lz_head_rec16.hip" if args.train_forward == "f16" else "") + "), " + ("f16" if args.train_forward == "f16" else args.train_records) + " records"), "lz": "csrc/lz_linear.hip (MFMA f32)",
                      "torch": "torch/rocBLAS"}[args.train_mlp])
 
 
@@ -298,6 +298,8 @@ def parse_args():
     ap.add_argument("--train-records", default="f32", choices=["f32", "f16"],
                     help="fused training head: precision of the per-sample records the weight gradients are reduced from (f16 = the operand "
                          "rounding of the reference's autocast dW GEMMs; forward, data gradient and accumulation stay f32)")
+    ap.add_argument("--train-forward", default="f32", choices=["f32", "f16"],
+                    help="fused training head: f16 = the forward in the reference's autocast arithmetic on the f16 matrix cores (implies f16 records)")
     ap.add_argument("--train-recompute", action="store_true",
                     help="fused training head with record=False: the backward recomputes the forward instead of reading what it recorded")
     ap.add_argument("--train-dp", action="store_true",
@@ -674,12 +676,16 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
         try:
             result["train_step"] = train_bench(args, device, P, golden, bits)
             torch.cuda.empty_cache()
-            if args.train_mlp == "fused" and not args.train_recompute and args.train_records == "f32":
+            if args.train_mlp == "fused" and not args.train_recompute and args.train_records == "f32" and args.train_forward == "f32":
                 # the same step with the weight-gradient operands in half (what the reference's autocast mode feeds its dW GEMMs)
                 import copy
                 a16 = copy.copy(args)
                 a16.train_records = "f16"
                 result["train_step_f16_records"] = train_bench(a16, device, P, golden, bits)
+                torch.cuda.empty_cache()
+                # and with the forward itself in the reference's autocast arithmetic (its usual `-O` training mode)
+                a16.train_forward = "f16"
+                result["train_step_f16_forward"] = train_bench(a16, device, P, golden, bits)
                 torch.cuda.empty_cache()
             # BASELINE cfg3's second size: every ray of the 512 x 512 frame (N = 262 144; 24 M samples, 80 GB of per-sample records + state)
             result["train_step_full_frame"] = train_bench(args, device, P, golden, bits, n_rays=H * W)

@@ -418,6 +418,18 @@ int lz_triplane_head_forward_record(const lz_head_params* p, const float* xyzs, 
 int lz_triplane_head_backward_recorded(const lz_head_params* p, const float* state, uint32_t M, const float* g_sigma, const float* g_rgb,
                                        const float* g_amb_aud, const float* g_amb_eye, const float* g_unc, const lz_head_bwd_out* out,
                                        int record_f16, lz_stream_t stream);
+/* The recording forward on the f16 matrix cores (lz_head_rec16.hip): the forward of the reference's usual training mode (autocast,
+ * TrainerUtil.py:865; rounding sequence of the f16 inference head, plus the uncertainty net) writing the f16 records and state row
+ * described above -- sigma / rgb / ambient outputs follow lz_triplane_head_forward(precision 1) (same rounding sequence), unc = softplus (f32) of the
+ * half pre-activation.  p->packed: lz_head_pack_weights_f16 image, p->precision = 1, p->testing = 0; packed_unc: the five fragments of
+ * unc_net from lz_head_pack_unc_f16 (lz_head_packed_unc_size_f16() bytes, 16-byte aligned).  The backward is
+ * lz_triplane_head_backward_recorded(record_f16 = 1) with the f32 image of the same weights (data gradient in f32), the weight
+ * gradients lz_triplane_head_grad_w_f16. */
+uint32_t lz_head_packed_unc_size_f16(void);
+int lz_head_pack_unc_f16(const float* unc0, const float* unc1, void* packed_unc, lz_stream_t stream);
+int lz_triplane_head_forward_record_f16(const lz_head_params* p, const void* packed_unc, const float* xyzs, const float* dirs, uint32_t M,
+                                        float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, void* rec16, float* state16,
+                                        lz_stream_t stream);
 /* inputs of the three table scatters of a training step in one launch: out [3, M, 2] = (x, y) | (y, z) | (x, z) of xyzs [M, 3], each mapped
  * (v + bound) / (2 bound) exactly as the fused forward maps it (grid.py:143; network.py:208-223 for the plane order) */
 int lz_triplane_plane_coords(const float* xyzs, uint32_t M, float bound, float* out, lz_stream_t stream);

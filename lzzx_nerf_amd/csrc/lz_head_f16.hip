@@ -23,14 +23,6 @@
 extern "C" uint32_t lz_head_packed_size_f16(void) { return (uint32_t)H_FRAGS * 64u * 16u; }
 
 // ---- weight packing: fragment (layer, k-step, feature tile), lane (m = l & 15, kg = l >> 4) holds W[16 ft + m][k(ks, kg, j)], j < 8
-__device__ __forceinline__ int h_chain(int ks, int kg, int j, int K) {   // two D tiles -> one B operand
-    const int f = 16 * (2 * ks + (j >> 2)) + 4 * kg + (j & 3);
-    return f < K ? f : -1;
-}
-__device__ __forceinline__ int h_encx(int ks, int kg, int j) {           // lane kg gathers features 4 i + kg, i = 8 ks + j < 9
-    const int i = 8 * ks + j;
-    return i < 9 ? 4 * i + kg : -1;
-}
 
 struct LzPack16Args {
     const float* w[H_COUNT];

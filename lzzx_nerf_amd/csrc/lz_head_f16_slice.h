@@ -50,6 +50,25 @@ __device__ __forceinline__ void h_layer(const lz_h8* __restrict__ wl, int lane, 
         for (int ft = 0; ft < NT; ft++) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag[(ks * NT + ft) * 64], b[ks], acc[ft], 0, 0, 0);
 }
 
+// input feature held by k slot (k-step ks, lane group kg, j) of a B operand: chained from two D tiles / the gathered enc_x
+__device__ __forceinline__ int h_chain(int ks, int kg, int j, int K) {   // two D tiles -> one B operand
+    const int f = 16 * (2 * ks + (j >> 2)) + 4 * kg + (j & 3);
+    return f < K ? f : -1;
+}
+__device__ __forceinline__ int h_encx(int ks, int kg, int j) {           // lane kg gathers features 4 i + kg, i = 8 ks + j < 9
+    const int i = 8 * ks + j;
+    return i < 9 ? 4 * i + kg : -1;
+}
+
+template <int KS, int NT>
+__device__ __forceinline__ void h_layer_at(const lz_h8* __restrict__ frags, int lane, const lz_h8 (&b)[KS], lz_f4 (&acc)[NT]) {
+    const lz_h8* frag = frags + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int ft = 0; ft < NT; ft++) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag[(ks * NT + ft) * 64], b[ks], acc[ft], 0, 0, 0);
+}
+
 __device__ __forceinline__ _Float16 h_relu16(float v) { return (_Float16)(v > 0.0f ? v : 0.0f); }   // relu(half(v)) == half(relu(v))
 
 // two D tiles of a layer -> one B operand of the next (ReLU + round to half = the half output of an autocast Linear + relu)

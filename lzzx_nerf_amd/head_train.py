@@ -48,7 +48,17 @@ class _FusedHeadTrain(Function):
         kw = dict(dtype=torch.float32, device=dev)
         sig, rgb, aa, ae, un = torch.empty(M, **kw), torch.empty(M, 3, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw)
         ctx.rec = ctx.state = None
-        if M > 0 and mod.record:
+        if M > 0 and mod.forward_f16:
+            # forward in the reference's autocast arithmetic on the f16 matrix cores (lz_head_rec16.hip); the backward below runs its
+            # f32 data-gradient chain from the state this forward records
+            call("lz_head_pack_weights_f16", *[ptr(t) for t in w[:9]], int(mod.has_eye), int(mod.has_ind), ptr(mod.packed16), stream())
+            call("lz_head_pack_unc_f16", ptr(w[9]), ptr(w[10]), ptr(mod.packed_unc16), stream())
+            p16 = mod._params(emb, enc_a_f, ind_f, eye_f)
+            p16.packed, p16.precision = mod.packed16.data_ptr(), 1
+            ctx.rec, ctx.state = torch.empty(M, _REC16, dtype=torch.float16, device=dev), torch.empty(M, _STATE16, **kw)
+            call("lz_triplane_head_forward_record_f16", C.byref(p16), ptr(mod.packed_unc16), ptr(xyzs), ptr(dirs), M, ptr(sig), ptr(rgb), ptr(aa),
+                 ptr(ae), ptr(un), ptr(ctx.rec), ptr(ctx.state), stream())
+        elif M > 0 and mod.record:
             # held until the backward consumes them (not through save_for_backward: nothing else may alias or modify them)
             if mod.record_f16:
                 ctx.rec, ctx.state = torch.empty(M, _REC16, dtype=torch.float16, device=dev), torch.empty(M, _STATE16, **kw)
@@ -137,10 +147,12 @@ class _FusedHeadTrain(Function):
 
 
 class FusedTriplaneTrainHead(nn.Module):
-    def __init__(self, state_dict=None, bound=1.0, exp_eye=True, ind_dim=4, record=True, record_dtype="f32"):
+    def __init__(self, state_dict=None, bound=1.0, exp_eye=True, ind_dim=4, record=True, record_dtype="f32", forward_dtype="f32"):
         super().__init__()
-        if record_dtype not in ("f32", "f16"):
-            raise ValueError("record_dtype must be 'f32' or 'f16'")
+        if record_dtype not in ("f32", "f16") or forward_dtype not in ("f32", "f16"):
+            raise ValueError("record_dtype / forward_dtype must be 'f32' or 'f16'")
+        if forward_dtype == "f16":
+            record, record_dtype = True, "f16"   # the f16 forward records what it holds: half operands
         if record_dtype == "f16" and not record:
             raise ValueError("record_dtype='f16' needs record=True (the recomputing backward writes f32 records)")
         self.bound = float(bound)
@@ -149,6 +161,10 @@ class FusedTriplaneTrainHead(nn.Module):
         # through memory, as the reference's autocast mode does for its dW GEMMs (TrainerUtil.py:103, 865-870); forward, data gradient
         # and accumulation stay f32.  Upstream gradients should come through a GradScaler like there (small ones flush to zero in half).
         self.record_f16 = record_dtype == "f16"
+        # forward_dtype="f16": the forward itself runs in the reference's autocast arithmetic (half Linear inputs / weights / outputs,
+        # f32 accumulate: lz_head_f16_slice.h) -- what `-O` training does there; the data gradient stays an f32 chain through the f32
+        # weights, evaluated at the recorded half activations, and the weight gradients are reduced from the half records.
+        self.forward_f16 = forward_dtype == "f16"
         mk = lambda: GridEncoder(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
                                  desired_resolution=512 * bound)
         self.encoder_xy, self.encoder_yz, self.encoder_xz = mk(), mk(), mk()                       # network.py:131-133
@@ -162,6 +178,9 @@ class FusedTriplaneTrainHead(nn.Module):
         self.S = float(np.float32(np.log2(self.encoder_xy.per_level_scale)))
         self.register_buffer("packed", torch.empty(_lib.load().lz_head_packed_size(), dtype=torch.float32), persistent=False)
         self._gw_ws = None   # partial-tile workspace of lz_triplane_head_grad_w, allocated on first backward
+        if self.forward_f16:
+            self.register_buffer("packed16", torch.empty(_lib.load().lz_head_packed_size_f16(), dtype=torch.uint8), persistent=False)
+            self.register_buffer("packed_unc16", torch.empty(_lib.load().lz_head_packed_unc_size_f16(), dtype=torch.uint8), persistent=False)
         if state_dict is not None:
             own = self.state_dict()
             self.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items() if k in own}, strict=False)

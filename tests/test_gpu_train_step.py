@@ -554,3 +554,78 @@ def test_fused_train_head_f16_records(params, golden, exp_eye, ind_dim):
         assert err < (1e-5 if data_path else 1e-3), (k, err)
         if not data_path and (exp_eye or not k.startswith("eye_att_net")):
             assert float(g2[k].abs().max()) > 0, k
+
+
+def test_fused_train_head_f16_forward(params, golden):
+    """forward_dtype="f16": the training forward in the reference's autocast arithmetic (lz_head_rec16.hip) + f32 data-gradient chain +
+    half records.  Checked against the same network built from the operator API under torch.autocast (what the reference's `-O`
+    training runs: half Linear on rocBLAS, half ReLU / sigmoid / products, f32 exp / norm / softplus, half gradients): outputs to half
+    rounding, every gradient to 2e-2 of its largest entry; and against the f16 inference kernel for the outputs they share."""
+    from lzzx_nerf_amd.encoding import get_encoder
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    rng = np.random.default_rng(13)
+    p = dict(params)
+    for n in ("xy", "yz", "xz"):
+        p[f"encoder_{n}.embeddings"] = params[f"encoder_{n}.embeddings"] * np.float32(30.0)
+    M = 16 * 800 + 7
+    xyz = torch.from_numpy(rng.uniform(-1, 1, (M, 3)).astype(np.float32)).cuda()
+    d = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)), dim=-1).cuda()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    gout = [torch.from_numpy(rng.normal(size=sh).astype(np.float32)).cuda() for sh in ((M,), (M, 3), (M, 1), (M, 1), (M, 1))]
+    gout[0] *= 1e-2   # d loss / d sigma times sigma has to fit a half: the job of the reference's GradScaler
+    enc_a_np = golden["net_enc_a"].astype(np.float16).astype(np.float32)   # enc_a is a half tensor under autocast (AudioNet output)
+    net = FusedTriplaneTrainHead(p, bound=1.0, forward_dtype="f16").cuda()
+    enc_a, ind, eye = dev(enc_a_np).requires_grad_(True), dev(golden["net_ind"]).requires_grad_(True), dev(golden["net_eye"])
+    outs = net(xyz, d, enc_a, ind, eye)
+    torch.autograd.backward(list(outs), gout)
+    # ---- the f16 inference kernel: same rounding sequence in a separately compiled kernel, bit-equal except where a last-bit difference
+    # of a gathered feature lands on a half rounding boundary (a few values in 1e4), and then one half ulp apart
+    inf = FusedTriplaneHead({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()}, bound=1.0, precision="f16")
+    oi = inf.forward(xyz, d, dev(enc_a_np), dev(golden["net_ind"]), eye)
+    for a, b, nm in zip(outs[:4], oi[:4], ("sigma", "rgb", "amb_aud", "amb_eye")):
+        a, b = a.detach().reshape(-1), b.reshape(-1)
+        assert float((a != b).float().mean()) < 5e-3, nm
+        assert float(((a - b).abs() / (b.abs() + 1e-3)).max()) < 1e-2, nm
+    # ---- the operator graph under autocast
+    encs = []
+    for n in ("xy", "yz", "xz"):
+        e = get_encoder("hashgrid", input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14, desired_resolution=512)[0].cuda()
+        e.embeddings.data.copy_(dev(p[f"encoder_{n}.embeddings"]))
+        encs.append(e)
+    sh = get_encoder("spherical_harmonics")[0]
+    Wg = {k: dev(v).requires_grad_(True) for k, v in p.items() if k.endswith(".weight")}
+    ea_r, ind_r = dev(enc_a_np).requires_grad_(True), dev(golden["net_ind"]).requires_grad_(True)
+
+    def mlp(h, name, n):
+        for i in range(n):
+            h = torch.nn.functional.linear(h, Wg[f"{name}.net.{i}.weight"])
+            if i < n - 1:
+                h = torch.relu(h)
+        return h
+
+    with torch.autocast("cuda", dtype=torch.float16):
+        enc_x = torch.cat([encs[0](xyz[:, :2], bound=1), encs[1](xyz[:, 1:], bound=1), encs[2](xyz[:, [0, 2]], bound=1)], -1)
+        att = mlp(enc_x, "aud_ch_att_net", 2)
+        eye_att = torch.sigmoid(mlp(enc_x, "eye_att_net", 2))
+        h = mlp(torch.cat([enc_x, ea_r.half() * att, eye * eye_att], -1), "sigma_net", 3)
+        rgb = torch.sigmoid(mlp(torch.cat([sh(d), h[:, 1:], ind_r.repeat(M, 1)], -1), "color_net", 2)) * 1.002 - 0.001
+        ref = [torch.exp(h[:, 0]), rgb, att.norm(dim=-1, keepdim=True), eye_att, torch.nn.functional.softplus(mlp(enc_x.detach(), "unc_net", 2))]
+    for o, r, nm in zip(outs, ref, ("sigma", "rgb", "amb_aud", "amb_eye", "unc")):
+        o, r = o.detach().reshape(-1), r.detach().float().reshape(-1)
+        assert float(((o - r).abs() / (r.abs() + 1e-2)).max()) < 3e-2, nm   # a half ulp of a pre-activation through exp
+        assert float(((o - r).abs() / (r.abs() + 1e-2)).mean()) < 1e-3, nm
+    torch.autograd.backward(ref, [g.to(r.dtype) for r, g in zip(ref, gout)])
+    sd = dict(net.named_parameters())
+
+    def close(a, b, name):
+        scale = float(b.float().abs().max()) + 1e-30
+        err = float((a - b.float()).abs().max()) / scale
+        assert err < 2e-2, (name, err)
+
+    for k, wg in Wg.items():
+        close(sd[k].grad, wg.grad, k)
+    for n, e in zip(("xy", "yz", "xz"), encs):
+        close(sd[f"encoder_{n}.embeddings"].grad, e.embeddings.grad, "encoder_" + n)
+    close(enc_a.grad, ea_r.grad, "enc_a")
+    close(ind.grad, ind_r.grad, "ind_code")
