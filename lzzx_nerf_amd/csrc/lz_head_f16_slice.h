@@ -60,6 +60,11 @@ __device__ __forceinline__ int h_encx(int ks, int kg, int j) {           // lane
     return i < 9 ? 4 * i + kg : -1;
 }
 
+// sigmoid whose result the caller rounds to half (autocast: sigmoid runs in half): hardware exp2 / reciprocal, a few f32 ulp, which the
+// half rounding absorbs except on a rounding boundary -- 4 VALU instructions where the bit-reproducible lz_sigmoidf (polynomial exp +
+// IEEE division) costs about 31, four times per slice in kernels that are bound by VALU issue
+__device__ __forceinline__ float h_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
+
 template <int KS, int NT>
 __device__ __forceinline__ void h_layer_at(const lz_h8* __restrict__ frags, int lane, const lz_h8 (&b)[KS], lz_f4 (&acc)[NT]) {
     const lz_h8* frag = frags + lane;
@@ -71,15 +76,26 @@ __device__ __forceinline__ void h_layer_at(const lz_h8* __restrict__ frags, int 
 
 __device__ __forceinline__ _Float16 h_relu16(float v) { return (_Float16)(v > 0.0f ? v : 0.0f); }   // relu(half(v)) == half(relu(v))
 
-// two D tiles of a layer -> one B operand of the next (ReLU + round to half = the half output of an autocast Linear + relu)
-__device__ __forceinline__ lz_h8 h_pair(const lz_f4& lo, const lz_f4& hi, bool relu) {
-    lz_h8 b;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        b[r] = relu ? h_relu16(lo[r]) : (_Float16)lo[r];
-        b[4 + r] = relu ? h_relu16(hi[r]) : (_Float16)hi[r];
+// two D tiles of a layer -> one B operand of the next (ReLU + round to half = the half output of an autocast Linear + relu).
+// The ReLU runs on the packed halves as a signed 16-bit max with zero -- a half is negative exactly when its bit pattern is a negative
+// int16, and relu(half(v)) == half(relu(v)) -- one v_pk_max_i16 per two values where the f32 form costs a canonicalising max and the
+// max itself per value (the f16 kernels are bound by VALU issue).
+typedef _Float16 lz_h2v __attribute__((ext_vector_type(2)));
+typedef short lz_s2v __attribute__((ext_vector_type(2)));
+typedef uint32_t lz_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t h_cvt2(float a, float b, bool relu) {
+    typedef float lz_f2v __attribute__((ext_vector_type(2)));
+    const lz_f2v f = {a, b};
+    const lz_h2v h = __builtin_convertvector(f, lz_h2v);   // one v_cvt_pk_f16_f32 (round to nearest even)
+    if (relu) {
+        const lz_s2v z = {0, 0};
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(lz_s2v, h), z));
     }
-    return b;
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ lz_h8 h_pair(const lz_f4& lo, const lz_f4& hi, bool relu) {
+    const lz_u4v w = {h_cvt2(lo[0], lo[1], relu), h_cvt2(lo[2], lo[3], relu), h_cvt2(hi[0], hi[1], relu), h_cvt2(hi[2], hi[3], relu)};
+    return __builtin_bit_cast(lz_h8, w);
 }
 
 struct LzHead16Ctx {
@@ -165,7 +181,7 @@ __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane,
         const lz_h8 be[1] = {h_pair(e1[0], z, true)};
         lz_f4 e2[1] = {lz_f4{0, 0, 0, 0}};
         h_layer<H_E2>(hc.wl, lane, be, e2);
-        eyeatt = (float)(_Float16)lz_sigmoidf((float)(_Float16)e2[0][0]);   // valid on lanes q == 0
+        eyeatt = (float)(_Float16)h_sigmoid((float)(_Float16)e2[0][0]);   // valid on lanes q == 0
     }
     // ---------------- sigma net: [enc_x 36 | enc_a * att 32 | eye * eye_att 1] -> 64 -> 64 -> 65 ----------------
     lz_h8 geo16[2];
@@ -208,7 +224,7 @@ __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane,
         h_layer<H_C2>(hc.wl, lane, b2, c2);
 #pragma unroll
         for (int c = 0; c < 3; c++) {   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
-            const _Float16 sg = (_Float16)lz_sigmoidf((float)(_Float16)c2[0][c]);
+            const _Float16 sg = (_Float16)h_sigmoid((float)(_Float16)c2[0][c]);
             const _Float16 t1 = (_Float16)((float)sg * 1.002f);
             rgb[c] = (float)(_Float16)((float)t1 - 0.001f);
         }

@@ -52,20 +52,26 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
         const float v = plane == 0 ? y01 : z01;
         oobf[i] = (u < 0 || u > 1 || v < 0 || v > 1);
         const float uc = lz_fminf(lz_fmaxf(u, 0.0f), 1.0f), vc = lz_fminf(lz_fmaxf(v, 0.0f), 1.0f);
-        const float* gl = emb[plane] + lv_off[mrec];
+        // byte offset in 32 bits off the plane's (wave-uniform) base: one VALU op and the scalar-base addressing mode per gather, where
+        // a per-lane 64-bit pointer costs two or three (the tables are 650 KB each)
+        const char* gb = reinterpret_cast<const char*>(emb[plane]);
         const float p0 = lz_fmaf(uc, lv_scale[mrec], 0.5f), p1 = lz_fmaf(vc, lv_scale[mrec], 0.5f);
         const uint32_t g0 = (uint32_t)floorf(p0), g1 = (uint32_t)floorf(p1);
         fr0[i] = p0 - (float)g0;
         fr1[i] = p1 - (float)g1;
+        // gridencoder.cu:54-72 for D = 2: dense while (res+1)^2 fits the level's table (then index < size and the modulo is the
+        // identity), else fast_hash (primes 1, 2654435761) modulo the table size.  A hashed level's size is min(2^T, .) = 2^T
+        // (grid.py:116), a power of two: the modulo is a mask (precondition, checked by the Python wrapper).  The row term of the upper
+        // corners is the lower one plus a constant (mod 2^32), and the dense product fits 24 bits (full-rate multiplier): one
+        // quarter-rate multiply per feature instead of four.
+        const uint32_t hrow0 = g1 * 2654435761u, hrow1 = hrow0 + 2654435761u;
+        const uint32_t drow0 = __umul24(g1, lv_stride[mrec]), drow1 = drow0 + lv_stride[mrec];
+        const uint32_t hmask = lv_hs[mrec] - 1u;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const uint32_t c0 = g0 + (c & 1), c1 = g1 + (c >> 1);
-            // gridencoder.cu:54-72 for D = 2: dense while (res+1)^2 fits the level's table (then index < size and the modulo is the
-            // identity), else fast_hash (primes 1, 2654435761) modulo the table size.  A hashed level's size is min(2^T, .) = 2^T
-            // (grid.py:116), a power of two: the modulo is a mask (precondition, checked by the Python wrapper).
-            const uint32_t hsh = c0 ^ (c1 * 2654435761u);
-            const uint32_t index = lv_dense[mrec] ? c0 + c1 * lv_stride[mrec] : (hsh & (lv_hs[mrec] - 1u));
-            gv[i][c] = gl[index];
+            const uint32_t c0 = g0 + (c & 1);
+            const uint32_t index = lv_dense[mrec] ? c0 + ((c >> 1) ? drow1 : drow0) : ((c0 ^ ((c >> 1) ? hrow1 : hrow0)) & hmask);
+            gv[i][c] = *reinterpret_cast<const float*>(gb + ((lv_off[mrec] + index) << 2));
         }
     }
     asm volatile("" ::"v"(gv[0][0]), "v"(gv[0][1]), "v"(gv[0][2]), "v"(gv[0][3]), "v"(gv[1][0]), "v"(gv[1][1]), "v"(gv[1][2]),

@@ -12,7 +12,7 @@
 typedef float lz_v4 __attribute__((ext_vector_type(4)));
 typedef uint32_t lz_u4 __attribute__((ext_vector_type(4)));
 
-#define LZ_FREC16_WG 768   // 128 VGPRs would spill 11; three waves per SIMD
+#define LZ_FREC16_WG 1024
 #define LZ_UNC16_FRAGS 5   // unc_net.0: 2 k-steps x 2 feature tiles; unc_net.1: 1 x 1
 
 extern "C" uint32_t lz_head_packed_unc_size_f16(void) { return (uint32_t)LZ_UNC16_FRAGS * 64u * 16u; }
@@ -167,7 +167,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             lz_dump_pair_h8(stq, LZ_S16_E1 / 16, be[0]);
             lz_f4 e2[1] = {lz_f4{0, 0, 0, 0}};
             h_layer<H_E2>(hc.wl, lane, be, e2);
-            eyeatt = (float)(_Float16)lz_sigmoidf((float)(_Float16)e2[0][0]);   // lanes q == 0
+            eyeatt = (float)(_Float16)h_sigmoid((float)(_Float16)e2[0][0]);   // lanes q == 0
             eyeatt = __shfl(eyeatt, s, 64);
         }
         // ---------------- uncertainty (training): 36 -> 32 -> 1, softplus in f32 on the half pre-activation ----------------
@@ -260,7 +260,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             unc_out[row] = lz_softplusf(upre);
             const int qc = q < 2 ? q : 2;
             const float cv = q == 0 ? cpre[0] : (q == 1 ? cpre[1] : cpre[2]);
-            const _Float16 sg = (_Float16)lz_sigmoidf(cv);   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
+            const _Float16 sg = (_Float16)h_sigmoid(cv);   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
             const _Float16 t1 = (_Float16)((float)sg * 1.002f);
             rgbs[row * 3 + qc] = (float)(_Float16)((float)t1 - 0.001f);
         }
