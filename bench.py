@@ -183,6 +183,14 @@ class TriplaneTrainNet(torch.nn.Module):
         return sigma, rgb, att.norm(dim=-1), eye_att.abs().sum(-1), unc
 
 
+def train_dtype(args):
+    if args.train_mlp != "fused" or "f16" not in (args.train_records, args.train_forward, args.train_backward):
+        return "f32"
+    fwd = "f16 forward (autocast arithmetic)" if args.train_forward == "f16" else "f32 forward"
+    bwd = "f16 data gradient (autocast arithmetic)" if args.train_backward == "f16" else "f32 data gradient"
+    return f"{fwd}, {bwd}, f16 weight-gradient operands, f32 accumulation; GradScaler(65536)"
+
+
 def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
     """BASELINE cfg3: one training step (fwd + bwd + Adam) on `--train-rays` random rays of the 512x512 frame through the
     operator API as the reference's run_cuda arranges it (renderer.py:279-304).  The MLP GEMMs are torch/rocBLAS here;
@@ -203,7 +211,7 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
     ro, rd, target = ro[sel[lo:hi]].contiguous(), rd[sel[lo:hi]].contiguous(), target[lo:hi].contiguous()
     if args.train_mlp == "fused":   # one kernel forward, one kernel for the backward data chain (lzzx_nerf_amd/head_train.py)
         from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
-        net = FusedTriplaneTrainHead(P, bound=1.0, record=not args.train_recompute, record_dtype=args.train_records, forward_dtype=args.train_forward).to(device)
+        net = FusedTriplaneTrainHead(P, bound=1.0, record=not args.train_recompute, record_dtype=args.train_records, forward_dtype=args.train_forward, backward_dtype=args.train_backward).to(device)
     else:
         net = TriplaneTrainNet(P, device, mlp=args.train_mlp)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-15, fused=True)
@@ -219,6 +227,8 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
     # count; every later step, the timed ones included, runs the steady state (noise perturbs t0 by less than one step, so the
     # count of a step stays within the 128-row padding of the first one's plus a margin).
     mean_count = [-1]
+    half = args.train_mlp == "fused" and "f16" in (args.train_records, args.train_forward, args.train_backward)
+    scaler = torch.amp.GradScaler("cuda", init_scale=65536.0) if (half and world == 1) else None
 
     def step():
         nears, fars = R.near_far_from_aabb(ro, rd, aabb, 0.05)
@@ -232,6 +242,12 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
             a0, a1, unc = a0[:, 0], a1[:, 0], unc[:, 0]
         ws, a0s, a1s, us, dep, img = R.composite_rays_train_triplane(sigma, rgb, a0, a1, unc, deltas, rays)
         loss = ((img + (1 - ws).unsqueeze(-1) - target) ** 2).mean() + 1e-4 * a0s.mean() + 1e-4 * a1s.mean() + 1e-3 * us.mean()
+        if scaler is not None:   # half operands: loss scaling exactly as the reference's trainer does it (TrainerUtil.py:103, 865-870)
+            opt.zero_grad(set_to_none=True)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            return loss
         if bucket is None:
             opt.zero_grad(set_to_none=True)
             loss.backward()
@@ -268,7 +284,7 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
                          "scatter-add) -> Adam; sample buffers sized by mean_count like the reference's steady state (no D2H copy in the step)",
                 rays=n_rays, samples_per_step=int(n_samples[0]), steps=k_steps, sample_buffer_overflow=overflow,
                 ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
-                loss=float(loss.detach()), dtype=("f32" if args.train_records == "f32" and args.train_forward == "f32" or args.train_mlp != "fused" else ("f16 forward (autocast arithmetic), f32 data gradient, f16 weight-gradient operands" if args.train_forward == "f16" else "f32 compute, f16 weight-gradient operands")), mlp={"fused": "fused head forward + backward kernels, " + ("activations recomputed in the backward (csrc/lz_head.hip, lz_head_bwd.hip)" if args.train_recompute else "forward records, backward starts from the record (csrc/lz_head_rec.hip" + (", lz_head_rec16.hip" if args.train_forward == "f16" else "") + "), " + ("f16" if args.train_forward == "f16" else args.train_records) + " records"), "lz": "csrc/lz_linear.hip (MFMA f32)",
+                loss=float(loss.detach()), dtype=train_dtype(args), mlp={"fused": "fused head forward + backward kernels, " + ("activations recomputed in the backward (csrc/lz_head.hip, lz_head_bwd.hip)" if args.train_recompute else "forward records, backward starts from the record (csrc/lz_head_rec.hip" + (", lz_head_rec16.hip" if args.train_forward == "f16" else "") + "), " + ("f16" if "f16" in (args.train_forward, args.train_backward) else args.train_records) + " records"), "lz": "csrc/lz_linear.hip (MFMA f32)",
                      "torch": "torch/rocBLAS"}[args.train_mlp])
 
 
@@ -300,6 +316,8 @@ def parse_args():
                          "rounding of the reference's autocast dW GEMMs; forward, data gradient and accumulation stay f32)")
     ap.add_argument("--train-forward", default="f32", choices=["f32", "f16"],
                     help="fused training head: f16 = the forward in the reference's autocast arithmetic on the f16 matrix cores (implies f16 records)")
+    ap.add_argument("--train-backward", default="f32", choices=["f32", "f16"],
+                    help="fused training head: f16 = the data-gradient products on the f16 matrix cores (autocast's half backward; implies f16 records)")
     ap.add_argument("--train-recompute", action="store_true",
                     help="fused training head with record=False: the backward recomputes the forward instead of reading what it recorded")
     ap.add_argument("--train-dp", action="store_true",
@@ -676,7 +694,7 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
         try:
             result["train_step"] = train_bench(args, device, P, golden, bits)
             torch.cuda.empty_cache()
-            if args.train_mlp == "fused" and not args.train_recompute and args.train_records == "f32" and args.train_forward == "f32":
+            if args.train_mlp == "fused" and not args.train_recompute and args.train_records == "f32" and args.train_forward == "f32" and args.train_backward == "f32":
                 # the same step with the weight-gradient operands in half (what the reference's autocast mode feeds its dW GEMMs)
                 import copy
                 a16 = copy.copy(args)
@@ -686,6 +704,10 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
                 # and with the forward itself in the reference's autocast arithmetic (its usual `-O` training mode)
                 a16.train_forward = "f16"
                 result["train_step_f16_forward"] = train_bench(a16, device, P, golden, bits)
+                torch.cuda.empty_cache()
+                # and the data gradient on the f16 matrix cores too: the whole step in autocast arithmetic
+                a16.train_backward = "f16"
+                result["train_step_f16"] = train_bench(a16, device, P, golden, bits)
                 torch.cuda.empty_cache()
             # BASELINE cfg3's second size: every ray of the 512 x 512 frame (N = 262 144; 24 M samples, 80 GB of per-sample records + state)
             result["train_step_full_frame"] = train_bench(args, device, P, golden, bits, n_rays=H * W)

@@ -417,7 +417,14 @@ int lz_triplane_head_forward_record(const lz_head_params* p, const float* xyzs, 
                                     float* amb_aud, float* amb_eye, float* unc, void* rec, float* state, int record_f16, lz_stream_t stream);
 int lz_triplane_head_backward_recorded(const lz_head_params* p, const float* state, uint32_t M, const float* g_sigma, const float* g_rgb,
                                        const float* g_amb_aud, const float* g_amb_eye, const float* g_unc, const lz_head_bwd_out* out,
-                                       int record_f16, lz_stream_t stream);
+                                       int record_f16, const void* packed_bwd16, lz_stream_t stream);
+/* packed_bwd16 (optional, with record_f16 = 1): the transposed weights as half fragments; the data-gradient products dX = W^T dY then
+ * run on v_mfma_f32_16x16x16_f16 with dY and W rounded to half and an f32 sum -- the arithmetic of the reference's autocast backward
+ * (half Linear gradients, TrainerUtil.py:865-870) -- one instruction per (input tile, output tile) instead of four f32 ones.
+ * eye0 may be NULL without an eye input.  lz_head_packed_bwd_size_f16() bytes, 16-byte aligned. */
+uint32_t lz_head_packed_bwd_size_f16(void);
+int lz_head_pack_weights_bwd_f16(const float* aud0, const float* aud1, const float* eye0, const float* sig0, const float* sig1,
+                                 const float* sig2, const float* col0, int has_eye, int has_ind, void* packed_bwd16, lz_stream_t stream);
 /* The recording forward on the f16 matrix cores (lz_head_rec16.hip): the forward of the reference's usual training mode (autocast,
  * TrainerUtil.py:865; rounding sequence of the f16 inference head, plus the uncertainty net) writing the f16 records and state row
  * described above -- sigma / rgb / ambient outputs follow lz_triplane_head_forward(precision 1) (same rounding sequence), unc = softplus (f32) of the

@@ -119,7 +119,8 @@ SIGNATURES = {
     "lz_linear_forward": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, i32, vp],
     "lz_linear_grad_w": [vp, u32, vp, vp, u32, vp, u32, u32, u32, u32, vp],
     "lz_triplane_head_forward_record": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, i32, vp],
-    "lz_triplane_head_backward_recorded": [C.POINTER(HeadParams), vp, u32, vp, vp, vp, vp, vp, C.POINTER(HeadBwdOut), i32, vp],
+    "lz_triplane_head_backward_recorded": [C.POINTER(HeadParams), vp, u32, vp, vp, vp, vp, vp, C.POINTER(HeadBwdOut), i32, vp, vp],
+    "lz_head_pack_weights_bwd_f16": [vp] * 7 + [i32, i32, vp, vp],
     "lz_triplane_plane_coords": [vp, u32, f32, vp, vp],
     "lz_head_pack_unc_f16": [vp, vp, vp, vp],
     "lz_triplane_head_forward_record_f16": [C.POINTER(HeadParams), vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -127,7 +128,7 @@ SIGNATURES = {
     "lz_triplane_head_grad_w": [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp],
 }
 PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),
-         "lz_head_packed_size": ([], u32), "lz_head_packed_size_f16": ([], u32), "lz_head_packed_unc_size_f16": ([], u32),
+         "lz_head_packed_size": ([], u32), "lz_head_packed_size_f16": ([], u32), "lz_head_packed_unc_size_f16": ([], u32), "lz_head_packed_bwd_size_f16": ([], u32),
          "lz_triplane_head_grad_w_workspace": ([], C.c_size_t)}
 
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))

@@ -43,6 +43,26 @@ struct LzPackArgs {
     int has_eye, has_ind;
 };
 
+// input feature of k slot `slot` of a layer's B operand (-1 = padding) / source row of output row `row` (-1 = padding row)
+__device__ __forceinline__ int lz_pack_kf(int layer, int slot, const LzPackArgs& a) {
+    switch (layer) {
+        case LZ_L_A1: case LZ_L_E1: case LZ_L_U1: return slot < 36 ? slot : -1;
+        case LZ_L_A2: case LZ_L_S2: case LZ_L_S3: return lz_chained(slot, 64);
+        case LZ_L_S1:
+            if (slot < 36) return slot;
+            if (slot < 68) return 36 + lz_chained(slot - 36, 32);
+            return (slot == 68 && a.has_eye) ? 68 : -1;
+        default:  // LZ_L_C1
+            if (slot < 16) return slot;
+            if (slot < 80) return 16 + lz_chained(slot - 16, 64);
+            return (slot < 84 && a.has_ind) ? slot : -1;
+    }
+}
+__device__ __forceinline__ int lz_pack_srow(int layer, int row, const LzPackArgs& a) {
+    if (layer == LZ_L_S3) return row < 64 ? row + 1 : -1;  // the 64 geo rows; the sigma row (0) is a VALU layer
+    return row < a.nout[layer] ? row : -1;
+}
+
 __global__ void __launch_bounds__(256) lz_k_head_pack(LzPackArgs a, float* __restrict__ packed) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= LZ_HEAD_PACKED_FLOATS) return;
@@ -66,24 +86,7 @@ __global__ void __launch_bounds__(256) lz_k_head_pack(LzPackArgs a, float* __res
     const int local = frag - fb;
     const int ks = local / LZ_NT[layer], ft = local - ks * LZ_NT[layer];
     const int row = 16 * ft + (lane & 15), slot = 4 * ks + (lane >> 4);
-    int kf;  // input feature of this k slot, -1 = padding
-    switch (layer) {
-        case LZ_L_A1: case LZ_L_E1: case LZ_L_U1: kf = slot < 36 ? slot : -1; break;
-        case LZ_L_A2: case LZ_L_S2: case LZ_L_S3: kf = lz_chained(slot, 64); break;
-        case LZ_L_S1:
-            if (slot < 36) kf = slot;
-            else if (slot < 68) kf = 36 + lz_chained(slot - 36, 32);
-            else kf = (slot == 68 && a.has_eye) ? 68 : -1;
-            break;
-        default:  // LZ_L_C1
-            if (slot < 16) kf = slot;
-            else if (slot < 80) kf = 16 + lz_chained(slot - 16, 64);
-            else kf = (slot < 84 && a.has_ind) ? slot : -1;
-            break;
-    }
-    int srow;  // source row of the weight matrix, -1 = padding row
-    if (layer == LZ_L_S3) srow = row < 64 ? row + 1 : -1;  // the 64 geo rows; the sigma row (0) is a VALU layer
-    else srow = row < a.nout[layer] ? row : -1;
+    const int kf = lz_pack_kf(layer, slot, a), srow = lz_pack_srow(layer, row, a);
     float v = 0.0f;
     if (kf >= 0 && srow >= 0 && a.w[layer]) v = a.w[layer][(size_t)srow * a.ld[layer] + kf];
     packed[gid] = v;
@@ -103,6 +106,54 @@ extern "C" int lz_head_pack_weights(const float* aud0, const float* aud1, const 
     a.has_eye = has_eye; a.has_ind = has_ind;
     hipLaunchKernelGGL(lz_k_head_pack, dim3(lz_div_up((uint64_t)LZ_HEAD_PACKED_FLOATS, 256)), dim3(256), 0, lz_st(stream), a, packed);
     LZ_CHECK_LAUNCH("head_pack_weights");
+    return LZ_OK;
+}
+
+// ---- transposed weights for the backward on the f16 matrix cores (lz_head_rec.hip, lz_layer_bwd16) -----------------------------
+// dX = W^T dY per layer with v_mfma_f32_16x16x16_f16: fragment (layer, kt, ft), lane (rho = l & 15, kg = l >> 4) holds the four halves
+// W[out row 16 ft + 4 kg + j][in slot 16 kt + 4 (rho & 3) + (rho >> 2)], j < 4 -- row rho of the backward D tile kt is the gradient of the
+// value lane q = rho >> 2 supplied to the forward k-step 4 kt + (rho & 3) (lz_head_bwd_common.h), and the K index of the instruction
+// runs over the output rows 4 kg + j of tile ft, which is how a D tile of dY sits in a lane's four registers.
+extern "C" uint32_t lz_head_packed_bwd_size_f16(void) { return (uint32_t)LZ_BFRAGS * 64u * 8u; }
+
+__global__ void __launch_bounds__(256) lz_k_head_pack_bwd_f16(LzPackArgs a, _Float16* __restrict__ packed) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= LZ_BFRAGS * 64) return;
+    const int frag = gid >> 6, lane = gid & 63;
+    int layer = 0, fb = 0;
+    for (int i = 0; i < LZ_L_COUNT; i++) {
+        const int n = i == LZ_L_U1 ? 0 : lz_kt(i) * LZ_NT[i];
+        if (frag < fb + n) { layer = i; break; }
+        fb += n;
+    }
+    const int local = frag - fb;
+    const int kt = local / LZ_NT[layer], ft = local - kt * LZ_NT[layer];
+    const int rho = lane & 15, kg = lane >> 4;
+    const int slot = 16 * kt + 4 * (rho & 3) + (rho >> 2);
+    const int kf = slot < 4 * LZ_KS[layer] ? lz_pack_kf(layer, slot, a) : -1;
+    for (int j = 0; j < 4; j++) {
+        const int srow = lz_pack_srow(layer, 16 * ft + 4 * kg + j, a);
+        float v = 0.0f;
+        if (kf >= 0 && srow >= 0 && a.w[layer]) v = a.w[layer][(size_t)srow * a.ld[layer] + kf];
+        packed[(size_t)gid * 4 + j] = (_Float16)v;
+    }
+}
+
+extern "C" int lz_head_pack_weights_bwd_f16(const float* aud0, const float* aud1, const float* eye0, const float* sig0, const float* sig1,
+                                            const float* sig2, const float* col0, int has_eye, int has_ind, void* packed_bwd16,
+                                            lz_stream_t stream) {
+    LZ_REQUIRE(aud0 && aud1 && sig0 && sig1 && sig2 && col0 && packed_bwd16, LZ_ERR_BAD_ARGUMENT, "head_pack_weights_bwd_f16: null weight");
+    LZ_REQUIRE(!has_eye || eye0, LZ_ERR_BAD_ARGUMENT, "head_pack_weights_bwd_f16: eye weights required when has_eye");
+    LzPackArgs a;
+    const float* w[LZ_L_COUNT] = {aud0, aud1, eye0, sig0, sig1, sig2, col0, nullptr};
+    const int nout[LZ_L_COUNT] = {64, 32, 16, 64, 64, 65, 64, 32};
+    const int ld[LZ_L_COUNT] = {36, 64, 36, 68 + (has_eye ? 1 : 0), 64, 64, 80 + (has_ind ? 4 : 0), 36};
+    for (int i = 0; i < LZ_L_COUNT; i++) { a.w[i] = w[i]; a.nout[i] = nout[i]; a.ld[i] = ld[i]; }
+    a.eye1 = a.col1 = a.unc1 = nullptr;
+    a.has_eye = has_eye; a.has_ind = has_ind;
+    hipLaunchKernelGGL(lz_k_head_pack_bwd_f16, dim3(lz_div_up((uint64_t)LZ_BFRAGS * 64, 256)), dim3(256), 0, lz_st(stream), a,
+                       reinterpret_cast<_Float16*>(packed_bwd16));
+    LZ_CHECK_LAUNCH("head_pack_weights_bwd_f16");
     return LZ_OK;
 }
 

@@ -416,6 +416,7 @@ extern "C" int lz_triplane_head_backward(const lz_head_params* p, const float* x
     }
     a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_amb_aud = g_amb_aud; a.g_amb_eye = g_amb_eye; a.g_unc = g_unc;
     a.o = o;
+    a.wb16 = nullptr;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;

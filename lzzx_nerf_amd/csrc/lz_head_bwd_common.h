@@ -10,6 +10,7 @@ struct LzHeadBwdArgs {
     LzHeadArgs fwd;
     const float *g_sigma, *g_rgb, *g_amb_aud, *g_amb_eye, *g_unc;     // upstream gradients [M], [M,3], [M], [M], [M]
     lz_head_bwd_out o;
+    const void* wb16;   // transposed f16 fragments (lz_head_pack_weights_bwd_f16) for the backward on the f16 matrix cores, else null
 };
 
 // dX = W^T dY on the matrix cores from the FORWARD fragments of `LAYER` (see the header comment for the address map)
@@ -44,6 +45,37 @@ __device__ __forceinline__ void lz_layer_bwd(const float* __restrict__ wl, int l
                 if (4 * kt + r < KS) dx[4 * kt + r] = acc[r];
         }
         a_cur = a_nxt;
+    }
+}
+
+// The same product on v_mfma_f32_16x16x16_f16 from the transposed half fragments (lz_head_pack_weights_bwd_f16): a D tile of dY sits in
+// a lane's four registers as the four k values 4 q + j of that tile, so one instruction per (input tile, output tile) replaces the four
+// f32 ones; dY and the weights are rounded to half (what the reference's autocast backward multiplies), the sum stays f32.
+typedef _Float16 lz_bh4 __attribute__((ext_vector_type(4)));
+template <int LAYER>
+__device__ __forceinline__ void lz_layer_bwd16(const uint2* __restrict__ wb, int lane, const float (&dy)[4 * LZ_NT[LAYER]], float (&dx)[LZ_KS[LAYER]]) {
+    constexpr int KS = LZ_KS[LAYER], NT = LZ_NT[LAYER], KT = (KS + 3) / 4;
+    typedef float lz_f2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 lz_h2v __attribute__((ext_vector_type(2)));
+    lz_bh4 b[NT];
+#pragma unroll
+    for (int ft = 0; ft < NT; ft++) {
+        const lz_f2v lo = {dy[4 * ft], dy[4 * ft + 1]}, hi = {dy[4 * ft + 2], dy[4 * ft + 3]};
+        const lz_h2v l = __builtin_convertvector(lo, lz_h2v), h = __builtin_convertvector(hi, lz_h2v);
+        b[ft] = lz_bh4{l[0], l[1], h[0], h[1]};
+    }
+    const uint2* frag = wb + lz_bfrag_base(LAYER) * 64 + lane;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        lz_f4 acc = lz_f4{0, 0, 0, 0};
+#pragma unroll
+        for (int ft = 0; ft < NT; ft++) {
+            const uint2 w = frag[(kt * NT + ft) * 64];
+            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(lz_bh4, w), b[ft], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (4 * kt + r < KS) dx[4 * kt + r] = acc[r];
     }
 }
 

@@ -20,6 +20,15 @@ constexpr int lz_frag_base(int layer) {
     for (int i = 0; i < layer; i++) b += LZ_KS[i] * LZ_NT[i];
     return b;
 }
+// backward on the f16 matrix cores: fragments (kt, ft) per layer, kt over the ceil(KS / 4) tiles of 16 input slots; unc_net has no
+// data gradient (its input is detached, network.py:241-249)
+constexpr int lz_kt(int layer) { return (LZ_KS[layer] + 3) / 4; }
+constexpr int lz_bfrag_base(int layer) {
+    int b = 0;
+    for (int i = 0; i < layer; i++) b += i == LZ_L_U1 ? 0 : lz_kt(i) * LZ_NT[i];
+    return b;
+}
+constexpr int LZ_BFRAGS = lz_bfrag_base(LZ_L_COUNT);     // 99
 constexpr int LZ_FRAGS_INFER = lz_frag_base(LZ_L_U1);   // 361
 constexpr int LZ_FRAGS_ALL = lz_frag_base(LZ_L_COUNT);  // 379
 // VALU-layer weights, plain rows indexed by input feature, after the fragments: colour.1 [3][64], sigma row [64], eye.1 [16], unc.1 [32]

@@ -10,6 +10,8 @@
 //     seven scalars (||att||, eye_att, the pre-activations of unc / sigma / rgb),
 // and the backward kernel reads the state row instead of xyz / dirs / the tables: no gather, no SH, no forward matrix work.  The
 // arithmetic of every gradient is unchanged (same values, same order), only where the forward values come from.
+#include <type_traits>
+
 #include "lz_head_bwd_common.h"
 #include "lz_head_gather.h"
 #include "lz_head_slice.h"
@@ -320,11 +322,12 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 // ------------------------------------------------------------------------------------------------
 // backward from the recorded state
 // ------------------------------------------------------------------------------------------------
-template <bool H16>
+// B16: the matrix work on the f16 cores from the transposed half fragments (99 x 512 B instead of the 379 f32 forward fragments)
+template <bool H16, bool B16>
 __global__ void __launch_bounds__(LZ_BWD_WG, LZ_BWD_WG / 256)
 lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, uint32_t M) {
     constexpr int NFRAG = LZ_FRAGS_ALL;
-    constexpr int WV = NFRAG * 64, TAB = WV + LZ_WV_FLOATS;
+    constexpr int WV = B16 ? LZ_BFRAGS * 128 : NFRAG * 64, TAB = WV + LZ_WV_FLOATS;
     __shared__ float wl[TAB + 96];
     const LzHeadArgs& P = A.fwd;
     const lz_head_bwd_out& O = A.o;
@@ -333,14 +336,20 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
     const uint32_t slice_hi = (uint32_t)(((uint64_t)n_slices * (blockIdx.x + 1)) / gridDim.x);
     if (slice_lo >= slice_hi) return;
     {
-        const float4* src = reinterpret_cast<const float4*>(P.packed);
+        const float4* src = reinterpret_cast<const float4*>(B16 ? A.wb16 : P.packed);
         float4* dst = reinterpret_cast<float4*>(wl);
-        for (int i = threadIdx.x; i < NFRAG * 16; i += LZ_BWD_WG) dst[i] = src[i];
+        for (int i = threadIdx.x; i < WV / 4; i += LZ_BWD_WG) dst[i] = src[i];
         if (threadIdx.x < LZ_WV_FLOATS) wl[WV + threadIdx.x] = P.packed[LZ_FRAGS_ALL * 64 + threadIdx.x];
         if (threadIdx.x < 32) wl[TAB + 64 + threadIdx.x] = P.enc_a[threadIdx.x];
         if (threadIdx.x == 0) reinterpret_cast<int*>(wl + TAB)[48] = 0;
     }
     __syncthreads();
+    // one spelling for both matrix paths
+    auto layer_bwd = [&](auto layer_tag, const auto& dy, auto& dx) {
+        constexpr int LAYER = decltype(layer_tag)::value;
+        if constexpr (B16) lz_layer_bwd16<LAYER>(reinterpret_cast<const uint2*>(wl), (int)(threadIdx.x & 63), dy, dx);
+        else lz_layer_bwd<LAYER>(wl, (int)(threadIdx.x & 63), dy, dx);
+    };
     const float* lenca = wl + TAB + 64;
     const float* wv = wl + WV;
     const int lane = threadIdx.x & 63;
@@ -484,7 +493,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 }
             }
             float dxc[21];
-            lz_layer_bwd<LZ_L_C1>(wl, lane, dc1, dxc);
+            layer_bwd(std::integral_constant<int, LZ_L_C1>{}, dc1, dxc);
 #pragma unroll
             for (int k = 0; k < 16; k++) dgeo[k] = dxc[4 + k];
             dind = dxc[20];
@@ -498,7 +507,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         float dencx[9], dencw[8], determ;
         {
             float ds2[16];
-            lz_layer_bwd<LZ_L_S3>(wl, lane, dgeo, ds2);
+            layer_bwd(std::integral_constant<int, LZ_L_S3>{}, dgeo, ds2);
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -516,7 +525,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 }
             }
             float ds1[16];
-            lz_layer_bwd<LZ_L_S2>(wl, lane, ds2, ds1);
+            layer_bwd(std::integral_constant<int, LZ_L_S2>{}, ds2, ds1);
 #pragma unroll
             for (int k = 0; k < 16; k++) ds1[k] = ((mk_s1 >> k) & 1u) ? ds1[k] : 0.0f;
             {
@@ -528,7 +537,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 }
             }
             float dxs[18];
-            lz_layer_bwd<LZ_L_S1>(wl, lane, ds1, dxs);
+            layer_bwd(std::integral_constant<int, LZ_L_S1>{}, ds1, dxs);
 #pragma unroll
             for (int i = 0; i < 9; i++) dencx[i] = dxs[i];
 #pragma unroll
@@ -572,7 +581,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
             for (int r = 0; r < 4; r++) de1[r] = ((mk_e1 >> r) & 1u) ? wv[LZ_WV_E2 + 4 * q + r] * de2 : 0.0f;
             float dxe[9];
-            lz_layer_bwd<LZ_L_E1>(wl, lane, de1, dxe);
+            layer_bwd(std::integral_constant<int, LZ_L_E1>{}, de1, dxe);
 #pragma unroll
             for (int i = 0; i < 9; i++) dencx[i] += dxe[i];
         }
@@ -587,7 +596,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         }
         {
             float da1[16];
-            lz_layer_bwd<LZ_L_A2>(wl, lane, datt, da1);
+            layer_bwd(std::integral_constant<int, LZ_L_A2>{}, datt, da1);
 #pragma unroll
             for (int k = 0; k < 16; k++) da1[k] = ((mk_a1 >> k) & 1u) ? da1[k] : 0.0f;
             {
@@ -599,7 +608,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 }
             }
             float dxa[9];
-            lz_layer_bwd<LZ_L_A1>(wl, lane, da1, dxa);
+            layer_bwd(std::integral_constant<int, LZ_L_A1>{}, da1, dxa);
 #pragma unroll
             for (int i = 0; i < 9; i++) dencx[i] += dxa[i];
         }
@@ -720,7 +729,8 @@ extern "C" int lz_triplane_head_forward_record(const lz_head_params* p, const fl
 
 extern "C" int lz_triplane_head_backward_recorded(const lz_head_params* p, const float* state, uint32_t M, const float* g_sigma,
                                                   const float* g_rgb, const float* g_amb_aud, const float* g_amb_eye, const float* g_unc,
-                                                  const lz_head_bwd_out* out, int record_f16, lz_stream_t stream) {
+                                                  const lz_head_bwd_out* out, int record_f16, const void* packed_bwd16,
+                                                  lz_stream_t stream) {
     LZ_REQUIRE(p && state && g_sigma && g_rgb && g_amb_aud && g_unc && out, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded: null tensor");
     LZ_REQUIRE(p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded: incomplete lz_head_params");
     LZ_REQUIRE(p->precision == 0 && !p->testing, LZ_ERR_UNSUPPORTED, "triplane_head_backward_recorded: f32 training mode only");
@@ -732,10 +742,13 @@ extern "C" int lz_triplane_head_backward_recorded(const lz_head_params* p, const
     lz_fill_head_args(p, a.fwd);
     a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_amb_aud = g_amb_aud; a.g_amb_eye = g_amb_eye; a.g_unc = g_unc;
     a.o = o;
-    if (record_f16)
-        hipLaunchKernelGGL(lz_k_triplane_head_backward_rec<true>, dim3(lz_rec_grid(M, LZ_BWD_WG)), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M);
-    else
-        hipLaunchKernelGGL(lz_k_triplane_head_backward_rec<false>, dim3(lz_rec_grid(M, LZ_BWD_WG)), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M);
+    a.wb16 = packed_bwd16;
+    LZ_REQUIRE(!packed_bwd16 || (record_f16 && ((uintptr_t)packed_bwd16 & 15u) == 0), LZ_ERR_BAD_ARGUMENT,
+               "triplane_head_backward_recorded: the f16 matrix path goes with f16 records and 16-byte aligned fragments");
+    const dim3 grid(lz_rec_grid(M, LZ_BWD_WG)), block(LZ_BWD_WG);
+    if (packed_bwd16) hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, true>), grid, block, 0, lz_st(stream), a, state, M);
+    else if (record_f16) hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, false>), grid, block, 0, lz_st(stream), a, state, M);
+    else hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<false, false>), grid, block, 0, lz_st(stream), a, state, M);
     LZ_CHECK_LAUNCH("triplane_head_backward_recorded");
     return LZ_OK;
 }

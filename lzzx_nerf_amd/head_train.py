@@ -108,8 +108,13 @@ class _FusedHeadTrain(Function):
         call("lz_head_pack_weights", *[ptr(t) for t in w], int(mod.has_eye), int(mod.has_ind), ptr(mod.packed), stream())
         p = mod._params(emb, enc_a_f, ind_f, eye_f)
         if ctx.state is not None:
+            wb16 = None
+            if mod.backward_f16:   # transposed half fragments of the weights THIS forward saw
+                call("lz_head_pack_weights_bwd_f16", ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[4]), ptr(w[5]), ptr(w[6]), ptr(w[7]), int(mod.has_eye),
+                     int(mod.has_ind), ptr(mod.packed_bwd16), stream())
+                wb16 = ptr(mod.packed_bwd16)
             call("lz_triplane_head_backward_recorded", C.byref(p), ptr(ctx.state), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
-                 C.byref(o), int(mod.record_f16), stream())
+                 C.byref(o), int(mod.record_f16), wb16, stream())
             ctx.state = None
         else:
             call("lz_triplane_head_backward", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
@@ -147,12 +152,13 @@ class _FusedHeadTrain(Function):
 
 
 class FusedTriplaneTrainHead(nn.Module):
-    def __init__(self, state_dict=None, bound=1.0, exp_eye=True, ind_dim=4, record=True, record_dtype="f32", forward_dtype="f32"):
+    def __init__(self, state_dict=None, bound=1.0, exp_eye=True, ind_dim=4, record=True, record_dtype="f32", forward_dtype="f32",
+                 backward_dtype="f32"):
         super().__init__()
-        if record_dtype not in ("f32", "f16") or forward_dtype not in ("f32", "f16"):
-            raise ValueError("record_dtype / forward_dtype must be 'f32' or 'f16'")
-        if forward_dtype == "f16":
-            record, record_dtype = True, "f16"   # the f16 forward records what it holds: half operands
+        if record_dtype not in ("f32", "f16") or forward_dtype not in ("f32", "f16") or backward_dtype not in ("f32", "f16"):
+            raise ValueError("record_dtype / forward_dtype / backward_dtype must be 'f32' or 'f16'")
+        if forward_dtype == "f16" or backward_dtype == "f16":
+            record, record_dtype = True, "f16"   # the f16 kernels record / consume half operands
         if record_dtype == "f16" and not record:
             raise ValueError("record_dtype='f16' needs record=True (the recomputing backward writes f32 records)")
         self.bound = float(bound)
@@ -165,6 +171,10 @@ class FusedTriplaneTrainHead(nn.Module):
         # f32 accumulate: lz_head_f16_slice.h) -- what `-O` training does there; the data gradient stays an f32 chain through the f32
         # weights, evaluated at the recorded half activations, and the weight gradients are reduced from the half records.
         self.forward_f16 = forward_dtype == "f16"
+        # backward_dtype="f16": the data-gradient products on the f16 matrix cores, dY and W rounded to half, f32 sums -- the
+        # reference's autocast backward; "f32" keeps the f32 chain (more accurate than autocast, 4 x the matrix instructions).
+        # forward_dtype = backward_dtype = "f16" is the whole step in the arithmetic of the reference's `-O` mode.
+        self.backward_f16 = backward_dtype == "f16"
         mk = lambda: GridEncoder(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
                                  desired_resolution=512 * bound)
         self.encoder_xy, self.encoder_yz, self.encoder_xz = mk(), mk(), mk()                       # network.py:131-133
@@ -178,6 +188,8 @@ class FusedTriplaneTrainHead(nn.Module):
         self.S = float(np.float32(np.log2(self.encoder_xy.per_level_scale)))
         self.register_buffer("packed", torch.empty(_lib.load().lz_head_packed_size(), dtype=torch.float32), persistent=False)
         self._gw_ws = None   # partial-tile workspace of lz_triplane_head_grad_w, allocated on first backward
+        if self.backward_f16:
+            self.register_buffer("packed_bwd16", torch.empty(_lib.load().lz_head_packed_bwd_size_f16(), dtype=torch.uint8), persistent=False)
         if self.forward_f16:
             self.register_buffer("packed16", torch.empty(_lib.load().lz_head_packed_size_f16(), dtype=torch.uint8), persistent=False)
             self.register_buffer("packed_unc16", torch.empty(_lib.load().lz_head_packed_unc_size_f16(), dtype=torch.uint8), persistent=False)

@@ -556,9 +556,10 @@ def test_fused_train_head_f16_records(params, golden, exp_eye, ind_dim):
             assert float(g2[k].abs().max()) > 0, k
 
 
-def test_fused_train_head_f16_forward(params, golden):
-    """forward_dtype="f16": the training forward in the reference's autocast arithmetic (lz_head_rec16.hip) + f32 data-gradient chain +
-    half records.  Checked against the same network built from the operator API under torch.autocast (what the reference's `-O`
+@pytest.mark.parametrize("backward_dtype", ["f32", "f16"])
+def test_fused_train_head_f16_forward(params, golden, backward_dtype):
+    """forward_dtype="f16": the training forward in the reference's autocast arithmetic (lz_head_rec16.hip) + data-gradient chain (f32, or
+    backward_dtype="f16": on the f16 matrix cores with half dY / W like autocast's own backward) + half records.  Checked against the same network built from the operator API under torch.autocast (what the reference's `-O`
     training runs: half Linear on rocBLAS, half ReLU / sigmoid / products, f32 exp / norm / softplus, half gradients): outputs to half
     rounding, every gradient to 2e-2 of its largest entry; and against the f16 inference kernel for the outputs they share."""
     from lzzx_nerf_amd.encoding import get_encoder
@@ -575,7 +576,7 @@ def test_fused_train_head_f16_forward(params, golden):
     gout = [torch.from_numpy(rng.normal(size=sh).astype(np.float32)).cuda() for sh in ((M,), (M, 3), (M, 1), (M, 1), (M, 1))]
     gout[0] *= 1e-2   # d loss / d sigma times sigma has to fit a half: the job of the reference's GradScaler
     enc_a_np = golden["net_enc_a"].astype(np.float16).astype(np.float32)   # enc_a is a half tensor under autocast (AudioNet output)
-    net = FusedTriplaneTrainHead(p, bound=1.0, forward_dtype="f16").cuda()
+    net = FusedTriplaneTrainHead(p, bound=1.0, forward_dtype="f16", backward_dtype=backward_dtype).cuda()
     enc_a, ind, eye = dev(enc_a_np).requires_grad_(True), dev(golden["net_ind"]).requires_grad_(True), dev(golden["net_eye"])
     outs = net(xyz, d, enc_a, ind, eye)
     torch.autograd.backward(list(outs), gout)
