@@ -113,7 +113,7 @@ struct LzGwOperand16 {
     __device__ __forceinline__ void load(const uint32_t* __restrict__ rec, size_t row0, bool ok, uint32_t i) {   // row0 = first of the lane's four
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            const uint32_t* r = rec + (row0 + m) * (LZ_BWD_REC16 / 2) + i;
+            const uint32_t* r = rec + (ok ? row0 + m : 0) * (LZ_BWD_REC16 / 2) + i;   // a lane without its four rows reads row 0 (M may be < 4)
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 const uint32_t v = r[16 * (P0 + p)];

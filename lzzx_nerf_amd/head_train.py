@@ -97,6 +97,10 @@ class _FusedHeadTrain(Function):
             return (None, None, None, g_enc_a, g_ind, None) + tuple(torch.zeros_like(t) for t in emb) + tuple(torch.zeros_like(t) for t in w)
         z = lambda g, shape: (torch.zeros(shape, **kw) if g is None else g.float().contiguous())
         g_sig, g_rgb, g_aa, g_ae, g_un = z(g_sig, (M,)), z(g_rgb, (M, 3)), z(g_aa, (M, 1)), z(g_ae, (M, 1)), z(g_un, (M, 1))
+        if mod.record and ctx.rec is None:
+            # the record and state of this forward were consumed (and released) by an earlier backward
+            raise RuntimeError("FusedTriplaneTrainHead(record=True): a second backward through the same forward needs record=False "
+                               "(the recomputing backward keeps nothing between the two)")
         # one record per sample: every layer input / output gradient the reductions need (the X half is there already in record mode)
         rec = ctx.rec if ctx.rec is not None else torch.empty(M, _REC, **kw)
         denc = torch.empty(3, 12, M, **kw)          # level-major: the grid backward reads one level at a time
