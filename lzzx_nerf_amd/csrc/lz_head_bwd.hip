@@ -87,8 +87,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
         const bool valid = base + s < M;
         const uint32_t m = valid ? base + s : M - 1;   // clamped rows are computed, never stored or accumulated
         const size_t row = m;
-        float* rec1 = O.rec + row * LZ_BWD_REC + q;   // this sample's record, + q / + 4 q: the two lane patterns of the dumps
-        float* recq = rec1 + 3 * q;
+        float* rb = lz_blk(O.rec, slice_lo + (uint32_t)slice, LZ_BWD_REC, s);   // this sample's slot in the slice block of the records
         float* dencq = O.denc + (size_t)q * M + row;
 
         // =============================== forward (as lz_k_triplane_head<true>) ===============================
@@ -113,7 +112,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) a1[0][4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_a1 = lz_mask_pos(a1[0]);
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_A1, a1[0]);
+            if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_X_A1, a1[0]);
             lz_f4 acc2[2][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_A2, 1>(wl, lane, a1, acc2);
 #pragma unroll
@@ -178,9 +177,9 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
             b1[0][17] = (has_eye && q == 0) ? eye_v * eyeatt : 0.0f;
             if (valid) {   // sigma_net.0 input [enc_x 36 | enc_a * att 32 | eye * eye_att 1], leading dimension 72
 #pragma unroll
-                for (int i = 0; i < 9; i++) rec1[LZ_BWD_X_SIG0 + 4 * i] = encx[i];
-                lz_dump_chained<2>(recq, LZ_BWD_X_SIG0 + 36, encw);
-                if (q == 0) rec1[LZ_BWD_X_SIG0 + 68] = b1[0][17];
+                for (int i = 0; i < 9; i++) rb[lz_tcol(LZ_BWD_X_SIG0 + 4 * i + q)] = encx[i];
+                lz_dump_chained<2>(rb, q, LZ_BWD_X_SIG0 + 36, encw);
+                if (q == 0) rb[lz_tcol(LZ_BWD_X_SIG0 + 68 + q)] = b1[0][17];
             }
             lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_S1, 1>(wl, lane, b1, acc1);
@@ -190,7 +189,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) s1[0][4 * ft + r] = lz_relu(acc1[ft][0][r]);
             mk_s1 = lz_mask_pos(s1[0]);
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_S1, s1[0]);
+            if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_X_S1, s1[0]);
             lz_f4 acc2[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_S2, 1>(wl, lane, s1, acc2);
             float s2[1][16];
@@ -199,7 +198,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) s2[0][4 * ft + r] = lz_relu(acc2[ft][0][r]);
             mk_s2 = lz_mask_pos(s2[0]);
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_X_S2C, s2[0]);
+            if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_X_S2C, s2[0]);
             lz_f4 acc3[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_S3, 1>(wl, lane, s2, acc3);
 #pragma unroll
@@ -222,8 +221,8 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
             b1[0][20] = indq;
             if (valid) {   // colour_net.0 input [SH 16 | geo 64 | ind 4]
 #pragma unroll
-                for (int i = 0; i < 4; i++) rec1[LZ_BWD_X_S2C + 64 + 4 * i] = b1[0][i];
-                rec1[LZ_BWD_X_S2C + 80] = indq;   // geo = s2 . Wg^T is not stored: its weight gradient is finished from sum G_c1^T s2
+                for (int i = 0; i < 4; i++) rb[lz_tcol(LZ_BWD_X_S2C + 64 + 4 * i + q)] = b1[0][i];
+                rb[lz_tcol(LZ_BWD_X_S2C + 80 + q)] = indq;   // geo = s2 . Wg^T is not stored: its weight gradient is finished from sum G_c1^T s2
             }
             lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
             lz_layer<LZ_L_C1, 1>(wl, lane, b1, acc1);
@@ -259,7 +258,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
                     v = lz_fmaf(wv[LZ_WV_C2 + 128 + f], dc[2], v);
                     dc1[k] = ((mk_c1 >> k) & 1u) ? v : 0.0f;
                 }
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_C1H, dc1);
+            if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_G_C1H, dc1);
             float dxc[21];
             lz_layer_bwd<LZ_L_C1>(wl, lane, dc1, dxc);
 #pragma unroll
@@ -270,7 +269,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
         // sigma net
         const float dh0 = g_sig * sigma;
         if (valid) {   // sigma_net.2 output gradient [d geo 64 | d h0], leading dimension 68 (16-byte rows: dwordx4 stores)
-            if (q == 0) rec1[LZ_BWD_G_C1H + 64] = dh0;   // d geo = G_c1 . W_c0[:, geo] is not stored either
+            if (q == 0) rb[lz_tcol(LZ_BWD_G_C1H + 64 + q)] = dh0;   // d geo = G_c1 . W_c0[:, geo] is not stored either
         }
         float dencx[9], dencw[8], determ;
         {
@@ -284,12 +283,12 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
                     const float v = lz_fmaf(wv[LZ_WV_SIG + 16 * t + 4 * q + r], dh0, ds2[k]);
                     ds2[k] = ((mk_s2 >> k) & 1u) ? v : 0.0f;
                 }
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_S2, ds2);
+            if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_G_S2, ds2);
             float ds1[16];
             lz_layer_bwd<LZ_L_S2>(wl, lane, ds2, ds1);
 #pragma unroll
             for (int k = 0; k < 16; k++) ds1[k] = ((mk_s1 >> k) & 1u) ? ds1[k] : 0.0f;
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_S1, ds1);
+            if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_G_S1, ds1);
             float dxs[18];
             lz_layer_bwd<LZ_L_S1>(wl, lane, ds1, dxs);
 #pragma unroll
@@ -310,7 +309,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
                     datt[k] = lz_fmaf(lenca[16 * t + 4 * q + r], dencw[k], inv * att[k]);
                     if (valid) acc_enca[k] = lz_fmaf(att[k], dencw[k], acc_enca[k]);
                 }
-            if (valid) lz_dump_chained<2>(recq, LZ_BWD_G_ATT, datt);
+            if (valid) lz_dump_chained<2>(rb, q, LZ_BWD_G_ATT, datt);
         }
         // eye attention: eterm = eye * eye_att (lane q == 0 holds its gradient), ambient_eye = |eye_att| = eye_att
         if (has_eye) {
@@ -324,14 +323,14 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
             float de1[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) de1[r] = ((mk_e1 >> r) & 1u) ? wv[LZ_WV_E2 + 4 * q + r] * de2 : 0.0f;
-            if (valid) lz_dump_chained<1>(recq, LZ_BWD_G_X + 64, de1);
+            if (valid) lz_dump_chained<1>(rb, q, LZ_BWD_G_X + 64, de1);
             float dxe[9];
             lz_layer_bwd<LZ_L_E1>(wl, lane, de1, dxe);
 #pragma unroll
             for (int i = 0; i < 9; i++) dencx[i] += dxe[i];
         } else if (valid) {   // the stacked reduction over G_x reads these columns: no eye input, no gradient
             const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            lz_dump_chained<1>(recq, LZ_BWD_G_X + 64, zero);
+            lz_dump_chained<1>(rb, q, LZ_BWD_G_X + 64, zero);
         }
         // audio channel attention
         {
@@ -339,7 +338,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
             lz_layer_bwd<LZ_L_A2>(wl, lane, datt, da1);
 #pragma unroll
             for (int k = 0; k < 16; k++) da1[k] = ((mk_a1 >> k) & 1u) ? da1[k] : 0.0f;
-            if (valid) lz_dump_chained<4>(recq, LZ_BWD_G_X, da1);
+            if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_G_X, da1);
             float dxa[9];
             lz_layer_bwd<LZ_L_A1>(wl, lane, da1, dxa);
 #pragma unroll
@@ -355,7 +354,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
                     const int k = 4 * t + r;
                     du1[k] = ((mk_u1 >> k) & 1u) ? wv[LZ_WV_U2 + 16 * t + 4 * q + r] * du : 0.0f;
                 }
-            if (valid) lz_dump_chained<2>(recq, LZ_BWD_G_X + 80, du1);
+            if (valid) lz_dump_chained<2>(rb, q, LZ_BWD_G_X + 80, du1);
         }
         // d(enc_x): feature 4 i + q = plane i / 3, level 4 (i % 3) + q
         if (valid) {

@@ -79,15 +79,27 @@ __device__ __forceinline__ void lz_layer_bwd16(const uint2* __restrict__ wb, int
     }
 }
 
-// chained-layout vector v[4 t + r] = feature 16 t + 4 q + r -> record columns col0 + feature; `recq` = this sample's record + 4 q, so every
-// store is (one per-slice address) + (an immediate offset): one dwordx4 per tile (records and slots are 16-byte aligned)
+// Record / state buffers are BLOCKED by 16-sample slice: [slice][tile of 16 dwords][sample 16][16 dwords], so that a store or load
+// instruction of a wave (16 samples x 4 lanes x 16 bytes) covers ONE contiguous kilobyte -- eight whole cache lines -- instead of sixteen
+// separate 64-byte pieces a row apart.  Column c of a sample (the per-sample layouts of include/lzzx_nerf_hip.h) sits at dword
+// lz_tcol(c) of its slot in the slice block; buffers are allocated for whole slices.
+__device__ __forceinline__ int lz_tcol(int c) { return ((c >> 4) << 8) + (c & 15); }
+__device__ __forceinline__ float* lz_blk(float* base, uint32_t slice, int row_dwords, int s) {
+    return base + (size_t)slice * (16u * (uint32_t)row_dwords) + s * 16;
+}
+__device__ __forceinline__ const float* lz_blk(const float* base, uint32_t slice, int row_dwords, int s) {
+    return base + (size_t)slice * (16u * (uint32_t)row_dwords) + s * 16;
+}
+
+// chained-layout vector v[4 t + r] = feature 16 t + 4 q + r -> record columns col0 + feature of the sample whose block slot is `rb`:
+// one dwordx4 per tile (a lane's four columns never straddle a tile: col0 is a multiple of 4)
 template <int NTILE>
-__device__ __forceinline__ void lz_dump_chained(float* __restrict__ recq, int col0, const float (&v)[4 * NTILE]) {
+__device__ __forceinline__ void lz_dump_chained(float* __restrict__ rb, int q, int col0, const float (&v)[4 * NTILE]) {
     typedef float lz_v4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int t = 0; t < NTILE; t++) {
         lz_v4 w = {v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
-        __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(recq + col0 + 16 * t));   // streamed: read back once by the weight-gradient pass
+        __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(rb + lz_tcol(col0 + 16 * t + 4 * q)));   // streamed: read back once
     }
 }
 

@@ -28,14 +28,15 @@ namespace {
 // first tile of each of the five products in the partial image
 constexpr int T_X3 = 0, T_AUD1 = 21, T_SIG1 = 29, T_SIG0 = 45, T_C1H = 65;
 
-// f32 records: lane (i, kk) of v_mfma_f32_16x16x4_f32 reads one float per (row, tile): row 4 j + kk of MFMA step j.
+// f32 records: lane (i, kk) of v_mfma_f32_16x16x4_f32 reads one float per (row, tile): row 4 j + kk of MFMA step j.  Records are
+// blocked by 16-sample slice, [slice][tile][sample][16 dwords]: the four rows of a load instruction are four consecutive 64-byte pieces.
 template <int T0, int NT>
 struct LzGwOperand32 {
     float raw[NT];
     __device__ __forceinline__ void load(const float* __restrict__ rec, size_t row, uint32_t i) {
-        const float* r = rec + row * LZ_BWD_REC + i;
+        const float* r = rec + (row >> 4) * (size_t)(16 * LZ_BWD_REC) + (row & 15) * 16 + i;   // blocked by 16-sample slice (lz_head_bwd_common.h)
 #pragma unroll
-        for (int t = 0; t < NT; t++) raw[t] = r[16 * (T0 + t)];
+        for (int t = 0; t < NT; t++) raw[t] = r[256 * (T0 + t)];
     }
 };
 
@@ -101,22 +102,26 @@ __device__ __forceinline__ void lz_gw_product(const float* __restrict__ rec, uin
 
 // f16 records (LZ_BWD_REC16 halves per sample, tiles interleaved in pairs: dword i of pair g = {tile 2 g column i, tile 2 g + 1
 // column i}).  The operands are halves already, so the product runs on v_mfma_f32_16x16x16_f16: one instruction per tile and 16
-// samples instead of four.  Its A / B operand wants, in lane (i, kk), FOUR CONSECUTIVE SAMPLES 4 kk .. 4 kk + 3 of column i: the lane
-// reads the pair's dword of those four rows (as many loads as the f32 path issues for 16 samples) and two byte-permutes per tile
-// gather the low (even tile) or high (odd tile) halves.  Products of halves are exact in f32 and the accumulation is f32, so the
+// samples instead of four.  Its A / B operand wants, in lane (i, kk), four samples of column i as its four k slots: the lane reads the
+// pair's dword of four rows of the block (as many loads as the f32 path issues for 16 samples) and two byte-permutes per tile gather
+// the low (even tile) or high (odd tile) halves.  Products of halves are exact in f32 and the accumulation is f32, so the
 // result equals converting to f32 first up to summation order.
 typedef _Float16 lz_h4 __attribute__((ext_vector_type(4)));
 template <int T0, int NT>
 struct LzGwOperand16 {
     static constexpr int P0 = T0 >> 1, NP = ((T0 + NT - 1) >> 1) - P0 + 1;
     uint32_t raw[4][NP];
-    __device__ __forceinline__ void load(const uint32_t* __restrict__ rec, size_t row0, bool ok, uint32_t i) {   // row0 = first of the lane's four
+    // k slot m of lane (i, kk) = sample 4 m + kk of the 16-sample block (any bijection works as long as both operands use it): the
+    // four lane groups of one load instruction then read four CONSECUTIVE 64-byte slots of the block, two whole cache lines.  Samples
+    // past M are padding slots of the last block (allocated, never written with anything that matters): read and zeroed.
+    __device__ __forceinline__ void load(const uint32_t* __restrict__ blk, uint32_t first_row, uint32_t M, bool block_ok, uint32_t i, uint32_t kk) {
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            const uint32_t* r = rec + (ok ? row0 + m : 0) * (LZ_BWD_REC16 / 2) + i;   // a lane without its four rows reads row 0 (M may be < 4)
+            const uint32_t* r = blk + (4 * m + kk) * 16 + i;
+            const bool ok = block_ok && first_row + 4 * m + kk < M;
 #pragma unroll
             for (int p = 0; p < NP; p++) {
-                const uint32_t v = r[16 * (P0 + p)];
+                const uint32_t v = r[256 * (P0 + p)];
                 raw[m][p] = ok ? v : 0u;
             }
         }
@@ -138,21 +143,18 @@ __device__ __forceinline__ void lz_gw_product16(const uint32_t* __restrict__ rec
     for (int t = 0; t < NBT; t++)
 #pragma unroll
         for (int u = 0; u < KBT; u++) acc[t][u] = lz_f4{0, 0, 0, 0};
-    const uint32_t n_groups = (M + 15) / 16;   // one group = 16 samples = one MFMA per tile
+    const uint32_t n_groups = (M + 15) / 16;   // one group = one 16-sample block = one MFMA per tile
     typedef LzGwOperand16<GT0, NBT> OpG;
     typedef LzGwOperand16<XT0, KBT> OpX;
     OpG a[2];
     OpX b[2];
-    // Whole rows past the end are zeroed on both sides; a group's last rows may be missing (M not a multiple of 16): those lanes read
-    // row 0 and are zeroed.  Unwritten padding columns may hold anything, NaN included: column n of G only reaches row n of D and
-    // column k of X only column k, and padding rows / columns of D are never written out.
+    // Unwritten padding columns may hold anything, NaN included: column n of G only reaches row n of D and column k of X only column
+    // k, and padding rows / columns of D are never written out.  A group past the end reads block 0 and is zeroed.
     auto load = [&](uint32_t g, OpG& aa, OpX& bb) {
-        const uint32_t row0 = g * 16 + 4 * kk;
-        // rows are loaded four at a time per lane: all four must exist, else the lane contributes nothing and the stragglers are
-        // handled by the scalar tail below
-        const bool ok = g < n_groups && row0 + 3 < M;
-        aa.load(rec, ok ? row0 : 0, ok, i);
-        bb.load(rec, ok ? row0 : 0, ok, i);
+        const bool ok = g < n_groups;
+        const uint32_t* blk = rec + (size_t)(ok ? g : 0) * (16 * (LZ_BWD_REC16 / 2));
+        aa.load(blk, g * 16, M, ok, i, kk);
+        bb.load(blk, g * 16, M, ok, i, kk);
     };
     auto mma = [&](const OpG& aa, const OpX& bb) {
         lz_h4 bv[KBT];
@@ -175,28 +177,6 @@ __device__ __forceinline__ void lz_gw_product16(const uint32_t* __restrict__ rec
         __builtin_amdgcn_sched_barrier(0);
         mma(a[1], b[1]);
         __builtin_amdgcn_sched_barrier(0);
-    }
-    // the last M % 4 rows (a lane's four rows did not all exist): workgroup 0 adds them one row per MFMA, the other three k slots zero
-    if (blockIdx.x == 0 && (M & 3u) != 0u) {
-        const uint32_t first = M & ~3u;
-        for (uint32_t row = first; row < M; row++) {
-            const uint32_t* r = rec + (size_t)row * (LZ_BWD_REC16 / 2) + i;
-            auto one = [&](int tile) -> lz_h4 {
-                const uint32_t v = r[16 * (tile >> 1)];
-                const uint16_t h = (tile & 1) ? (uint16_t)(v >> 16) : (uint16_t)(v & 0xffffu);
-                const _Float16 x = kk == 0 ? __builtin_bit_cast(_Float16, h) : (_Float16)0.0f;
-                return lz_h4{x, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
-            };
-            lz_h4 bv[KBT];
-#pragma unroll
-            for (int u = 0; u < KBT; u++) bv[u] = one(XT0 + u);
-#pragma unroll
-            for (int t = 0; t < NBT; t++) {
-                const lz_h4 at = one(GT0 + t);
-#pragma unroll
-                for (int u = 0; u < KBT; u++) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x16f16(at, bv[u], acc[t][u], 0, 0, 0);
-            }
-        }
     }
 #pragma unroll
     for (int t = 0; t < NBT; t++)

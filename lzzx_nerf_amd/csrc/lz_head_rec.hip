@@ -33,11 +33,11 @@ __device__ __forceinline__ float lz_pack_h2(float lo, float hi) {
     const lz_h2 v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(float, v);
 }
-// rowq = this sample's f16 row (as dwords) + 4 q; `pair` = tile / 2
+// rowq = this sample's slot in the slice block (lz_blk) + 4 q; `pair` = tile / 2: a pair is one 16-dword tile of the block
 __device__ __forceinline__ void lz_dump_pair(float* __restrict__ rowq, int pair, float l0, float l1, float l2, float l3, float h0, float h1,
                                              float h2, float h3) {
     lz_v4 w = {lz_pack_h2(l0, h0), lz_pack_h2(l1, h1), lz_pack_h2(l2, h2), lz_pack_h2(l3, h3)};
-    __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(rowq + 16 * pair));
+    __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(rowq + 256 * pair));
 }
 // tiles t0, t0 + 1 of a chained-layout vector -> pair
 template <int N>
@@ -101,10 +101,8 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
         const bool valid = base + s < M;
         const uint32_t m = valid ? base + s : M - 1;   // clamped lanes repeat the last row: the same values are stored again
         const size_t row = m;
-        float* rec1 = rec + row * (H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC) + q;   // f16: rows counted in dwords
-        float* recq = rec1 + 3 * q;
-        float* strow = st + row * (H16 ? LZ_FWD_STATE16 : LZ_FWD_STATE);
-        float* stq = strow + 4 * q;
+        float* rb = lz_blk(rec, slice_lo + (uint32_t)slice, H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC, s);   // f16: rows counted in dwords
+        float* sb = lz_blk(st, slice_lo + (uint32_t)slice, H16 ? LZ_FWD_STATE16 : LZ_FWD_STATE, s);
 
         float encx[9];
         lz_head_gather(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx);
@@ -131,10 +129,10 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             mk_a1 = lz_mask_pos(a1[0]);
             {
                 if constexpr (H16) {
-                    lz_dump_pair_chained(recq, LZ_R16_X_A1 / 2, a1[0], 0);
-                    lz_dump_pair_chained(recq, LZ_R16_X_A1 / 2 + 1, a1[0], 2);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_X_A1 / 2, a1[0], 0);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_X_A1 / 2 + 1, a1[0], 2);
                 } else {
-                    lz_dump_chained<4>(recq, LZ_BWD_X_A1, a1[0]);
+                    lz_dump_chained<4>(rb, q, LZ_BWD_X_A1, a1[0]);
                 }
             }
             lz_f4 acc2[2][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
@@ -144,7 +142,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) att[4 * ft + r] = acc2[ft][0][r];
         }
-        lz_dump_chained<2>(stq, LZ_ST_ATT, att);   // f32 in both layouts: the data gradient uses it
+        lz_dump_chained<2>(sb, q, LZ_ST_ATT, att);   // f32 in both layouts: the data gradient uses it
         float norm;
         {
             float acc = 0.0f;
@@ -165,8 +163,8 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             for (int r = 0; r < 4; r++) e1[r] = lz_relu(acce[0][0][r]);
             mk_e1 = lz_mask_pos(e1);
             {
-                if constexpr (H16) lz_dump_pair(stq, LZ_S16_E1 / 16, e1[0], e1[1], e1[2], e1[3], 0.0f, 0.0f, 0.0f, 0.0f);
-                else lz_dump_chained<1>(stq, LZ_ST_E1, e1);
+                if constexpr (H16) lz_dump_pair(sb + 4 * q, LZ_S16_E1 / 16, e1[0], e1[1], e1[2], e1[3], 0.0f, 0.0f, 0.0f, 0.0f);
+                else lz_dump_chained<1>(sb, q, LZ_ST_E1, e1);
             }
             eyeatt = lz_sigmoidf(lz_lane_dot<1>(wv + LZ_WV_E2, q, e1));
         }
@@ -183,8 +181,8 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
                 for (int r = 0; r < 4; r++) u1[4 * ft + r] = lz_relu(accu[ft][0][r]);
             mk_u1 = lz_mask_pos(u1);
             {
-                if constexpr (H16) lz_dump_pair_chained(stq, LZ_S16_U1 / 16, u1, 0);
-                else lz_dump_chained<2>(stq, LZ_ST_U1, u1);
+                if constexpr (H16) lz_dump_pair_chained(sb + 4 * q, LZ_S16_U1 / 16, u1, 0);
+                else lz_dump_chained<2>(sb, q, LZ_ST_U1, u1);
             }
             upre = lz_lane_dot<2>(wv + LZ_WV_U2, q, u1);
         }
@@ -208,14 +206,14 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
                 if constexpr (H16) {
                     // tiles 0, 1: enc_x features 4 i + q, i < 8 (half 2 r + p of the lane's eight = i); tile 2: feature 32 + q at column
                     // 4 q, the eye term at column 1; tiles 3, 4: enc_a * att; tile 5: padding
-                    lz_dump_pair(recq, LZ_R16_X_SIG0 / 2, encx[0], encx[2], encx[4], encx[6], encx[1], encx[3], encx[5], encx[7]);
-                    lz_dump_pair(recq, LZ_R16_X_SIG0 / 2 + 1, encx[8], b1[0][17], 0.0f, 0.0f, encw[0], encw[1], encw[2], encw[3]);
-                    lz_dump_pair(recq, LZ_R16_X_SIG0 / 2 + 2, encw[4], encw[5], encw[6], encw[7], 0.0f, 0.0f, 0.0f, 0.0f);
+                    lz_dump_pair(rb + 4 * q, LZ_R16_X_SIG0 / 2, encx[0], encx[2], encx[4], encx[6], encx[1], encx[3], encx[5], encx[7]);
+                    lz_dump_pair(rb + 4 * q, LZ_R16_X_SIG0 / 2 + 1, encx[8], b1[0][17], 0.0f, 0.0f, encw[0], encw[1], encw[2], encw[3]);
+                    lz_dump_pair(rb + 4 * q, LZ_R16_X_SIG0 / 2 + 2, encw[4], encw[5], encw[6], encw[7], 0.0f, 0.0f, 0.0f, 0.0f);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 9; i++) rec1[LZ_BWD_X_SIG0 + 4 * i] = encx[i];
-                    lz_dump_chained<2>(recq, LZ_BWD_X_SIG0 + 36, encw);
-                    rec1[LZ_BWD_X_SIG0 + 68] = b1[0][17];   // lanes q > 0 write zeros into the padding columns 69..71
+                    for (int i = 0; i < 9; i++) rb[lz_tcol(LZ_BWD_X_SIG0 + 4 * i + q)] = encx[i];
+                    lz_dump_chained<2>(rb, q, LZ_BWD_X_SIG0 + 36, encw);
+                    rb[lz_tcol(LZ_BWD_X_SIG0 + 68 + q)] = b1[0][17];   // lanes q > 0 write zeros into the padding columns 69..71
                 }
             }
             lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
@@ -228,10 +226,10 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             mk_s1 = lz_mask_pos(s1[0]);
             {
                 if constexpr (H16) {
-                    lz_dump_pair_chained(recq, LZ_R16_X_S1 / 2, s1[0], 0);
-                    lz_dump_pair_chained(recq, LZ_R16_X_S1 / 2 + 1, s1[0], 2);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_X_S1 / 2, s1[0], 0);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_X_S1 / 2 + 1, s1[0], 2);
                 } else {
-                    lz_dump_chained<4>(recq, LZ_BWD_X_S1, s1[0]);
+                    lz_dump_chained<4>(rb, q, LZ_BWD_X_S1, s1[0]);
                 }
             }
             lz_f4 acc2[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
@@ -244,10 +242,10 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             mk_s2 = lz_mask_pos(s2[0]);
             {
                 if constexpr (H16) {
-                    lz_dump_pair_chained(recq, LZ_R16_X_S2C / 2, s2[0], 0);
-                    lz_dump_pair_chained(recq, LZ_R16_X_S2C / 2 + 1, s2[0], 2);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_X_S2C / 2, s2[0], 0);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_X_S2C / 2 + 1, s2[0], 2);
                 } else {
-                    lz_dump_chained<4>(recq, LZ_BWD_X_S2C, s2[0]);
+                    lz_dump_chained<4>(rb, q, LZ_BWD_X_S2C, s2[0]);
                 }
             }
             lz_f4 acc3[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
@@ -272,11 +270,11 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             b1[0][20] = hc.indq;
             {   // colour_net.0 input [SH 16 | geo 64 | ind 4]; geo = s2 . Wg^T is not stored (lz_head_bwd.hip)
                 if constexpr (H16) {   // tile 4: SH component 4 r + q at column 4 q + r; tile 5: ind_code[q] at column 4 q
-                    lz_dump_pair(recq, LZ_R16_X_S2C / 2 + 2, b1[0][0], b1[0][1], b1[0][2], b1[0][3], hc.indq, 0.0f, 0.0f, 0.0f);
+                    lz_dump_pair(rb + 4 * q, LZ_R16_X_S2C / 2 + 2, b1[0][0], b1[0][1], b1[0][2], b1[0][3], hc.indq, 0.0f, 0.0f, 0.0f);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) rec1[LZ_BWD_X_S2C + 64 + 4 * i] = b1[0][i];
-                    rec1[LZ_BWD_X_S2C + 80] = hc.indq;
+                    for (int i = 0; i < 4; i++) rb[lz_tcol(LZ_BWD_X_S2C + 64 + 4 * i + q)] = b1[0][i];
+                    rb[lz_tcol(LZ_BWD_X_S2C + 80 + q)] = hc.indq;
                 }
             }
             lz_f4 acc1[4][1] = {{lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}, {lz_f4{0, 0, 0, 0}}};
@@ -289,10 +287,10 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             mk_c1 = lz_mask_pos(c1);
             {
                 if constexpr (H16) {
-                    lz_dump_pair_chained(stq, LZ_S16_C1 / 16, c1, 0);
-                    lz_dump_pair_chained(stq, LZ_S16_C1 / 16 + 1, c1, 2);
+                    lz_dump_pair_chained(sb + 4 * q, LZ_S16_C1 / 16, c1, 0);
+                    lz_dump_pair_chained(sb + 4 * q, LZ_S16_C1 / 16 + 1, c1, 2);
                 } else {
-                    lz_dump_chained<4>(stq, LZ_ST_C1, c1);
+                    lz_dump_chained<4>(sb, q, LZ_ST_C1, c1);
                 }
             }
 #pragma unroll
@@ -303,10 +301,10 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             // masks + one scalar per lane: q = 0 ||att||, 1 eye_att, 2 unc pre-activation, 3 sigma
             const float sc = q == 0 ? norm : (q == 1 ? eyeatt : (q == 2 ? upre : sigma));
             lz_v4 w = {__uint_as_float(mk_a1 | (mk_s1 << 16)), __uint_as_float(mk_s2 | (mk_c1 << 16)), __uint_as_float(mk_u1 | (mk_e1 << 8)), sc};
-            __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(stq + (H16 ? LZ_S16_MK : LZ_ST_MK)));
+            __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(sb + lz_tcol((H16 ? LZ_S16_MK : LZ_ST_MK) + 4 * q)));
             // the four lanes of a sample hold the same bits: all of them store (same address, same value), no lane-dependent branch
             lz_v4 cw = {cpre[0], cpre[1], cpre[2], 0.0f};
-            __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(strow + (H16 ? LZ_S16_CLR : LZ_ST_CLR)));
+            __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(sb + lz_tcol(H16 ? LZ_S16_CLR : LZ_ST_CLR)));
             sigmas[m] = sigma;
             amb_aud[m] = norm;
             if (amb_eye) amb_eye[m] = eyeatt;
@@ -392,23 +390,22 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         if (gs >= slice_hi) gs = slice_hi - 1;
         const uint32_t b = gs * 16 + s;
         const size_t row = b < M ? b : M - 1;
-        const float* strow = st + row * (H16 ? LZ_FWD_STATE16 : LZ_FWD_STATE);
-        const float* stq = strow + 4 * q;
+        const float* sb = lz_blk(st, gs, H16 ? LZ_FWD_STATE16 : LZ_FWD_STATE, s);   // lanes past the end read their (unwritten-or-stale) padding slot: never accumulated
         In in;
         const lz_v4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        in.att0 = ld4(stq + LZ_ST_ATT); in.att1 = ld4(stq + LZ_ST_ATT + 16);
+        in.att0 = ld4(sb + lz_tcol(LZ_ST_ATT + 4 * q)); in.att1 = ld4(sb + lz_tcol(LZ_ST_ATT + 16 + 4 * q));
         in.c2 = z; in.c3 = z; in.u1 = z; in.e = z;
         if constexpr (H16) {
-            in.c0 = ld4(stq + LZ_S16_C1); in.c1 = ld4(stq + LZ_S16_C1 + 16);
-            in.u0 = ld4(stq + LZ_S16_U1);
-            if (has_eye) in.e = ld4(stq + LZ_S16_E1);
+            in.c0 = ld4(sb + lz_tcol(LZ_S16_C1 + 4 * q)); in.c1 = ld4(sb + lz_tcol(LZ_S16_C1 + 16 + 4 * q));
+            in.u0 = ld4(sb + lz_tcol(LZ_S16_U1 + 4 * q));
+            if (has_eye) in.e = ld4(sb + lz_tcol(LZ_S16_E1 + 4 * q));
         } else {
-            in.c0 = ld4(stq + LZ_ST_C1); in.c1 = ld4(stq + LZ_ST_C1 + 16); in.c2 = ld4(stq + LZ_ST_C1 + 32); in.c3 = ld4(stq + LZ_ST_C1 + 48);
-            in.u0 = ld4(stq + LZ_ST_U1); in.u1 = ld4(stq + LZ_ST_U1 + 16);
-            if (has_eye) in.e = ld4(stq + LZ_ST_E1);
+            in.c0 = ld4(sb + lz_tcol(LZ_ST_C1 + 4 * q)); in.c1 = ld4(sb + lz_tcol(LZ_ST_C1 + 16 + 4 * q)); in.c2 = ld4(sb + lz_tcol(LZ_ST_C1 + 32 + 4 * q)); in.c3 = ld4(sb + lz_tcol(LZ_ST_C1 + 48 + 4 * q));
+            in.u0 = ld4(sb + lz_tcol(LZ_ST_U1 + 4 * q)); in.u1 = ld4(sb + lz_tcol(LZ_ST_U1 + 16 + 4 * q));
+            if (has_eye) in.e = ld4(sb + lz_tcol(LZ_ST_E1 + 4 * q));
         }
-        in.mk = ld4(stq + (H16 ? LZ_S16_MK : LZ_ST_MK));
-        in.clr = ld4(strow + (H16 ? LZ_S16_CLR : LZ_ST_CLR));
+        in.mk = ld4(sb + lz_tcol((H16 ? LZ_S16_MK : LZ_ST_MK) + 4 * q));
+        in.clr = ld4(sb + lz_tcol(H16 ? LZ_S16_CLR : LZ_ST_CLR));
         in.g_sig = A.g_sigma[row]; in.g_aa = A.g_amb_aud[row]; in.g_ae = A.g_amb_eye ? A.g_amb_eye[row] : 0.0f; in.g_un = A.g_unc[row];
         in.g_r0 = A.g_rgb[row * 3]; in.g_r1 = A.g_rgb[row * 3 + 1]; in.g_r2 = A.g_rgb[row * 3 + 2];
         return in;
@@ -421,8 +418,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         const bool valid = base + s < M;
         const uint32_t m = valid ? base + s : M - 1;   // clamped lanes repeat the last row: same values stored again, nothing accumulated
         const size_t row = m;
-        float* rec1 = O.rec + row * (H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC) + q;   // f16: rows counted in dwords
-        float* recq = rec1 + 3 * q;
+        float* rb = lz_blk(O.rec, slice_lo + (uint32_t)slice, H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC, s);   // f16: rows counted in dwords
         float* dencq = O.denc + (size_t)q * M + row;
         const In in = nx;
         const int next = grab();
@@ -486,10 +482,10 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 }
             {
                 if constexpr (H16) {
-                    lz_dump_pair_chained(recq, LZ_R16_G_C1H / 2, dc1, 0);
-                    lz_dump_pair_chained(recq, LZ_R16_G_C1H / 2 + 1, dc1, 2);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_C1H / 2, dc1, 0);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_C1H / 2 + 1, dc1, 2);
                 } else {
-                    lz_dump_chained<4>(recq, LZ_BWD_G_C1H, dc1);
+                    lz_dump_chained<4>(rb, q, LZ_BWD_G_C1H, dc1);
                 }
             }
             float dxc[21];
@@ -501,8 +497,8 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         if (valid) acc_ind += dind;
         const float dh0 = g_sig * sigma;
         {   // every q lane writes: columns 1..3 (f32) / 4 q (f16) of this tile are padding rows of dW
-            if constexpr (H16) lz_dump_pair(recq, LZ_R16_G_C1H / 2 + 2, dh0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);   // tile 4, column 0
-            else rec1[LZ_BWD_G_C1H + 64] = dh0;
+            if constexpr (H16) lz_dump_pair(rb + 4 * q, LZ_R16_G_C1H / 2 + 2, dh0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);   // tile 4, column 0
+            else rb[lz_tcol(LZ_BWD_G_C1H + 64 + q)] = dh0;
         }
         float dencx[9], dencw[8], determ;
         {
@@ -518,10 +514,10 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 }
             {
                 if constexpr (H16) {
-                    lz_dump_pair_chained(recq, LZ_R16_G_S2 / 2, ds2, 0);
-                    lz_dump_pair_chained(recq, LZ_R16_G_S2 / 2 + 1, ds2, 2);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_S2 / 2, ds2, 0);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_S2 / 2 + 1, ds2, 2);
                 } else {
-                    lz_dump_chained<4>(recq, LZ_BWD_G_S2, ds2);
+                    lz_dump_chained<4>(rb, q, LZ_BWD_G_S2, ds2);
                 }
             }
             float ds1[16];
@@ -530,10 +526,10 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             for (int k = 0; k < 16; k++) ds1[k] = ((mk_s1 >> k) & 1u) ? ds1[k] : 0.0f;
             {
                 if constexpr (H16) {
-                    lz_dump_pair_chained(recq, LZ_R16_G_S1 / 2, ds1, 0);
-                    lz_dump_pair_chained(recq, LZ_R16_G_S1 / 2 + 1, ds1, 2);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_S1 / 2, ds1, 0);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_S1 / 2 + 1, ds1, 2);
                 } else {
-                    lz_dump_chained<4>(recq, LZ_BWD_G_S1, ds1);
+                    lz_dump_chained<4>(rb, q, LZ_BWD_G_S1, ds1);
                 }
             }
             float dxs[18];
@@ -556,8 +552,8 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     if (valid) acc_enca[k] = lz_fmaf(att[k], dencw[k], acc_enca[k]);
                 }
             {
-                if constexpr (H16) lz_dump_pair_chained(recq, LZ_R16_G_ATT / 2, datt, 0);
-                else lz_dump_chained<2>(recq, LZ_BWD_G_ATT, datt);
+                if constexpr (H16) lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_ATT / 2, datt, 0);
+                else lz_dump_chained<2>(rb, q, LZ_BWD_G_ATT, datt);
             }
         }
         // uncertainty: unc = softplus(u); its input is detached (network.py:241-249): weight gradients only
@@ -587,11 +583,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         }
         {   // G_X = [aud_ch_att_net.0 64 | eye_att_net.0 16 | unc_net.0 32]: the last three tiles
             if constexpr (H16) {
-                lz_dump_pair(recq, LZ_R16_G_X / 2 + 2, de1[0], de1[1], de1[2], de1[3], du1[0], du1[1], du1[2], du1[3]);
-                lz_dump_pair(recq, LZ_R16_G_X / 2 + 3, du1[4], du1[5], du1[6], du1[7], 0.0f, 0.0f, 0.0f, 0.0f);
+                lz_dump_pair(rb + 4 * q, LZ_R16_G_X / 2 + 2, de1[0], de1[1], de1[2], de1[3], du1[0], du1[1], du1[2], du1[3]);
+                lz_dump_pair(rb + 4 * q, LZ_R16_G_X / 2 + 3, du1[4], du1[5], du1[6], du1[7], 0.0f, 0.0f, 0.0f, 0.0f);
             } else {
-                lz_dump_chained<1>(recq, LZ_BWD_G_X + 64, de1);
-                lz_dump_chained<2>(recq, LZ_BWD_G_X + 80, du1);
+                lz_dump_chained<1>(rb, q, LZ_BWD_G_X + 64, de1);
+                lz_dump_chained<2>(rb, q, LZ_BWD_G_X + 80, du1);
             }
         }
         {
@@ -601,10 +597,10 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             for (int k = 0; k < 16; k++) da1[k] = ((mk_a1 >> k) & 1u) ? da1[k] : 0.0f;
             {
                 if constexpr (H16) {
-                    lz_dump_pair_chained(recq, LZ_R16_G_X / 2, da1, 0);
-                    lz_dump_pair_chained(recq, LZ_R16_G_X / 2 + 1, da1, 2);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_X / 2, da1, 0);
+                    lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_X / 2 + 1, da1, 2);
                 } else {
-                    lz_dump_chained<4>(recq, LZ_BWD_G_X, da1);
+                    lz_dump_chained<4>(rb, q, LZ_BWD_G_X, da1);
                 }
             }
             float dxa[9];

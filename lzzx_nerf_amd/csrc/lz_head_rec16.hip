@@ -8,6 +8,7 @@
 // network.py:241-249) adds five fragments that are packed separately (lz_head_pack_unc_f16), so the inference image and kernels stay
 // as they are.  sigma / rgb / ambient outputs follow lz_k_triplane_head_f16 (same rounding sequence).
 #include "lz_head_f16_slice.h"
+#include "lz_head_bwd_common.h"   // lz_blk / lz_tcol: the blocked record layout
 
 typedef float lz_v4 __attribute__((ext_vector_type(4)));
 typedef uint32_t lz_u4 __attribute__((ext_vector_type(4)));
@@ -48,7 +49,7 @@ __device__ __forceinline__ void lz_dump_pair_h8(float* __restrict__ rowq, int pa
     const lz_u4 p = __builtin_bit_cast(lz_u4, b);
     const lz_u4 w = {__builtin_amdgcn_perm(p[2], p[0], 0x05040100u), __builtin_amdgcn_perm(p[2], p[0], 0x07060302u),
                      __builtin_amdgcn_perm(p[3], p[1], 0x05040100u), __builtin_amdgcn_perm(p[3], p[1], 0x07060302u)};
-    __builtin_nontemporal_store(__builtin_bit_cast(lz_v4, w), reinterpret_cast<lz_v4*>(rowq + 16 * pair));
+    __builtin_nontemporal_store(__builtin_bit_cast(lz_v4, w), reinterpret_cast<lz_v4*>(rowq + 256 * pair));
 }
 __device__ __forceinline__ float lz_pack_h2f(float lo, float hi) {
     typedef _Float16 lz_h2 __attribute__((ext_vector_type(2)));
@@ -58,7 +59,7 @@ __device__ __forceinline__ float lz_pack_h2f(float lo, float hi) {
 __device__ __forceinline__ void lz_dump_pair_f(float* __restrict__ rowq, int pair, float l0, float l1, float l2, float l3, float h0, float h1,
                                                float h2, float h3) {
     lz_v4 w = {lz_pack_h2f(l0, h0), lz_pack_h2f(l1, h1), lz_pack_h2f(l2, h2), lz_pack_h2f(l3, h3)};
-    __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(rowq + 16 * pair));
+    __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(rowq + 256 * pair));
 }
 // bit 8 p + j of a layer's mask <-> slot j of its B operand p <-> chained index 4 t + r (lz_head_bwd_common.h: lz_mask_pos)
 __device__ __forceinline__ uint32_t lz_mask_h8(const lz_h8& b) {
@@ -109,9 +110,8 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
     for (;;) {
         if (slice_lo + (uint32_t)slice >= slice_hi) break;
         const size_t row = row_of(slice);   // lanes past the end repeat the last row: the same values are stored again
-        float* recq = rec + row * (LZ_BWD_REC16 / 2) + 4 * q;
-        float* strow = st + row * LZ_FWD_STATE16;
-        float* stq = strow + 4 * q;
+        float* rb = lz_blk(rec, slice_lo + (uint32_t)slice, LZ_BWD_REC16 / 2, s);
+        float* sb = lz_blk(st, slice_lo + (uint32_t)slice, LZ_FWD_STATE16, s);
 
         float encx[9];
         lz_head_gather(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx);
@@ -136,8 +136,8 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             h_layer<H_A1>(hc.wl, lane, bx, a1);
             const lz_h8 b2[2] = {h_pair(a1[0], a1[1], true), h_pair(a1[2], a1[3], true)};
             mk_a1 = lz_mask_h8(b2[0]) | (lz_mask_h8(b2[1]) << 8);
-            lz_dump_pair_h8(recq, LZ_R16_X_A1 / 2, b2[0]);
-            lz_dump_pair_h8(recq, LZ_R16_X_A1 / 2 + 1, b2[1]);
+            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_A1 / 2, b2[0]);
+            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_A1 / 2 + 1, b2[1]);
             lz_f4 a2[2] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
             h_layer<H_A2>(hc.wl, lane, b2, a2);
 #pragma unroll
@@ -146,8 +146,8 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
         {
             lz_v4 w0 = {(float)att16[0], (float)att16[1], (float)att16[2], (float)att16[3]};
             lz_v4 w1 = {(float)att16[4], (float)att16[5], (float)att16[6], (float)att16[7]};
-            __builtin_nontemporal_store(w0, reinterpret_cast<lz_v4*>(stq + LZ_ST_ATT));
-            __builtin_nontemporal_store(w1, reinterpret_cast<lz_v4*>(stq + LZ_ST_ATT + 16));
+            __builtin_nontemporal_store(w0, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_ST_ATT + 4 * q)));
+            __builtin_nontemporal_store(w1, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_ST_ATT + 16 + 4 * q)));
         }
         float ss = 0.0f;
 #pragma unroll
@@ -164,7 +164,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             const lz_f4 z = lz_f4{0, 0, 0, 0};
             const lz_h8 be[1] = {h_pair(e1[0], z, true)};
             mk_e1 = lz_mask_h8(be[0]) & 0xfu;
-            lz_dump_pair_h8(stq, LZ_S16_E1 / 16, be[0]);
+            lz_dump_pair_h8(sb + 4 * q, LZ_S16_E1 / 16, be[0]);
             lz_f4 e2[1] = {lz_f4{0, 0, 0, 0}};
             h_layer<H_E2>(hc.wl, lane, be, e2);
             eyeatt = (float)(_Float16)h_sigmoid((float)(_Float16)e2[0][0]);   // lanes q == 0
@@ -178,7 +178,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             h_layer_at<2, 2>(wl_unc, lane, bx, u1);
             const lz_h8 bu[1] = {h_pair(u1[0], u1[1], true)};
             mk_u1 = lz_mask_h8(bu[0]);
-            lz_dump_pair_h8(stq, LZ_S16_U1 / 16, bu[0]);
+            lz_dump_pair_h8(sb + 4 * q, LZ_S16_U1 / 16, bu[0]);
             lz_f4 u2[1] = {lz_f4{0, 0, 0, 0}};
             h_layer_at<1, 1>(wl_unc + 4 * 64, lane, bu, u2);
             upre = __shfl((float)(_Float16)u2[0][0], s, 64);
@@ -196,22 +196,22 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             for (int j = 0; j < 8; j++) b1[2][j] = (_Float16)(hc.lenca[16 * (j >> 2) + 4 * q + (j & 3)] * (float)att16[j]);
             // sigma_net.0 input in the record's arrangement (lz_head_rec.hip: tiles 0, 1 enc_x, tile 2 feature 32 + q and the eye term,
             // tiles 3, 4 enc_a * att); the conversions to half repeat the ones above, value for value
-            lz_dump_pair_f(recq, LZ_R16_X_SIG0 / 2, encx[0], encx[2], encx[4], encx[6], encx[1], encx[3], encx[5], encx[7]);
-            lz_dump_pair_f(recq, LZ_R16_X_SIG0 / 2 + 1, encx[8], (float)b1[1][1], 0.0f, 0.0f, (float)b1[2][0], (float)b1[2][1], (float)b1[2][2],
+            lz_dump_pair_f(rb + 4 * q, LZ_R16_X_SIG0 / 2, encx[0], encx[2], encx[4], encx[6], encx[1], encx[3], encx[5], encx[7]);
+            lz_dump_pair_f(rb + 4 * q, LZ_R16_X_SIG0 / 2 + 1, encx[8], (float)b1[1][1], 0.0f, 0.0f, (float)b1[2][0], (float)b1[2][1], (float)b1[2][2],
                            (float)b1[2][3]);
-            lz_dump_pair_f(recq, LZ_R16_X_SIG0 / 2 + 2, (float)b1[2][4], (float)b1[2][5], (float)b1[2][6], (float)b1[2][7], 0.0f, 0.0f, 0.0f, 0.0f);
+            lz_dump_pair_f(rb + 4 * q, LZ_R16_X_SIG0 / 2 + 2, (float)b1[2][4], (float)b1[2][5], (float)b1[2][6], (float)b1[2][7], 0.0f, 0.0f, 0.0f, 0.0f);
             lz_f4 s1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
             h_layer<H_S1>(hc.wl, lane, b1, s1);
             const lz_h8 b2[2] = {h_pair(s1[0], s1[1], true), h_pair(s1[2], s1[3], true)};
             mk_s1 = lz_mask_h8(b2[0]) | (lz_mask_h8(b2[1]) << 8);
-            lz_dump_pair_h8(recq, LZ_R16_X_S1 / 2, b2[0]);
-            lz_dump_pair_h8(recq, LZ_R16_X_S1 / 2 + 1, b2[1]);
+            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_S1 / 2, b2[0]);
+            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_S1 / 2 + 1, b2[1]);
             lz_f4 s2[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
             h_layer<H_S2>(hc.wl, lane, b2, s2);
             const lz_h8 b3[2] = {h_pair(s2[0], s2[1], true), h_pair(s2[2], s2[3], true)};
             mk_s2 = lz_mask_h8(b3[0]) | (lz_mask_h8(b3[1]) << 8);
-            lz_dump_pair_h8(recq, LZ_R16_X_S2C / 2, b3[0]);
-            lz_dump_pair_h8(recq, LZ_R16_X_S2C / 2 + 1, b3[1]);
+            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_S2C / 2, b3[0]);
+            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_S2C / 2 + 1, b3[1]);
             lz_f4 s3[5] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
             h_layer<H_S3>(hc.wl, lane, b3, s3);
             geo16[0] = h_pair(s3[0], s3[1], false);
@@ -234,14 +234,14 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             b1[1] = geo16[0];
             b1[2] = geo16[1];
             // colour_net.0's SH / ind columns as the record keeps them: SH component 4 r + q at column 4 q + r, ind_code[q] at column 4 q
-            lz_dump_pair_f(recq, LZ_R16_X_S2C / 2 + 2, shfn.comp_iq(0, q), shfn.comp_iq(1, q), shfn.comp_iq(2, q), shfn.comp_iq(3, q), indq, 0.0f, 0.0f,
+            lz_dump_pair_f(rb + 4 * q, LZ_R16_X_S2C / 2 + 2, shfn.comp_iq(0, q), shfn.comp_iq(1, q), shfn.comp_iq(2, q), shfn.comp_iq(3, q), indq, 0.0f, 0.0f,
                            0.0f);
             lz_f4 c1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
             h_layer<H_C1>(hc.wl, lane, b1, c1);
             const lz_h8 b2[2] = {h_pair(c1[0], c1[1], true), h_pair(c1[2], c1[3], true)};
             mk_c1 = lz_mask_h8(b2[0]) | (lz_mask_h8(b2[1]) << 8);
-            lz_dump_pair_h8(stq, LZ_S16_C1 / 16, b2[0]);
-            lz_dump_pair_h8(stq, LZ_S16_C1 / 16 + 1, b2[1]);
+            lz_dump_pair_h8(sb + 4 * q, LZ_S16_C1 / 16, b2[0]);
+            lz_dump_pair_h8(sb + 4 * q, LZ_S16_C1 / 16 + 1, b2[1]);
             lz_f4 c2[1] = {lz_f4{0, 0, 0, 0}};
             h_layer<H_C2>(hc.wl, lane, b2, c2);
 #pragma unroll
@@ -251,9 +251,9 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
         {
             const float sc = q == 0 ? norm : (q == 1 ? eyeatt : (q == 2 ? upre : sigma));
             lz_v4 w = {__uint_as_float(mk_a1 | (mk_s1 << 16)), __uint_as_float(mk_s2 | (mk_c1 << 16)), __uint_as_float(mk_u1 | (mk_e1 << 8)), sc};
-            __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(stq + LZ_S16_MK));
+            __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_S16_MK + 4 * q)));
             lz_v4 cw = {cpre[0], cpre[1], cpre[2], 0.0f};
-            __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(strow + LZ_S16_CLR));
+            __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_S16_CLR)));
             sigmas[row] = sigma;
             amb_aud[row] = norm;
             if (amb_eye) amb_eye[row] = eyeatt;

@@ -48,6 +48,7 @@ class _FusedHeadTrain(Function):
         kw = dict(dtype=torch.float32, device=dev)
         sig, rgb, aa, ae, un = torch.empty(M, **kw), torch.empty(M, 3, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw)
         ctx.rec = ctx.state = None
+        Mb = (M + 15) // 16 * 16   # records and state are blocked by 16-sample slice: whole slices
         if M > 0 and mod.forward_f16:
             # forward in the reference's autocast arithmetic on the f16 matrix cores (lz_head_rec16.hip); the backward below runs its
             # f32 data-gradient chain from the state this forward records
@@ -55,15 +56,15 @@ class _FusedHeadTrain(Function):
             call("lz_head_pack_unc_f16", ptr(w[9]), ptr(w[10]), ptr(mod.packed_unc16), stream())
             p16 = mod._params(emb, enc_a_f, ind_f, eye_f)
             p16.packed, p16.precision = mod.packed16.data_ptr(), 1
-            ctx.rec, ctx.state = torch.empty(M, _REC16, dtype=torch.float16, device=dev), torch.empty(M, _STATE16, **kw)
+            ctx.rec, ctx.state = torch.empty(Mb, _REC16, dtype=torch.float16, device=dev), torch.empty(Mb, _STATE16, **kw)
             call("lz_triplane_head_forward_record_f16", C.byref(p16), ptr(mod.packed_unc16), ptr(xyzs), ptr(dirs), M, ptr(sig), ptr(rgb), ptr(aa),
                  ptr(ae), ptr(un), ptr(ctx.rec), ptr(ctx.state), stream())
         elif M > 0 and mod.record:
             # held until the backward consumes them (not through save_for_backward: nothing else may alias or modify them)
             if mod.record_f16:
-                ctx.rec, ctx.state = torch.empty(M, _REC16, dtype=torch.float16, device=dev), torch.empty(M, _STATE16, **kw)
+                ctx.rec, ctx.state = torch.empty(Mb, _REC16, dtype=torch.float16, device=dev), torch.empty(Mb, _STATE16, **kw)
             else:
-                ctx.rec, ctx.state = torch.empty(M, _REC, **kw), torch.empty(M, _STATE, **kw)
+                ctx.rec, ctx.state = torch.empty(Mb, _REC, **kw), torch.empty(Mb, _STATE, **kw)
             call("lz_triplane_head_forward_record", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un),
                  ptr(ctx.rec), ptr(ctx.state), int(mod.record_f16), stream())
         elif M > 0:   # an empty batch (every ray missed the box) has empty outputs and zero gradients
@@ -102,7 +103,7 @@ class _FusedHeadTrain(Function):
             raise RuntimeError("FusedTriplaneTrainHead(record=True): a second backward through the same forward needs record=False "
                                "(the recomputing backward keeps nothing between the two)")
         # one record per sample: every layer input / output gradient the reductions need (the X half is there already in record mode)
-        rec = ctx.rec if ctx.rec is not None else torch.empty(M, _REC, **kw)
+        rec = ctx.rec if ctx.rec is not None else torch.empty((M + 15) // 16 * 16, _REC, **kw)
         denc = torch.empty(3, 12, M, **kw)          # level-major: the grid backward reads one level at a time
         small = torch.zeros(32 + 4 + 16 + 32 + 192, **kw)   # d_enc_a | d_ind | dW of the three skinny output layers (reduced in the kernel)
         d_enc_a, d_ind, dw_e2, dw_u2, dw_c2 = small[:32], small[32:36], small[36:52], small[52:84], small[84:]
