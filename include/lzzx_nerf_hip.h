@@ -337,7 +337,7 @@ int lz_linear_grad_w(const float* dY, uint32_t ldd, const float* mask, const flo
  *   small  [LZ_BWD_SMALL]  sums over the samples, reduced INSIDE the kernel (registers -> LDS -> one atomic per element and workgroup;
  *          zero it first): d_enc_a [32] | d_ind_code [4] | then the weight gradients of the three skinny output layers
  *          eye_att_net.1 [16] | unc_net.1 [32] | color_net.1 [3,64]
- *   rec    [M, LZ_BWD_REC]  one record per sample (16-byte aligned) holding the input X of the wide Linear layers and the gradient G
+ *   rec    [ceil(M / 16) * 16, LZ_BWD_REC]  one record per sample (16-byte aligned) holding the input X of the wide Linear layers and the gradient G
  *          of their outputs (ReLU mask applied), consumed by lz_triplane_head_grad_w.  One buffer, fixed columns: the kernel needs one
  *          address per sample and immediate offsets (separate buffers cost it two address registers each, spilled), every slot
  *          starts on a 64-byte boundary:
@@ -351,6 +351,9 @@ int lz_linear_grad_w(const float* dY, uint32_t ldd, const float* mask, const flo
  *            LZ_BWD_G_C1H  [65]  = [color_net.0 64 | sigma row of sigma_net.2 1]
  *          Neither geo nor d geo is stored: both are linear maps of stored columns, so their weight gradients are finished from the
  *          64 x 64 sum R = G_c1^T s2 (lz_triplane_head_grad_w).  2 624 bytes per sample (3 664 with one buffer per layer). */
+/* MEMORY ORDER of rec (and of the state buffer below): blocked by 16-sample slice, [slice][tile of 16 dwords][sample 16][16 dwords] --
+ * column c of sample m sits at dword (m / 16) * 16 * ROW + (c / 16) * 256 + (m % 16) * 16 + c % 16 (ROW = dwords per sample) -- so that
+ * a wave's store / load instruction (16 samples x 4 lanes x 16 bytes) covers one contiguous kilobyte.  Buffers hold whole slices. */
 #define LZ_BWD_REC 656
 #define LZ_BWD_SMALL 276
 #define LZ_BWD_X_A1 0
@@ -373,7 +376,7 @@ int lz_triplane_head_backward(const lz_head_params* p, const float* xyzs, const 
 /* The same step without the recompute (lz_head_rec.hip): the forward records, the backward starts from the record.
  * lz_triplane_head_forward_record = lz_triplane_head_forward in training mode (same bits in the five outputs) that also writes the X
  * columns of rec [M, LZ_BWD_REC] (LZ_BWD_X_*: what the recomputing backward wrote itself) and one state row per sample:
- *   state  [M, LZ_FWD_STATE] (16-byte aligned), columns in the lane layout of the kernels (feature 16 t + 4 q + r at 16 t + 4 q + r):
+ *   state  [ceil(M / 16) * 16, LZ_FWD_STATE] (16-byte aligned, blocked by slice like rec), columns in the lane layout of the kernels (feature 16 t + 4 q + r at 16 t + 4 q + r):
  *            LZ_ST_ATT [32] aud_ch_att_net output   LZ_ST_C1 [64] input of color_net.1   LZ_ST_U1 [32] input of unc_net.1
  *            LZ_ST_E1  [16] input of eye_att_net.1 (unwritten without an eye input)
  *            LZ_ST_MK  [16] four words per q: ReLU masks aud.0 | sigma.0 << 16, sigma.1 | color.0 << 16, unc.0 | eye.0 << 8, and one
