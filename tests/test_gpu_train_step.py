@@ -681,3 +681,53 @@ def test_fused_train_head_tiny_batches_all_arrangements(params, golden, M):
             for k in g_ref:
                 scale = float(g_ref[k].abs().max()) + 1e-30
                 assert float((g[k] - g_ref[k]).abs().max()) / scale < (2e-3 if kw else 1e-5), (kw, k)
+
+
+@pytest.mark.parametrize("M,k_sig0", [(1, 69), (3, 68), (15, 69), (16, 69), (1000, 68), (70001, 69)])
+def test_head_grad_w_f16_products_match_float64(M, k_sig0):
+    """lz_triplane_head_grad_w_f16 on random half records built here from the documented layout (LZ_R16_*: 16-column tiles interleaved in
+    pairs, a few natural-layout inputs regrouped; buffers blocked by 16-sample slice): the five products against float64 matmuls of the
+    logical matrices.  Padding tiles / columns and the rows past M hold NaN: none of it may reach a written output."""
+    from lzzx_nerf_amd import _lib
+    from lzzx_nerf_amd._util import call, ptr, stream
+    g = torch.Generator(device="cuda").manual_seed(100 + M)
+    h = lambda *sh: torch.randn(*sh, device="cuda", generator=g).half()
+    enc_x, enc_w, eye, a1, s1, s2, sh, ind = h(M, 36), h(M, 32), h(M), h(M, 64), h(M, 64), h(M, 64), h(M, 16), h(M, 4)
+    g_x, g_att, g_s1, g_s2, g_c1, dh0 = h(M, 112), h(M, 32), h(M, 64), h(M, 64), h(M, 64), h(M)
+    T = torch.full((M, 44, 16), float("nan"), device="cuda", dtype=torch.float16)   # logical tiles of 16 columns
+    put = lambda t0, mat: T[:, t0:t0 + mat.shape[1] // 16].copy_(mat.reshape(M, -1, 16))
+    put(0, a1)                                               # X_A1
+    j = torch.arange(16, device="cuda")
+    for p in (0, 1):                                         # X_SIG0 tiles 0, 1: enc_x feature 8 (j % 4) + 4 p + j / 4 at column j
+        T[:, 4 + p] = enc_x[:, 8 * (j % 4) + 4 * p + j // 4]
+    T[:, 6] = 0
+    T[:, 6, 0::4] = enc_x[:, 32:36]                          # tile 2: feature 32 + q at column 4 q, the eye term at column 1
+    T[:, 6, 1] = eye
+    put(7, enc_w)                                            # tiles 3, 4: enc_a * att
+    put(10, s1)                                              # X_S1
+    put(14, s2)                                              # X_S2C: s2 | SH component 4 (j % 4) + j / 4 at column j | ind q at column 4 q
+    T[:, 18] = sh[:, 4 * (j % 4) + j // 4]
+    T[:, 19] = 0
+    T[:, 19, 0::4] = ind
+    put(20, g_x)                                             # G_X 7 tiles (+ 1 padding)
+    put(28, g_att)
+    put(30, g_s1)
+    put(34, g_s2)
+    put(38, g_c1)                                            # G_C1H: colour.0 gradient | d h0 at column 0 of the fifth tile
+    T[:, 42, 0] = dh0
+    Mb = (M + 15) // 16 * 16
+    pairs = torch.full((Mb, 22, 16, 2), float("nan"), device="cuda", dtype=torch.float16)
+    pairs[:M] = T.reshape(M, 22, 2, 16).permute(0, 1, 3, 2)  # dword j of pair g = {tile 2 g column j, tile 2 g + 1 column j}
+    rec = pairs.reshape(Mb // 16, 16, 22, 32).permute(0, 2, 1, 3).contiguous()   # [slice][pair][sample][16 dwords]
+    shapes = dict(x3=(112, 36), aud1=(32, 64), sig0=(64, k_sig0), sig1=(64, 64), c1h=(65, 84))
+    out = {n: torch.full(shp, 7.0, device="cuda") for n, shp in shapes.items()}
+    ws = torch.empty(_lib.load().lz_triplane_head_grad_w_workspace() // 4, device="cuda")
+    call("lz_triplane_head_grad_w_f16", ptr(rec), M, k_sig0, *[ptr(out[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")], ptr(ws), stream())
+    d = lambda t: t.double()
+    x_sig0 = torch.cat([d(enc_x), d(enc_w)] + ([d(eye)[:, None]] if k_sig0 == 69 else []), 1)
+    want = dict(x3=d(g_x).T @ d(enc_x), aud1=d(g_att).T @ d(a1), sig0=d(g_s1).T @ x_sig0, sig1=d(g_s2).T @ d(s1),
+                c1h=torch.cat([d(g_c1), d(dh0)[:, None]], 1).T @ torch.cat([d(s2), d(sh), d(ind)], 1))
+    for n in shapes:
+        got = out[n].double()
+        assert torch.isfinite(got).all(), n
+        assert float((got - want[n]).abs().max()) <= 2e-5 * float(want[n].abs().max()) + 1e-6, n
