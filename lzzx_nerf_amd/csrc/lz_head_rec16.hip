@@ -61,12 +61,16 @@ __device__ __forceinline__ void lz_dump_pair_f(float* __restrict__ rowq, int pai
     lz_v4 w = {lz_pack_h2f(l0, h0), lz_pack_h2f(l1, h1), lz_pack_h2f(l2, h2), lz_pack_h2f(l3, h3)};
     __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(rowq + 256 * pair));
 }
-// bit 8 p + j of a layer's mask <-> slot j of its B operand p <-> chained index 4 t + r (lz_head_bwd_common.h: lz_mask_pos)
+// bit 8 p + j of a layer's mask <-> slot j of its B operand p <-> chained index 4 t + r (lz_head_bwd_common.h: lz_mask_pos).  The operand is
+// what ReLU left: halves >= +0, so "positive" is "bit pattern not zero" -- an unsigned 16-bit min with 1 per packed pair, then the
+// eight 0 / 1 halves are folded into one byte (10 instructions; a compare + select + or per half costs 17)
 __device__ __forceinline__ uint32_t lz_mask_h8(const lz_h8& b) {
-    uint32_t mk = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) mk |= (b[j] > (_Float16)0.0f) ? (1u << j) : 0u;
-    return mk;
+    typedef unsigned short lz_us8 __attribute__((ext_vector_type(8)));
+    const lz_us8 one = {1, 1, 1, 1, 1, 1, 1, 1};
+    // whole-vector operations only: a bit_cast of a single vector ELEMENT to a 2-vector was miscompiled here (see lz_head_rec.hip)
+    const lz_u4 q = __builtin_bit_cast(lz_u4, __builtin_elementwise_min(__builtin_bit_cast(lz_us8, b), one));   // halves 2 d, 2 d + 1 of dword d -> 0 / 1
+    const uint32_t m = q[0] | (q[1] << 2) | (q[2] << 4) | (q[3] << 6);                                          // bits 2 d and 16 + 2 d
+    return (m | (m >> 15)) & 0xffu;
 }
 
 __global__ void __launch_bounds__(LZ_FREC16_WG, 1)
