@@ -48,6 +48,7 @@ class _FusedHeadTrain(Function):
         kw = dict(dtype=torch.float32, device=dev)
         sig, rgb, aa, ae, un = torch.empty(M, **kw), torch.empty(M, 3, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw)
         ctx.rec = ctx.state = None
+        ctx.recompute = not mod.record
         Mb = (M + 15) // 16 * 16   # records and state are blocked by 16-sample slice: whole slices
         if M > 0 and mod.forward_f16:
             # forward in the reference's autocast arithmetic on the f16 matrix cores (lz_head_rec16.hip); the backward below runs its
@@ -61,13 +62,21 @@ class _FusedHeadTrain(Function):
                  ptr(ae), ptr(un), ptr(ctx.rec), ptr(ctx.state), stream())
         elif M > 0 and mod.record:
             # held until the backward consumes them (not through save_for_backward: nothing else may alias or modify them)
-            if mod.record_f16:
-                ctx.rec, ctx.state = torch.empty(Mb, _REC16, dtype=torch.float16, device=dev), torch.empty(Mb, _STATE16, **kw)
-            else:
-                ctx.rec, ctx.state = torch.empty(Mb, _REC, **kw), torch.empty(Mb, _STATE, **kw)
+            try:
+                if mod.record_f16:
+                    ctx.rec, ctx.state = torch.empty(Mb, _REC16, dtype=torch.float16, device=dev), torch.empty(Mb, _STATE16, **kw)
+                else:
+                    ctx.rec, ctx.state = torch.empty(Mb, _REC, **kw), torch.empty(Mb, _STATE, **kw)
+            except torch.cuda.OutOfMemoryError:
+                if mod.record_f16:
+                    raise
+                # 3.3 KB per sample do not fit: this step runs the recomputing pair instead (same gradients, nothing held)
+                ctx.rec = ctx.state = None
+                ctx.recompute = True
+        if M > 0 and mod.record and not mod.forward_f16 and ctx.rec is not None:
             call("lz_triplane_head_forward_record", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un),
                  ptr(ctx.rec), ptr(ctx.state), int(mod.record_f16), stream())
-        elif M > 0:   # an empty batch (every ray missed the box) has empty outputs and zero gradients
+        elif M > 0 and not mod.forward_f16:   # an empty batch (every ray missed the box) has empty outputs and zero gradients
             call("lz_triplane_head_forward", C.byref(p), ptr(xyzs), ptr(dirs), M, None, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un), stream())
         # save_for_backward (not attributes): autograd then detects an in-place update of a weight / table between forward and
         # backward (detach() shares the version counter), and the tensors are released with the graph
@@ -98,7 +107,7 @@ class _FusedHeadTrain(Function):
             return (None, None, None, g_enc_a, g_ind, None) + tuple(torch.zeros_like(t) for t in emb) + tuple(torch.zeros_like(t) for t in w)
         z = lambda g, shape: (torch.zeros(shape, **kw) if g is None else g.float().contiguous())
         g_sig, g_rgb, g_aa, g_ae, g_un = z(g_sig, (M,)), z(g_rgb, (M, 3)), z(g_aa, (M, 1)), z(g_ae, (M, 1)), z(g_un, (M, 1))
-        if mod.record and ctx.rec is None:
+        if not ctx.recompute and ctx.rec is None:
             # the record and state of this forward were consumed (and released) by an earlier backward
             raise RuntimeError("FusedTriplaneTrainHead(record=True): a second backward through the same forward needs record=False "
                                "(the recomputing backward keeps nothing between the two)")
