@@ -597,6 +597,21 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             result["reference_schedule"] = leg
         except Exception as exc:
             err("reference_schedule", exc)
+    if args.precision == "f32" and args.mode == "fused" and not args.no_fat_schedule:
+        try:
+            # the same frame with geo = Wg s2 folded into color_net.0 at pack time (head.py fold_geo, precision 2): 297 instead of 361
+            # MFMAs per slice; sigma, sample counts, weights and depth are the headline's bit for bit, rgb moves by the reassociation
+            hf = FusedTriplaneHead(sd, bound=1.0, device=device, fold_geo=True)
+            leg, imgf, fms, fst = side_leg(hf, args.budget_factor, args.n_step_cap, mode="fused")
+            leg["max_abs_diff_vs_headline_image"] = float((imgf - image).abs().max())
+            leg["samples_equal_to_headline"] = bool(int(fst[5]) == samples_per_frame)
+            # FLOP_PER_SAMPLE is the reference network's count; the folded kernel issues 8 192 FLOP per sample fewer
+            leg["frac_of_f32_mfma_peak_algorithmic"] = round(FLOP_PER_SAMPLE * int(fst[5]) * args.steps / (fms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)
+            leg["frac_of_f32_mfma_peak_executed"] = round((FLOP_PER_SAMPLE - 8192) * int(fst[5]) * args.steps / (fms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)
+            result["folded_geo"] = leg
+            del hf
+        except Exception as exc:
+            err("folded_geo", exc)
     h16 = None
     log("leg: if args.precision == 'f32' and not args.no_fp16_leg:")
     if args.precision == "f32" and not args.no_fp16_leg:

@@ -229,7 +229,10 @@ typedef struct {
     uint32_t H;               /* base resolution (64) */
     int testing;              /* 1: uncertainty = softplus(0) constant (network.py:243-249) */
     int precision;            /* 0: f32 MFMA, bit-exact fma chains.  1: f16 MFMA with the rounding sequence of the reference
-                               * under torch autocast (opt.fp16): half Linear inputs/weights/outputs, f32 accumulate; inference only */
+                               * under torch autocast (opt.fp16): half Linear inputs/weights/outputs, f32 accumulate; inference only.
+                               * 2: f32 MFMA with geo = Wg s2 folded into color_net.0 -- pack color_net.0 with its geo columns replaced
+                               * by W_c0[:, 16:80] . sigma_net.2[1:65] (64 x 64); sigma_net.2's geo rows are then not evaluated (64 of
+                               * 361 MFMAs per 16 samples).  Inference only; sigma bit for bit as precision 0, rgb to the reassociation */
 } lz_head_params;
 
 /* host-side helper: number of floats lz_head_pack_weights writes */

@@ -180,6 +180,12 @@ template <> struct LzfHead<0> {
         lz_head_slice<false>(c, lane, x, y, z, f, o);
     }
 };
+template <> struct LzfHead<2> : LzfHead<0> {   // f32 with the geo projection folded into colour_net.0 (lz_head_slice.h: FOLD)
+    template <typename ShFn>
+    __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
+        lz_head_slice<false, true>(c, lane, x, y, z, f, o);
+    }
+};
 template <> struct LzfHead<1> {
     using Args = LzHead16Args; using Ctx = LzHead16Ctx; using Out = LzHead16Out;
     static constexpr int LDS_WORDS = LZ_HEAD16_LDS_H8 * 4;
@@ -484,7 +490,7 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
                LZ_ERR_BAD_ARGUMENT, "frame_render: incomplete lz_frame_fused");
     LZ_REQUIRE(p->emb_xy && p->emb_yz && p->emb_xz && p->offsets && p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT, "frame_render: incomplete lz_head_params");
     LZ_REQUIRE(p->testing, LZ_ERR_UNSUPPORTED, "frame_render: inference only (head.testing must be 1)");
-    LZ_REQUIRE(p->precision == 0 || p->precision == 1, LZ_ERR_BAD_ARGUMENT, "frame_render: precision must be 0 (f32) or 1 (f16)");
+    LZ_REQUIRE(p->precision >= 0 && p->precision <= 2, LZ_ERR_BAD_ARGUMENT, "frame_render: precision must be 0 (f32), 1 (f16) or 2 (f32, folded geo)");
     LZ_REQUIRE(f->C >= 1 && f->C <= 8 && f->H > 0, LZ_ERR_BAD_ARGUMENT, "frame_render: cascade must be in [1, 8]");
     if (f->N == 0) return LZ_OK;
     hipStream_t st = lz_st(stream);
@@ -547,7 +553,7 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
         a.offsets = p->offsets; a.packed = reinterpret_cast<const float*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code; a.eye = p->eye;
         a.bound = p->bound; a.testing = 1;
         lzf_level_tables(p, a.scale, a.res);
-        LZF_SWITCH(0)
+        if (p->precision == 2) { LZF_SWITCH(2) } else { LZF_SWITCH(0) }
     }
 #undef LZF_SWITCH
 #undef LZF_LAUNCH

@@ -165,7 +165,7 @@ extern "C" int lz_head_pack_weights_bwd_f16(const float* aud0, const float* aud1
 // recent launch spent in the kernel -> the sustained shader clock under this kernel's load (lz_debug_head_clocks)
 __device__ unsigned long long lz_head_probe[2];
 
-template <bool TRAIN_UNC>
+template <bool TRAIN_UNC, bool FOLD = false>
 __global__ void __launch_bounds__(LZ_WG, LZ_WG / 256)
 lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M,
                    const int* __restrict__ count, float* __restrict__ sigmas, float* __restrict__ rgbs,
@@ -209,7 +209,7 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
         if (m >= Meff) m = Meff - 1;  // clamp: computed, never stored
         const float px = xyzs[(size_t)m * 3], py = xyzs[(size_t)m * 3 + 1], pz = xyzs[(size_t)m * 3 + 2];
         LzHeadOut o;
-        lz_head_slice<TRAIN_UNC>(ctx, lane, px, py, pz,
+        lz_head_slice<TRAIN_UNC, FOLD>(ctx, lane, px, py, pz,
                                  lz_sh_from_dir([&](float& dx, float& dy, float& dz) { dx = dirs[(size_t)m * 3]; dy = dirs[(size_t)m * 3 + 1]; dz = dirs[(size_t)m * 3 + 2]; }), o);
         // ---------------- store (lanes q == 0 own sample s) ----------------
         if (q == 0 && base + s < Meff) {
@@ -247,7 +247,8 @@ extern "C" int lz_triplane_head_forward(const lz_head_params* p, const float* xy
         LZ_CHECK_LAUNCH("triplane_head_forward(f16)");
         return LZ_OK;
     }
-    LZ_REQUIRE(p->precision == 0, LZ_ERR_BAD_ARGUMENT, "triplane_head_forward: precision must be 0 (f32) or 1 (f16)");
+    LZ_REQUIRE(p->precision == 0 || p->precision == 2, LZ_ERR_BAD_ARGUMENT, "triplane_head_forward: precision must be 0 (f32), 1 (f16) or 2 (f32, folded geo)");
+    LZ_REQUIRE(p->precision == 0 || p->testing, LZ_ERR_UNSUPPORTED, "triplane_head_forward: the folded colour net is inference-only");
     LzHeadArgs a;
     a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
     a.offsets = p->offsets; a.packed = reinterpret_cast<const float*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code; a.eye = p->eye;
@@ -266,7 +267,9 @@ extern "C" int lz_triplane_head_forward(const lz_head_params* p, const float* xy
     }
     const uint32_t tiles = lz_div_up(M, LZ_WG_SAMPLES);
     const uint32_t grid = tiles < (uint32_t)n_cu ? tiles : (uint32_t)n_cu;
-    if (p->testing)
+    if (p->precision == 2)
+        hipLaunchKernelGGL((lz_k_triplane_head<false, true>), dim3(grid), dim3(LZ_WG), 0, lz_st(stream), a, xyzs, dirs, M, count, sigmas, rgbs, amb_aud, amb_eye, unc);
+    else if (p->testing)
         hipLaunchKernelGGL((lz_k_triplane_head<false>), dim3(grid), dim3(LZ_WG), 0, lz_st(stream), a, xyzs, dirs, M, count, sigmas, rgbs, amb_aud, amb_eye, unc);
     else
         hipLaunchKernelGGL((lz_k_triplane_head<true>), dim3(grid), dim3(LZ_WG), 0, lz_st(stream), a, xyzs, dirs, M, count, sigmas, rgbs, amb_aud, amb_eye, unc);

@@ -88,8 +88,13 @@ __device__ __forceinline__ LzShFromDir<DirFn> lz_sh_from_dir(DirFn f) { return L
 
 // one slice: (px, py, pz) = this lane's sample position; shfn supplies SH(4) of its view direction when the colour net needs it
 // (LzShFromDir: evaluated here from the direction, like the reference per sample; the fused frame kernel reads it per ray from LDS)
-template <bool TRAIN_UNC, typename ShFn>
+// FOLD (inference only): geo = Wg s2 feeds colour_net.0 with nothing but a linear map in between (network.py:304-306), so
+// W_c0[:, geo] (Wg s2) = (W_c0[:, geo] Wg) s2: the host packs the 64 x 64 product into colour_net.0's geo columns (head.py: fold_geo) and
+// the slice hands s2 to the colour net directly -- 64 of the 361 MFMAs per slice are never issued.  sigma (the VALU row of sigma_net.2 on
+// s2) is unchanged bit for bit; rgb moves by the reassociation, a few 1e-7.
+template <bool TRAIN_UNC, bool FOLD = false, typename ShFn>
 __device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, float px, float py, float pz, ShFn shfn, LzHeadOut& out) {
+    static_assert(!(TRAIN_UNC && FOLD), "the folded colour net is an inference arrangement");
     constexpr int WV = LzHeadLds<TRAIN_UNC>::WV;
     const int q = lane >> 4;
     // ---------------- gather: enc_x features f = 4i + q of sample s -> B operands (lz_head_gather.h) ----------------
@@ -217,20 +222,27 @@ __device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, flo
             for (int ft = 0; ft < 4; ft++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) b3[j][4 * ft + r] = lz_relu(acc2[ft][j][r]);
-        lz_f4 acc3[4][LZ_T];
+        if constexpr (FOLD) {
 #pragma unroll
-        for (int ft = 0; ft < 4; ft++)
+            for (int j = 0; j < LZ_T; j++)
 #pragma unroll
-            for (int j = 0; j < LZ_T; j++) acc3[ft][j] = lz_f4{0, 0, 0, 0};
-        lz_layer<LZ_L_S3, LZ_T>(hc.wl, lane, b3, acc3);
-#pragma unroll
-        for (int j = 0; j < LZ_T; j++) {
+                for (int k = 0; k < 16; k++) geo[j][k] = b3[j][k];   // s2 itself: the geo projection lives in the packed colour_net.0
+        } else {
+            lz_f4 acc3[4][LZ_T];
 #pragma unroll
             for (int ft = 0; ft < 4; ft++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) geo[j][4 * ft + r] = acc3[ft][j][r];   // geo_feat, no activation (network.py:304)
-            sigma[j] = lz_expf(lz_lane_dot<4>(hc.wl + WV + LZ_WV_SIG, q, b3[j]));     // row 0 of sigma_net.2 on the VALU
+                for (int j = 0; j < LZ_T; j++) acc3[ft][j] = lz_f4{0, 0, 0, 0};
+            lz_layer<LZ_L_S3, LZ_T>(hc.wl, lane, b3, acc3);
+#pragma unroll
+            for (int j = 0; j < LZ_T; j++)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) geo[j][4 * ft + r] = acc3[ft][j][r];   // geo_feat, no activation (network.py:304)
         }
+#pragma unroll
+        for (int j = 0; j < LZ_T; j++) sigma[j] = lz_expf(lz_lane_dot<4>(hc.wl + WV + LZ_WV_SIG, q, b3[j]));     // row 0 of sigma_net.2 on the VALU
     }
     // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
     float rgb[LZ_T][3];

@@ -24,12 +24,19 @@ _W_KEYS = ["aud_ch_att_net.net.0.weight", "aud_ch_att_net.net.1.weight", "eye_at
 class FusedTriplaneHead:
     """Inference/forward-only fused head (autograd for training goes through the operator path)."""
 
-    def __init__(self, state_dict, bound=1.0, exp_eye=True, device="cuda", precision="f32"):
+    def __init__(self, state_dict, bound=1.0, exp_eye=True, device="cuda", precision="f32", fold_geo=False):
         """precision "f32": f32 MFMA, bit-exact against the checker.  "f16": the reference's opt.fp16 / autocast arithmetic
         (half Linear inputs, weights and outputs, f32 accumulate) on the f16 matrix cores; inference only."""
         if precision not in ("f32", "f16"):
             raise ValueError("precision must be 'f32' or 'f16'")
         self.precision = precision
+        # fold_geo (f32, inference): geo_feat = sigma_net.2[1:65] s2 reaches color_net.0 through nothing but that linear map
+        # (network.py:304-306), so the 64 x 64 product of the two matrices is packed in color_net.0's geo columns and the geo rows of
+        # sigma_net.2 are never evaluated: 64 of 361 MFMAs per 16 samples less.  sigma is unchanged bit for bit, rgb moves by the
+        # reassociation (a few 1e-7).
+        if fold_geo and precision != "f32":
+            raise ValueError("fold_geo goes with precision='f32' (the f16 head keeps autocast's rounding points)")
+        self.fold_geo = bool(fold_geo)
         self.device = torch.device(device)
         self.bound = float(bound)
         sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
@@ -73,6 +80,10 @@ class FusedTriplaneHead:
         if self.precision == "f16":
             call("lz_head_pack_weights_f16", *[ptr(t) for t in w[:9]], int(self.has_eye), int(self.has_ind), ptr(self.packed), stream())
         else:
+            if self.fold_geo:
+                w = list(w)
+                folded = (w[7][:, 16:80].double() @ w[6][1:65].double()).float()
+                w[7] = torch.cat([w[7][:, :16], folded, w[7][:, 80:]], 1).contiguous()
             call("lz_head_pack_weights", *[ptr(t) for t in w], int(self.has_eye), int(self.has_ind), ptr(self.packed), stream())
 
     def _params(self, enc_a, ind_code, eye, testing):
@@ -82,7 +93,7 @@ class FusedTriplaneHead:
         p.ind_code = ind_code.data_ptr() if (ind_code is not None and self.has_ind) else None
         p.eye = eye.data_ptr() if (eye is not None and self.has_eye) else None
         p.bound, p.S, p.H, p.testing = self.bound, self.S, self.H, int(bool(testing))
-        p.precision = 1 if self.precision == "f16" else 0
+        p.precision = 1 if self.precision == "f16" else (2 if self.fold_geo and testing else 0)
         return p
 
     def forward(self, xyzs, dirs, enc_a, ind_code=None, eye=None, testing=True, count_ptr=None, out=None):
@@ -99,6 +110,8 @@ class FusedTriplaneHead:
             raise RuntimeError("training-mode uncertainty needs unc_net weights")
         if not testing and self.precision == "f16":
             raise RuntimeError("the f16 head is inference-only")
+        if not testing and self.fold_geo:
+            raise RuntimeError("fold_geo packs an inference-only arrangement of color_net.0")
         if out is None:
             kw = dict(dtype=torch.float32, device=xyzs.device)
             out = (torch.empty(M, **kw), torch.empty(M, 3, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw),

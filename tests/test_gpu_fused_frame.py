@@ -205,3 +205,30 @@ def test_fused_frame_two_cascades(golden, S):
     assert np.array_equal(fused["ray_counts"].cpu().numpy().astype(np.int64), st["samples_per_ray"])
     cnt = st["samples_per_ray"]
     assert cnt.max() > 20 and (cnt == 0).any()        # rays through the shell and the ball, and rays that miss everything
+
+
+@pytest.mark.parametrize("scene,H,W,kw", [("ellipsoid", 64, 64, dict(max_steps=64)), ("ones", 48, 40, dict(max_steps=96, T_thresh=0.3))])
+def test_fold_geo_frame_and_head(params, golden, scene, H, W, kw):
+    """fold_geo (precision 2): geo = Wg s2 folded into color_net.0 at pack time.  sigma -- and with it every ray's sample count, the weights,
+    depth and the ambient sums -- is the exact path's bit for bit; rgb and the image move by the reassociation only (north_star's bar
+    is 1e-4 abs).  Fused frame and loop mode, and the bare head on random points."""
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    head, bits, ro, rd, cond = setup(params, golden, H, W, scene)
+    folded = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in params.items()}, bound=1.0, fold_geo=True)
+    for mode in ("fused", "loop"):
+        a = TriplaneRenderer(head, dev(bits), bound=1.0, mode=mode).render(ro, rd, *cond, count_samples=True, **kw)
+        a = {k: v.clone() for k, v in a.items()}
+        b = TriplaneRenderer(folded, dev(bits), bound=1.0, mode=mode).render(ro, rd, *cond, count_samples=True, **kw)
+        for k in ("weights_sum", "depth", "amb_aud_sum", "amb_eye_sum", "uncertainty_sum", "nears", "fars", "ray_counts"):
+            assert torch.equal(a[k], b[k]), (mode, k)
+        assert float((a["image"] - b["image"]).abs().max()) < 2e-6, mode
+        assert not torch.equal(a["image_raw"], b["image_raw"]) or scene == "never"   # it IS a different association
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xyz = torch.rand(5000, 3, device="cuda", generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(5000, 3, device="cuda", generator=g), dim=-1)
+    o0, o1 = head.forward(xyz, d, *cond), folded.forward(xyz, d, *cond)
+    assert torch.equal(o0[0], o1[0]) and torch.equal(o0[2], o1[2]) and torch.equal(o0[3], o1[3])
+    assert float((o0[1] - o1[1]).abs().max()) < 2e-6
+    with pytest.raises(RuntimeError):
+        folded.forward(xyz, d, *cond, testing=False)
