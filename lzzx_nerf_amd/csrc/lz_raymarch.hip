@@ -154,36 +154,42 @@ __global__ void __launch_bounds__(256) lz_k_dilation(const float* __restrict__ g
 
 extern "C" int lz_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
                                      float* nears, float* fars, lz_stream_t stream) {
+    LZ_REQUIRE(N == 0 || (rays_o && rays_d && aabb && nears && fars), LZ_ERR_BAD_ARGUMENT, "near_far_from_aabb: null tensor");
     if (N == 0) return LZ_OK;
     hipLaunchKernelGGL(lz_k_near_far, dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), rays_o, rays_d, aabb, N, min_near, nears, fars);
     LZ_CHECK_LAUNCH("near_far_from_aabb");
     return LZ_OK;
 }
 extern "C" int lz_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, lz_stream_t stream) {
+    LZ_REQUIRE(N == 0 || (rays_o && rays_d && coords), LZ_ERR_BAD_ARGUMENT, "sph_from_ray: null tensor");
     if (N == 0) return LZ_OK;
     hipLaunchKernelGGL(lz_k_sph_from_ray, dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), rays_o, rays_d, radius, N, coords);
     LZ_CHECK_LAUNCH("sph_from_ray");
     return LZ_OK;
 }
 extern "C" int lz_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, lz_stream_t stream) {
+    LZ_REQUIRE(N == 0 || (coords && indices), LZ_ERR_BAD_ARGUMENT, "morton3D: null tensor");
     if (N == 0) return LZ_OK;
     hipLaunchKernelGGL(lz_k_morton3D, dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), coords, N, indices);
     LZ_CHECK_LAUNCH("morton3D");
     return LZ_OK;
 }
 extern "C" int lz_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, lz_stream_t stream) {
+    LZ_REQUIRE(N == 0 || (coords && indices), LZ_ERR_BAD_ARGUMENT, "morton3D_invert: null tensor");
     if (N == 0) return LZ_OK;
     hipLaunchKernelGGL(lz_k_morton3D_invert, dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), indices, N, coords);
     LZ_CHECK_LAUNCH("morton3D_invert");
     return LZ_OK;
 }
 extern "C" int lz_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, lz_stream_t stream) {
+    LZ_REQUIRE(N == 0 || (grid && bitfield), LZ_ERR_BAD_ARGUMENT, "packbits: null tensor");
     if (N == 0) return LZ_OK;
     hipLaunchKernelGGL(lz_k_packbits, dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), grid, N, density_thresh, bitfield);
     LZ_CHECK_LAUNCH("packbits");
     return LZ_OK;
 }
 extern "C" int lz_morton3D_dilation(const float* grid, uint32_t C, uint32_t H, float* grid_dilation, lz_stream_t stream) {
+    LZ_REQUIRE(grid && grid_dilation, LZ_ERR_BAD_ARGUMENT, "morton3D_dilation: null tensor");
     if (C * H == 0) return LZ_OK;
     hipLaunchKernelGGL(lz_k_dilation, dim3(lz_div_up((uint64_t)C * H * H * H, 256)), dim3(256), 0, lz_st(stream), grid, C, H, grid_dilation);
     LZ_CHECK_LAUNCH("morton3D_dilation");
@@ -563,6 +569,7 @@ lz_k_march_train_backward(const float* __restrict__ grad_xyzs, const float* __re
 
 extern "C" int lz_march_rays_train_backward(const float* grad_xyzs, const float* grad_dirs, const int32_t* rays, const float* deltas,
                                             uint32_t N, uint32_t M, float* grad_rays_o, float* grad_rays_d, lz_stream_t stream) {
+    LZ_REQUIRE(N == 0 || (grad_xyzs && grad_dirs && rays && deltas && grad_rays_o && grad_rays_d), LZ_ERR_BAD_ARGUMENT, "march_rays_train_backward: null tensor");
     if (N == 0) return LZ_OK;
     hipLaunchKernelGGL(lz_k_march_train_backward, dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), grad_xyzs, grad_dirs, rays, deltas, N, M, grad_rays_o, grad_rays_d);
     LZ_CHECK_LAUNCH("march_rays_train_backward");
@@ -985,6 +992,10 @@ extern "C" int lz_composite_train_forward_v(const float* sigmas, const float* rg
                                                float T_thresh, int n_amb, int amb_weighted, int has_unc, float* weights_sum,
                                                float* amb0_sum, float* amb1_sum, float* unc_sum, float* depth, float* image,
                                                lz_stream_t stream) {
+    LZ_REQUIRE(N == 0 || (sigmas && rgbs && deltas && rays && weights_sum && depth && image), LZ_ERR_BAD_ARGUMENT, "composite_rays_train_forward: null tensor");
+    LZ_REQUIRE(n_amb >= 0 && n_amb <= 2, LZ_ERR_BAD_ARGUMENT, "composite_rays_train_forward: n_amb must be 0, 1 or 2");
+    LZ_REQUIRE(N == 0 || ((n_amb < 1 || (amb0 && amb0_sum)) && (n_amb < 2 || (amb1 && amb1_sum)) && (!has_unc || (unc && unc_sum))), LZ_ERR_BAD_ARGUMENT,
+               "composite_rays_train_forward: a channel selected by (n_amb, has_unc) has a null tensor");
     if (N == 0) return LZ_OK;
     dim3 grid(lz_div_up(N, 64)), block(64);   // one wave per workgroup (wave-local barriers)
     hipStream_t st = lz_st(stream);
@@ -1003,6 +1014,12 @@ extern "C" int lz_composite_train_backward_v(const float* grad_weights_sum, cons
                                                 uint32_t N, float T_thresh, int n_amb, int amb_weighted, int has_unc,
                                                 float* grad_sigmas, float* grad_rgbs, float* grad_amb0, float* grad_amb1,
                                                 float* grad_unc, lz_stream_t stream) {
+    LZ_REQUIRE(N == 0 || (grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs),
+               LZ_ERR_BAD_ARGUMENT, "composite_rays_train_backward: null tensor");
+    LZ_REQUIRE(n_amb >= 0 && n_amb <= 2, LZ_ERR_BAD_ARGUMENT, "composite_rays_train_backward: n_amb must be 0, 1 or 2");
+    LZ_REQUIRE(N == 0 || ((n_amb < 1 || (amb0 && grad_amb0_sum && grad_amb0)) && (n_amb < 2 || (amb1 && grad_amb1_sum && grad_amb1)) &&
+                          (!has_unc || (unc && unc_sum && grad_unc_sum && grad_unc))),
+               LZ_ERR_BAD_ARGUMENT, "composite_rays_train_backward: a channel selected by (n_amb, has_unc) has a null tensor");
     (void)amb1;
     if (N == 0) return LZ_OK;
     dim3 grid(lz_div_up(N, 64)), block(64);
@@ -1018,6 +1035,11 @@ extern "C" int lz_composite_rays_v(uint32_t n_alive, uint32_t n_step, float T_th
                                  const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,
                                  const float* unc, int n_amb, int amb_weighted, int has_unc, float* weights_sum, float* depth,
                                  float* image, float* amb0_sum, float* amb1_sum, float* unc_sum, lz_stream_t stream) {
+    LZ_REQUIRE(n_alive == 0 || (rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image), LZ_ERR_BAD_ARGUMENT,
+               "composite_rays: null tensor");
+    LZ_REQUIRE(n_amb >= 0 && n_amb <= 2, LZ_ERR_BAD_ARGUMENT, "composite_rays: n_amb must be 0, 1 or 2");
+    LZ_REQUIRE(n_alive == 0 || ((n_amb < 1 || (amb0 && amb0_sum)) && (n_amb < 2 || (amb1 && amb1_sum)) && (!has_unc || (unc && unc_sum))),
+               LZ_ERR_BAD_ARGUMENT, "composite_rays: a channel selected by (n_amb, has_unc) has a null tensor");
     if (n_alive == 0) return LZ_OK;
     dim3 grid(lz_div_up(n_alive, 256)), block(256);
     hipStream_t st = lz_st(stream);
@@ -1232,6 +1254,7 @@ lz_k_final_blend(const float* __restrict__ image, const float* __restrict__ weig
 
 extern "C" int lz_final_blend(const float* image, const float* weights_sum, const float* bg, float bg_scalar, uint32_t N, float* out,
                               lz_stream_t stream) {
+    LZ_REQUIRE(N == 0 || (image && weights_sum && out), LZ_ERR_BAD_ARGUMENT, "final_blend: null tensor");
     if (N == 0) return LZ_OK;
     hipLaunchKernelGGL(lz_k_final_blend, dim3(lz_div_up((uint64_t)N * 3, 256)), dim3(256), 0, lz_st(stream), image, weights_sum, bg, bg_scalar, N, out,
                        (uint8_t*)nullptr);
