@@ -78,3 +78,38 @@ def test_bench_self_spawns_two_ranks_and_prints_the_contract_line(tmp_path):
     assert "one frame ray-sharded x2" in r["config"]["parallelism"] and r["config"]["rays_per_rank"] == 128 * 128 // 2
     assert r["clip_weak_scaling"]["scaling"] == "weak" and r["clip_weak_scaling"]["frames_per_step"] == 2
     assert "tiles_contiguous" in r and "roofline" in r
+
+
+def test_rccl_backend_runs_the_two_collectives_world_1(tmp_path):
+    """One GPU is all a test box has, so the N-way exchange itself cannot run here; what can: the RCCL backend ("nccl" on ROCm) initialises
+    on this image and executes, on the device and on a side stream behind an event exactly as TileGatherer issues it, the two collectives
+    the repo uses (all_gather_into_tensor of a tile, all_reduce of the flat gradient buffer) in a world of one.  The multi-rank logic
+    around them is covered by the gloo world-2/3 tests (tests/test_dist_cpu.py) and the 8-shard test above."""
+    script = tmp_path / "rccl1.py"
+    script.write_text('''
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+tile = torch.rand(32768, 3, device="cuda")
+out = torch.empty_like(tile)
+side = torch.cuda.Stream()
+ready = torch.cuda.Event(); ready.record(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    side.wait_event(ready)
+    dist.all_gather_into_tensor(out, tile)
+torch.cuda.current_stream().wait_stream(side)
+assert torch.equal(out, tile)
+flat = torch.arange(515_000, device="cuda", dtype=torch.float32)
+ref = flat.clone()
+dist.all_reduce(flat)
+assert torch.equal(flat, ref)
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl ok")
+''')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "rccl ok" in p.stdout, p.stderr[-2000:]
