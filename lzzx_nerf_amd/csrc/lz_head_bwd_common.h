@@ -6,6 +6,13 @@
 
 #define LZ_BWD_WG 512
 
+// record / state stores: written once, read back once by a later kernel
+#ifdef LZ_REC_PLAIN_STORES
+#define LZ_REC_STORE(v, p) (*(p) = (v))
+#else
+#define LZ_REC_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 struct LzHeadBwdArgs {
     LzHeadArgs fwd;
     const float *g_sigma, *g_rgb, *g_amb_aud, *g_amb_eye, *g_unc;     // upstream gradients [M], [M,3], [M], [M], [M]
@@ -99,7 +106,7 @@ __device__ __forceinline__ void lz_dump_chained(float* __restrict__ rb, int q, i
 #pragma unroll
     for (int t = 0; t < NTILE; t++) {
         lz_v4 w = {v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
-        __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(rb + lz_tcol(col0 + 16 * t + 4 * q)));   // streamed: read back once
+        LZ_REC_STORE(w, reinterpret_cast<lz_v4*>(rb + lz_tcol(col0 + 16 * t + 4 * q)));   // streamed: read back once
     }
 }
 

@@ -37,7 +37,7 @@ __device__ __forceinline__ float lz_pack_h2(float lo, float hi) {
 __device__ __forceinline__ void lz_dump_pair(float* __restrict__ rowq, int pair, float l0, float l1, float l2, float l3, float h0, float h1,
                                              float h2, float h3) {
     lz_v4 w = {lz_pack_h2(l0, h0), lz_pack_h2(l1, h1), lz_pack_h2(l2, h2), lz_pack_h2(l3, h3)};
-    __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(rowq + 256 * pair));
+    LZ_REC_STORE(w, reinterpret_cast<lz_v4*>(rowq + 256 * pair));
 }
 // tiles t0, t0 + 1 of a chained-layout vector -> pair
 template <int N>
@@ -301,10 +301,10 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
             // masks + one scalar per lane: q = 0 ||att||, 1 eye_att, 2 unc pre-activation, 3 sigma
             const float sc = q == 0 ? norm : (q == 1 ? eyeatt : (q == 2 ? upre : sigma));
             lz_v4 w = {__uint_as_float(mk_a1 | (mk_s1 << 16)), __uint_as_float(mk_s2 | (mk_c1 << 16)), __uint_as_float(mk_u1 | (mk_e1 << 8)), sc};
-            __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(sb + lz_tcol((H16 ? LZ_S16_MK : LZ_ST_MK) + 4 * q)));
+            LZ_REC_STORE(w, reinterpret_cast<lz_v4*>(sb + lz_tcol((H16 ? LZ_S16_MK : LZ_ST_MK) + 4 * q)));
             // the four lanes of a sample hold the same bits: all of them store (same address, same value), no lane-dependent branch
             lz_v4 cw = {cpre[0], cpre[1], cpre[2], 0.0f};
-            __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(sb + lz_tcol(H16 ? LZ_S16_CLR : LZ_ST_CLR)));
+            LZ_REC_STORE(cw, reinterpret_cast<lz_v4*>(sb + lz_tcol(H16 ? LZ_S16_CLR : LZ_ST_CLR)));
             sigmas[m] = sigma;
             amb_aud[m] = norm;
             if (amb_eye) amb_eye[m] = eyeatt;

@@ -49,7 +49,7 @@ __device__ __forceinline__ void lz_dump_pair_h8(float* __restrict__ rowq, int pa
     const lz_u4 p = __builtin_bit_cast(lz_u4, b);
     const lz_u4 w = {__builtin_amdgcn_perm(p[2], p[0], 0x05040100u), __builtin_amdgcn_perm(p[2], p[0], 0x07060302u),
                      __builtin_amdgcn_perm(p[3], p[1], 0x05040100u), __builtin_amdgcn_perm(p[3], p[1], 0x07060302u)};
-    __builtin_nontemporal_store(__builtin_bit_cast(lz_v4, w), reinterpret_cast<lz_v4*>(rowq + 256 * pair));
+    LZ_REC_STORE(__builtin_bit_cast(lz_v4, w), reinterpret_cast<lz_v4*>(rowq + 256 * pair));
 }
 __device__ __forceinline__ float lz_pack_h2f(float lo, float hi) {
     typedef _Float16 lz_h2 __attribute__((ext_vector_type(2)));
@@ -59,7 +59,7 @@ __device__ __forceinline__ float lz_pack_h2f(float lo, float hi) {
 __device__ __forceinline__ void lz_dump_pair_f(float* __restrict__ rowq, int pair, float l0, float l1, float l2, float l3, float h0, float h1,
                                                float h2, float h3) {
     lz_v4 w = {lz_pack_h2f(l0, h0), lz_pack_h2f(l1, h1), lz_pack_h2f(l2, h2), lz_pack_h2f(l3, h3)};
-    __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(rowq + 256 * pair));
+    LZ_REC_STORE(w, reinterpret_cast<lz_v4*>(rowq + 256 * pair));
 }
 // bit 8 p + j of a layer's mask <-> slot j of its B operand p <-> chained index 4 t + r (lz_head_bwd_common.h: lz_mask_pos).  The operand is
 // what ReLU left: halves >= +0, so "positive" is "bit pattern not zero" -- an unsigned 16-bit min with 1 per packed pair, then the
@@ -150,8 +150,8 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
         {
             lz_v4 w0 = {(float)att16[0], (float)att16[1], (float)att16[2], (float)att16[3]};
             lz_v4 w1 = {(float)att16[4], (float)att16[5], (float)att16[6], (float)att16[7]};
-            __builtin_nontemporal_store(w0, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_ST_ATT + 4 * q)));
-            __builtin_nontemporal_store(w1, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_ST_ATT + 16 + 4 * q)));
+            LZ_REC_STORE(w0, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_ST_ATT + 4 * q)));
+            LZ_REC_STORE(w1, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_ST_ATT + 16 + 4 * q)));
         }
         float ss = 0.0f;
 #pragma unroll
@@ -255,9 +255,9 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
         {
             const float sc = q == 0 ? norm : (q == 1 ? eyeatt : (q == 2 ? upre : sigma));
             lz_v4 w = {__uint_as_float(mk_a1 | (mk_s1 << 16)), __uint_as_float(mk_s2 | (mk_c1 << 16)), __uint_as_float(mk_u1 | (mk_e1 << 8)), sc};
-            __builtin_nontemporal_store(w, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_S16_MK + 4 * q)));
+            LZ_REC_STORE(w, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_S16_MK + 4 * q)));
             lz_v4 cw = {cpre[0], cpre[1], cpre[2], 0.0f};
-            __builtin_nontemporal_store(cw, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_S16_CLR)));
+            LZ_REC_STORE(cw, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_S16_CLR)));
             sigmas[row] = sigma;
             amb_aud[row] = norm;
             if (amb_eye) amb_eye[row] = eyeatt;
