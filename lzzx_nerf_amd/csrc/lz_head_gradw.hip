@@ -2,12 +2,13 @@
 // lz_triplane_head_backward writes (include/lzzx_nerf_hip.h: LZ_BWD_*), in ONE pass over the records.
 //
 // dW_layer[n, k] = sum over samples of G[s, n] * X[s, k] (network.py:73-94: bias-free nn.Linear; torch derives the same sums through
-// addmm).  Five products over the same M ~ 6e6 records (2 624 B each), all HBM-bound.  A workgroup is five waves, each owning the
-// accumulator tiles (16 x 16) of one product or half of one, and all five walk the same records at the same time:
+// addmm).  Five products over the same M ~ 6e6 records (2 624 B each, or 1 408 B in half), all HBM-bound.  A workgroup is six waves, each
+// owning the accumulator tiles (16 x 16) of one product or part of one, and all six walk the same records at the same time, one pass each:
 //     wave 0  {aud_ch_att_net.0 | eye_att_net.0 | unc_net.0} stacked  G_X [112] x X_SIG0[:36]                      21 tiles
-//     wave 1  aud_ch_att_net.1  G_ATT [32] x X_A1 [64], then sigma_net.1  G_S2 [64] x X_S1 [64]                     8 + 16
+//     wave 1  aud_ch_att_net.1  G_ATT [32] x X_A1 [64]                                                              8
 //     wave 2  sigma_net.0       G_S1 [64] x X_SIG0 [68 | 69]                                                        20
 //     wave 3, 4  {color_net.0 | sigma row of sigma_net.2}  G_C1H [65] x X_S2C [84] = [s2 | SH | ind]                 18 + 12
+//     wave 5  sigma_net.1       G_S2 [64] x X_S1 [64]                                                               16
 // The last product is the shared factor of two layers: geo = s2 . Wg^T is linear in s2 and d geo = G_c1 . W_c0[:, geo] is linear in
 // G_c1, so with R = sum G_c1^T s2 (its rows 0..63, columns 0..63) the host finishes dW_color0[:, geo] = R . Wg^T and
 // dW_sigma2[geo rows] = W_c0[:, geo]^T . R with two 64^3 products; neither geo nor d geo is ever written to the records.
@@ -21,7 +22,7 @@
 typedef float lz_f4 __attribute__((ext_vector_type(4)));
 
 #define LZ_GW_TILES 95
-#define LZ_GW_WAVES 5
+#define LZ_GW_WAVES 6
 #define LZ_GW_MAX_PARTS 768
 
 namespace {
@@ -169,6 +170,10 @@ __device__ __forceinline__ void lz_gw_product16(const uint32_t* __restrict__ rec
     };
     load(blockIdx.x, a[0], b[0]);
     for (uint32_t g = blockIdx.x; g < n_groups; g += 2 * gridDim.x) {
+        // every wave of the workgroup makes the same trips: keeping them on the same blocks lets the columns two waves share (the
+        // sigma_net.0 / color_net.0 inputs) come from HBM once and from the cache the second time (FETCH_SIZE 9.8 -> 8.x GB; 1.81 ->
+        // 1.72 ms).  The f32 product is left free-running: there the barrier costs more than the 18 % of re-read it saves (3.8 -> 4.1 ms)
+        __syncthreads();
         load(g + gridDim.x, a[1], b[1]);
         __builtin_amdgcn_sched_barrier(0);
         mma(a[0], b[0]);
@@ -196,13 +201,11 @@ lz_k_head_grad_w(const float* __restrict__ rec, uint32_t M, float* __restrict__ 
                   G_ATT = LZ_BWD_G_ATT / 16, G_S1 = LZ_BWD_G_S1 / 16, G_S2 = LZ_BWD_G_S2 / 16, G_C1H = LZ_BWD_G_C1H / 16;
     switch (threadIdx.x >> 6) {   // wave-uniform
         case 0: lz_gw_product<7, 3, G_X, X_SIG0>(rec, M, part + T_X3 * 256); break;
-        case 1:
-            lz_gw_product<2, 4, G_ATT, X_A1>(rec, M, part + T_AUD1 * 256);
-            lz_gw_product<4, 4, G_S2, X_S1>(rec, M, part + T_SIG1 * 256);
-            break;
+        case 1: lz_gw_product<2, 4, G_ATT, X_A1>(rec, M, part + T_AUD1 * 256); break;
         case 2: lz_gw_product<4, 5, G_S1, X_SIG0>(rec, M, part + T_SIG0 * 256); break;
         case 3: lz_gw_product<3, 6, G_C1H, X_S2C>(rec, M, part + T_C1H * 256); break;
-        default: lz_gw_product<2, 6, G_C1H + 3, X_S2C>(rec, M, part + (T_C1H + 18) * 256); break;
+        case 4: lz_gw_product<2, 6, G_C1H + 3, X_S2C>(rec, M, part + (T_C1H + 18) * 256); break;
+        default: lz_gw_product<4, 4, G_S2, X_S1>(rec, M, part + T_SIG1 * 256); break;
     }
 }
 
@@ -211,13 +214,11 @@ lz_k_head_grad_w16(const uint32_t* __restrict__ rec, uint32_t M, float* __restri
     float* part = parts + (size_t)blockIdx.x * (LZ_GW_TILES * 256);
     switch (threadIdx.x >> 6) {
         case 0: lz_gw_product16<7, 3, LZ_R16_G_X, LZ_R16_X_SIG0>(rec, M, part + T_X3 * 256); break;
-        case 1:
-            lz_gw_product16<2, 4, LZ_R16_G_ATT, LZ_R16_X_A1>(rec, M, part + T_AUD1 * 256);
-            lz_gw_product16<4, 4, LZ_R16_G_S2, LZ_R16_X_S1>(rec, M, part + T_SIG1 * 256);
-            break;
+        case 1: lz_gw_product16<2, 4, LZ_R16_G_ATT, LZ_R16_X_A1>(rec, M, part + T_AUD1 * 256); break;
         case 2: lz_gw_product16<4, 5, LZ_R16_G_S1, LZ_R16_X_SIG0>(rec, M, part + T_SIG0 * 256); break;
         case 3: lz_gw_product16<3, 6, LZ_R16_G_C1H, LZ_R16_X_S2C>(rec, M, part + T_C1H * 256); break;
-        default: lz_gw_product16<2, 6, LZ_R16_G_C1H + 3, LZ_R16_X_S2C>(rec, M, part + (T_C1H + 18) * 256); break;
+        case 4: lz_gw_product16<2, 6, LZ_R16_G_C1H + 3, LZ_R16_X_S2C>(rec, M, part + (T_C1H + 18) * 256); break;
+        default: lz_gw_product16<4, 4, LZ_R16_G_S2, LZ_R16_X_S1>(rec, M, part + T_SIG1 * 256); break;
     }
 }
 
