@@ -132,6 +132,7 @@ PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_dev
          "lz_triplane_head_grad_w_workspace": ([], C.c_size_t)}
 
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
+ABI_VERSION = 6   # lz_abi_version() of the library this binding table describes (include/lzzx_nerf_hip.h)
 
 _lib = None
 

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(_lib.ALL_SYMBOLS) == _declared()
     bound = _lib.load()
-    assert bound.lz_abi_version() == 6
+    assert bound.lz_abi_version() == _lib.ABI_VERSION == 6
     assert bound.lz_head_packed_size() == 24576 and bound.lz_head_packed_size_f16() == 60416
 
 
@@ -102,3 +102,10 @@ def test_operator_api_surface():
     with pytest.raises(AssertionError):
         from lzzx_nerf_amd.shencoder import SHEncoder
         SHEncoder(input_dim=2)
+
+
+def test_graft_entry_build_check_matches_the_library():
+    """__graft_entry__.build() must not pin a stale ABI number (it did once: the driver's build check would have failed)"""
+    import __graft_entry__ as g
+    src = open(g.__file__).read()
+    assert "ABI_VERSION" in src and "lz_abi_version() == 5" not in src
