@@ -60,6 +60,15 @@ __device__ __forceinline__ int h_encx(int ks, int kg, int j) {           // lane
     return i < 9 ? 4 * i + kg : -1;
 }
 
+// round an f32 RESULT to half: the value must exist as an f32 first (torch's half ops with an f32 scalar compute in f32, round to f32, then
+// to half).  Without the barrier the compiler may fold the multiply / subtract and the conversion into v_fma_mixlo_f16, which rounds the
+// exact result ONCE -- a different value in ~2^-13 of the cases, and whether it does so depends on the surrounding code, so two kernels
+// built from this same slice would disagree (the fused frame and the stand-alone head did, in a few pixels by 2e-7).
+__device__ __forceinline__ _Float16 h_round(float v) {
+    asm volatile("" : "+v"(v));
+    return (_Float16)v;
+}
+
 // sigmoid whose result the caller rounds to half (autocast: sigmoid runs in half): hardware exp2 / reciprocal, a few f32 ulp, which the
 // half rounding absorbs except on a rounding boundary -- 4 VALU instructions where the bit-reproducible lz_sigmoidf (polynomial exp +
 // IEEE division) costs about 31, four times per slice in kernels that are bound by VALU issue
@@ -142,12 +151,12 @@ __device__ __forceinline__ void lz_head16_stage(const LzHead16Args& P, lz_h8* wl
     hc.unc_const = lz_softplusf(0.0f);   // test mode (network.py:243-249, 278)
 }
 
-template <typename ShFn>   // SH(4) source: LzShFromDir (lz_head_slice.h) or the frame kernel's per-ray LDS copy
+template <bool IN_RANGE = false, typename ShFn>   // SH(4) source: LzShFromDir (lz_head_slice.h) or the frame kernel's per-ray LDS copy
 __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane, float px, float py, float pz, ShFn shfn, LzHead16Out& out) {
     const int q = lane >> 4;
     // ---------------- gather (f32, the same code as lz_k_triplane_head: lz_head_gather.h): lane q holds enc_x features 4 i + q
     float encx[9];
-    lz_head_gather(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx);
+    lz_head_gather<IN_RANGE>(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx);
     // enc_x as two half B operands (slot j of k-step ks <-> i = 8 ks + j); slot (1, q = 0, 1) is filled in for the sigma net
     lz_h8 bx[2];
 #pragma unroll
@@ -190,7 +199,7 @@ __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane,
         lz_h8 b1[3];
         b1[0] = bx[0];
         b1[1] = bx[1];
-        b1[1][1] = (hc.has_eye && q == 0) ? (_Float16)(hc.eye_v * eyeatt) : (_Float16)0.0f;
+        b1[1][1] = (hc.has_eye && q == 0) ? h_round(hc.eye_v * eyeatt) : (_Float16)0.0f;
 #pragma unroll
         for (int j = 0; j < 8; j++) b1[2][j] = (_Float16)(hc.lenca[16 * (j >> 2) + 4 * q + (j & 3)] * (float)att16[j]);
         lz_f4 s1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
@@ -225,8 +234,8 @@ __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane,
 #pragma unroll
         for (int c = 0; c < 3; c++) {   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
             const _Float16 sg = (_Float16)h_sigmoid((float)(_Float16)c2[0][c]);
-            const _Float16 t1 = (_Float16)((float)sg * 1.002f);
-            rgb[c] = (float)(_Float16)((float)t1 - 0.001f);
+            const _Float16 t1 = h_round((float)sg * 1.002f);
+            rgb[c] = (float)h_round((float)t1 - 0.001f);
         }
     }    out.sigma = sigma;
     out.rgb[0] = rgb[0]; out.rgb[1] = rgb[1]; out.rgb[2] = rgb[2];

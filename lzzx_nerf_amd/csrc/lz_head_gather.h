@@ -9,6 +9,11 @@
 #include "lzzx_detmath.h"
 
 // offs / lscale / lres: the per-level table in LDS ([0,13) offsets, scale, resolution); emb: the three planes' tables; (px, py, pz): the sample
+// IN_RANGE drops the range clamps / out-of-range selects for a caller that guarantees |x|, |y|, |z| <= bound.  NOT USED: in the fused frame
+// kernel (whose march clamps every sample) the f32 build stayed bit-identical with it, the f16 build did not (28 pixels of a 96 x 96 frame
+// off by 2e-7 against the loop: the variant compiles to something that is not an identity there); 3 % of the f16 kernel's instructions
+// were not worth finding out why.
+template <bool IN_RANGE = false>
 __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], const int* __restrict__ offs, const float* __restrict__ lscale,
                                                const int* __restrict__ lres, float px, float py, float pz, int q, float bound,
                                                float two_bound, float (&encx)[9]) {
@@ -50,8 +55,8 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
         const int plane = kPlaneOf[i], mrec = i % 3;
         const float u = plane == 1 ? y01 : x01;          // xy: (x,y)  yz: (y,z)  xz: (x,z)   network.py:211
         const float v = plane == 0 ? y01 : z01;
-        oobf[i] = (u < 0 || u > 1 || v < 0 || v > 1);
-        const float uc = lz_fminf(lz_fmaxf(u, 0.0f), 1.0f), vc = lz_fminf(lz_fmaxf(v, 0.0f), 1.0f);
+        oobf[i] = IN_RANGE ? false : (u < 0 || u > 1 || v < 0 || v > 1);
+        const float uc = IN_RANGE ? u : lz_fminf(lz_fmaxf(u, 0.0f), 1.0f), vc = IN_RANGE ? v : lz_fminf(lz_fmaxf(v, 0.0f), 1.0f);
         // byte offset in 32 bits off the plane's (wave-uniform) base: one VALU op and the scalar-base addressing mode per gather, where
         // a per-lane 64-bit pointer costs two or three (the tables are 650 KB each)
         const char* gb = reinterpret_cast<const char*>(emb[plane]);

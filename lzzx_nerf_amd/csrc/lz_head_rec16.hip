@@ -195,7 +195,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             lz_h8 b1[3];
             b1[0] = bx[0];
             b1[1] = bx[1];
-            b1[1][1] = (hc.has_eye && q == 0) ? (_Float16)(hc.eye_v * eyeatt) : (_Float16)0.0f;
+            b1[1][1] = (hc.has_eye && q == 0) ? h_round(hc.eye_v * eyeatt) : (_Float16)0.0f;
 #pragma unroll
             for (int j = 0; j < 8; j++) b1[2][j] = (_Float16)(hc.lenca[16 * (j >> 2) + 4 * q + (j & 3)] * (float)att16[j]);
             // sigma_net.0 input in the record's arrangement (lz_head_rec.hip: tiles 0, 1 enc_x, tile 2 feature 32 + q and the eye term,
@@ -265,8 +265,8 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             const int qc = q < 2 ? q : 2;
             const float cv = q == 0 ? cpre[0] : (q == 1 ? cpre[1] : cpre[2]);
             const _Float16 sg = (_Float16)h_sigmoid(cv);   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
-            const _Float16 t1 = (_Float16)((float)sg * 1.002f);
-            rgbs[row * 3 + qc] = (float)(_Float16)((float)t1 - 0.001f);
+            const _Float16 t1 = h_round((float)sg * 1.002f);
+            rgbs[row * 3 + qc] = (float)h_round((float)t1 - 0.001f);
         }
         slice = next;
     }
