@@ -727,6 +727,12 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             # BASELINE cfg3's second size: every ray of the 512 x 512 frame (N = 262 144; 24 M samples, 80 GB of per-sample records + state)
             result["train_step_full_frame"] = train_bench(args, device, P, golden, bits, n_rays=H * W)
             torch.cuda.empty_cache()
+            if args.train_mlp == "fused" and not args.train_recompute and (args.train_records, args.train_forward, args.train_backward) == ("f32", "f32", "f32"):
+                import copy
+                a16 = copy.copy(args)
+                a16.train_records = a16.train_forward = a16.train_backward = "f16"
+                result["train_step_full_frame_f16"] = train_bench(a16, device, P, golden, bits, n_rays=H * W)
+                torch.cuda.empty_cache()
         except Exception as exc:   # an optional leg must never take the headline line down
             err("train_step", exc)
     log("leg: if not args.no_occupancy and args.precision == 'f32':")
