@@ -433,7 +433,7 @@ int lz_head_pack_weights_bwd_f16(const float* aud0, const float* aud1, const flo
                                  const float* sig2, const float* col0, int has_eye, int has_ind, void* packed_bwd16, lz_stream_t stream);
 /* The recording forward on the f16 matrix cores (lz_head_rec16.hip): the forward of the reference's usual training mode (autocast,
  * TrainerUtil.py:865; rounding sequence of the f16 inference head, plus the uncertainty net) writing the f16 records and state row
- * described above -- sigma / rgb / ambient outputs follow lz_triplane_head_forward(precision 1) (same rounding sequence), unc = softplus (f32) of the
+ * described above -- sigma / rgb / ambient outputs have the bits of lz_triplane_head_forward(precision 1), unc = softplus (f32) of the
  * half pre-activation.  p->packed: lz_head_pack_weights_f16 image, p->precision = 1, p->testing = 0; packed_unc: the five fragments of
  * unc_net from lz_head_pack_unc_f16 (lz_head_packed_unc_size_f16() bytes, 16-byte aligned).  The backward is
  * lz_triplane_head_backward_recorded(record_f16 = 1) with the f32 image of the same weights (data gradient in f32), the weight

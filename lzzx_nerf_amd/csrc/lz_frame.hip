@@ -192,7 +192,7 @@ template <> struct LzfHead<1> {
     __device__ static __forceinline__ void stage(const Args& P, float* lds, int, Ctx& c) { lz_head16_stage(P, reinterpret_cast<lz_h8*>(lds), LZF_WG, c); }
     template <typename ShFn>
     __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
-        lz_head16_slice(c, lane, x, y, z, f, o);
+        lz_head16_slice<true>(c, lane, x, y, z, f, o);
     }
 };
 
@@ -536,6 +536,9 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
         default: LZF_LAUNCH(PREC, 16); break;                                   \
     }
     if (p->precision == 1) {
+        // the f16 head's gather runs without range clamps here (lz_head_gather<IN_RANGE>): every sample the march emits is clamped to ITS bound
+        LZ_REQUIRE(f->bound > 0.0f && f->bound <= p->bound, LZ_ERR_BAD_ARGUMENT,
+                   "frame_render: the march's bound must not exceed the head's (the reference uses one `bound` for both, renderer.py:94, network.py:100)");
         LzHead16Args a;
         a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
         a.offsets = p->offsets; a.packed = reinterpret_cast<const lz_h8*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code;

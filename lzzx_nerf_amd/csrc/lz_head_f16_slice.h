@@ -160,8 +160,8 @@ __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane,
     // enc_x as two half B operands (slot j of k-step ks <-> i = 8 ks + j); slot (1, q = 0, 1) is filled in for the sigma net
     lz_h8 bx[2];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { bx[0][j] = (_Float16)encx[j]; bx[1][j] = (_Float16)0.0f; }
-    bx[1][0] = (_Float16)encx[8];
+    for (int j = 0; j < 8; j++) { bx[0][j] = h_round(encx[j]); bx[1][j] = (_Float16)0.0f; }   // h_round: the f32 feature first, then its half
+    bx[1][0] = h_round(encx[8]);
 
     // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
     _Float16 att16[8];   // [4 t + r] = feature 16 t + 4 q + r

@@ -9,10 +9,11 @@
 #include "lzzx_detmath.h"
 
 // offs / lscale / lres: the per-level table in LDS ([0,13) offsets, scale, resolution); emb: the three planes' tables; (px, py, pz): the sample
-// IN_RANGE drops the range clamps / out-of-range selects for a caller that guarantees |x|, |y|, |z| <= bound.  NOT USED: in the fused frame
-// kernel (whose march clamps every sample) the f32 build stayed bit-identical with it, the f16 build did not (28 pixels of a 96 x 96 frame
-// off by 2e-7 against the loop: the variant compiles to something that is not an identity there); 3 % of the f16 kernel's instructions
-// were not worth finding out why.
+// IN_RANGE drops the range clamps / out-of-range selects for a caller that guarantees |x|, |y|, |z| <= bound -- the fused f16 frame kernel,
+// whose march clamps every sample (raymarching.cu:866-889) and which is bound by VALU issue; the host checks that the march's bound does
+// not exceed the head's.  An identity on the values -- but mind what it exposes: with the select gone, `(_Float16)encx[i]` sat directly
+// behind the last fma of the interpolation and the compiler folded the two into v_fma_mixlo_f16 (one rounding instead of f32-then-half):
+// 28 pixels of a 96 x 96 frame moved by 2e-7 against the loop until the conversions went through h_round (lz_head_f16_slice.h).
 template <bool IN_RANGE = false>
 __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], const int* __restrict__ offs, const float* __restrict__ lscale,
                                                const int* __restrict__ lres, float px, float py, float pz, int q, float bound,

@@ -30,6 +30,7 @@ __device__ __forceinline__ uint32_t lz_fbits(float v) { return __float_as_uint(v
 // dwordx4 store per lane covers its share of a pair (64 bytes per sample), values rounded to nearest even.
 typedef _Float16 lz_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float lz_pack_h2(float lo, float hi) {
+    asm volatile("" : "+v"(lo), "+v"(hi));   // the f32 values first, then their halves: no fused single rounding (v_fma_mixlo_f16)
     const lz_h2 v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(float, v);
 }

@@ -6,7 +6,7 @@
 // The layer inputs a half Linear sees ARE the halves this kernel holds as MFMA B operands, so the record costs two byte-permutes per
 // dword on top of the inference slice; 64 MFMAs per 16 samples instead of 379 f32 ones.  The uncertainty net (training only:
 // network.py:241-249) adds five fragments that are packed separately (lz_head_pack_unc_f16), so the inference image and kernels stay
-// as they are.  sigma / rgb / ambient outputs follow lz_k_triplane_head_f16 (same rounding sequence).
+// as they are.  sigma / rgb / ambient outputs have the bits of lz_k_triplane_head_f16 on the same inputs.
 #include "lz_head_f16_slice.h"
 #include "lz_head_bwd_common.h"   // lz_blk / lz_tcol: the blocked record layout
 
@@ -53,7 +53,7 @@ __device__ __forceinline__ void lz_dump_pair_h8(float* __restrict__ rowq, int pa
 }
 __device__ __forceinline__ float lz_pack_h2f(float lo, float hi) {
     typedef _Float16 lz_h2 __attribute__((ext_vector_type(2)));
-    const lz_h2 v = {(_Float16)lo, (_Float16)hi};
+    const lz_h2 v = {h_round(lo), h_round(hi)};   // the same halves the B operands hold (no fused single rounding)
     return __builtin_bit_cast(float, v);
 }
 __device__ __forceinline__ void lz_dump_pair_f(float* __restrict__ rowq, int pair, float l0, float l1, float l2, float l3, float h0, float h1,
@@ -129,8 +129,8 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
         __builtin_amdgcn_sched_barrier(0);
         lz_h8 bx[2];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { bx[0][j] = (_Float16)encx[j]; bx[1][j] = (_Float16)0.0f; }
-        bx[1][0] = (_Float16)encx[8];
+        for (int j = 0; j < 8; j++) { bx[0][j] = h_round(encx[j]); bx[1][j] = (_Float16)0.0f; }   // h_round: the f32 feature first, then its half
+        bx[1][0] = h_round(encx[8]);
 
         // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
         _Float16 att16[8];

@@ -586,14 +586,12 @@ def test_fused_train_head_f16_forward(params, golden, backward_dtype):
     enc_a, ind, eye = dev(enc_a_np).requires_grad_(True), dev(golden["net_ind"]).requires_grad_(True), dev(golden["net_eye"])
     outs = net(xyz, d, enc_a, ind, eye)
     torch.autograd.backward(list(outs), gout)
-    # ---- the f16 inference kernel: same rounding sequence in a separately compiled kernel, bit-equal except where a last-bit difference
-    # of a gathered feature lands on a half rounding boundary (a few values in 1e4), and then one half ulp apart
+    # ---- the f16 inference kernel: the same rounding sequence in a separately compiled kernel -- bit for bit, now that every f32 result
+    # is materialised before its conversion to half (h_round: no v_fma_mixlo_f16 single rounding that depends on the surrounding code)
     inf = FusedTriplaneHead({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()}, bound=1.0, precision="f16")
     oi = inf.forward(xyz, d, dev(enc_a_np), dev(golden["net_ind"]), eye)
     for a, b, nm in zip(outs[:4], oi[:4], ("sigma", "rgb", "amb_aud", "amb_eye")):
-        a, b = a.detach().reshape(-1), b.reshape(-1)
-        assert float((a != b).float().mean()) < 5e-3, nm
-        assert float(((a - b).abs() / (b.abs() + 1e-3)).max()) < 1e-2, nm
+        assert torch.equal(a.detach().reshape(-1), b.reshape(-1)), nm
     # ---- the operator graph under autocast
     encs = []
     for n in ("xy", "yz", "xz"):
