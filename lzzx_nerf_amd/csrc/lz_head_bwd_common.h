@@ -7,7 +7,9 @@
 #define LZ_BWD_WG 512
 
 // record / state stores: written once, read back once by a later kernel
-#ifdef LZ_REC_PLAIN_STORES
+#if defined(LZ_REC_NO_STORES)   /* experiment: the kernels without their record traffic (results are garbage) */
+#define LZ_REC_STORE(v, p) ((void)(p), (void)(v))
+#elif defined(LZ_REC_PLAIN_STORES)
 #define LZ_REC_STORE(v, p) (*(p) = (v))
 #else
 #define LZ_REC_STORE(v, p) __builtin_nontemporal_store((v), (p))
