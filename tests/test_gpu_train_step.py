@@ -562,8 +562,8 @@ def test_fused_train_head_f16_records(params, golden, exp_eye, ind_dim):
             assert float(g2[k].abs().max()) > 0, k
 
 
-@pytest.mark.parametrize("backward_dtype", ["f32", "f16"])
-def test_fused_train_head_f16_forward(params, golden, backward_dtype):
+@pytest.mark.parametrize("backward_dtype,exp_eye,ind_dim", [("f32", True, 4), ("f16", True, 4), ("f16", False, 0), ("f16", True, 0)])
+def test_fused_train_head_f16_forward(params, golden, backward_dtype, exp_eye, ind_dim):
     """forward_dtype="f16": the training forward in the reference's autocast arithmetic (lz_head_rec16.hip) + data-gradient chain (f32, or
     backward_dtype="f16": on the f16 matrix cores with half dY / W like autocast's own backward) + half records.  Checked against the same network built from the operator API under torch.autocast (what the reference's `-O`
     training runs: half Linear on rocBLAS, half ReLU / sigmoid / products, f32 exp / norm / softplus, half gradients): outputs to half
@@ -573,6 +573,8 @@ def test_fused_train_head_f16_forward(params, golden, backward_dtype):
     from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
     rng = np.random.default_rng(13)
     p = dict(params)
+    p["sigma_net.net.0.weight"] = np.ascontiguousarray(params["sigma_net.net.0.weight"][:, :68 + int(exp_eye)])
+    p["color_net.net.0.weight"] = np.ascontiguousarray(params["color_net.net.0.weight"][:, :80 + ind_dim])
     for n in ("xy", "yz", "xz"):
         p[f"encoder_{n}.embeddings"] = params[f"encoder_{n}.embeddings"] * np.float32(30.0)
     M = 16 * 800 + 7
@@ -582,15 +584,21 @@ def test_fused_train_head_f16_forward(params, golden, backward_dtype):
     gout = [torch.from_numpy(rng.normal(size=sh).astype(np.float32)).cuda() for sh in ((M,), (M, 3), (M, 1), (M, 1), (M, 1))]
     gout[0] *= 1e-2   # d loss / d sigma times sigma has to fit a half: the job of the reference's GradScaler
     enc_a_np = golden["net_enc_a"].astype(np.float16).astype(np.float32)   # enc_a is a half tensor under autocast (AudioNet output)
-    net = FusedTriplaneTrainHead(p, bound=1.0, forward_dtype="f16", backward_dtype=backward_dtype).cuda()
-    enc_a, ind, eye = dev(enc_a_np).requires_grad_(True), dev(golden["net_ind"]).requires_grad_(True), dev(golden["net_eye"])
+    net = FusedTriplaneTrainHead(p, bound=1.0, exp_eye=exp_eye, ind_dim=ind_dim, forward_dtype="f16", backward_dtype=backward_dtype).cuda()
+    enc_a = dev(enc_a_np).requires_grad_(True)
+    ind = dev(golden["net_ind"]).requires_grad_(True) if ind_dim else None
+    eye = dev(golden["net_eye"]) if exp_eye else None
     outs = net(xyz, d, enc_a, ind, eye)
-    torch.autograd.backward(list(outs), gout)
+    live = [k for k in range(5) if outs[k].requires_grad]
+    torch.autograd.backward([outs[k] for k in live], [gout[k] for k in live])
     # ---- the f16 inference kernel: the same rounding sequence in a separately compiled kernel -- bit for bit, now that every f32 result
     # is materialised before its conversion to half (h_round: no v_fma_mixlo_f16 single rounding that depends on the surrounding code)
-    inf = FusedTriplaneHead({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()}, bound=1.0, precision="f16")
-    oi = inf.forward(xyz, d, dev(enc_a_np), dev(golden["net_ind"]), eye)
+    pi = dict(p) if ind_dim else {k: v for k, v in p.items() if k != "individual_codes"}
+    inf = FusedTriplaneHead({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in pi.items()}, bound=1.0, exp_eye=exp_eye, precision="f16")
+    oi = inf.forward(xyz, d, dev(enc_a_np), dev(golden["net_ind"]) if ind_dim else None, eye)
     for a, b, nm in zip(outs[:4], oi[:4], ("sigma", "rgb", "amb_aud", "amb_eye")):
+        if nm == "amb_eye" and not exp_eye:
+            continue
         assert torch.equal(a.detach().reshape(-1), b.reshape(-1)), nm
     # ---- the operator graph under autocast
     encs = []
@@ -600,7 +608,8 @@ def test_fused_train_head_f16_forward(params, golden, backward_dtype):
         encs.append(e)
     sh = get_encoder("spherical_harmonics")[0]
     Wg = {k: dev(v).requires_grad_(True) for k, v in p.items() if k.endswith(".weight")}
-    ea_r, ind_r = dev(enc_a_np).requires_grad_(True), dev(golden["net_ind"]).requires_grad_(True)
+    ea_r = dev(enc_a_np).requires_grad_(True)
+    ind_r = dev(golden["net_ind"]).requires_grad_(True) if ind_dim else None
 
     def mlp(h, name, n):
         for i in range(n):
@@ -612,15 +621,17 @@ def test_fused_train_head_f16_forward(params, golden, backward_dtype):
     with torch.autocast("cuda", dtype=torch.float16):
         enc_x = torch.cat([encs[0](xyz[:, :2], bound=1), encs[1](xyz[:, 1:], bound=1), encs[2](xyz[:, [0, 2]], bound=1)], -1)
         att = mlp(enc_x, "aud_ch_att_net", 2)
-        eye_att = torch.sigmoid(mlp(enc_x, "eye_att_net", 2))
-        h = mlp(torch.cat([enc_x, ea_r.half() * att, eye * eye_att], -1), "sigma_net", 3)
-        rgb = torch.sigmoid(mlp(torch.cat([sh(d), h[:, 1:], ind_r.repeat(M, 1)], -1), "color_net", 2)) * 1.002 - 0.001
+        eye_att = torch.sigmoid(mlp(enc_x, "eye_att_net", 2)) if exp_eye else None
+        h = mlp(torch.cat([enc_x, ea_r.half() * att] + ([eye * eye_att] if exp_eye else []), -1), "sigma_net", 3)
+        rgb = torch.sigmoid(mlp(torch.cat([sh(d), h[:, 1:]] + ([ind_r.repeat(M, 1)] if ind_dim else []), -1), "color_net", 2)) * 1.002 - 0.001
         ref = [torch.exp(h[:, 0]), rgb, att.norm(dim=-1, keepdim=True), eye_att, torch.nn.functional.softplus(mlp(enc_x.detach(), "unc_net", 2))]
     for o, r, nm in zip(outs, ref, ("sigma", "rgb", "amb_aud", "amb_eye", "unc")):
+        if r is None:
+            continue
         o, r = o.detach().reshape(-1), r.detach().float().reshape(-1)
         assert float(((o - r).abs() / (r.abs() + 1e-2)).max()) < 3e-2, nm   # a half ulp of a pre-activation through exp
         assert float(((o - r).abs() / (r.abs() + 1e-2)).mean()) < 1e-3, nm
-    torch.autograd.backward(ref, [g.to(r.dtype) for r, g in zip(ref, gout)])
+    torch.autograd.backward([r for r in ref if r is not None], [g.to(r.dtype) for r, g in zip(ref, gout) if r is not None])
     sd = dict(net.named_parameters())
 
     def close(a, b, name):
@@ -629,11 +640,14 @@ def test_fused_train_head_f16_forward(params, golden, backward_dtype):
         assert err < 2e-2, (name, err)
 
     for k, wg in Wg.items():
+        if not exp_eye and k.startswith("eye_att_net"):
+            continue
         close(sd[k].grad, wg.grad, k)
     for n, e in zip(("xy", "yz", "xz"), encs):
         close(sd[f"encoder_{n}.embeddings"].grad, e.embeddings.grad, "encoder_" + n)
     close(enc_a.grad, ea_r.grad, "enc_a")
-    close(ind.grad, ind_r.grad, "ind_code")
+    if ind_dim:
+        close(ind.grad, ind_r.grad, "ind_code")
 
 
 @pytest.mark.parametrize("M", [1, 17, 33])
