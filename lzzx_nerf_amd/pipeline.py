@@ -39,11 +39,11 @@ class TalkingHeadFrame:
     SMOOTH_LIPS_LAMBDA = 0.35   # renderer.py:254-258, 456-460
 
     def __init__(self, state_dict, density_bitfield, bound=1.0, exp_eye=True, torso_shrink=0.8, precision="f32", device="cuda",
-                 smooth_lips=False, **renderer_kw):
+                 smooth_lips=False, fold_geo=False, **renderer_kw):
         self.smooth_lips = bool(smooth_lips)   # opt.smooth_lips: enc_a of a frame is blended with the previous frame's
         self._enc_a_prev = None
         self.audio = FusedAudioEncoder(state_dict, device=device)
-        self.head = FusedTriplaneHead(state_dict, bound=bound, exp_eye=exp_eye, device=device, precision=precision)
+        self.head = FusedTriplaneHead(state_dict, bound=bound, exp_eye=exp_eye, device=device, precision=precision, fold_geo=fold_geo)
         self.torso = FusedTorso(state_dict, torso_shrink=torso_shrink, device=device) if "torso_net.net.0.weight" in state_dict else None
         self.renderer = TriplaneRenderer(self.head, density_bitfield, bound=bound, **renderer_kw)
 
