@@ -185,35 +185,57 @@ def _lin16(x16, W):
     return (x16.astype(F32) @ _h(W).astype(F32).T).astype(F16)
 
 
-def head_forward_fp16(spec, P, xyz, dirs, enc_a, ind_code, eye):
-    """NeRFNetwork.forward (network.py:252-311) in test mode with autocast enabled: the grid encoders stay f32 (C = 1,
-    grid.py:38), SH is f32 (custom_fwd cast_inputs), every Linear returns half, relu / sigmoid / products run in half
-    (f32 internally, rounded to half), trunc_exp and norm run in f32.  The summation order inside a half GEMM is the
-    library's (here numpy's), so this pins the GPU's f16 head to half rounding, not to the bit."""
+def head_forward_fp16(spec, P, xyz, dirs, enc_a, ind_code, eye, testing=True, enc_a_half=True, trace=None):
+    """NeRFNetwork.forward (network.py:252-311) with CUDA autocast enabled (`torch.cuda.amp.autocast`, TrainerUtil.py:455,535,649,858):
+    the grid encoders stay f32 (C = 1, grid.py:38), SH is f32 (custom_fwd cast_inputs), every Linear casts its input and weight to
+    half and returns half (f32 accumulation), relu / sigmoid / half products run in half (f32 internally, rounded to half), `cat`
+    promotes to the widest input, `exp`, `norm` and `log` are on autocast's fp32 list (half -> f32 in, f32 out).
+    `enc_a_half`: the conditioning feature is half, as `encode_audio` returns it inside the autocast region (renderer.py:241); with
+    False it is f32 and `enc_a * att` is an f32 product (type promotion) that only sigma_net's first Linear rounds to half.
+    PINNED (tests/test_golden_autocast.py) to the reference's own Python run under torch autocast, layer by layer
+    (tests/golden/reference_autocast.npz, make_golden_autocast.py).  The summation order inside a half GEMM is the library's (here
+    numpy's f32 matmul), so agreement with any other implementation is to half rounding, not to the bit.
+    `trace` (dict): filled with the half output of every Linear under the reference's module names."""
     relu = lambda a: np.maximum(a, F16(0))
+    tr = trace if trace is not None else {}
+
+    def mlp16(x16, name, n):
+        for i in range(n):
+            x16 = _lin16(x16, P[f"{name}.net.{i}.weight"])
+            tr[f"{name}.net.{i}"] = x16
+            if i != n - 1:
+                x16 = relu(x16)
+        return x16
+
     enc_x = encode_x(spec, xyz, P)
     M = enc_x.shape[0]
     x16 = _h(enc_x)
-    att = _lin16(relu(_lin16(x16, P["aud_ch_att_net.net.0.weight"])), P["aud_ch_att_net.net.1.weight"])
-    enc_a16 = _h(enc_a).reshape(1, -1)
-    parts = [x16, (enc_a16.astype(F32) * att.astype(F32)).astype(F16)]
+    att = mlp16(x16, "aud_ch_att_net", 2)
+    if enc_a_half:
+        enc_w = (_h(enc_a).reshape(1, -1).astype(F32) * att.astype(F32)).astype(F16)          # half * half -> half
+    else:
+        enc_w = _h(np.asarray(enc_a, dtype=F32).reshape(1, -1) * att.astype(F32))             # f32 * half -> f32, rounded by the Linear's cast
+    parts = [x16, enc_w]
     eye_att = None
     if eye is not None:
-        e2 = _lin16(relu(_lin16(x16, P["eye_att_net.net.0.weight"])), P["eye_att_net.net.1.weight"])
+        e2 = mlp16(x16, "eye_att_net", 2)
         eye_att = _h(O.unary("sigmoid", np.ascontiguousarray(e2.astype(F32))))
-        parts.append(_h(np.asarray(eye, dtype=F32).reshape(1, 1) * eye_att.astype(F32)))
-    h = np.concatenate(parts, axis=1)
-    s3 = _lin16(relu(_lin16(relu(_lin16(h, P["sigma_net.net.0.weight"])), P["sigma_net.net.1.weight"])), P["sigma_net.net.2.weight"])
-    sigma = O.unary("exp", np.ascontiguousarray(s3[:, 0].astype(F32)))
+        parts.append(_h(np.asarray(eye, dtype=F32).reshape(1, 1) * eye_att.astype(F32)))     # f32 [1,1] * half -> f32 -> cast by the Linear
+    s3 = mlp16(np.concatenate(parts, axis=1), "sigma_net", 3)
+    sigma = O.unary("exp", np.ascontiguousarray(s3[:, 0].astype(F32)))                        # fp32 list
     enc_d, _ = O.sh_encode_forward(dirs, 4)
     parts = [_h(enc_d), s3[:, 1:]]
     if ind_code is not None:
         parts.append(np.repeat(_h(ind_code).reshape(1, -1), M, axis=0))
-    c2 = _lin16(relu(_lin16(np.concatenate(parts, axis=1), P["color_net.net.0.weight"])), P["color_net.net.1.weight"])
+    c2 = mlp16(np.concatenate(parts, axis=1), "color_net", 2)
     sg = _h(O.unary("sigmoid", np.ascontiguousarray(c2.astype(F32))))
     rgb = _h(_h(sg.astype(F32) * F32(1 + 2 * 0.001)).astype(F32) - F32(0.001)).astype(F32)
-    amb_aud = np.sqrt((att.astype(F32) ** 2).sum(1, keepdims=True)).astype(F32)
-    unc = np.full((M, 1), O.unary("softplus", np.zeros(1, F32))[0], dtype=F32)
+    amb_aud = np.sqrt((att.astype(F32) ** 2).sum(1, keepdims=True)).astype(F32)              # norm: fp32 list
+    if testing:
+        unc = np.full((M, 1), O.unary("softplus", np.zeros(1, F32))[0], dtype=F32)           # zeros_like(enc_x): f32
+    else:
+        u2 = mlp16(x16, "unc_net", 2)
+        unc = O.unary("softplus", np.ascontiguousarray(u2.astype(F32)))                       # exp, log: fp32 list
     return sigma, rgb, amb_aud, None if eye_att is None else eye_att.astype(F32), unc
 
 

@@ -3,6 +3,7 @@ same seeded inputs.  Integer / index outputs must be bit-exact; float outputs ar
 both sides evaluate the same IEEE operation sequence (that is the design: explicit FMAs, deterministic exp/sin,
 f32 MFMA == fma chain), and to a stated tolerance where a reduction order is free (atomics) or libm is involved.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -626,6 +627,28 @@ def test_fused_head_f16_matches_autocast_checker(params, golden, boost, use_eye)
     assert np.allclose(rg, host(r32), atol=2e-2) and not np.array_equal(rg, host(r32))
     with pytest.raises(RuntimeError, match="inference-only"):
         head.forward(dev(xyz), dev(d), dev(enc_a), dev(ind), None if eye is None else dev(eye), testing=False)
+
+
+def test_fused_head_f16_matches_reference_autocast_fixture(params, golden):
+    """the f16 kernel against the REFERENCE's own forward under torch autocast(float16) (tests/golden/reference_autocast.npz, arrangement
+    `h`: enc_a half as encode_audio returns it; produced by tests/golden/make_golden_autocast.py from the imported reference Python).
+    rgb / eye attention: the fixture's halves; sigma, ||att||: the fixture ran exp / norm in half (CPU autocast), CUDA autocast and
+    the kernel run them in f32 on the same half argument -- compared after rounding to half (tests/test_golden_autocast.py)."""
+    ac = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_autocast.npz"), allow_pickle=False)
+    head = _head(params, precision="f16")
+    enc_a, ind, eye = golden["net_enc_a"], golden["net_ind"], golden["net_eye"]
+    sg, rg, ag, eg, ug = (host(t) for t in head.forward(dev(golden["net_xyz"]), dev(golden["net_dirs"]), dev(enc_a), dev(ind), dev(eye)))
+    F16 = np.float16
+
+    def ulps(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return np.abs(a - b) / 2.0 ** (np.floor(np.log2(np.maximum(np.maximum(np.abs(a), np.abs(b)), 2.0 ** -10))) - 10)
+    rgb = ac["h_test_rgb"]
+    assert ulps(rg, rgb).max() <= 4 and np.mean(rg.astype(F16) == rgb) > 0.85, (ulps(rg, rgb).max(), np.mean(rg.astype(F16) == rgb))
+    assert ulps(eg, ac["h_test_amb_eye"]).max() <= 2
+    assert ulps(sg.astype(F16), ac["h_test_sigma"]).max() <= 4 and np.mean(sg.astype(F16) == ac["h_test_sigma"]) > 0.85
+    assert ulps(ag.astype(F16), ac["h_test_amb_aud"]).max() <= 2
+    assert np.allclose(ug, ac["h_test_unc"], atol=1e-7)
 
 
 def test_render_loop_python_driven_equals_native(params, golden):
