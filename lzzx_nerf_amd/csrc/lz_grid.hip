@@ -77,8 +77,9 @@ template <> struct LzElem<__half> {
     // at::Half semantics: the f32 product is rounded to f32 FIRST, then to half.  The opaque asm keeps the compiler from
     // selecting v_fma_mixlo_f16 for cvt(mul(cvt(g), w)), which rounds the exact product once and differs in ~2^-13 of cases.
     static __device__ __forceinline__ float mul32(float a, float b) { float p = a * b; asm("" : "+v"(p)); return p; }
-    static __device__ __forceinline__ float acc(float r, float w, float g) { return rh(r + rh(mul32(w, g))); }
-    static __device__ __forceinline__ float accd(float r, float w, float gr, float gl) { return rh(r + rh(mul32(w, rh(gr - gl)))); }
+    static __device__ __forceinline__ float sum32(float a, float b) { float p = a + b; asm("" : "+v"(p)); return p; }
+    static __device__ __forceinline__ float acc(float r, float w, float g) { return rh(sum32(r, rh(mul32(w, g)))); }
+    static __device__ __forceinline__ float accd(float r, float w, float gr, float gl) { return rh(sum32(r, rh(mul32(w, rh(sum32(gr, -gl)))))); }
     static __device__ __forceinline__ __half st(float v) { return __float2half_rn(v); }
 };
 
@@ -208,7 +209,9 @@ lz_k_grid_forward_sm(const float* __restrict__ inputs, const T* __restrict__ gri
         const bool wrapped = stride_exact != (uint64_t)stride;   // very fine levels: the reference's uint32 stride wraps; keep
                                                                   // its exact (index % size) behaviour via the generic path
         const bool hashed = gridtype == 0 && stride > hs;
-        const bool dense = stride <= hs && !wrapped;          // every stride fitted: index < hs, modulo is the identity
+        const bool dense = stride <= hs && !wrapped && !align_corners;   // every stride fitted: index < hs, modulo is the identity --
+                                                                  // not with align_corners: side = res, and the +1 corner of x = 1
+                                                                  // lands one stride past the level (gridencoder.cu:71 wraps it)
         const bool pow2 = (hs & (hs - 1u)) == 0u;
         s_scale[tid] = lv.scale[tid];
         s_res[tid] = res; s_off[tid] = off0; s_hs[tid] = hs;
@@ -379,7 +382,7 @@ lz_k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
             if constexpr (C % 2 == 0) {
 #pragma unroll
                 for (uint32_t ch = 0; ch < C; ch += 2) {
-                    const __half2 v = __halves2half2(__float2half_rn(w * gcur[ch]), __float2half_rn(w * gcur[ch + 1]));
+                    const __half2 v = __halves2half2(__float2half_rn(LzElem<__half>::mul32(w, gcur[ch])), __float2half_rn(LzElem<__half>::mul32(w, gcur[ch + 1])));
                     unsafeAtomicAdd(reinterpret_cast<__half2*>(gg + index + ch), v);
                 }
             } else {
@@ -392,7 +395,7 @@ lz_k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
                 do {
                     assumed = old;
                     const unsigned short cur = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
-                    const __half nv = __float2half_rn(__half2float(__ushort_as_half(cur)) + __half2float(__float2half_rn(w * gcur[0])));
+                    const __half nv = __float2half_rn(LzElem<__half>::sum32(__half2float(__ushort_as_half(cur)), __half2float(__float2half_rn(LzElem<__half>::mul32(w, gcur[0])))));
                     const unsigned int nb = __half_as_ushort(nv);
                     const unsigned int repl = hi ? ((assumed & 0xffffu) | (nb << 16)) : ((assumed & 0xffff0000u) | nb);
                     old = atomicCAS(word, assumed, repl);
@@ -467,7 +470,7 @@ lz_k_grid_input_backward(const T* __restrict__ grad, const T* __restrict__ dy_dx
             const size_t gi = sample_major ? ((size_t)b * L + l) * C + ch : ((size_t)l * B + b) * C + ch;
             const float gv = LzElem<T>::ld(grad + gi), jv = LzElem<T>::ld(dd + (size_t)l * D * C + d * C + ch);
             if constexpr (sizeof(T) == 4) r = lz_fmaf(gv, jv, r);
-            else r = LzElem<T>::rh(r + LzElem<T>::rh(gv * jv));
+            else r = LzElem<__half>::rh(LzElem<__half>::sum32(r, LzElem<__half>::rh(LzElem<__half>::mul32(gv, jv))));
         }
     }
     grad_inputs[t] = LzElem<T>::st(r);
@@ -570,7 +573,7 @@ lz_k_grid_forward_lds(const float* __restrict__ inputs, const T* __restrict__ gr
         }
     const bool wrapped = stride_exact != (uint64_t)stride;
     const bool hashed = gridtype == 0 && stride > hs;
-    const bool dense = stride <= hs && !wrapped;
+    const bool dense = stride <= hs && !wrapped && !align_corners;   // align_corners: the +1 corner of x = 1 needs the wrap
     const bool pow2 = (hs & (hs - 1u)) == 0u;
     const uint32_t mode = dense ? 0u : ((hashed && pow2 && !wrapped) ? 1u : 2u);
     const T* gsrc = grid + (size_t)off0 * C;
@@ -622,7 +625,7 @@ __device__ __forceinline__ uint32_t lz_grid_level_mode(uint32_t hs, uint32_t res
         }
     const bool wrapped = stride_exact != (uint64_t)stride;
     const bool hashed = gridtype == 0 && stride > hs;
-    const bool dense = stride <= hs && !wrapped;
+    const bool dense = stride <= hs && !wrapped && !align_corners;   // align_corners: the +1 corner of x = 1 needs the wrap
     const bool pow2 = (hs & (hs - 1u)) == 0u;
     return dense ? 0u : ((hashed && pow2 && !wrapped) ? 1u : 2u);   // 0 identity, 1 hash + mask, 2 generic modulo
 }

@@ -219,6 +219,70 @@ void lzo_grid_encode_backward(const float* grad, const float* inputs, const int3
     }
 }
 
+/* The same backward with half tables (scalar_t = at::Half: the autocast branch of grid.py:38-39 when C is even; the torso encoder
+ * D2 L16 C2 under `-O`), gridencoder.cu:296-311: the gradient is half, each term is `(__half)(w * grad_cur[c])` -- an f32 product of
+ * the float weight and the promoted half, rounded to half -- and every atomicAdd (`__half2` pairs when N_C is even, at::Half CAS
+ * otherwise) is a half + half addition rounded to nearest even INTO the half table.  grad: [L, B, C] half; grad_emb [sO, C] half,
+ * zero-filled by the caller.  The order of the atomics is unspecified in the reference; this restatement accumulates in (level,
+ * sample, corner) order, so a table entry with one or two terms is order-free (half addition commutes) and one with more is
+ * compared to tolerance.  For that comparison `exact` (double, or NULL) receives the exact sum of the SAME half-rounded terms,
+ * `absum` (double, or NULL) the sum of their magnitudes and `terms` (int32, or NULL) their count per entry.
+ * grad_inputs (gridencoder.cu:316-342 with scalar_t = at::Half): `result += grad * dy_dx` is Half += Half * Half -- the product
+ * and the running sum are each rounded to half -- sequential over (level, channel): deterministic. */
+void lzo_grid_encode_backward_f16(const uint16_t* grad, const float* inputs, const int32_t* offsets, uint16_t* grad_emb,
+                                  double* exact, double* absum, int32_t* terms,
+                                  uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                  const uint16_t* dy_dx, uint16_t* grad_inputs, uint32_t gridtype, int align_corners) {
+    for (uint32_t level = 0; level < L; level++) {
+        const size_t goff = (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        float scale; uint32_t resolution;
+        lzo_grid_level_params(level, S, H, &scale, &resolution);
+        for (uint32_t b = 0; b < B; b++) {
+            const float* x = inputs + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) if (x[d] < 0 || x[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[LZO_MAX_D]; uint32_t pg[LZO_MAX_D];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = lz_fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+                pg[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pg[d];
+            }
+            const uint16_t* g = grad + ((size_t)level * B + b) * C;
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1; uint32_t pl[LZO_MAX_D];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                const uint32_t index = grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pl);
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    const size_t e = goff + index + ch;
+                    const float term = lz_round_to_half(w * lz_half_to_float(g[ch]));
+                    grad_emb[e] = lz_float_to_half(lz_half_to_float(grad_emb[e]) + term);
+                    if (exact) exact[e] += (double)term;
+                    if (absum) absum[e] += fabs((double)term);
+                    if (terms) terms[e] += 1;
+                }
+            }
+        }
+    }
+    if (dy_dx && grad_inputs) {
+        for (uint32_t b = 0; b < B; b++)
+            for (uint32_t d = 0; d < D; d++) {
+                float r = 0;
+                for (uint32_t l = 0; l < L; l++)
+                    for (uint32_t ch = 0; ch < C; ch++) {
+                        const float gv = lz_half_to_float(grad[((size_t)l * B + b) * C + ch]);
+                        const float jv = lz_half_to_float(dy_dx[(size_t)b * L * D * C + (size_t)l * D * C + d * C + ch]);
+                        r = lz_round_to_half(r + lz_round_to_half(gv * jv));
+                    }
+                grad_inputs[(size_t)b * D + d] = lz_float_to_half(r);
+            }
+    }
+}
+
 /* Table layout of GridEncoder.__init__ (gridencoder/grid.py:108-121): float64 resolution, cap at
  * 2^log2_hashmap_size, round up to a multiple of 8.  offsets must hold L+1 entries. */
 void lzo_grid_offsets(uint32_t D, uint32_t L, double per_level_scale, uint32_t H, uint32_t log2_hashmap_size,

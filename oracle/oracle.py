@@ -148,6 +148,29 @@ def grid_encode_backward(grad, inputs, embeddings_shape, offsets, per_level_scal
     return ge, gi
 
 
+def grid_encode_backward_f16(grad, inputs, embeddings_shape, offsets, per_level_scale, base_resolution, dy_dx=None,
+                             gridtype=0, align_corners=False):
+    """_grid_encode.backward with half tables (the autocast branch, grid.py:38-39 + gridencoder.cu:296-311).  grad: [B, L*C] float16.
+    Returns dict(grad_embeddings half [sO, C] accumulated in (level, sample, corner) order, exact float64 sum of the same half terms,
+    absum of their magnitudes, terms int32 count per entry, grad_inputs half [B, D] | None)."""
+    inputs = _f32(inputs)
+    B, D = inputs.shape
+    L = offsets.shape[0] - 1
+    Cc = embeddings_shape[1]
+    S = np.float32(np.log2(per_level_scale))
+    g = np.ascontiguousarray(np.asarray(grad, dtype=np.float16).reshape(B, L, Cc).transpose(1, 0, 2))
+    ge = np.zeros(embeddings_shape, dtype=np.float16)
+    exact = np.zeros(embeddings_shape, dtype=np.float64)
+    absum = np.zeros(embeddings_shape, dtype=np.float64)
+    terms = np.zeros(embeddings_shape, dtype=np.int32)
+    gi = np.zeros((B, D), dtype=np.float16) if dy_dx is not None else None
+    dd = None if dy_dx is None else np.ascontiguousarray(np.asarray(dy_dx, dtype=np.float16))
+    lib().lzo_grid_encode_backward_f16(_p(g), _p(inputs), _p(_i32(offsets)), _p(ge), _p(exact), _p(absum), _p(terms), u32(B), u32(D),
+                                       u32(Cc), u32(L), f32c(S), u32(base_resolution), _p(dd), _p(gi), u32(gridtype),
+                                       i32c(int(align_corners)))
+    return dict(grad_embeddings=ge, exact=exact, absum=absum, terms=terms, grad_inputs=gi)
+
+
 # ----------------------------------------------------------------------------------------------
 # shencoder / freqencoder
 # ----------------------------------------------------------------------------------------------

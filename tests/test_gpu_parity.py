@@ -199,6 +199,135 @@ def test_grid_backward_level_resident(D, L, C, H, T, res, gt):
         assert np.max(np.abs(host(enc.embeddings.grad) - ge)) < 1e-4 * np.abs(ge).max()
 
 
+@pytest.mark.parametrize("D,L,C,H,T,res,gt", [
+    (2, 16, 2, 16, 16, 2048, "tiled"),   # the torso encoder (network.py:166): the table that goes half under `-O` training
+    (3, 8, 2, 16, 15, 512, "hash"),
+    (3, 4, 4, 8, 12, 64, "hash"),        # two half2 atomics per corner
+    (2, 6, 8, 8, 10, 128, "tiled"),
+    (2, 12, 1, 64, 14, 512, "hash"),     # C odd: the at::Half CAS branch (never reached through grid.py:38, kept correct)
+])
+def test_grid_backward_half_tables(D, L, C, H, T, res, gt):
+    """emb_f16 = 1: `__half2` atomics of half(w * g) into a half table (gridencoder.cu:296-311) against the checker's restatement
+    (oracle/grid_oracle.c:lzo_grid_encode_backward_f16).  Atomic order is free: entries with <= 2 terms must match bit for bit (half
+    addition commutes), the others stay inside the rounding budget of their own terms, (terms - 1) half-ulps of sum |term|.
+    grad_inputs (Half += Half * Half over (level, channel), gridencoder.cu:316-342) is sequential: bit for bit."""
+    from lzzx_nerf_amd.gridencoder import GridEncoder
+    from lzzx_nerf_amd._util import call, ptr, stream
+    enc = GridEncoder(input_dim=D, num_levels=L, level_dim=C, base_resolution=H, log2_hashmap_size=T, desired_resolution=res,
+                      gridtype=gt).cuda()
+    rng = np.random.default_rng(81 + D + C)
+    B = 3000 + 11
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[:3] = [[0.0] * D, [1.0] * D, [1.0000001] + [0.5] * (D - 1)]
+    x[3:40] = x[40]                                       # 38 samples in ONE cell: entries with many terms
+    g = (rng.normal(size=(B, L * C)) * rng.choice([1e-3, 1.0, 30.0], size=(B, 1))).astype(np.float16)
+    emb = rng.uniform(-1, 1, tuple(enc.embeddings.shape)).astype(np.float16)
+    gid = 0 if gt == "hash" else 1
+    off = host(enc.offsets)
+    _, dd = O.grid_encode_forward(x, emb, off, enc.per_level_scale, H, True, gid)
+    r = O.grid_encode_backward_f16(g, x, tuple(emb.shape), off, enc.per_level_scale, H, dd, gid)
+    S = float(np.float32(np.log2(enc.per_level_scale)))
+    xt, et, ddt = dev(x), dev(emb), dev(dd)
+    terms, exact, absum = r["terms"], r["exact"], r["absum"]
+    assert terms.max() >= 38 and ((terms == 1) | (terms == 2)).sum() > 50
+    for layout in (0, 1):
+        gin = dev(g) if layout == 1 else dev(np.ascontiguousarray(g.reshape(B, L, C).transpose(1, 0, 2)))
+        gemb = torch.zeros_like(et)
+        ginp = torch.zeros(B, D, dtype=torch.float16, device="cuda")
+        call("lz_grid_encode_backward", ptr(gin), ptr(xt), ptr(et), ptr(enc.offsets), ptr(gemb), B, D, C, L, S, H, ptr(ddt), ptr(ginp),
+             gid, 0, 1, layout, stream())
+        ge = host(gemb)
+        few = terms <= 2
+        assert np.array_equal(ge[few].view(np.uint16), r["grad_embeddings"][few].view(np.uint16)), layout
+        err = np.abs(ge.astype(np.float64) - exact)
+        budget = np.maximum(terms - 1, 0) * 2.0 ** -11 * np.maximum(absum, 2.0 ** -14) + 2.0 ** -11 * np.abs(exact) + 2.0 ** -25
+        assert np.all(err <= budget), (layout, float((err / budget).max()))
+        assert np.array_equal(host(ginp).view(np.uint16), r["grad_inputs"].view(np.uint16)), layout
+    # the operator under autocast: _grid_encode.forward casts an even-C table to half (grid.py:38-39) and backward returns its gradient
+    if C % 2 == 0:
+        from lzzx_nerf_amd.gridencoder import grid_encode
+        enc.embeddings.data.copy_(dev(emb).float())
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = grid_encode(xt, enc.embeddings, enc.offsets, enc.per_level_scale, H, False, gid, False)
+        assert out.dtype == torch.float16
+        out_o, _ = O.grid_encode_forward(x, emb, off, enc.per_level_scale, H, False, gid)
+        assert np.array_equal(host(out).view(np.uint16), out_o.view(np.uint16))
+        out.backward(dev(g))
+        gg = host(enc.embeddings.grad)
+        assert gg.dtype == np.float32                       # autograd hands the parameter its own dtype back
+        few = terms <= 2
+        assert np.array_equal(gg[few].astype(np.float16).view(np.uint16), r["grad_embeddings"][few].view(np.uint16))
+
+
+GRID_AC_CASES = [
+    (2, 12, 1, 64, 14, 512, "hash"),     # a triplane plane with align_corners
+    (3, 16, 2, 16, 19, 2048, "hash"),    # cfg2's table
+    (2, 16, 2, 16, 16, 2048, "tiled"),
+    (3, 5, 4, 8, 12, 64, "tiled"),
+    (1, 4, 8, 8, 10, 64, "hash"),
+]
+
+
+@pytest.mark.parametrize("D,L,C,H,T,res,gt", GRID_AC_CASES)
+def test_grid_align_corners_bit_exact(D, L, C, H, T, res, gt):
+    """align_corners=True (encoding.py:9,25,29 -> gridencoder.cu:62,135: no half-cell offset, side = resolution): table layout, corner
+    indices, values and dy_dx through every forward kernel, and the backward, against the checker (whose branch is pinned to
+    grid_sample(align_corners=True) by tests/test_oracle_known_answers.py)"""
+    from lzzx_nerf_amd.gridencoder import GridEncoder, grid_encode
+    from lzzx_nerf_amd._util import call, ptr, stream
+    enc = GridEncoder(input_dim=D, num_levels=L, level_dim=C, base_resolution=H, log2_hashmap_size=T, desired_resolution=res,
+                      gridtype=gt, align_corners=True).cuda()
+    off = host(enc.offsets)
+    assert np.array_equal(off, O.grid_offsets(D, L, enc.per_level_scale, H, T, align_corners=True))
+    assert not np.array_equal(off, O.grid_offsets(D, L, enc.per_level_scale, H, T))
+    rng = np.random.default_rng(300 + D * 10 + C)
+    emb = rng.uniform(-1, 1, tuple(enc.embeddings.shape)).astype(np.float32)
+    enc.embeddings.data.copy_(dev(emb))
+    gid = 0 if gt == "hash" else 1
+    S = float(np.float32(np.log2(enc.per_level_scale)))
+    for B in (5003, 70000 + 19):           # small: sample-major / dy_dx kernels; large: level-resident and tiled level-major kernels
+        x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+        x[:4] = [[0.0] * D, [1.0] * D, [1.0000001] + [0.5] * (D - 1), [0.5] * (D - 1) + [-1e-7]]
+        out_o, dd_o = O.grid_encode_forward(x, emb, off, enc.per_level_scale, H, True, gid, True)
+        xt = dev(x)
+        out = grid_encode(xt, enc.embeddings, enc.offsets, enc.per_level_scale, H, True, gid, True)
+        assert np.array_equal(host(out), out_o)
+        out2 = grid_encode(xt, enc.embeddings, enc.offsets, enc.per_level_scale, H, False, gid, True)     # the wrapper's kernel choice
+        assert np.array_equal(host(out2), out_o)
+        for layout in (0, 1, 2):
+            o = torch.full((L, B, C) if layout == 0 else (B, L * C), 7.0, device="cuda")
+            dd = torch.empty(B, L * D * C, device="cuda") if layout == 0 else None
+            call("lz_grid_encode_forward", ptr(xt), ptr(enc.embeddings.data), ptr(enc.offsets), ptr(o), B, D, C, L, S, H, ptr(dd), gid, 1, 0,
+                 layout, stream())
+            got = host(o.permute(1, 0, 2).reshape(B, L * C)) if layout == 0 else host(o)
+            assert np.array_equal(got, out_o), (B, layout)
+            if dd is not None:
+                assert np.array_equal(host(dd), dd_o)
+        idx = torch.empty(L, B, 1 << D, dtype=torch.int32, device="cuda")
+        call("lz_grid_corner_indices", ptr(xt), ptr(enc.offsets), ptr(idx), B, D, C, L, S, H, gid, 1, stream())
+        assert np.array_equal(host(idx), O.grid_corner_indices(x, off, C, enc.per_level_scale, H, gid, True))
+        # it is a different function of x than the default convention
+        out_d, _ = O.grid_encode_forward(x[:64], emb, off, enc.per_level_scale, H, False, gid, False)
+        assert not np.array_equal(out_d, out_o[:64])
+        # backward: every layout (plain atomics, level-resident LDS accumulation where it applies) + grad_inputs
+        g = rng.normal(size=(B, L * C)).astype(np.float32)
+        ge, gi = O.grid_encode_backward(g, x, tuple(emb.shape), off, enc.per_level_scale, H, dd_o, gid, True)
+        gt_, ddt = dev(g), dev(dd_o)
+        for layout in (0, 1, 2, 3):
+            gin = gt_ if layout in (1, 2) else gt_.view(B, L, C).permute(1, 0, 2).contiguous()
+            gemb = torch.zeros_like(enc.embeddings.data)
+            ginp = torch.zeros(B, D, device="cuda")
+            call("lz_grid_encode_backward", ptr(gin), ptr(xt), ptr(enc.embeddings.data), ptr(enc.offsets), ptr(gemb), B, D, C, L, S, H,
+                 ptr(ddt), ptr(ginp), gid, 1, 0, layout, stream())
+            assert np.max(np.abs(host(gemb) - ge)) < 1e-4 * np.abs(ge).max(), (B, layout)
+            assert np.array_equal(host(ginp), gi), (B, layout)
+    # the module end to end (GridEncoder.forward maps [-bound, bound] -> [0, 1] and passes self.align_corners, grid.py:143-150)
+    xm = rng.uniform(-1, 1, (777, D)).astype(np.float32)
+    u = (xm + np.float32(1)) / np.float32(2)
+    ref, _ = O.grid_encode_forward(u, emb, off, enc.per_level_scale, H, False, gid, True)
+    assert np.array_equal(host(enc(dev(xm), bound=1)), ref)
+
+
 def test_grid_backward_level_resident_propagates_nan():
     """a NaN (or inf) output gradient reaches grad_embeddings like the reference's float atomicAdd (gridencoder.cu:226-313): GradScaler's
     non-finite check looks at exactly these tensors.  The fixed-point LDS path cannot represent it, so the (level, chunk) is rerouted."""

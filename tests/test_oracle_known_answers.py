@@ -222,6 +222,98 @@ def test_grid_half_tables_round_like_at_half():
     assert np.max(np.abs(oh.astype(np.float32) - of)) < 1e-2 and np.any(oh.astype(np.float32) != of)
 
 
+def test_grid_align_corners_dense_levels_are_grid_sample_align_corners():
+    """align_corners=True (encoding.py:9,25,29; gridencoder.cu:62,135): scale = H s^l - 1 with NO half-cell offset, side = resolution
+    (not resolution + 1): lattice node i sits at x = i / (res - 1), i.e. torch's grid_sample(align_corners=True) over a res x res image"""
+    import torch
+    import torch.nn.functional as F
+    D, L, H, pls = 2, 3, 8, 2.0
+    off = O.grid_offsets(D, L, pls, H, 19, align_corners=True)
+    assert list(np.diff(off)) == [64, 256, 1024]                      # side^2 = (H 2^l)^2, already multiples of 8
+    assert list(np.diff(O.grid_offsets(D, L, pls, H, 19))) == [88, 296, 1096]   # (side + 1)^2 rounded up to 8 without it
+    rng = np.random.default_rng(16)
+    emb = rng.normal(size=(off[-1], 1)).astype(np.float32)
+    x = rng.uniform(0, 1, (500, 2)).astype(np.float32)
+    x[:4] = [[0, 0], [1, 1], [1, 0], [0.5, 0.5]]
+    out, dydx = O.grid_encode_forward(x, emb, off, pls, H, True, 0, True)
+    g = torch.from_numpy(x.astype(np.float64) * 2 - 1).view(1, -1, 1, 2)
+    for l in range(L):
+        side = H * 2 ** l
+        img = torch.from_numpy(emb[off[l]:off[l + 1], 0].astype(np.float64)).view(1, 1, side, side)   # index = x + y * side
+        ref = F.grid_sample(img, g, mode="bilinear", padding_mode="border", align_corners=True).view(-1).numpy()
+        assert np.allclose(out[:, l], ref, atol=3e-6), l
+    assert out[0, 0] == emb[0, 0] and out[1, 0] == emb[63, 0] and out[2, 0] == emb[7, 0]      # nodes are hit exactly at 0 and 1
+    # indices: corner (0, 0) of x = (1, 1) is the last node; x + 1 / y + 1 neighbours carry weight 0 and wrap modulo the level size
+    idx = O.grid_corner_indices(x[:2], off, 1, pls, H, 0, True)
+    assert idx[0, 0, 0] == 0 and idx[0, 1, 0] == 63 and idx[1, 1, 0] == off[1] + 255
+    # dy/dx0 at the centre of a cell = scale * (v10 - v00 ...): finite differences of the interpolant
+    eps = 1e-3
+    xm = x[4:].copy()
+    xm = xm[(np.abs((xm * (H - 1)) % 1 - 0.5) < 0.3).all(1)]           # stay inside level 0's cell for the central difference
+    op, _ = O.grid_encode_forward(xm + np.float32([eps, 0]), emb, off, pls, H, False, 0, True)
+    om, _ = O.grid_encode_forward(xm - np.float32([eps, 0]), emb, off, pls, H, False, 0, True)
+    _, dd = O.grid_encode_forward(xm, emb, off, pls, H, True, 0, True)
+    assert np.allclose(dd.reshape(-1, L, 2, 1)[:, 0, 0, 0], (op[:, 0] - om[:, 0]) / (2 * eps), atol=2e-2)
+    # differs from the default convention on the same table
+    o2, _ = O.grid_encode_forward(x, emb, off, pls, H, False, 0, False)
+    assert not np.allclose(o2[4:], out[4:], atol=1e-3)
+
+
+def test_grid_half_backward_restatement():
+    """half tables (gridencoder.cu:296-311): every term is half(w * g), every add is a half + half -> half into the table"""
+    D, L, C, H, pls = 2, 3, 2, 8, 2.0
+    off = O.grid_offsets(D, L, pls, H, 9)
+    rng = np.random.default_rng(17)
+    B = 60
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[0] = [1.0000001, 0.5]                                            # out of range: contributes nothing
+    g = rng.normal(size=(B, L * C)).astype(np.float16)
+    r = O.grid_encode_backward_f16(g, x, (off[-1], C), off, pls, H)
+    idx = O.grid_corner_indices(x, off, C, pls, H)                      # [L, B, 4] element index of channel 0 (offset included)
+    sc, _ = O.grid_level_params(L, np.float32(np.log2(pls)), H)
+    ge = np.zeros((off[-1] * C,), np.float16)
+    exact = np.zeros((off[-1] * C,), np.float64)
+    cnt = np.zeros((off[-1] * C,), np.int32)
+    for l in range(L):
+        for b in range(B):
+            if idx[l, b, 0] < 0:
+                continue
+            pos = (x[b].astype(np.float64) * float(sc[l]) + 0.5).astype(np.float32)      # one rounding: the kernel's fma
+            fr = pos - np.floor(pos)
+            for c in range(4):
+                w = np.float32(1)
+                for d in range(2):
+                    w = np.float32(w * (fr[d] if (c >> d) & 1 else np.float32(1) - fr[d]))
+                for ch in range(C):
+                    term = np.float16(w * np.float32(g[b, l * C + ch]))
+                    e = idx[l, b, c] + ch
+                    ge[e] = np.float16(np.float32(ge[e]) + np.float32(term))
+                    exact[e] += float(term)
+                    cnt[e] += 1
+    assert np.array_equal(r["grad_embeddings"].reshape(-1).view(np.uint16), ge.view(np.uint16))
+    assert np.array_equal(r["terms"].reshape(-1), cnt) and np.allclose(r["exact"].reshape(-1), exact, rtol=0, atol=1e-12)
+    assert cnt.max() >= 3 and (cnt == 0).any() and r["terms"].sum() == (B - 1) * L * 4 * C
+    # an entry with one or two terms does not depend on the order (half addition commutes); any entry stays within its rounding budget
+    few = cnt <= 2
+    assert np.array_equal(ge[few].astype(np.float64), exact[few].astype(np.float16).astype(np.float64))
+    assert np.all(np.abs(ge.astype(np.float64) - exact) <= np.maximum(cnt - 1, 0) * 2.0 ** -11 * np.maximum(r["absum"].reshape(-1), 2.0 ** -14) + 1e-12)
+    # grad_inputs with half dy_dx: Half += Half * Half, sequential over (level, channel)
+    emb = rng.normal(size=(off[-1], C)).astype(np.float16)
+    _, dd = O.grid_encode_forward(x, emb, off, pls, H, True)
+    r2 = O.grid_encode_backward_f16(g, x, (off[-1], C), off, pls, H, dy_dx=dd)
+    dd4 = dd.reshape(B, L, D, C)
+    gi = np.zeros((B, D), np.float16)
+    for b in range(B):
+        for d in range(D):
+            acc = np.float16(0)
+            for l in range(L):
+                for ch in range(C):
+                    acc = np.float16(np.float32(acc) + np.float32(np.float16(np.float32(g[b, l * C + ch]) * np.float32(dd4[b, l, d, ch]))))
+            gi[b, d] = acc
+    assert np.array_equal(r2["grad_inputs"].view(np.uint16), gi.view(np.uint16))
+    assert np.array_equal(r2["grad_embeddings"], r["grad_embeddings"])
+
+
 def _composite_ref64(sig, rgb, dl, rays, unc=None, T_thresh=1e-4):
     N = rays.shape[0]
     ws, dep, img, us = np.zeros(N), np.zeros(N), np.zeros((N, 3)), np.zeros(N)
