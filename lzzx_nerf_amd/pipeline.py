@@ -47,13 +47,40 @@ class TalkingHeadFrame:
         self.torso = FusedTorso(state_dict, torso_shrink=torso_shrink, device=device) if "torso_net.net.0.weight" in state_dict else None
         self.renderer = TriplaneRenderer(self.head, density_bitfield, bound=bound, **renderer_kw)
 
+    @classmethod
+    def from_checkpoint(cls, path_or_dict, density_thresh=10.0, density_thresh_torso=0.01, bitfield="auto", device="cuda", **kw):
+        """Build the frame pipeline from a checkpoint the reference's trainer wrote (TrainerUtil.py:1222-1281) or from a bare state dict
+        (:1297-1300) -- see lzzx_nerf_amd/checkpoint.py for the two layouts.  `bound` and `exp_eye` default to what the tensors say;
+        the occupancy bitfield is the stored buffer, else packbits(density_grid, min(mean_density, density_thresh)) (renderer.py:765),
+        else all ones (`bitfield` = "auto" | "bitfield" | "grid" | "ones").  The running means travel with the object: `mean_count`
+        (march_rays_train's buffer size, renderer.py:287), `mean_density`, `mean_density_torso`; with a torso grid in the file `render`
+        masks the torso with `min(density_thresh_torso, mean_density_torso)` like run_torso (renderer.py:603) unless told otherwise."""
+        from .checkpoint import infer_hyper, read_checkpoint, resolve_bitfield
+        ck = read_checkpoint(path_or_dict)
+        hyper = infer_hyper(ck.model)
+        kw.setdefault("bound", hyper.get("bound", 1.0))
+        kw.setdefault("exp_eye", hyper.get("exp_eye", True))
+        if "aabb_infer" in ck.model:                                    # the box inference marches in (renderer.py:113, 476)
+            kw.setdefault("aabb", ck.model["aabb_infer"])
+        bits, grid, plan = resolve_bitfield(ck, density_thresh, device=device, source=bitfield)
+        self = cls(ck.model, bits, device=device, **kw)
+        self.checkpoint_kind, self.bitfield_plan = ck.kind, plan
+        self.mean_count, self.mean_density, self.mean_density_torso = ck.mean_count, ck.mean_density, ck.mean_density_torso
+        self.epoch, self.global_step = ck.epoch, ck.global_step
+        self.density_grid = grid                                        # [cascade, G^3] on device (None for 'best' checkpoints)
+        gt = ck.model.get("density_grid_torso")
+        self.density_grid_torso = None if gt is None else gt.to(device=device, dtype=torch.float32).contiguous()
+        self.density_thresh_torso = min(float(density_thresh_torso), ck.mean_density_torso)
+        self.individual_codes = ck.model.get("individual_codes")
+        return self
+
     def reset(self):
         """forget the previous frame's audio code (start of a new clip)"""
         self._enc_a_prev = None
 
     @torch.no_grad()
     def render(self, rays_o, rays_d, auds, eye=None, ind_code=None, bg_coords=None, poses=None, ind_code_torso=None, bg_color=1.0,
-               density_grid_torso=None, density_thresh_torso=0.0, **render_kw):
+               density_grid_torso=None, density_thresh_torso=None, **render_kw):
         """auds [8, dim_in, 16]; bg_color: scalar or [N,3]; returns the renderer's dict plus enc_a and (with a torso) torso_alpha,
         torso_color (= the mixed background, as results['torso_color'] in run_torso) and deform."""
         enc_a = self.audio(auds)                                                            # renderer.py:455
@@ -63,6 +90,10 @@ class TalkingHeadFrame:
             self._enc_a_prev = enc_a
         extra = dict(enc_a=enc_a)
         if self.torso is not None and bg_coords is not None:
+            if density_grid_torso is None:                      # from_checkpoint: the file's torso occupancy and its threshold
+                density_grid_torso = getattr(self, "density_grid_torso", None)
+            if density_thresh_torso is None:
+                density_thresh_torso = getattr(self, "density_thresh_torso", 0.0) if density_grid_torso is not None else 0.0
             alpha, color, deform = self.torso(bg_coords, poses, ind_code_torso, density_grid=density_grid_torso,
                                               density_thresh=density_thresh_torso)         # renderer.py:572-617
             if not torch.is_tensor(bg_color):
