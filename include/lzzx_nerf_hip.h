@@ -559,7 +559,10 @@ int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterations, lz_ti
 
 /* One inference frame as ONE persistent kernel (csrc/lz_frame.hip): near/far + first occupied cell + longest-rays-first queue
  * (2 small launches), then march -> head -> composite per ray slot with refill from the queue; no per-sample buffers, no host round
- * trip.  Equals the reference loop (renderer.py:406-570) under the schedule n_step = 1; pixels do not depend on the schedule.
+ * trip.  Equals the reference loop (renderer.py:406-570) under the schedule n_step = S (= steps_per_pass, 1 for whole frames).
+ * Pixels do not depend on the schedule for any ray that ends (leaves the box / T < T_thresh) before max_steps; a ray still alive at
+ * the cap stops at ceil(max_steps / S) * S samples -- the reference's loop tests the cap once per iteration (renderer.py:503-548), so
+ * under ITS varying n_step such a ray gets up to max_steps + 7.  Callers that compare tiles of one frame on such rays pin S.
  * All pointers are device pointers; the caller owns every buffer.  state words after the call (stream order):
  *   [1] rays that had at least one sample, [3] 1, [5] marched samples, [6] 1, [72] sample rows evaluated by the head (16 per slice)
  *   -- words 3 / 5 / 6 / 72 as in lz_loop_state / LZ_LOOP_STAT_ROWS. */

@@ -507,13 +507,7 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     const uint32_t nb = lz_div_up(f->N, 256);
     hipLaunchKernelGGL(lz_k_frame_prepare, dim3(nb), dim3(256), 0, st, K);
     hipLaunchKernelGGL(lz_k_frame_scatter, dim3(nb), dim3(256), 0, st, K);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = lz_cu_count();   // of the current device, per call (cached per device)
     // one workgroup per CU (the weights fill most of its LDS); fewer when there are not enough rays for one slot row per wave
     uint32_t grid = lz_div_up(f->N, 16 * 4);   // at least 4 waves' worth of slots per workgroup
     if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu;

@@ -805,7 +805,8 @@ lz_k_grid_untile(uint32_t* __restrict__ out, uint32_t B, uint32_t L, uint32_t W,
     const uint32_t n = (B - b0 < Tn) ? B - b0 : Tn;
     const uint32_t LW = L * W, nW = n * W;
     uint32_t* reg = out + (size_t)b0 * LW;
-    const bool vec = (n == Tn) && (nW % 4u == 0u) && (LW % 4u == 0u) && (pitch % 4u == 0u) && (((size_t)b0 * LW) % 4u == 0u);   // workgroup-uniform
+    const bool vec = (n == Tn) && (nW % 4u == 0u) && (LW % 4u == 0u) && (pitch % 4u == 0u) && (((size_t)b0 * LW) % 4u == 0u) &&
+                     ((reinterpret_cast<uintptr_t>(out) & 15u) == 0u);   // workgroup-uniform; a caller may hand over a sliced / offset buffer
     if (vec) {
         const uint32_t per_level = nW / 4u, chunks = L * per_level;             // 16-byte chunks of the tile
         for (uint32_t c0 = 0; c0 < chunks; c0 += 8u * blockDim.x) {
@@ -1210,6 +1211,7 @@ extern "C" int lz_grid_corner_indices(const float* inputs, const int32_t* offset
     LzGridLevels lv;
     LZ_REQUIRE(lz_fill_levels(lv, L, S, H) == 0, LZ_ERR_UNSUPPORTED, "grid_corner_indices: at most %d levels", LZ_MAX_LEVELS);
     if (B == 0) return LZ_OK;
+    LZ_REQUIRE(inputs && offsets && corner_idx, LZ_ERR_BAD_ARGUMENT, "grid_corner_indices: null tensor");
     dim3 grid(lz_div_up(B, 256), L, 1), block(256);
     const bool ac = align_corners != 0;
     hipStream_t st = lz_st(stream);

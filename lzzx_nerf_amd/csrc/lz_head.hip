@@ -258,13 +258,7 @@ extern "C" int lz_triplane_head_forward(const lz_head_params* p, const float* xy
         a.scale[l] = sc;
         a.res[l] = (uint32_t)ceilf(sc) + 1u;
     }
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = lz_cu_count();   // of the current device, per call (cached per device)
     const uint32_t tiles = lz_div_up(M, LZ_WG_SAMPLES);
     const uint32_t grid = tiles < (uint32_t)n_cu ? tiles : (uint32_t)n_cu;
     if (p->precision == 2)

@@ -416,13 +416,7 @@ extern "C" int lz_triplane_head_backward(const lz_head_params* p, const float* x
     a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_amb_aud = g_amb_aud; a.g_amb_eye = g_amb_eye; a.g_unc = g_unc;
     a.o = o;
     a.wb16 = nullptr;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = lz_cu_count();   // of the current device, per call (cached per device)
     const uint32_t slices = lz_div_up(M, 16);
     const uint32_t want = lz_div_up(slices, LZ_BWD_WG / 64);
     const uint32_t grid = want < (uint32_t)n_cu ? want : (uint32_t)n_cu;

@@ -148,13 +148,7 @@ int lz_head_forward_f16_impl(const lz_head_params* p, const float* xyzs, const f
         a.scale[l] = sc;
         a.res[l] = (uint32_t)ceilf(sc) + 1u;
     }
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = lz_cu_count();   // of the current device, per call (cached per device)
     const uint32_t tiles = lz_div_up(M, 256);
     const uint32_t grid = tiles < (uint32_t)n_cu ? tiles : (uint32_t)n_cu;
     hipLaunchKernelGGL(lz_k_triplane_head_f16, dim3(grid), dim3(H_WG), 0, st, a, xyzs, dirs, M, count, sigmas, rgbs, amb_aud, amb_eye, unc);

@@ -268,13 +268,7 @@ static int lz_grad_w_launch(const void* rec, bool h16, uint32_t M, uint32_t k_si
     LZ_REQUIRE(dW_x3 && dW_aud1 && dW_sig0 && dW_sig1 && dW_c1h && workspace, LZ_ERR_BAD_ARGUMENT, "head_grad_w: null tensor");
     LZ_REQUIRE(M == 0 || rec, LZ_ERR_BAD_ARGUMENT, "head_grad_w: null records");
     LZ_REQUIRE(k_sig0 == 68 || k_sig0 == 69, LZ_ERR_BAD_ARGUMENT, "head_grad_w: sigma_net.0 takes 68 or 69 inputs");
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = lz_cu_count();   // of the current device, per call (cached per device)
     const uint32_t groups = lz_div_up(M, h16 ? 16 : 8);
     uint32_t grid = 3u * (uint32_t)n_cu;   // the registers of a CU hold two workgroups; a third queued one evens out the tail
     if (grid > LZ_GW_MAX_PARTS) grid = LZ_GW_MAX_PARTS;

@@ -691,13 +691,7 @@ static void lz_fill_head_args(const lz_head_params* p, LzHeadArgs& a) {
 }
 
 static uint32_t lz_rec_grid(uint32_t M, uint32_t wg) {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = lz_cu_count();   // of the current device, per call (cached per device)
     const uint32_t want = lz_div_up(lz_div_up(M, 16), wg / 64);
     return want < (uint32_t)n_cu ? want : (uint32_t)n_cu;
 }

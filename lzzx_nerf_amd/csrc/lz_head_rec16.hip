@@ -292,13 +292,7 @@ extern "C" int lz_triplane_head_forward_record_f16(const lz_head_params* p, cons
         a.scale[l] = sc;
         a.res[l] = (uint32_t)ceilf(sc) + 1u;
     }
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = lz_cu_count();   // of the current device, per call (cached per device)
     const uint32_t want = lz_div_up(lz_div_up(M, 16), LZ_FREC16_WG / 64);
     const uint32_t grid = want < (uint32_t)n_cu ? want : (uint32_t)n_cu;
     hipLaunchKernelGGL(lz_k_triplane_head_forward_rec16, dim3(grid), dim3(LZ_FREC16_WG), 0, lz_st(stream), a,

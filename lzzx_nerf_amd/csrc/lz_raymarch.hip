@@ -268,9 +268,11 @@ lz_k_mark_untrained(const float* __restrict__ poses, uint32_t B, float cx_fx, fl
 
 extern "C" int lz_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t C, uint32_t G,
                                       float bound, float* density_grid, int32_t* count, lz_stream_t stream) {
-    if (C * G == 0) return LZ_OK;
+    if (C == 0 || G == 0) return LZ_OK;
     LZ_REQUIRE(poses && density_grid, LZ_ERR_BAD_ARGUMENT, "mark_untrained_grid: null tensor");
     LZ_REQUIRE(C <= 8 && G >= 2 && G <= 1024, LZ_ERR_BAD_ARGUMENT, "mark_untrained_grid: cascade <= 8, 2 <= grid_size <= 1024");
+    // the kernel's linear cell index and its bound are 32-bit: C * G^3 must not wrap (G = 1024 allows C <= 3)
+    LZ_REQUIRE((uint64_t)C * G * G * G < (1ull << 32), LZ_ERR_BAD_ARGUMENT, "mark_untrained_grid: cascade * grid_size^3 must be < 2^32");
     // cx / fx is a python double narrowed when it multiplies the f32 tensor (renderer.py:684)
     const float cx_fx = (float)((double)cx / (double)fx), cy_fy = (float)((double)cy / (double)fy);
     hipLaunchKernelGGL(lz_k_mark_untrained, dim3(lz_div_up((uint64_t)C * G * G * G, 256)), dim3(256), 0, lz_st(stream), poses, B, cx_fx, cy_fy, C,
@@ -565,6 +567,9 @@ extern "C" int lz_march_rays_train(const float* rays_o, const float* rays_d, con
     LZ_REQUIRE(workspace, LZ_ERR_BAD_ARGUMENT, "march_rays_train: workspace of (N + 2) * 4 bytes required");
     LZ_REQUIRE(C >= 1 && C <= 8 && H > 0, LZ_ERR_BAD_ARGUMENT, "march_rays_train: cascade must be in [1, 8]");
     if (N == 0) return LZ_OK;
+    // noises is always a tensor (zeros without perturb, raymarching.py:226-229); with M == 0 the sample buffers are not written
+    LZ_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises, LZ_ERR_BAD_ARGUMENT, "march_rays_train: null tensor");
+    LZ_REQUIRE(M == 0 || (xyzs && dirs && deltas), LZ_ERR_BAD_ARGUMENT, "march_rays_train: null sample buffers with M > 0");
     int* counts = reinterpret_cast<int*>(workspace);
     int* base = counts + N;
     hipStream_t st = lz_st(stream);

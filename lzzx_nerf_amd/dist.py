@@ -136,8 +136,15 @@ class ShardedFrame:
         frame = sf.assemble(gathered)                       # pixel order (no-op for contiguous tiles)
     """
 
-    def __init__(self, H, W, rank, world, tiles="contiguous", device="cuda", channels=3, dtype=torch.float32, group=None):
+    def __init__(self, H, W, rank, world, tiles="contiguous", device="cuda", channels=3, dtype=torch.float32, group=None,
+                 steps_per_pass=None):
+        """steps_per_pass: pin the fused renderer's samples-per-ray-and-pass S (`configure(renderer)`).  The fused frame is the
+        reference loop under the schedule n_step = S, and S is otherwise chosen from the ray count -- a rank's tile (N / world rays)
+        gets a larger S than the whole frame.  Pixels are schedule-independent for every ray that ends before `max_steps`; a ray
+        that reaches the cap receives ceil(max_steps / S) * S samples (the reference's loop tests the cap once per iteration,
+        renderer.py:503-548), so only a pinned S makes tiles and the unsharded frame agree on such rays too."""
         self.H, self.W, self.rank, self.world, self.tiles = H, W, rank, world, tiles
+        self.steps_per_pass = steps_per_pass
         self.pixels = tile_pixels(H, W, rank, world, tiles, device)
         self.sizes = [len(tile_rows(H, r, world, tiles)) * W for r in range(world)]
         self.n_local = self.sizes[rank]
@@ -146,6 +153,12 @@ class ShardedFrame:
     def rays(self, pose, intrinsics):
         from .utils import frame_rays
         return frame_rays(pose, intrinsics, self.H, self.W, self.pixels)
+
+    def configure(self, renderer):
+        """apply the pinned schedule (if any) to a TriplaneRenderer; returns it"""
+        if self.steps_per_pass is not None:
+            renderer.steps_per_pass = int(self.steps_per_pass)
+        return renderer
 
     def gather(self, tile):
         return tile if self.gatherer is None else self.gatherer.gather(tile)

@@ -61,7 +61,15 @@ class TriplaneRenderer:
                  min_near=0.05, density_scale=1, budget_factor=1, n_step_cap=8, mode="loop"):
         """mode "loop": the reference's iteration structure, 3 launches per iteration (march, head, composite), schedule
         (budget_factor, n_step_cap).  mode "fused": the whole frame as one persistent kernel (csrc/lz_frame.hip) -- the loop under
-        the schedule n_step = 1 with on-the-fly refill of finished ray slots; same pixels, depth and sums, bit for bit."""
+        the schedule n_step = S (`steps_per_pass`; 0 = chosen from the ray count: 1 for a whole frame, up to 16 for small tiles) with
+        on-the-fly refill of finished ray slots; same pixels, depth and sums, bit for bit, as the loop run with (budget_factor,
+        n_step_cap) = (S, S).
+        Cap semantics: the reference tests `step < max_steps` once per ITERATION (renderer.py:503-548), so a ray that is still alive
+        at the cap has received ceil(max_steps / n_step) * n_step samples -- up to max_steps + 7 under the reference's own varying
+        n_step.  Fused mode stops such a ray at ceil(max_steps / S) * S samples (exactly max_steps for S = 1).  Every ray that leaves
+        the box or falls under T_thresh before the cap -- all rays of a bounded scene with max_steps >= the longest chord / dt_min,
+        e.g. the 512^2 / 192-step headline frame -- is schedule-independent; for the others pin S (dist.ShardedFrame(steps_per_pass=))
+        when tiles of one frame must agree with each other."""
         if mode not in ("loop", "fused"):
             raise ValueError("mode must be 'loop' or 'fused'")
         self.mode = mode

@@ -81,6 +81,28 @@ int main() {
     CHECK(near[2] > 1e30f && far[2] > 1e30f);   // a miss is FLT_MAX on both (raymarching.cu:120-145)
     // ---- argument errors come back as codes with a message, never as a crash
     CHECK(lz_morton3D(nullptr, 4, d_idx, st) != 0 && lz_last_error()[0] != 0);
+    // ... on every family of entry points (round 2's incident: a null pointer launched instead of rejected faulted the GPU)
+    float* fnull = nullptr;
+    CHECK(lz_grid_encode_forward(nullptr, nullptr, nullptr, nullptr, 4, 2, 1, 1, 1.0f, 16, nullptr, 0, 0, 0, 0, st) != 0);
+    CHECK(lz_grid_encode_backward(nullptr, nullptr, nullptr, nullptr, nullptr, 4, 2, 1, 1, 1.0f, 16, nullptr, nullptr, 0, 0, 0, 0, st) != 0);
+    CHECK(lz_grid_corner_indices(nullptr, nullptr, nullptr, 4, 2, 1, 1, 1.0f, 16, 0, 0, st) != 0);
+    CHECK(lz_sh_encode_forward(nullptr, nullptr, 4, 3, 4, nullptr, st) != 0);
+    CHECK(lz_sh_encode_backward(nullptr, nullptr, 4, 3, 4, nullptr, nullptr, st) != 0);
+    CHECK(lz_freq_encode_forward(nullptr, 4, 2, 4, 18, nullptr, st) != 0);
+    CHECK(lz_freq_encode_backward(nullptr, nullptr, 4, 2, 4, 18, nullptr, st) != 0);
+    CHECK(lz_triplane_head_forward(nullptr, fnull, fnull, 16, nullptr, fnull, fnull, fnull, fnull, fnull, st) != 0);
+    lz_head_params hp{};                                  // zeroed parameter block: every table / weight pointer null
+    CHECK(lz_triplane_head_forward(&hp, d_near, d_near, 16, nullptr, d_near, d_near, d_near, d_near, d_near, st) != 0);
+    CHECK(lz_march_rays_train(nullptr, nullptr, nullptr, 1.0f, 0.0f, 16, 4, 1, 128, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, d_idx, st) != 0);
+    CHECK(lz_composite_rays_train_triplane_forward(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 8, 4, 1e-4f, nullptr, nullptr, nullptr,
+                                                   nullptr, nullptr, nullptr, st) != 0);
+    CHECK(lz_near_far_from_aabb(nullptr, nullptr, nullptr, 4, 0.05f, nullptr, nullptr, st) != 0);
+    CHECK(lz_packbits(nullptr, 8, 0.5f, nullptr, st) != 0);
+    CHECK(lz_last_error()[0] != 0);
+    HIP_OK(hipStreamSynchronize(st));                     // nothing was launched: the stream is still healthy
+    LZ_OK_(lz_packbits(d_grid, G, 0.5f, d_bits, st));
+    HIP_OK(hipStreamSynchronize(st));
     std::printf("cabi consumer ok\n");
     return 0;
 }

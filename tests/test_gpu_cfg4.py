@@ -55,6 +55,44 @@ def test_frame_as_8_ray_shards_equals_unsharded(params, golden, tiles):
         assert float(per.max() / per.mean()) < 1.25
 
 
+def test_pinned_schedule_makes_tiles_agree_on_rays_that_reach_the_cap(params, golden):
+    """fused mode stops a ray that is still alive at the cap after ceil(max_steps / S) * S samples (the reference tests the cap once per
+    iteration, renderer.py:503-548) and picks S from the ray count -- so a tile and the whole frame differ on such rays unless S is
+    pinned (ShardedFrame(steps_per_pass=)).  All-ones occupancy, dt_gamma 0 and a 19-step cap: every ray that enters the box hits it."""
+    from lzzx_nerf_amd import dist as D
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    from lzzx_nerf_amd.synthetic import ones_bitfield, synthetic_camera
+    H = W = 128
+    pose, intr = synthetic_camera(H, W)
+    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in params.items()}, bound=1.0)
+    bits = dev(ones_bitfield())
+    cond = (dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]))
+    kw = dict(max_steps=19, dt_gamma=0.0, count_samples=True)
+    world = 4
+    for S, cap in ((1, 19), (4, 20), (8, 24)):
+        full_sf = D.ShardedFrame(H, W, 0, 1, device="cuda", steps_per_pass=S)
+        r = full_sf.configure(TriplaneRenderer(head, bits, bound=1.0, mode="fused"))
+        ro, rd = full_sf.rays(dev(pose), intr)
+        ref = {k: v.clone() for k, v in r.render(ro, rd, *cond, **kw).items()}
+        assert int(ref["ray_counts"].max()) == cap and int((ref["ray_counts"] == cap).sum()) > 1000      # ceil(19 / S) * S
+        loop = TriplaneRenderer(head, bits, bound=1.0, budget_factor=S, n_step_cap=S).render(ro, rd, *cond, **kw)
+        assert torch.equal(loop["image"], ref["image"]) and torch.equal(loop["ray_counts"], ref["ray_counts"])
+        imgs, cnts = [], []
+        for g in range(world):
+            sf = D.ShardedFrame(H, W, g, world, "interleaved", device="cuda", steps_per_pass=S)
+            sf.gatherer = None
+            rr = sf.configure(TriplaneRenderer(head, bits, bound=1.0, mode="fused"))
+            o = rr.render(*sf.rays(dev(pose), intr), *cond, **kw)
+            imgs.append(o["image"].clone())
+            cnts.append(o["ray_counts"].clone())
+        assert torch.equal(D.assemble_frame(torch.cat(imgs), H, W, world, "interleaved"), ref["image"]), S
+        assert torch.equal(D.assemble_frame(torch.cat(cnts)[:, None], H, W, world, "interleaved")[:, 0], ref["ray_counts"]), S
+    # unpinned: the 4 096-ray tile picks S > 1, the 16 384-ray frame may pick another -> counts at the cap differ, as documented
+    auto_tile = TriplaneRenderer(head, bits, bound=1.0, mode="fused").render(*D.ShardedFrame(H, W, 0, world, "interleaved", device="cuda").rays(dev(pose), intr), *cond, **kw)
+    assert int(auto_tile["ray_counts"].max()) in (19, 20, 24, 32)
+
+
 def test_device_built_ellipsoid_bitfield_equals_checker():
     from conftest import ellipsoid_bitfield
     from lzzx_nerf_amd.synthetic import ellipsoid_bitfield_device
