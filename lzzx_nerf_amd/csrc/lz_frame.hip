@@ -161,18 +161,34 @@ struct LzShFromSlot {
     __device__ __forceinline__ float comp_iq(int i, int q) const { return slot[(SF_SH + 4 * i + q) * ns + ls]; }
     __device__ __forceinline__ float comp_qj(int q, int j) const { return slot[(SF_SH + 4 * q + j) * ns + ls]; }
 };
+// the f16 head consumes SH as halves: the slot keeps them packed (components 2 k, 2 k + 1 in word k of 8), converted once per ray
+struct LzShFromSlot16 {
+    const float* slot;
+    int ls, ns;
+    __device__ __forceinline__ void prepare() const {}
+};
+__device__ __forceinline__ void h_sh_pk(const LzShFromSlot16& f, int q, uint32_t (&w)[2]) {
+    w[0] = __float_as_uint(f.slot[(SF_SH + 2 * q) * f.ns + f.ls]);
+    w[1] = __float_as_uint(f.slot[(SF_SH + 2 * q + 1) * f.ns + f.ls]);
+}
 // evaluated by the lane that takes the ray (the same lz_sh_eval call on the same direction as the stand-alone head makes per sample)
+template <int PREC>
 __device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* slot, int s, int ns) {
     const float* d = F.rays_d + (size_t)ray * 3;
     float o[16];
     lz_sh_eval(d[0], d[1], d[2], 4, o, nullptr, nullptr, nullptr);
+    if constexpr (PREC == 1) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) slot[(SF_SH + k) * ns + s] = o[k];
+        for (int k = 0; k < 8; k++) slot[(SF_SH + k) * ns + s] = __uint_as_float(h_cvt2(o[2 * k], o[2 * k + 1], false));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) slot[(SF_SH + k) * ns + s] = o[k];
+    }
 }
 
 template <int PREC> struct LzfHead;
 template <> struct LzfHead<0> {
-    using Args = LzHeadArgs; using Ctx = LzHeadCtx; using Out = LzHeadOut;
+    using Args = LzHeadArgs; using Ctx = LzHeadCtx; using Out = LzHeadOut; using ShSlot = LzShFromSlot;
     static constexpr int LDS_WORDS = LzHeadLds<false>::FLOATS;
     __device__ static __forceinline__ void stage(const Args& P, float* lds, int q, Ctx& c) { lz_head_stage<false>(P, lds, LZF_WG, q, c); }
     template <typename ShFn>
@@ -187,7 +203,7 @@ template <> struct LzfHead<2> : LzfHead<0> {   // f32 with the geo projection fo
     }
 };
 template <> struct LzfHead<1> {
-    using Args = LzHead16Args; using Ctx = LzHead16Ctx; using Out = LzHead16Out;
+    using Args = LzHead16Args; using Ctx = LzHead16Ctx; using Out = LzHead16Out; using ShSlot = LzShFromSlot16;
     static constexpr int LDS_WORDS = LZ_HEAD16_LDS_H8 * 4;
     __device__ static __forceinline__ void stage(const Args& P, float* lds, int, Ctx& c) { lz_head16_stage(P, reinterpret_cast<lz_h8*>(lds), LZF_WG, c); }
     template <typename ShFn>
@@ -252,7 +268,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
                             sloti[SF_CNT * 16 + s] = 0;
                             sloti[SF_IT * 16 + s] = 0;
-                            lzf_store_sh(F, ray, slot, s, 16);
+                            lzf_store_sh<PREC>(F, ray, slot, s, 16);
                         }
                     }
                     if (base + take >= n_queue) dry = true;
@@ -292,7 +308,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
             const bool live = sloti[SF_RAY * 16 + lead] >= 0 && j < lkk;
             const float px = live ? slot[SF_X * 16 + s] : 0.0f, py = live ? slot[SF_Y * 16 + s] : 0.0f, pz = live ? slot[SF_Z * 16 + s] : 0.0f;
             typename HD::Out o;
-            HD::slice(ctx, lane, px, py, pz, LzShFromSlot{slot, lead, 16}, o);
+            HD::slice(ctx, lane, px, py, pz, typename HD::ShSlot{slot, lead, 16}, o);
             my_slices++;
             if (q == 0) {
                 slot[SF_OSIG * 16 + s] = o.sigma;
@@ -367,7 +383,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
 #pragma unroll
                             for (int f = SF_WS; f <= SF_U; f++) slot[f * NS + sl] = 0.0f;
                             sloti[SF_CNT * NS + sl] = 0;
-                            lzf_store_sh(F, ray, slot, sl, NS);
+                            lzf_store_sh<PREC>(F, ray, slot, sl, NS);
                         }
                     }
                     if (base + take >= n_queue) dry = true;    // wave-uniform
@@ -412,7 +428,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 if (ROWS > 1 && !((have_mask >> (16 * row)) & 0xffffull)) continue;   // no sample in this row
                 const int rs = 16 * row + s;                   // the slot whose sample this lane works on
                 const float px = __shfl(x, rs, 64), py = __shfl(y, rs, 64), pz = __shfl(z, rs, 64);
-                HD::slice(ctx, lane, px, py, pz, LzShFromSlot{slot, rs, NS}, o);
+                HD::slice(ctx, lane, px, py, pz, typename HD::ShSlot{slot, rs, NS}, o);
                 my_slices++;
                 if (ROWS > 1 && q == 0) {   // park the row's outputs for the compositing below (lanes q == 0 hold valid bits in both heads)
                     slot[SF_OSIG * NS + rs] = o.sigma;

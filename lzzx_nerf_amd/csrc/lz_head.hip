@@ -195,7 +195,7 @@ lz_k_triplane_head(LzHeadArgs P, const float* __restrict__ xyzs, const float* __
     // Work distribution: the workgroup owns slices [slice_lo, slice_hi); its 16 waves pull 16-sample slices from a queue
     // in LDS (one ds_add_rtn per slice).  The waves that share a SIMD drift apart: some gather (texture-address bound)
     // while another feeds the matrix pipe, instead of all gathering and then all multiplying in lockstep.
-    int* queue = reinterpret_cast<int*>(wl + LzHeadLds<TRAIN_UNC>::TAB) + 48;
+    int* queue = reinterpret_cast<int*>(wl + LzHeadLds<TRAIN_UNC>::TAB) + LZ_LVTAB_QUEUE;
     for (;;) {
         int slice = 0;
         if (lane == 0) slice = atomicAdd(queue, 1);

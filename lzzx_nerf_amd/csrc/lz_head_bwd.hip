@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(LZ_BWD_WG, LZ_BWD_WG / 256)
 lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, const float* __restrict__ dirs, uint32_t M) {
     constexpr int NFRAG = LZ_FRAGS_ALL;
     constexpr int WV = NFRAG * 64, TAB = WV + LZ_WV_FLOATS;
-    __shared__ float wl[TAB + 96];
+    __shared__ float wl[TAB + LZ_LVTAB_WORDS];
     const LzHeadArgs& P = A.fwd;
     const lz_head_bwd_out& O = A.o;
     const uint32_t n_slices = (M + 15) / 16;
@@ -34,20 +34,12 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
         float4* dst = reinterpret_cast<float4*>(wl);
         for (int i = threadIdx.x; i < NFRAG * 16; i += LZ_BWD_WG) dst[i] = src[i];
         if (threadIdx.x < LZ_WV_FLOATS) wl[WV + threadIdx.x] = P.packed[LZ_FRAGS_ALL * 64 + threadIdx.x];
-        int* tab = reinterpret_cast<int*>(wl + TAB);
-        if (threadIdx.x < 13) tab[threadIdx.x] = P.offsets[threadIdx.x];
-        if (threadIdx.x < 12) {
-            wl[TAB + 16 + threadIdx.x] = P.scale[threadIdx.x];
-            tab[32 + threadIdx.x] = (int)P.res[threadIdx.x];
-        }
-        if (threadIdx.x < 32) wl[TAB + 64 + threadIdx.x] = P.enc_a[threadIdx.x];
-        if (threadIdx.x == 0) tab[48] = 0;
+        lz_level_table_fill(reinterpret_cast<int*>(wl + TAB), P.offsets, P.scale, P.res);   // + the slice queue head
+        if (threadIdx.x < 32) wl[TAB + LZ_LVTAB_ENCA + threadIdx.x] = P.enc_a[threadIdx.x];
     }
     __syncthreads();
-    const int* offs = reinterpret_cast<const int*>(wl + TAB);
-    const float* lscale = wl + TAB + 16;
-    const int* lres = offs + 32;
-    const float* lenca = wl + TAB + 64;
+    const int* tab = reinterpret_cast<const int*>(wl + TAB);
+    const float* lenca = wl + TAB + LZ_LVTAB_ENCA;
     const float* wv = wl + WV;
 
     const int lane = threadIdx.x & 63;
@@ -56,7 +48,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
     const bool has_eye = P.eye != nullptr;
     const float eye_v = has_eye ? P.eye[0] : 0.0f;
     const float indq = P.ind_code ? P.ind_code[q] : 0.0f;
-    int* queue = reinterpret_cast<int*>(wl + TAB) + 48;
+    int* queue = reinterpret_cast<int*>(wl + TAB) + LZ_LVTAB_QUEUE;
     // The two waves that share a SIMD would otherwise run in lockstep (same code, same start): both in their matrix phases, then both in
     // their VALU / store phases.  Delaying the second one by about half a slice lets one wave's MFMAs overlap the other's VALU work.
     if ((threadIdx.x >> 6) >= 4) {
@@ -92,7 +84,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 
         // =============================== forward (as lz_k_triplane_head<true>) ===============================
         float encx[9];
-        lz_head_gather(P.emb, offs, lscale, lres, xyzs[(size_t)m * 3], xyzs[(size_t)m * 3 + 1], xyzs[(size_t)m * 3 + 2], q, P.bound, two_bound, encx);
+        lz_head_gather(P.emb, tab, xyzs[(size_t)m * 3], xyzs[(size_t)m * 3 + 1], xyzs[(size_t)m * 3 + 2], q, P.bound, two_bound, encx);
         // every per-sample input is loaded here, before the first dump store of the slice: a load issued after stores can only be waited
         // for once those stores have been acknowledged (one counter, in order), which under this kernel's write stream takes microseconds
         const float g_sig = A.g_sigma[row], g_aa = A.g_amb_aud[row], g_ae = A.g_amb_eye ? A.g_amb_eye[row] : 0.0f, g_un = A.g_unc[row];

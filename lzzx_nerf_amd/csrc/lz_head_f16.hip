@@ -111,7 +111,7 @@ lz_k_triplane_head_f16(LzHead16Args P, const float* __restrict__ xyzs, const flo
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int s = lane & 15, q = lane >> 4;
-    int* queue = reinterpret_cast<int*>(wl + H_FRAGS * 64) + 48;
+    int* queue = reinterpret_cast<int*>(wl + H_FRAGS * 64) + LZ_LVTAB_QUEUE;
     for (;;) {
         int slice = 0;
         if (lane == 0) slice = atomicAdd(queue, 1);

@@ -74,6 +74,13 @@ __device__ __forceinline__ _Float16 h_round(float v) {
 // IEEE division) costs about 31, four times per slice in kernels that are bound by VALU issue
 __device__ __forceinline__ float h_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 
+// exp and sqrt that autocast runs in f32 on a half-valued argument (sigma = exp(h[..., 0]), ||att||: network.py:302,308; both on torch's
+// "autocast to float32" list): hardware v_exp_f32 / v_sqrt_f32 -- about 1 ulp, as good a float exp / sqrt as the reference's (CUDA's expf is
+// 2 ulp) -- where the bit-reproducible lz_expf polynomial and the IEEE sqrtf expansion cost ~22 and ~10 instructions per slice in kernels
+// bound by vector-instruction issue.  Every f16 kernel (inference slice, fused frame, recording forward) calls these, so they agree bit for bit.
+__device__ __forceinline__ float h_exp32(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float h_sqrt32(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 template <int KS, int NT>
 __device__ __forceinline__ void h_layer_at(const lz_h8* __restrict__ frags, int lane, const lz_h8 (&b)[KS], lz_f4 (&acc)[NT]) {
     const lz_h8* frag = frags + lane;
@@ -102,6 +109,27 @@ __device__ __forceinline__ uint32_t h_cvt2(float a, float b, bool relu) {
     }
     return __builtin_bit_cast(uint32_t, h);
 }
+// two f32 RESULTS -> packed halves, each through its own f32 value first (h_round's reason), one v_cvt_pk_f16_f32
+__device__ __forceinline__ uint32_t h_round2(float a, float b) {
+    asm volatile("" : "+v"(a), "+v"(b));
+    return h_cvt2(a, b, false);
+}
+// enc_a * att, half * half -> half (network.py:291 under autocast with enc_a half): the exact product of two halves has 22 significant
+// bits, so "f32 product, then round to half" is ONE rounding of the exact product = v_pk_mul_f16, two products per instruction.
+// enca16: this lane's eight enc_a halves (features 16 (j >> 2) + 4 q + (j & 3)) from the LDS table
+__device__ __forceinline__ lz_h8 h_encw(const int* __restrict__ tab, int q, const lz_h8& att) {
+    typedef uint32_t lz_u2v __attribute__((ext_vector_type(2)));
+    const lz_u2v lo = *reinterpret_cast<const lz_u2v*>(tab + LZ_LVTAB_ENCA16 + 2 * q), hi = *reinterpret_cast<const lz_u2v*>(tab + LZ_LVTAB_ENCA16 + 8 + 2 * q);
+    const lz_u4v e = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(lz_h8, e) * att;
+}
+// the SH / ind_code half of colour_net.0's first B operand: SH components 4 q .. 4 q + 3 as halves, then ind_code (lanes q == 0)
+template <typename ShFn>
+__device__ __forceinline__ void h_sh_pk(const ShFn& f, int q, uint32_t (&w)[2]) {
+    w[0] = h_cvt2(f.comp_qj(q, 0), f.comp_qj(q, 1), false);
+    w[1] = h_cvt2(f.comp_qj(q, 2), f.comp_qj(q, 3), false);
+}
+
 __device__ __forceinline__ lz_h8 h_pair(const lz_f4& lo, const lz_f4& hi, bool relu) {
     const lz_u4v w = {h_cvt2(lo[0], lo[1], relu), h_cvt2(lo[2], lo[3], relu), h_cvt2(hi[0], hi[1], relu), h_cvt2(hi[2], hi[3], relu)};
     return __builtin_bit_cast(lz_h8, w);
@@ -109,9 +137,7 @@ __device__ __forceinline__ lz_h8 h_pair(const lz_f4& lo, const lz_f4& hi, bool r
 
 struct LzHead16Ctx {
     const lz_h8* wl;        // LDS: packed A fragments
-    const int* offs;        // LDS: level offsets [13]
-    const float* lscale;    // LDS: level scale [12]
-    const int* lres;        // LDS: level resolution [12]
+    const int* tab;         // LDS: the level table (lz_head_gather.h: LZ_LVTAB_*)
     const float* lenca;     // LDS: enc_a rounded to half [32]
     const float* emb[3];
     const float* ind_code;
@@ -123,25 +149,20 @@ struct LzHead16Out {
     float sigma, rgb[3], ambaud, eyeatt, unc;   // sigma / eyeatt are valid on lanes q == 0 only
 };
 
-constexpr int LZ_HEAD16_LDS_H8 = H_FRAGS * 64 + 24;   // lz_h8 elements: fragments, then 96 words (level table 64, enc_a 32)
+constexpr int LZ_HEAD16_LDS_H8 = H_FRAGS * 64 + LZ_LVTAB_WORDS / 4;   // lz_h8 elements: fragments, then the level table (enc_a inside)
 
 // stage weights + tables into LDS (all threads; caller synchronises afterwards) and fill the context
 __device__ __forceinline__ void lz_head16_stage(const LzHead16Args& P, lz_h8* wl, uint32_t n_threads, LzHead16Ctx& hc) {
     float* tabf = reinterpret_cast<float*>(wl + H_FRAGS * 64);
     int* tab = reinterpret_cast<int*>(tabf);
     for (uint32_t i = threadIdx.x; i < (uint32_t)H_FRAGS * 64; i += n_threads) wl[i] = P.packed[i];
-    if (threadIdx.x < 13) tab[threadIdx.x] = P.offsets[threadIdx.x];
-    if (threadIdx.x < 12) {
-        tabf[16 + threadIdx.x] = P.scale[threadIdx.x];
-        tab[32 + threadIdx.x] = (int)P.res[threadIdx.x];
-    }
-    if (threadIdx.x < 32) tabf[64 + threadIdx.x] = (float)(_Float16)P.enc_a[threadIdx.x];   // enc_a is half under autocast
-    if (threadIdx.x == 0) tab[48] = 0;   // slice queue head of the stand-alone kernel
+    lz_level_table_fill(tab, P.offsets, P.scale, P.res);   // + the slice queue head of the stand-alone kernel
+    if (threadIdx.x < 32) tabf[LZ_LVTAB_ENCA + threadIdx.x] = (float)(_Float16)P.enc_a[threadIdx.x];   // enc_a is half under autocast
+    if (threadIdx.x < 16) tab[LZ_LVTAB_ENCA16 + threadIdx.x] = (int)h_cvt2(P.enc_a[2 * threadIdx.x], P.enc_a[2 * threadIdx.x + 1], false);
+    if (threadIdx.x < 2) tab[LZ_LVTAB_IND16 + threadIdx.x] = P.ind_code ? (int)h_cvt2(P.ind_code[2 * threadIdx.x], P.ind_code[2 * threadIdx.x + 1], false) : 0;
     hc.wl = wl;
-    hc.offs = tab;
-    hc.lscale = tabf + 16;
-    hc.lres = tab + 32;
-    hc.lenca = tabf + 64;
+    hc.tab = tab;
+    hc.lenca = tabf + LZ_LVTAB_ENCA;
     hc.emb[0] = P.emb[0]; hc.emb[1] = P.emb[1]; hc.emb[2] = P.emb[2];
     hc.ind_code = P.ind_code;
     hc.bound = P.bound;
@@ -156,23 +177,25 @@ __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane,
     const int q = lane >> 4;
     // ---------------- gather (f32, the same code as lz_k_triplane_head: lz_head_gather.h): lane q holds enc_x features 4 i + q
     float encx[9];
-    lz_head_gather<IN_RANGE>(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx);
+    lz_head_gather<IN_RANGE, true>(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx);
     // enc_x as two half B operands (slot j of k-step ks <-> i = 8 ks + j); slot (1, q = 0, 1) is filled in for the sigma net
     lz_h8 bx[2];
-#pragma unroll
-    for (int j = 0; j < 8; j++) { bx[0][j] = h_round(encx[j]); bx[1][j] = (_Float16)0.0f; }   // h_round: the f32 feature first, then its half
-    bx[1][0] = h_round(encx[8]);
+    {   // h_round2: every f32 feature exists first, then its half (no v_fma_mixlo_f16 with the interpolation's last fma)
+        const lz_u4v w0 = {h_round2(encx[0], encx[1]), h_round2(encx[2], encx[3]), h_round2(encx[4], encx[5]), h_round2(encx[6], encx[7])};
+        const lz_u4v w1 = {h_round2(encx[8], 0.0f), 0u, 0u, 0u};
+        bx[0] = __builtin_bit_cast(lz_h8, w0);
+        bx[1] = __builtin_bit_cast(lz_h8, w1);
+    }
 
     // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
-    _Float16 att16[8];   // [4 t + r] = feature 16 t + 4 q + r
+    lz_h8 att16;   // [4 t + r] = feature 16 t + 4 q + r
     {
         lz_f4 a1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
         h_layer<H_A1>(hc.wl, lane, bx, a1);
         const lz_h8 b2[2] = {h_pair(a1[0], a1[1], true), h_pair(a1[2], a1[3], true)};
         lz_f4 a2[2] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
         h_layer<H_A2>(hc.wl, lane, b2, a2);
-#pragma unroll
-        for (int r = 0; r < 4; r++) { att16[r] = (_Float16)a2[0][r]; att16[4 + r] = (_Float16)a2[1][r]; }
+        att16 = h_pair(a2[0], a2[1], false);
     }
     // ambient_aud = || att ||_2 in f32 (norm is an autocast-to-f32 op): lane partial over its 8 features, then over q
     float ss = 0.0f;
@@ -180,7 +203,7 @@ __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane,
     for (int k = 0; k < 8; k++) ss = lz_fmaf((float)att16[k], (float)att16[k], ss);
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
-    const float ambaud = sqrtf(ss);
+    const float ambaud = h_sqrt32(ss);
     // ---------------- eye attention: 36 -> 16 -> 1, sigmoid (half) ----------------
     float eyeatt = 0.0f;
     if (hc.has_eye) {
@@ -200,8 +223,7 @@ __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane,
         b1[0] = bx[0];
         b1[1] = bx[1];
         b1[1][1] = (hc.has_eye && q == 0) ? h_round(hc.eye_v * eyeatt) : (_Float16)0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; j++) b1[2][j] = (_Float16)(hc.lenca[16 * (j >> 2) + 4 * q + (j & 3)] * (float)att16[j]);
+        b1[2] = h_encw(hc.tab, q, att16);
         lz_f4 s1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
         h_layer<H_S1>(hc.wl, lane, b1, s1);
         const lz_h8 b2[2] = {h_pair(s1[0], s1[1], true), h_pair(s1[2], s1[3], true)};
@@ -212,17 +234,18 @@ __device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane,
         h_layer<H_S3>(hc.wl, lane, b3, s3);
         geo16[0] = h_pair(s3[0], s3[1], false);   // geo_feat, no activation (network.py:304)
         geo16[1] = h_pair(s3[2], s3[3], false);
-        sigma = lz_expf((float)(_Float16)s3[4][0]);   // trunc_exp casts its half input to f32; lanes q == 0
+        sigma = h_exp32((float)(_Float16)s3[4][0]);   // exp is an autocast-to-f32 op: half -> f32 in, f32 out; lanes q == 0
     }
     // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
     float rgb[3];
     {
         shfn.prepare();
         lz_h8 b1[3];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            b1[0][j] = (_Float16)shfn.comp_qj(q, j);   // SH 4 q + j
-            b1[0][4 + j] = (q == 0 && hc.ind_code) ? (_Float16)hc.ind_code[j] : (_Float16)0.0f;
+        {
+            uint32_t shw[2];
+            h_sh_pk(shfn, q, shw);                                                  // SH 4 q + j, j < 4
+            const lz_u4v w = {shw[0], shw[1], q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16] : 0u, q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16 + 1] : 0u};
+            b1[0] = __builtin_bit_cast(lz_h8, w);
         }
         b1[1] = geo16[0];
         b1[2] = geo16[1];

@@ -3,81 +3,139 @@
 // Lane (s, q) of a wave owns sample s and the 9 enc_x features f = 4 i + q (i < 9): plane = i / 3 (xy, yz, xz;
 // nerf_triplane/network.py:208-223), level = 4 (i % 3) + q of the D = 2, L = 12, C = 1 hash grid (gridencoder.cu:75-177).
 // Arithmetic is the grid encoder's, bit for bit: pos = fma(x, scale, 0.5), corner weights in corner order, fma accumulation.
+//
+// Instruction budget (round 3; the f16 kernels are bound by vector-instruction issue, 4 cycles per wave64 instruction): the census of
+// round 2's version was 59 (per-level setup) + 213 (positions, indices) + ~60 (interpolation) VALU instructions per 16-sample slice.
+//   * the per-level constants are records in LDS written once per workgroup (lz_level_table_fill), not rebuilt per slice;
+//   * ONE index formula for dense and hashed levels, no select: element = ((col ^ rowH) & mask) + rowD with
+//         hashed: rowH = row * P (mod 2^24), mask = size - 1, rowD = off          (gridencoder.cu:35-51, primes 1 and 2654435761)
+//         dense:  rowH = 0,                  mask = ~0,       rowD = off + row * (res + 1)
+//     -- two instructions per corner (v_bitop3_b32, v_add_lshl_u32).  The hash product only matters modulo the table size (a power of
+//     two <= 2^24), so it is a full-rate 24-bit multiply by P mod 2^24 instead of a quarter-rate 32-bit one;
+//   * what two planes share is computed once: positions / fractions / 1 - fraction per (coordinate, level) -- 9 sets, not 18 -- and the
+//     row terms of the yz and xz planes (both rows are z);
+//   * PACK: the interpolation runs two features per instruction on v_pk_mul_f32 / v_pk_fma_f32 (IEEE per half, same bits).
 #ifndef LZ_HEAD_GATHER_H
 #define LZ_HEAD_GATHER_H
 #include "lz_common.h"
 #include "lzzx_detmath.h"
 
-// offs / lscale / lres: the per-level table in LDS ([0,13) offsets, scale, resolution); emb: the three planes' tables; (px, py, pz): the sample
+// The small per-workgroup table in LDS, LZ_LVTAB_WORDS 32-bit words:
+//   [0,13) level offsets | [16,28) scale (f32) | [32,44) dense row stride res + 1 (0 on hashed levels) | [48] slice queue head of the
+//   stand-alone kernels | [49,61) hash multiplier P mod 2^24 (0 on dense levels) | [64,96) enc_a (f32) | [96,108) index mask (size - 1 on
+//   hashed levels, ~0 on dense ones) | f16 heads: [108,124) enc_a as 32 packed halves | [124,126) ind_code as 4 packed halves
+#define LZ_LVTAB_WORDS 128
+#define LZ_LVTAB_SCALE 16
+#define LZ_LVTAB_STRIDE 32
+#define LZ_LVTAB_QUEUE 48
+#define LZ_LVTAB_HMUL 49
+#define LZ_LVTAB_ENCA 64
+#define LZ_LVTAB_MASK 96
+#define LZ_LVTAB_ENCA16 108
+#define LZ_LVTAB_IND16 124
+
+// threads 0..12 of a workgroup write the level part of the table (caller synchronises afterwards).  gridencoder.cu:54-72 for D = 2:
+// a level is dense while (res + 1)^2 fits its table, else hashed with size = 2^T (grid.py:116; the Python wrapper checks the power of two).
+__device__ __forceinline__ void lz_level_table_fill(int* tab, const int* __restrict__ offsets, const float* scale, const uint32_t* res) {
+    const uint32_t t = threadIdx.x;
+    if (t < 13) tab[t] = offsets[t];
+    if (t < 12) {
+        const uint32_t hs = (uint32_t)(offsets[t + 1] - offsets[t]), stride = res[t] + 1u;
+        const bool dense = stride <= hs && (uint64_t)stride * stride <= hs;
+        reinterpret_cast<float*>(tab)[LZ_LVTAB_SCALE + t] = scale[t];
+        tab[LZ_LVTAB_STRIDE + t] = dense ? (int)stride : 0;
+        tab[LZ_LVTAB_HMUL + t] = dense ? 0 : (int)(2654435761u & 0x00ffffffu);
+        tab[LZ_LVTAB_MASK + t] = dense ? -1 : (int)(hs - 1u);
+    }
+    if (t == 0) tab[LZ_LVTAB_QUEUE] = 0;
+}
+
+typedef float lz_gf2 __attribute__((ext_vector_type(2)));
+
+// tab: the table above; emb: the three planes' tables; (px, py, pz): the sample
 // IN_RANGE drops the range clamps / out-of-range selects for a caller that guarantees |x|, |y|, |z| <= bound -- the fused f16 frame kernel,
 // whose march clamps every sample (raymarching.cu:866-889) and which is bound by VALU issue; the host checks that the march's bound does
 // not exceed the head's.  An identity on the values -- but mind what it exposes: with the select gone, `(_Float16)encx[i]` sat directly
 // behind the last fma of the interpolation and the compiler folded the two into v_fma_mixlo_f16 (one rounding instead of f32-then-half):
 // 28 pixels of a 96 x 96 frame moved by 2e-7 against the loop until the conversions went through h_round (lz_head_f16_slice.h).
-template <bool IN_RANGE = false>
-__device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], const int* __restrict__ offs, const float* __restrict__ lscale,
-                                               const int* __restrict__ lres, float px, float py, float pz, int q, float bound,
-                                               float two_bound, float (&encx)[9]) {
-    // the three grid levels this lane touches (level = 4 m + q), gridencoder.cu:124-126; rebuilt per slice from LDS so that they
-    // do not occupy registers during the matrix phase
-    uint32_t lv_off[3], lv_hs[3], lv_stride[3];
+template <bool IN_RANGE = false, bool PACK = false>
+__device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], const int* __restrict__ tab, float px, float py, float pz, int q,
+                                               float bound, float two_bound, float (&encx)[9]) {
+    // the three grid levels this lane touches (level = 4 m + q); read per slice from LDS so that they do not occupy registers during the
+    // matrix phase
+    uint32_t lv_off[3], lv_strd[3], lv_hmul[3], lv_mask[3];
     float lv_scale[3];
-    bool lv_dense[3];
 #pragma unroll
     for (int mrec = 0; mrec < 3; mrec++) {
         const int level = 4 * mrec + q;
-        lv_off[mrec] = (uint32_t)offs[level];
-        lv_hs[mrec] = (uint32_t)offs[level + 1] - lv_off[mrec];
-        lv_scale[mrec] = lscale[level];
-        lv_stride[mrec] = (uint32_t)lres[level] + 1u;
-        lv_dense[mrec] = lv_stride[mrec] <= lv_hs[mrec] && lv_stride[mrec] * lv_stride[mrec] <= lv_hs[mrec];
+        lv_off[mrec] = (uint32_t)tab[level];
+        lv_scale[mrec] = reinterpret_cast<const float*>(tab)[LZ_LVTAB_SCALE + level];
+        lv_strd[mrec] = (uint32_t)tab[LZ_LVTAB_STRIDE + level];
+        lv_hmul[mrec] = (uint32_t)tab[LZ_LVTAB_HMUL + level];
+        lv_mask[mrec] = (uint32_t)tab[LZ_LVTAB_MASK + level];
     }
     // (x + bound) / (2 bound), grid.py:143.  When 2 bound is a power of two (bound 1, 2, 4 ...: every scene of the reference) the
     // division equals the multiplication by its exact reciprocal bit for bit, and an IEEE division is ~11 VALU instructions
     const uint32_t tb_bits = __float_as_uint(two_bound);
     const bool pow2 = (tb_bits & 0x007fffffu) == 0u && tb_bits > 0x00800000u && tb_bits < 0x7f000000u;   // wave-uniform
-    float x01, y01, z01;
+    float c01[3];
     if (pow2) {
         const float inv = __uint_as_float(0x7f000000u - tb_bits);    // 2^-k for two_bound = 2^k
-        x01 = (px + bound) * inv; y01 = (py + bound) * inv; z01 = (pz + bound) * inv;
+        c01[0] = (px + bound) * inv; c01[1] = (py + bound) * inv; c01[2] = (pz + bound) * inv;
     } else {
-        x01 = (px + bound) / two_bound; y01 = (py + bound) / two_bound; z01 = (pz + bound) / two_bound;
+        c01[0] = (px + bound) / two_bound; c01[1] = (py + bound) / two_bound; c01[2] = (pz + bound) / two_bound;
     }
     // Branch-free: out-of-range coordinates are clamped for ADDRESSING only and the feature is zeroed by a select
     // (gridencoder.cu:98-122), so all 36 gathers of a sample are independent loads.  Two passes so that the 36 table reads are IN
     // FLIGHT TOGETHER (one L2 round trip per slice instead of one per read): pass 1 computes fractions + table indices and issues
     // every load, the empty asm pins all 36 results as live at one point (so the compiler cannot sink a load next to its use),
     // pass 2 forms the bilinear weights and accumulates in corner order.
-    float fr0[9], fr1[9], gv[9][4];
-    bool oobf[9];
+    bool oobc[3];
+    float cc[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        oobc[d] = IN_RANGE ? false : (c01[d] < 0 || c01[d] > 1);
+        cc[d] = IN_RANGE ? c01[d] : lz_fminf(lz_fmaxf(c01[d], 0.0f), 1.0f);
+    }
+    // per (coordinate, level): cell, fraction, 1 - fraction (gridencoder.cu:128-133).  p >= 0.5, so p - floor(p) is the reference's
+    // p - (float)(uint32_t)floor(p) without the two conversions.
+    uint32_t cell[3][3];
+    float fr[3][3], om[3][3];
+#pragma unroll
+    for (int mrec = 0; mrec < 3; mrec++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float p = lz_fmaf(cc[d], lv_scale[mrec], 0.5f), fl = floorf(p);
+            cell[mrec][d] = (uint32_t)fl;
+            fr[mrec][d] = p - fl;
+            om[mrec][d] = 1 - fr[mrec][d];
+        }
+    // row terms per (row coordinate, level): y for the xy plane, z for yz and xz (network.py:211: xy = (x, y), yz = (y, z), xz = (x, z))
+    uint32_t rowH[2][3][2], rowD[2][3][2];     // [row coordinate: 0 = y, 1 = z][level record][lower / upper corner]
+#pragma unroll
+    for (int rc = 0; rc < 2; rc++)
+#pragma unroll
+        for (int mrec = 0; mrec < 3; mrec++) {
+            const uint32_t g1 = cell[mrec][1 + rc];
+            rowH[rc][mrec][0] = __umul24(g1, lv_hmul[mrec]);                       // exact modulo 2^24 >= the table size
+            rowH[rc][mrec][1] = rowH[rc][mrec][0] + lv_hmul[mrec];
+            rowD[rc][mrec][0] = __umul24(g1, lv_strd[mrec]) + lv_off[mrec];        // v_mad_u32_u24
+            rowD[rc][mrec][1] = rowD[rc][mrec][0] + lv_strd[mrec];
+        }
+    float gv[9][4];
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         constexpr int kPlaneOf[9] = {0, 0, 0, 1, 1, 1, 2, 2, 2};
         const int plane = kPlaneOf[i], mrec = i % 3;
-        const float u = plane == 1 ? y01 : x01;          // xy: (x,y)  yz: (y,z)  xz: (x,z)   network.py:211
-        const float v = plane == 0 ? y01 : z01;
-        oobf[i] = IN_RANGE ? false : (u < 0 || u > 1 || v < 0 || v > 1);
-        const float uc = IN_RANGE ? u : lz_fminf(lz_fmaxf(u, 0.0f), 1.0f), vc = IN_RANGE ? v : lz_fminf(lz_fmaxf(v, 0.0f), 1.0f);
-        // byte offset in 32 bits off the plane's (wave-uniform) base: one VALU op and the scalar-base addressing mode per gather, where
-        // a per-lane 64-bit pointer costs two or three (the tables are 650 KB each)
+        const int cd = plane == 1 ? 1 : 0, rc = plane == 0 ? 0 : 1;          // column coordinate (x, y, x), row coordinate (y, z, z)
+        // byte offset in 32 bits off the plane's (wave-uniform) base: the scalar-base addressing mode, no per-lane 64-bit pointer
         const char* gb = reinterpret_cast<const char*>(emb[plane]);
-        const float p0 = lz_fmaf(uc, lv_scale[mrec], 0.5f), p1 = lz_fmaf(vc, lv_scale[mrec], 0.5f);
-        const uint32_t g0 = (uint32_t)floorf(p0), g1 = (uint32_t)floorf(p1);
-        fr0[i] = p0 - (float)g0;
-        fr1[i] = p1 - (float)g1;
-        // gridencoder.cu:54-72 for D = 2: dense while (res+1)^2 fits the level's table (then index < size and the modulo is the
-        // identity), else fast_hash (primes 1, 2654435761) modulo the table size.  A hashed level's size is min(2^T, .) = 2^T
-        // (grid.py:116), a power of two: the modulo is a mask (precondition, checked by the Python wrapper).  The row term of the upper
-        // corners is the lower one plus a constant (mod 2^32), and the dense product fits 24 bits (full-rate multiplier): one
-        // quarter-rate multiply per feature instead of four.
-        const uint32_t hrow0 = g1 * 2654435761u, hrow1 = hrow0 + 2654435761u;
-        const uint32_t drow0 = __umul24(g1, lv_stride[mrec]), drow1 = drow0 + lv_stride[mrec];
-        const uint32_t hmask = lv_hs[mrec] - 1u;
+        const uint32_t g0 = cell[mrec][cd];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const uint32_t c0 = g0 + (c & 1);
-            const uint32_t index = lv_dense[mrec] ? c0 + ((c >> 1) ? drow1 : drow0) : ((c0 ^ ((c >> 1) ? hrow1 : hrow0)) & hmask);
-            gv[i][c] = *reinterpret_cast<const float*>(gb + ((lv_off[mrec] + index) << 2));
+            const uint32_t index = ((c0 ^ rowH[rc][mrec][c >> 1]) & lv_mask[mrec]) + rowD[rc][mrec][c >> 1];
+            gv[i][c] = *reinterpret_cast<const float*>(gb + (index << 2));
         }
     }
     asm volatile("" ::"v"(gv[0][0]), "v"(gv[0][1]), "v"(gv[0][2]), "v"(gv[0][3]), "v"(gv[1][0]), "v"(gv[1][1]), "v"(gv[1][2]),
@@ -86,15 +144,49 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
                  "v"(gv[8][1]), "v"(gv[8][2]), "v"(gv[8][3]), "v"(gv[7][0]), "v"(gv[7][1]), "v"(gv[7][2]), "v"(gv[7][3]));
     asm volatile("" ::"v"(gv[5][0]), "v"(gv[5][1]), "v"(gv[5][2]), "v"(gv[5][3]), "v"(gv[6][0]), "v"(gv[6][1]), "v"(gv[6][2]),
                  "v"(gv[6][3]));
+    // bilinear weights in the reference's corner order, w = (1 * w0) * w1 with w_d = 1 - f_d or f_d (gridencoder.cu:141-152), fma chain
+    if constexpr (PACK) {
+        // features (i, i + 1) of a plane share the coordinates and differ in the level: two of them per packed instruction; the ninth
+        // (and each plane's third) pairs up across planes -- any pairing gives the same bits, the lanes of a packed op are independent
+        constexpr int kPair[5][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 8}};
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-        float acc = 0.0f;
+        for (int pr = 0; pr < 5; pr++) {
+            const int ia = kPair[pr][0], ib = kPair[pr][1];
+            constexpr int kPl[9] = {0, 0, 0, 1, 1, 1, 2, 2, 2};
+            const int ca = kPl[ia] == 1 ? 1 : 0, ra = kPl[ia] == 0 ? 1 : 2, cb = kPl[ib] == 1 ? 1 : 0, rb = kPl[ib] == 0 ? 1 : 2;
+            const int ma = ia % 3, mb = ib % 3;
+            const lz_gf2 f0 = {fr[ma][ca], fr[mb][cb]}, f1 = {fr[ma][ra], fr[mb][rb]}, o0 = {om[ma][ca], om[mb][cb]}, o1 = {om[ma][ra], om[mb][rb]};
+            lz_gf2 acc = {0.0f, 0.0f};
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float w = ((c & 1) ? fr0[i] : 1 - fr0[i]) * ((c >> 1) ? fr1[i] : 1 - fr1[i]);
-            acc = lz_fmaf(w, gv[i][c], acc);
+            for (int c = 0; c < 4; c++) {
+                const lz_gf2 w = ((c & 1) ? f0 : o0) * ((c >> 1) ? f1 : o1);
+                const lz_gf2 g = {gv[ia][c], gv[ib][c]};
+                acc = __builtin_elementwise_fma(w, g, acc);
+            }
+            encx[ia] = acc[0];
+            if (ib != ia) encx[ib] = acc[1];
         }
-        encx[i] = oobf[i] ? 0.0f : acc;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            constexpr int kPl[9] = {0, 0, 0, 1, 1, 1, 2, 2, 2};
+            const int cd = kPl[i] == 1 ? 1 : 0, rd = kPl[i] == 0 ? 1 : 2, mrec = i % 3;
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float w = ((c & 1) ? fr[mrec][cd] : om[mrec][cd]) * ((c >> 1) ? fr[mrec][rd] : om[mrec][rd]);
+                acc = lz_fmaf(w, gv[i][c], acc);
+            }
+            encx[i] = acc;
+        }
+    }
+    if constexpr (!IN_RANGE) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            constexpr int kPl[9] = {0, 0, 0, 1, 1, 1, 2, 2, 2};
+            const bool oob = kPl[i] == 0 ? (oobc[0] || oobc[1]) : (kPl[i] == 1 ? (oobc[1] || oobc[2]) : (oobc[0] || oobc[2]));
+            encx[i] = oob ? 0.0f : encx[i];
+        }
     }
 }
 #endif

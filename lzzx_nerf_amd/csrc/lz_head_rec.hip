@@ -73,7 +73,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
     lz_head_stage<true>(P, wl, LZ_FREC_WG, q, hc);
     __syncthreads();
     const float* wv = wl + LzHeadLds<true>::WV;
-    int* queue = reinterpret_cast<int*>(wl + LzHeadLds<true>::TAB) + 48;
+    int* queue = reinterpret_cast<int*>(wl + LzHeadLds<true>::TAB) + LZ_LVTAB_QUEUE;
     for (int w = threadIdx.x >> 8; w > 0; w--) {   // see lz_k_triplane_head_backward: the waves that share a SIMD start a part of a slice apart
         __builtin_amdgcn_s_sleep(127);
         __builtin_amdgcn_s_sleep(127);
@@ -106,7 +106,7 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
         float* sb = lz_blk(st, slice_lo + (uint32_t)slice, H16 ? LZ_FWD_STATE16 : LZ_FWD_STATE, s);
 
         float encx[9];
-        lz_head_gather(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx);
+        lz_head_gather(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx);
         const float cd0 = dir0, cd1 = dir1, cd2 = dir2;
         const int next = grab();
         if (slice_lo + (uint32_t)next < slice_hi) {
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(LZ_BWD_WG, LZ_BWD_WG / 256)
 lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, uint32_t M) {
     constexpr int NFRAG = LZ_FRAGS_ALL;
     constexpr int WV = B16 ? LZ_BFRAGS * 128 : NFRAG * 64, TAB = WV + LZ_WV_FLOATS;
-    __shared__ float wl[TAB + 96];
+    __shared__ float wl[TAB + LZ_LVTAB_WORDS];
     const LzHeadArgs& P = A.fwd;
     const lz_head_bwd_out& O = A.o;
     const uint32_t n_slices = (M + 15) / 16;
@@ -339,8 +339,8 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         float4* dst = reinterpret_cast<float4*>(wl);
         for (int i = threadIdx.x; i < WV / 4; i += LZ_BWD_WG) dst[i] = src[i];
         if (threadIdx.x < LZ_WV_FLOATS) wl[WV + threadIdx.x] = P.packed[LZ_FRAGS_ALL * 64 + threadIdx.x];
-        if (threadIdx.x < 32) wl[TAB + 64 + threadIdx.x] = P.enc_a[threadIdx.x];
-        if (threadIdx.x == 0) reinterpret_cast<int*>(wl + TAB)[48] = 0;
+        if (threadIdx.x < 32) wl[TAB + LZ_LVTAB_ENCA + threadIdx.x] = P.enc_a[threadIdx.x];
+        if (threadIdx.x == 0) reinterpret_cast<int*>(wl + TAB)[LZ_LVTAB_QUEUE] = 0;
     }
     __syncthreads();
     // one spelling for both matrix paths
@@ -349,13 +349,13 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         if constexpr (B16) lz_layer_bwd16<LAYER>(reinterpret_cast<const uint2*>(wl), (int)(threadIdx.x & 63), dy, dx);
         else lz_layer_bwd<LAYER>(wl, (int)(threadIdx.x & 63), dy, dx);
     };
-    const float* lenca = wl + TAB + 64;
+    const float* lenca = wl + TAB + LZ_LVTAB_ENCA;
     const float* wv = wl + WV;
     const int lane = threadIdx.x & 63;
     const int s = lane & 15, q = lane >> 4;
     const bool has_eye = P.eye != nullptr;
     const float eye_v = has_eye ? P.eye[0] : 0.0f;
-    int* queue = reinterpret_cast<int*>(wl + TAB) + 48;
+    int* queue = reinterpret_cast<int*>(wl + TAB) + LZ_LVTAB_QUEUE;
     if ((threadIdx.x >> 6) >= 4) {
         __builtin_amdgcn_s_sleep(127);
         __builtin_amdgcn_s_sleep(127);

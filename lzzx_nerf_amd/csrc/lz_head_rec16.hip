@@ -91,7 +91,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
     const int lane = threadIdx.x & 63;
     const int s = lane & 15, q = lane >> 4;
     const float indq = hc.ind_code ? hc.ind_code[q] : 0.0f;
-    int* queue = reinterpret_cast<int*>(wl + H_FRAGS * 64) + 48;
+    int* queue = reinterpret_cast<int*>(wl + H_FRAGS * 64) + LZ_LVTAB_QUEUE;
     auto grab = [&]() -> int {
         int sl = 0;
         if (lane == 0) sl = atomicAdd(queue, 1);
@@ -118,7 +118,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
         float* sb = lz_blk(st, slice_lo + (uint32_t)slice, LZ_FWD_STATE16, s);
 
         float encx[9];
-        lz_head_gather(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx);
+        lz_head_gather(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx);
         const float cdx = dx, cdy = dy, cdz = dz;
         const int next = grab();
         {
@@ -128,12 +128,15 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
         }
         __builtin_amdgcn_sched_barrier(0);
         lz_h8 bx[2];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { bx[0][j] = h_round(encx[j]); bx[1][j] = (_Float16)0.0f; }   // h_round: the f32 feature first, then its half
-        bx[1][0] = h_round(encx[8]);
+        {   // as in lz_head16_slice
+            const lz_u4v w0 = {h_round2(encx[0], encx[1]), h_round2(encx[2], encx[3]), h_round2(encx[4], encx[5]), h_round2(encx[6], encx[7])};
+            const lz_u4v w1 = {h_round2(encx[8], 0.0f), 0u, 0u, 0u};
+            bx[0] = __builtin_bit_cast(lz_h8, w0);
+            bx[1] = __builtin_bit_cast(lz_h8, w1);
+        }
 
         // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
-        _Float16 att16[8];
+        lz_h8 att16;
         uint32_t mk_a1;
         {
             lz_f4 a1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
@@ -144,8 +147,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_A1 / 2 + 1, b2[1]);
             lz_f4 a2[2] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
             h_layer<H_A2>(hc.wl, lane, b2, a2);
-#pragma unroll
-            for (int r = 0; r < 4; r++) { att16[r] = (_Float16)a2[0][r]; att16[4 + r] = (_Float16)a2[1][r]; }
+            att16 = h_pair(a2[0], a2[1], false);
         }
         {
             lz_v4 w0 = {(float)att16[0], (float)att16[1], (float)att16[2], (float)att16[3]};
@@ -158,7 +160,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
         for (int k = 0; k < 8; k++) ss = lz_fmaf((float)att16[k], (float)att16[k], ss);
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
-        const float norm = sqrtf(ss);
+        const float norm = h_sqrt32(ss);
         // ---------------- eye attention ----------------
         float eyeatt = 0.0f;
         uint32_t mk_e1 = 0;
@@ -196,8 +198,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             b1[0] = bx[0];
             b1[1] = bx[1];
             b1[1][1] = (hc.has_eye && q == 0) ? h_round(hc.eye_v * eyeatt) : (_Float16)0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; j++) b1[2][j] = (_Float16)(hc.lenca[16 * (j >> 2) + 4 * q + (j & 3)] * (float)att16[j]);
+            b1[2] = h_encw(hc.tab, q, att16);
             // sigma_net.0 input in the record's arrangement (lz_head_rec.hip: tiles 0, 1 enc_x, tile 2 feature 32 + q and the eye term,
             // tiles 3, 4 enc_a * att); the conversions to half repeat the ones above, value for value
             lz_dump_pair_f(rb + 4 * q, LZ_R16_X_SIG0 / 2, encx[0], encx[2], encx[4], encx[6], encx[1], encx[3], encx[5], encx[7]);
@@ -222,7 +223,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             geo16[1] = h_pair(s3[2], s3[3], false);
             spre = __shfl((float)(_Float16)s3[4][0], s, 64);
         }
-        const float sigma = lz_expf(spre);
+        const float sigma = h_exp32(spre);
         // ---------------- colour net ----------------
         float cpre[3];
         uint32_t mk_c1;
@@ -230,10 +231,11 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             auto shfn = lz_sh_from_dir([&](float& ox, float& oy, float& oz) { ox = cdx; oy = cdy; oz = cdz; });
             shfn.prepare();
             lz_h8 b1[3];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                b1[0][j] = (_Float16)shfn.comp_qj(q, j);
-                b1[0][4 + j] = (q == 0 && hc.ind_code) ? (_Float16)hc.ind_code[j] : (_Float16)0.0f;
+            {
+                uint32_t shw[2];
+                h_sh_pk(shfn, q, shw);
+                const lz_u4v w = {shw[0], shw[1], q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16] : 0u, q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16 + 1] : 0u};
+                b1[0] = __builtin_bit_cast(lz_h8, w);
             }
             b1[1] = geo16[0];
             b1[2] = geo16[1];

@@ -15,9 +15,7 @@
 // per-workgroup context: the packed weights and small tables staged in LDS (lz_head_stage), per-launch constants
 struct LzHeadCtx {
     const float* wl;        // LDS: packed A fragments, then the VALU-layer rows
-    const int* offs;        // LDS: level offsets [13]
-    const float* lscale;    // LDS: level scale [12]
-    const int* lres;        // LDS: level resolution [12]
+    const int* tab;         // LDS: the level table (lz_head_gather.h: LZ_LVTAB_*)
     const float* lenca;     // LDS: enc_a [32]
     const float* emb[3];    // the three planes' tables (global)
     float bound, two_bound, eye_v, indq;
@@ -28,11 +26,11 @@ struct LzHeadOut {
     float sigma, rgb[3], ambaud, eyeatt, unc;   // every lane of a sample ends with the same bits
 };
 
-// LDS floats the stage needs: fragments + VALU rows + 96 words (level table 64, enc_a 32)
+// LDS floats the stage needs: fragments + VALU rows + the level table (lz_head_gather.h: LZ_LVTAB_WORDS, enc_a inside)
 template <bool TRAIN_UNC>
 struct LzHeadLds {
     static constexpr int NFRAG = TRAIN_UNC ? LZ_FRAGS_ALL : LZ_FRAGS_INFER;
-    static constexpr int WV = NFRAG * 64, TAB = WV + LZ_WV_FLOATS, FLOATS = TAB + 96;
+    static constexpr int WV = NFRAG * 64, TAB = WV + LZ_WV_FLOATS, FLOATS = TAB + LZ_LVTAB_WORDS;
 };
 
 // stage weights + tables into LDS (all threads of the workgroup; caller synchronises afterwards) and fill the context
@@ -43,20 +41,13 @@ __device__ __forceinline__ void lz_head_stage(const LzHeadArgs& P, float* wl, ui
     float4* dst = reinterpret_cast<float4*>(wl);
     for (uint32_t i = threadIdx.x; i < (uint32_t)L::NFRAG * 16; i += n_threads) dst[i] = src[i];   // 16 B per lane per step, coalesced
     if (threadIdx.x < LZ_WV_FLOATS) wl[L::WV + threadIdx.x] = P.packed[LZ_FRAGS_ALL * 64 + threadIdx.x];
-    // per-level table (indexed per lane in the gather): [0,13) offsets, [16,28) scale, [32,44) resolution
+    // per-level table (indexed per lane in the gather) + the slice queue head of the stand-alone kernel
     int* tab = reinterpret_cast<int*>(wl + L::TAB);
-    if (threadIdx.x < 13) tab[threadIdx.x] = P.offsets[threadIdx.x];
-    if (threadIdx.x < 12) {
-        wl[L::TAB + 16 + threadIdx.x] = P.scale[threadIdx.x];
-        tab[32 + threadIdx.x] = (int)P.res[threadIdx.x];
-    }
-    if (threadIdx.x < 32) wl[L::TAB + 64 + threadIdx.x] = P.enc_a[threadIdx.x];
-    if (threadIdx.x == 0) tab[48] = 0;   // slice queue head of the stand-alone kernel
+    lz_level_table_fill(tab, P.offsets, P.scale, P.res);
+    if (threadIdx.x < 32) wl[L::TAB + LZ_LVTAB_ENCA + threadIdx.x] = P.enc_a[threadIdx.x];
     hc.wl = wl;
-    hc.offs = reinterpret_cast<const int*>(wl + L::TAB);
-    hc.lscale = wl + L::TAB + 16;
-    hc.lres = hc.offs + 32;
-    hc.lenca = wl + L::TAB + 64;
+    hc.tab = tab;
+    hc.lenca = wl + L::TAB + LZ_LVTAB_ENCA;
     hc.emb[0] = P.emb[0]; hc.emb[1] = P.emb[1]; hc.emb[2] = P.emb[2];
     hc.bound = P.bound;
     hc.two_bound = 2.0f * P.bound;
@@ -99,7 +90,7 @@ __device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, flo
     const int q = lane >> 4;
     // ---------------- gather: enc_x features f = 4i + q of sample s -> B operands (lz_head_gather.h) ----------------
     float encx[LZ_T][9];
-    lz_head_gather<IN_RANGE>(hc.emb, hc.offs, hc.lscale, hc.lres, px, py, pz, q, hc.bound, hc.two_bound, encx[0]);
+    lz_head_gather<IN_RANGE>(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx[0]);
     __builtin_amdgcn_sched_barrier(0);  // the tile's 36 reads in flight at a time: bounds the register footprint
 
     // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------

@@ -747,7 +747,9 @@ def test_fused_head_f16_matches_autocast_checker(params, golden, boost, use_eye)
     sg, rg, ag, ug = host(sg), host(rg), host(ag), host(ug)
     assert np.array_equal(ug, uo)
     assert np.allclose(rg, ro, atol=4e-3) and np.mean(rg == ro) > 0.85, (np.abs(rg - ro).max(), np.mean(rg == ro))
-    assert np.allclose(sg, so, rtol=2e-2) and np.mean(sg == so) > 0.85, (np.abs(sg / so - 1).max(), np.mean(sg == so))
+    # sigma = exp in f32 of the half pre-activation: where the half argument agrees the two f32 exps (hardware v_exp_f32 in the kernel, the
+    # checker's polynomial) agree to a few ulp; where the argument differs by a half ulp, sigma differs by ~1e-3 relative
+    assert np.allclose(sg, so, rtol=2e-2) and np.mean(np.abs(sg / so - 1) < 4e-6) > 0.85, (np.abs(sg / so - 1).max(), np.mean(np.abs(sg / so - 1) < 4e-6))
     assert np.allclose(ag, ao, rtol=5e-3, atol=1e-4)
     if use_eye:
         assert np.allclose(host(eg), eo, atol=2e-3)
