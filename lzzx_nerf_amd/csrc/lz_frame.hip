@@ -148,10 +148,20 @@ __global__ void __launch_bounds__(256) lz_k_frame_scatter(LzFrameK F) {
 // ---- pass 3: the persistent kernel --------------------------------------------------------------------------------------------
 // slot state in LDS, per wave [field][16]
 enum { SF_RAY = 0, SF_T, SF_FAR, SF_DT, SF_WS, SF_D, SF_R, SF_G, SF_B, SF_A0, SF_A1, SF_U, SF_CNT,
-       SF_SH,                       // 16 fields: SH(4) of the ray's direction, evaluated once per ray at refill (the head needs it per sample)
-       SF_FIELDS = SF_SH + 16,
-       // S > 1 only: per-SAMPLE staging (march -> head, head -> composite) and the per-ray pass counter
-       SF_X = SF_FIELDS, SF_Y, SF_Z, SF_TS, SF_OSIG, SF_OR, SF_OG, SF_OB, SF_OA0, SF_OA1, SF_OU, SF_IT, SF_FIELDS_MULTI };
+       SF_SH };                     // SH(4) of the ray's direction, evaluated once per ray at refill (the head needs it per sample): 16 f32
+                                    // words, or 8 words of packed halves for the f16 head.  The staging fields behind it depend on the
+                                    // kernel's arrangement: LzfFields
+// fields behind SF_SH.  S > 1: per-SAMPLE staging (march -> head: X Y Z TS; head -> composite: OSIG .. OU) and the per-ray pass counter IT;
+// S == 1 with several slot rows: only the parked head outputs; one row: nothing
+template <int PREC, int S, int ROWS> struct LzfFields {
+    static constexpr int SH_WORDS = PREC == 1 ? 8 : 16;
+    static constexpr int ST = SF_SH + SH_WORDS;
+    static constexpr int X = ST, Y = ST + 1, Z = ST + 2, TS = ST + 3;                       // S > 1 only
+    static constexpr int OSIG = S > 1 ? ST + 4 : ST, OR = OSIG + 1, OG = OSIG + 2, OB = OSIG + 3, OA0 = OSIG + 4, OA1 = OSIG + 5, OU = OSIG + 6;
+    static constexpr int IT = OSIG + 7;                                                       // S > 1 only
+    static constexpr int RD = S > 1 ? ST + 12 : (ROWS > 1 ? ST + 7 : ST);                    // 1 / direction (3 words), set when the slot takes the ray
+    static constexpr int COUNT = RD + 3;
+};
 
 // SH(4) of the slot's ray from LDS: component k of the ray whose state sits at slot `ls` (fields are `ns` slots wide)
 struct LzShFromSlot {
@@ -173,10 +183,13 @@ __device__ __forceinline__ void h_sh_pk(const LzShFromSlot16& f, int q, uint32_t
 }
 // evaluated by the lane that takes the ray (the same lz_sh_eval call on the same direction as the stand-alone head makes per sample)
 template <int PREC>
-__device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* slot, int s, int ns) {
+__device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* slot, int s, int ns, int rd_field) {
     const float* d = F.rays_d + (size_t)ray * 3;
     float o[16];
     lz_sh_eval(d[0], d[1], d[2], 4, o, nullptr, nullptr, nullptr);
+    slot[rd_field * ns + s] = 1 / d[0];              // LzMarch's reciprocals: per ray here, not per pass
+    slot[(rd_field + 1) * ns + s] = 1 / d[1];
+    slot[(rd_field + 2) * ns + s] = 1 / d[2];
     if constexpr (PREC == 1) {
 #pragma unroll
         for (int k = 0; k < 8; k++) slot[(SF_SH + k) * ns + s] = __uint_as_float(h_cvt2(o[2 * k], o[2 * k + 1], false));
@@ -223,7 +236,11 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     using HD = LzfHead<PREC>;
     static_assert(ROWS == 1 || S == 1, "several slot rows per wave only with one sample per ray and pass");
     constexpr int NS = 16 * ROWS;                                   // ray slots per wave
-    constexpr int NF = (S == 1 && ROWS == 1) ? (int)SF_FIELDS : (int)SF_FIELDS_MULTI;
+    using FL = LzfFields<PREC, S, ROWS>;
+    constexpr int NF = FL::COUNT;
+    constexpr int SF_X = FL::X, SF_Y = FL::Y, SF_Z = FL::Z, SF_TS = FL::TS, SF_OSIG = FL::OSIG, SF_OR = FL::OR, SF_OG = FL::OG, SF_OB = FL::OB,
+                  SF_OA0 = FL::OA0, SF_OA1 = FL::OA1, SF_OU = FL::OU, SF_IT = FL::IT, SF_RD = FL::RD;
+    (void)SF_RD; (void)SF_X; (void)SF_Y; (void)SF_Z; (void)SF_TS; (void)SF_IT; (void)SF_OSIG; (void)SF_OR; (void)SF_OG; (void)SF_OB; (void)SF_OA0; (void)SF_OA1; (void)SF_OU;
     constexpr int SLOT_WORDS = LZF_WAVES * NF * NS;
     __shared__ __align__(16) float lds[HD::LDS_WORDS + SLOT_WORDS + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -268,13 +285,14 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
                             sloti[SF_CNT * 16 + s] = 0;
                             sloti[SF_IT * 16 + s] = 0;
-                            lzf_store_sh<PREC>(F, ray, slot, s, 16);
+                            lzf_store_sh<PREC>(F, ray, slot, s, 16, SF_RD);
                         }
                     }
                     if (base + take >= n_queue) dry = true;
                 }
                 if (leader && ray >= 0 && kk == 0) {
-                    m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+                    m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, slot[SF_RD * 16 + s], slot[(SF_RD + 1) * 16 + s], slot[(SF_RD + 2) * 16 + s],
+                           F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
                     float t = slot[SF_T * 16 + s];
                     const float far = slot[SF_FAR * 16 + s];
                     while (t < far && kk < S) {
@@ -383,13 +401,14 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
 #pragma unroll
                             for (int f = SF_WS; f <= SF_U; f++) slot[f * NS + sl] = 0.0f;
                             sloti[SF_CNT * NS + sl] = 0;
-                            lzf_store_sh<PREC>(F, ray, slot, sl, NS);
+                            lzf_store_sh<PREC>(F, ray, slot, sl, NS, SF_RD);
                         }
                     }
                     if (base + take >= n_queue) dry = true;    // wave-uniform
                 }
                 if (slot_lane && ray >= 0 && !have) {
-                    m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+                    m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, slot[SF_RD * NS + sl], slot[(SF_RD + 1) * NS + sl], slot[(SF_RD + 2) * NS + sl],
+                           F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
                     float t = slot[SF_T * NS + sl], dt = 0.0f;
                     const float far = slot[SF_FAR * NS + sl];
                     // at most LZF_MARCH_PROBES empty cells per attempt: a ray crossing empty space (behind the object, between two blobs) keeps
@@ -554,8 +573,16 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
         a.offsets = p->offsets; a.packed = reinterpret_cast<const lz_h8*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code;
         a.eye = p->eye; a.bound = p->bound;
         lzf_level_tables(p, a.scale, a.res);
-        static const bool one_row = getenv("LZ_FRAME_ONE_ROW") != nullptr;   // diagnostic: the 16-slot layout for the f16 head too
-        if (S == 1 && !one_row && (uint64_t)f->N >= (uint64_t)n_cu * LZF_WAVES * 32) {   // two slot rows per wave (f16: VALU-issue bound)
+        // slot rows per wave (f16: bound by vector-instruction issue, and the march / refill / compositing sections cost the same
+        // instructions for 16, 32 or 48 active lanes).  Two rows once the rays fill them; three only when the rays fill them TWICE over:
+        // with most rays resident from the start few slots are ever refilled and the second half of the frame runs on emptying slices
+        // (512^2 dense frame, 262 144 rays on 196 608 slots: 2.21 ms with three rows, 2.10 with two; 1024^2 cfg5: 0.98 vs 1.03 ms).
+        // LZ_FRAME_ROWS=1|2|3 caps the layout (diagnostic)
+        static const int max_rows = getenv("LZ_FRAME_ROWS") ? atoi(getenv("LZ_FRAME_ROWS")) : (getenv("LZ_FRAME_ONE_ROW") ? 1 : 3);
+        static const bool force_rows = getenv("LZ_FRAME_ROWS") != nullptr;
+        if (S == 1 && max_rows >= 3 && (uint64_t)f->N >= (uint64_t)n_cu * LZF_WAVES * 48 * (force_rows ? 1 : 2)) {
+            hipLaunchKernelGGL((lz_k_frame<1, 1, 3>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
+        } else if (S == 1 && max_rows >= 2 && (uint64_t)f->N >= (uint64_t)n_cu * LZF_WAVES * 32) {
             hipLaunchKernelGGL((lz_k_frame<1, 1, 2>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
         } else {
             LZF_SWITCH(1)
