@@ -125,6 +125,8 @@ SIGNATURES = {
     "lz_head_pack_unc_f16": [vp, vp, vp, vp],
     "lz_triplane_head_forward_record_f16": [C.POINTER(HeadParams), vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_triplane_head_grad_w_f16": [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp],
+    "lz_triplane_head_backward_recorded_dw16": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, C.POINTER(HeadBwdOut), vp, u32, vp, vp, vp, vp, vp,
+                                                vp, vp],
     "lz_triplane_head_grad_w": [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp],
 }
 PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),
@@ -132,7 +134,7 @@ PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_dev
          "lz_triplane_head_grad_w_workspace": ([], C.c_size_t)}
 
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
-ABI_VERSION = 6   # lz_abi_version() of the library this binding table describes (include/lzzx_nerf_hip.h)
+ABI_VERSION = 7   # lz_abi_version() of the library this binding table describes (include/lzzx_nerf_hip.h)
 
 _lib = None
 

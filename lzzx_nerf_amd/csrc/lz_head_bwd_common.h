@@ -6,6 +6,19 @@
 
 #define LZ_BWD_WG 512
 
+// partial-tile image of the weight-gradient products (lz_head_gradw.hip; also written by the fused backward of lz_head_rec.hip):
+// 95 tiles of 16 x 16, first tile of each product
+#define LZ_DW_TILES 95
+#define LZ_DW_MAX_PARTS 768
+#define LZ_DW_T_X3 0
+#define LZ_DW_T_AUD1 21
+#define LZ_DW_T_SIG1 29
+#define LZ_DW_T_SIG0 45
+#define LZ_DW_T_C1H 65
+// sums `n_parts` partial images and scatters them into the five row-major matrices (lz_head_gradw.hip)
+int lz_head_grad_w_reduce_launch(const float* parts, uint32_t n_parts, bool h16, uint32_t k_sig0, float* dW_x3, float* dW_aud1, float* dW_sig0,
+                                 float* dW_sig1, float* dW_c1h, lz_stream_t stream);
+
 // record / state stores: written once, read back once by a later kernel
 #if defined(LZ_REC_NO_STORES)   /* experiment: the kernels without their record traffic (results are garbage) */
 #define LZ_REC_STORE(v, p) ((void)(p), (void)(v))

@@ -18,16 +18,17 @@
 // (95 x 256 floats, fragment order) to the workspace and a second small kernel sums the partials and scatters them into the
 // row-major outputs -- deterministic for a given grid.
 #include "lz_common.h"
+#include "lz_head_bwd_common.h"
 
 typedef float lz_f4 __attribute__((ext_vector_type(4)));
 
-#define LZ_GW_TILES 95
+#define LZ_GW_TILES LZ_DW_TILES
 #define LZ_GW_WAVES 6
-#define LZ_GW_MAX_PARTS 768
+#define LZ_GW_MAX_PARTS LZ_DW_MAX_PARTS
 
 namespace {
 // first tile of each of the five products in the partial image
-constexpr int T_X3 = 0, T_AUD1 = 21, T_SIG1 = 29, T_SIG0 = 45, T_C1H = 65;
+constexpr int T_X3 = LZ_DW_T_X3, T_AUD1 = LZ_DW_T_AUD1, T_SIG1 = LZ_DW_T_SIG1, T_SIG0 = LZ_DW_T_SIG0, T_C1H = LZ_DW_T_C1H;
 
 // f32 records: lane (i, kk) of v_mfma_f32_16x16x4_f32 reads one float per (row, tile): row 4 j + kk of MFMA step j.  Records are
 // blocked by 16-sample slice, [slice][tile][sample][16 dwords]: the four rows of a load instruction are four consecutive 64-byte pieces.
@@ -280,6 +281,12 @@ static int lz_grad_w_launch(const void* rec, bool h16, uint32_t M, uint32_t k_si
         else hipLaunchKernelGGL(lz_k_head_grad_w, dim3(grid), dim3(64 * LZ_GW_WAVES), 0, st, static_cast<const float*>(rec), M, parts);
         LZ_CHECK_LAUNCH("head_grad_w");
     }
+    return lz_head_grad_w_reduce_launch(parts, grid, h16, k_sig0, dW_x3, dW_aud1, dW_sig0, dW_sig1, dW_c1h, stream);
+}
+
+int lz_head_grad_w_reduce_launch(const float* parts, uint32_t grid, bool h16, uint32_t k_sig0, float* dW_x3, float* dW_aud1, float* dW_sig0,
+                                 float* dW_sig1, float* dW_c1h, lz_stream_t stream) {
+    hipStream_t st = lz_st(stream);
     LzGwOut o;
     float* dws[5] = {dW_x3, dW_aud1, dW_sig1, dW_sig0, dW_c1h};
     const int Ns[5] = {112, 32, 64, 64, 65}, Ks[5] = {36, 64, 64, (int)k_sig0, 84}, KB[5] = {3, 4, 4, 5, 6};

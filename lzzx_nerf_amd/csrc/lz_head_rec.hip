@@ -18,6 +18,7 @@
 #include "lzzx_sh_eval.h"
 
 typedef float lz_v4 __attribute__((ext_vector_type(4)));
+typedef uint32_t lz_v2u __attribute__((ext_vector_type(2)));
 
 #ifndef LZ_FREC_WG
 #define LZ_FREC_WG 768   // forward: 143 VGPRs -> three waves per SIMD
@@ -322,12 +323,33 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 // backward from the recorded state
 // ------------------------------------------------------------------------------------------------
 // B16: the matrix work on the f16 cores from the transposed half fragments (99 x 512 B instead of the 379 f32 forward fragments)
-template <bool H16, bool B16>
+//
+// FUSE (with H16 and B16: the whole step in the reference's autocast arithmetic): the weight gradients of the wide layers are reduced
+// INSIDE this kernel, so the G half of the record is never written and the separate pass over the records (lz_k_head_grad_w16: 8.4 GB
+// read per cfg3 step) disappears.  dW = sum over samples of G^T X needs the SAMPLE index as the contraction index of the matrix core,
+// while the chain holds G with the sample on the lane: a transpose, done through LDS with gfx950's transposing read
+// (ds_read_b64_tr_b16).  95 accumulator tiles do not fit one wave, so the 8 waves of the workgroup share them: the waves advance in
+// lockstep ROUNDS of 8 slices (one per wave); after each of five chain segments every wave drops the G tiles it just produced and the
+// matching X tiles of its slice (loaded from the X half of the record the forward wrote) into its AREA of an LDS buffer, a workgroup
+// barrier follows, and every wave multiplies the tiles it OWNS of that product over all 8 areas.  Two buffers alternate, so one
+// barrier per segment suffices (a wave that writes buffer b at segment g has passed barrier g - 1, which every wave reaches only after
+// its reads of segment g - 2).  Products and owners (G row tiles t x X column tiles u; w = wave):
+//     after dc1, dh0   c1h   5 x 6 = 30   w < 6: column u = w, rows 0..4
+//     after ds2        sig1  4 x 4 = 16   all:   column u = w & 3, rows 2 (w >> 2), + 1
+//     after ds1        sig0  4 x 5 = 20   w in {6, 7, 0, 1, 2}: column u = (w + 2) & 7, rows 0..3
+//     after datt       aud1  2 x 4 =  8   all:   row t = w >> 2, column u = w & 3
+//     after da1        x3    7 x 3 = 21   w >= 1: row t = w - 1, columns 0..2
+// -- at most 15 tiles = 60 accumulator registers per wave.  At the end a workgroup writes its partial tiles in the layout of
+// lz_k_head_grad_w16 and the same lz_k_head_grad_w_reduce sums them over the workgroups.
+#define LZ_FUSE_AREA_TILES 11                                 // largest segment: c1h, 5 G + 6 X tiles
+#define LZ_FUSE_LDS_FLOATS (2 * 8 * LZ_FUSE_AREA_TILES * 128)   // two buffers x 8 areas x 11 tiles x 512 bytes = 88 KB
+template <bool H16, bool B16, bool FUSE = false>
 __global__ void __launch_bounds__(LZ_BWD_WG, LZ_BWD_WG / 256)
-lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, uint32_t M) {
+lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, uint32_t M, float* __restrict__ parts) {
+    static_assert(!FUSE || (H16 && B16), "the fused weight-gradient products run on half operands");
     constexpr int NFRAG = LZ_FRAGS_ALL;
     constexpr int WV = B16 ? LZ_BFRAGS * 128 : NFRAG * 64, TAB = WV + LZ_WV_FLOATS;
-    __shared__ float wl[TAB + LZ_LVTAB_WORDS];
+    __shared__ __align__(16) float wl[TAB + LZ_LVTAB_WORDS + (FUSE ? LZ_FUSE_LDS_FLOATS : 0)];
     const LzHeadArgs& P = A.fwd;
     const lz_head_bwd_out& O = A.o;
     const uint32_t n_slices = (M + 15) / 16;
@@ -411,19 +433,140 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         in.g_r0 = A.g_rgb[row * 3]; in.g_r1 = A.g_rgb[row * 3 + 1]; in.g_r2 = A.g_rgb[row * 3 + 2];
         return in;
     };
-    int slice = grab();
+    // ---- FUSE: accumulators of the tiles this wave owns, the two LDS buffers, the helpers of the five segments --------------------
+    const int wave = threadIdx.x >> 6;
+    const uint32_t n_local = slice_hi - slice_lo;
+    float* fuse = wl + TAB + LZ_LVTAB_WORDS;
+    constexpr int AREA = LZ_FUSE_AREA_TILES * 128;          // floats per area
+    uint32_t seg = 0;                                       // running segment number: buffer = seg & 1
+    lz_f4 acc_c1h[5], acc_sig1[2], acc_sig0[4], acc_aud1[1], acc_x3[3];
+#pragma unroll
+    for (int t = 0; t < 5; t++) acc_c1h[t] = lz_f4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc_sig0[t] = lz_f4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 3; t++) acc_x3[t] = lz_f4{0, 0, 0, 0};
+    acc_sig1[0] = acc_sig1[1] = acc_aud1[0] = lz_f4{0, 0, 0, 0};
+    // a 16 x 16 half tile in LDS: [row][16 halves], row = rho(sample) so that the four rows one lane group of the transposing read
+    // takes are samples kg, 4 + kg, 8 + kg, 12 + kg -- the k-slot order both operands of lz_k_head_grad_w16 use
+    const int rho = 4 * (s & 3) + (s >> 2);
+    int slice = FUSE ? wave : grab();       // FUSE: static rounds of 8 slices, slice = 8 round + wave
     In nx = fetch(slice);
     for (;;) {
-        if (slice_lo + (uint32_t)slice >= slice_hi) break;
-        const uint32_t base = (slice_lo + (uint32_t)slice) * 16;
-        const bool valid = base + s < M;
-        const uint32_t m = valid ? base + s : M - 1;   // clamped lanes repeat the last row: same values stored again, nothing accumulated
+        if constexpr (FUSE) {
+            if ((uint32_t)(slice - wave) >= n_local) break;                     // workgroup-uniform: the round's first slice
+        } else {
+            if (slice_lo + (uint32_t)slice >= slice_hi) break;
+        }
+        // FUSE: a wave without a slice in the last round repeats the workgroup's last slice with every lane invalid -- zeros in its area,
+        // nothing accumulated, the same denc values stored again -- so that all waves pass the same barriers
+        const bool have = !FUSE || (uint32_t)slice < n_local;
+        const uint32_t gslice = slice_lo + (have ? (uint32_t)slice : n_local - 1);
+        const uint32_t base = gslice * 16;
+        const bool valid = have && base + s < M;
+        const uint32_t m = base + s < M ? base + s : M - 1;   // clamped lanes repeat the last row: same values stored again, nothing accumulated
         const size_t row = m;
-        float* rb = lz_blk(O.rec, slice_lo + (uint32_t)slice, H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC, s);   // f16: rows counted in dwords
+        float* rb = lz_blk(O.rec, gslice, H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC, s);   // f16: rows counted in dwords
         float* dencq = O.denc + (size_t)q * M + row;
         const In in = nx;
-        const int next = grab();
-        nx = fetch(next);
+        const int next = FUSE ? slice + 8 : grab();
+        if constexpr (!FUSE) nx = fetch(next);   // FUSE fetches later in the slice (after the sig0 segment): 51 registers less across the chain
+        // FUSE helpers (all lanes take part in every LDS access: the transposing read needs EXEC all ones)
+        float* const my_area0 = fuse + wave * AREA;
+        auto g_put = [&](int tile, float v0, float v1, float v2, float v3) {     // this lane's four columns 4 q .. 4 q + 3 of a G tile
+            float* ar = my_area0 + (seg & 1u) * (8 * AREA);
+            lz_v2u w = {__float_as_uint(lz_pack_h2(v0, v1)), __float_as_uint(lz_pack_h2(v2, v3))};
+            if (!valid) w = lz_v2u{0u, 0u};
+            *reinterpret_cast<lz_v2u*>(ar + tile * 128 + rho * 8 + 2 * q) = w;
+        };
+        auto x_load = [&](int pair) -> lz_v4 { return ld4(rb + 256 * pair + 4 * q); };     // X half of the record: dword j = {tile 2 p, tile 2 p + 1} column 4 q + j
+        auto x_put = [&](int tile, const lz_v4& d, bool odd) {                               // one tile of the pair, de-interleaved
+            float* ar = my_area0 + (seg & 1u) * (8 * AREA);
+            const uint32_t sel = odd ? 0x07060302u : 0x05040100u;
+            lz_v2u w = {__builtin_amdgcn_perm(__float_as_uint(d[1]), __float_as_uint(d[0]), sel),
+                        __builtin_amdgcn_perm(__float_as_uint(d[3]), __float_as_uint(d[2]), sel)};
+            if (!valid) w = lz_v2u{0u, 0u};                                                  // padding rows of the record are never written: not even NaN may pass
+            *reinterpret_cast<lz_v2u*>(ar + tile * 128 + rho * 8 + 2 * q) = w;
+        };
+        auto tr = [&](const float* ar, int tile) -> lz_bh4 {     // lane (i, kg): column i, rows 4 kg .. 4 kg + 3 of the tile image
+            const int l16 = lane & 15;
+            const _Float16* ph = reinterpret_cast<const _Float16*>(ar + tile * 128) + (4 * (lane >> 4) + (l16 >> 2)) * 16 + 4 * (l16 & 3);
+            typedef short lz_s4 __attribute__((ext_vector_type(4)));
+            return __builtin_bit_cast(lz_bh4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lz_s4*)ph));
+        };
+        // one segment: barrier (every area of this buffer is written), then this wave's tiles of the product over the 8 areas
+        // NG = G tiles of the segment (the X tiles follow them in the area)
+        auto mma16 = [](const lz_bh4& g, const lz_bh4& x, lz_f4& acc) { acc = __builtin_amdgcn_mfma_f32_16x16x16f16(g, x, acc, 0, 0, 0); };
+        auto seg_c1h = [&]() {
+            __syncthreads();
+            if (wave < 6) {
+                const float* buf = fuse + (seg & 1u) * (8 * AREA);
+#pragma unroll 2
+                for (int a = 0; a < 8; a++) {
+                    const float* ar = buf + a * AREA;
+                    const lz_bh4 x = tr(ar, 5 + wave);
+#pragma unroll
+                    for (int t = 0; t < 5; t++) mma16(tr(ar, t), x, acc_c1h[t]);
+                }
+            }
+            seg++;
+        };
+        auto seg_sig1 = [&]() {
+            __syncthreads();
+            const float* buf = fuse + (seg & 1u) * (8 * AREA);
+            const int u = wave & 3, t0 = 2 * (wave >> 2);
+#pragma unroll 2
+            for (int a = 0; a < 8; a++) {
+                const float* ar = buf + a * AREA;
+                const lz_bh4 x = tr(ar, 4 + u);
+                mma16(tr(ar, t0), x, acc_sig1[0]);
+                mma16(tr(ar, t0 + 1), x, acc_sig1[1]);
+            }
+            seg++;
+        };
+        auto seg_sig0 = [&]() {
+            __syncthreads();
+            const int u = (wave + 2) & 7;                    // waves 6, 7, 0, 1, 2 own columns 0 .. 4
+            if (u < 5) {
+                const float* buf = fuse + (seg & 1u) * (8 * AREA);
+#pragma unroll 2
+                for (int a = 0; a < 8; a++) {
+                    const float* ar = buf + a * AREA;
+                    const lz_bh4 x = tr(ar, 4 + u);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) mma16(tr(ar, t), x, acc_sig0[t]);
+                }
+            }
+            seg++;
+        };
+        auto seg_aud1 = [&]() {
+            __syncthreads();
+            const float* buf = fuse + (seg & 1u) * (8 * AREA);
+#pragma unroll 2
+            for (int a = 0; a < 8; a++) {
+                const float* ar = buf + a * AREA;
+                mma16(tr(ar, wave >> 2), tr(ar, 2 + (wave & 3)), acc_aud1[0]);
+            }
+            seg++;
+        };
+        auto seg_x3 = [&]() {
+            __syncthreads();
+            if (wave >= 1) {
+                const float* buf = fuse + (seg & 1u) * (8 * AREA);
+#pragma unroll 2
+                for (int a = 0; a < 8; a++) {
+                    const float* ar = buf + a * AREA;
+                    const lz_bh4 g = tr(ar, wave - 1);
+#pragma unroll
+                    for (int u = 0; u < 3; u++) mma16(g, tr(ar, 7 + u), acc_x3[u]);
+                }
+            }
+            seg++;
+        };
+        lz_v4 xa[3];
+        if constexpr (FUSE) {
+            xa[0] = x_load(LZ_R16_X_S2C / 2); xa[1] = x_load(LZ_R16_X_S2C / 2 + 1); xa[2] = x_load(LZ_R16_X_S2C / 2 + 2);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const lz_v4 l_att0 = in.att0, l_att1 = in.att1, l_c0 = in.c0, l_c1 = in.c1, l_c2 = in.c2, l_c3 = in.c3, l_u0 = in.u0, l_u1 = in.u1,
                     l_e = in.e, l_mk = in.mk, l_clr = in.clr;
@@ -481,7 +624,10 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     v = lz_fmaf(wv[LZ_WV_C2 + 128 + f], dc[2], v);
                     dc1[k] = ((mk_c1 >> k) & 1u) ? v : 0.0f;
                 }
-            {
+            if constexpr (FUSE) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) g_put(t, dc1[4 * t], dc1[4 * t + 1], dc1[4 * t + 2], dc1[4 * t + 3]);
+            } else {
                 if constexpr (H16) {
                     lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_C1H / 2, dc1, 0);
                     lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_C1H / 2 + 1, dc1, 2);
@@ -497,7 +643,13 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         }
         if (valid) acc_ind += dind;
         const float dh0 = g_sig * sigma;
-        {   // every q lane writes: columns 1..3 (f32) / 4 q (f16) of this tile are padding rows of dW
+        if constexpr (FUSE) {
+            g_put(4, dh0, 0.0f, 0.0f, 0.0f);                 // tile 4: the sigma row (columns 4 q are copies in padding rows of dW)
+#pragma unroll
+            for (int pp = 0; pp < 3; pp++) { x_put(5 + 2 * pp, xa[pp], false); x_put(6 + 2 * pp, xa[pp], true); }   // X_S2C: 6 tiles
+            xa[0] = x_load(LZ_R16_X_S1 / 2); xa[1] = x_load(LZ_R16_X_S1 / 2 + 1);                                    // for the next segment
+            seg_c1h();
+        } else {   // every q lane writes: columns 1..3 (f32) / 4 q (f16) of this tile are padding rows of dW
             if constexpr (H16) lz_dump_pair(rb + 4 * q, LZ_R16_G_C1H / 2 + 2, dh0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);   // tile 4, column 0
             else rb[lz_tcol(LZ_BWD_G_C1H + 64 + q)] = dh0;
         }
@@ -513,7 +665,13 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     const float v = lz_fmaf(wv[LZ_WV_SIG + 16 * t + 4 * q + r], dh0, ds2[k]);
                     ds2[k] = ((mk_s2 >> k) & 1u) ? v : 0.0f;
                 }
-            {
+            if constexpr (FUSE) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) g_put(t, ds2[4 * t], ds2[4 * t + 1], ds2[4 * t + 2], ds2[4 * t + 3]);
+                x_put(4, xa[0], false); x_put(5, xa[0], true); x_put(6, xa[1], false); x_put(7, xa[1], true);             // X_S1: 4 tiles
+                xa[0] = x_load(LZ_R16_X_SIG0 / 2); xa[1] = x_load(LZ_R16_X_SIG0 / 2 + 1); xa[2] = x_load(LZ_R16_X_SIG0 / 2 + 2);
+                seg_sig1();
+            } else {
                 if constexpr (H16) {
                     lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_S2 / 2, ds2, 0);
                     lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_S2 / 2 + 1, ds2, 2);
@@ -525,7 +683,14 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             layer_bwd(std::integral_constant<int, LZ_L_S2>{}, ds2, ds1);
 #pragma unroll
             for (int k = 0; k < 16; k++) ds1[k] = ((mk_s1 >> k) & 1u) ? ds1[k] : 0.0f;
-            {
+            if constexpr (FUSE) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) g_put(t, ds1[4 * t], ds1[4 * t + 1], ds1[4 * t + 2], ds1[4 * t + 3]);
+                x_put(4, xa[0], false); x_put(5, xa[0], true); x_put(6, xa[1], false); x_put(7, xa[1], true); x_put(8, xa[2], false);   // X_SIG0: 5 tiles
+                xa[0] = x_load(LZ_R16_X_A1 / 2); xa[1] = x_load(LZ_R16_X_A1 / 2 + 1);
+                seg_sig0();
+                nx = fetch(next);                    // the next slice's state row and upstream gradients: in flight during the last two segments
+            } else {
                 if constexpr (H16) {
                     lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_S1 / 2, ds1, 0);
                     lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_S1 / 2 + 1, ds1, 2);
@@ -552,7 +717,13 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     datt[k] = lz_fmaf(lenca[16 * t + 4 * q + r], dencw[k], inv * att[k]);
                     if (valid) acc_enca[k] = lz_fmaf(att[k], dencw[k], acc_enca[k]);
                 }
-            {
+            if constexpr (FUSE) {
+                g_put(0, datt[0], datt[1], datt[2], datt[3]);
+                g_put(1, datt[4], datt[5], datt[6], datt[7]);
+                x_put(2, xa[0], false); x_put(3, xa[0], true); x_put(4, xa[1], false); x_put(5, xa[1], true);             // X_A1: 4 tiles
+                xa[0] = x_load(LZ_R16_X_SIG0 / 2); xa[1] = x_load(LZ_R16_X_SIG0 / 2 + 1);                                  // enc_x again, for x3
+                seg_aud1();
+            } else {
                 if constexpr (H16) lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_ATT / 2, datt, 0);
                 else lz_dump_chained<2>(rb, q, LZ_BWD_G_ATT, datt);
             }
@@ -582,7 +753,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
             for (int i = 0; i < 9; i++) dencx[i] += dxe[i];
         }
-        {   // G_X = [aud_ch_att_net.0 64 | eye_att_net.0 16 | unc_net.0 32]: the last three tiles
+        if constexpr (FUSE) {   // G_X tiles 4 .. 6 (the first four follow the A2 product below); same buffer, same segment
+            g_put(4, de1[0], de1[1], de1[2], de1[3]);
+            g_put(5, du1[0], du1[1], du1[2], du1[3]);
+            g_put(6, du1[4], du1[5], du1[6], du1[7]);
+        } else {   // G_X = [aud_ch_att_net.0 64 | eye_att_net.0 16 | unc_net.0 32]: the last three tiles
             if constexpr (H16) {
                 lz_dump_pair(rb + 4 * q, LZ_R16_G_X / 2 + 2, de1[0], de1[1], de1[2], de1[3], du1[0], du1[1], du1[2], du1[3]);
                 lz_dump_pair(rb + 4 * q, LZ_R16_G_X / 2 + 3, du1[4], du1[5], du1[6], du1[7], 0.0f, 0.0f, 0.0f, 0.0f);
@@ -596,7 +771,12 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             layer_bwd(std::integral_constant<int, LZ_L_A2>{}, datt, da1);
 #pragma unroll
             for (int k = 0; k < 16; k++) da1[k] = ((mk_a1 >> k) & 1u) ? da1[k] : 0.0f;
-            {
+            if constexpr (FUSE) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) g_put(t, da1[4 * t], da1[4 * t + 1], da1[4 * t + 2], da1[4 * t + 3]);
+                x_put(7, xa[0], false); x_put(8, xa[0], true); x_put(9, xa[1], false);                                     // X_SIG0 tiles 0 .. 2 (enc_x and the slot of feature 32 + q)
+                seg_x3();
+            } else {
                 if constexpr (H16) {
                     lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_X / 2, da1, 0);
                     lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_X / 2 + 1, da1, 2);
@@ -614,6 +794,30 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             for (int i = 0; i < 9; i++) dencq[(size_t)(4 * i) * M] = dencx[i];   // [3 planes][12 levels][M], level-major; feature 4 i + q
         }
         slice = next;
+    }
+    if constexpr (FUSE) {
+        // this workgroup's partial tiles, in the image lz_k_head_grad_w16 writes (tile = product base + t * KBT + u, fragment order):
+        // lz_k_head_grad_w_reduce sums the images of all workgroups
+        float* part = parts + (size_t)blockIdx.x * (LZ_DW_TILES * 256);
+        auto put_tile = [&](int tile, const lz_f4& a) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[(tile * 4 + r) * 64 + lane] = a[r];
+        };
+        if (wave < 6) {
+#pragma unroll
+            for (int t = 0; t < 5; t++) put_tile(LZ_DW_T_C1H + t * 6 + wave, acc_c1h[t]);
+        }
+        put_tile(LZ_DW_T_SIG1 + (2 * (wave >> 2)) * 4 + (wave & 3), acc_sig1[0]);
+        put_tile(LZ_DW_T_SIG1 + (2 * (wave >> 2) + 1) * 4 + (wave & 3), acc_sig1[1]);
+        if (((wave + 2) & 7) < 5) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) put_tile(LZ_DW_T_SIG0 + t * 5 + ((wave + 2) & 7), acc_sig0[t]);
+        }
+        put_tile(LZ_DW_T_AUD1 + (wave >> 2) * 4 + (wave & 3), acc_aud1[0]);
+        if (wave >= 1) {
+#pragma unroll
+            for (int u = 0; u < 3; u++) put_tile(LZ_DW_T_X3 + (wave - 1) * 3 + u, acc_x3[u]);
+        }
     }
     // per-lane sums -> 16 sample lanes -> the workgroup's waves in LDS -> one atomic per value (layout of lz_head_bwd_out.small)
     constexpr int NRED = 32 + 4 + 16 + 32 + 192;
@@ -737,9 +941,47 @@ extern "C" int lz_triplane_head_backward_recorded(const lz_head_params* p, const
     LZ_REQUIRE(!packed_bwd16 || (record_f16 && ((uintptr_t)packed_bwd16 & 15u) == 0), LZ_ERR_BAD_ARGUMENT,
                "triplane_head_backward_recorded: the f16 matrix path goes with f16 records and 16-byte aligned fragments");
     const dim3 grid(lz_rec_grid(M, LZ_BWD_WG)), block(LZ_BWD_WG);
-    if (packed_bwd16) hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, true>), grid, block, 0, lz_st(stream), a, state, M);
-    else if (record_f16) hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, false>), grid, block, 0, lz_st(stream), a, state, M);
-    else hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<false, false>), grid, block, 0, lz_st(stream), a, state, M);
+    if (packed_bwd16) hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, true>), grid, block, 0, lz_st(stream), a, state, M, (float*)nullptr);
+    else if (record_f16) hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, false>), grid, block, 0, lz_st(stream), a, state, M, (float*)nullptr);
+    else hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<false, false>), grid, block, 0, lz_st(stream), a, state, M, (float*)nullptr);
     LZ_CHECK_LAUNCH("triplane_head_backward_recorded");
     return LZ_OK;
+}
+
+// The all-f16 arrangement with the weight gradients of the wide layers reduced inside the backward kernel (FUSE above): reads the state
+// rows and the X half of the f16 records the forward wrote, writes denc / small and the five weight-gradient matrices; the G half of
+// the records is never touched.  workspace: lz_triplane_head_grad_w_workspace() bytes.
+extern "C" int lz_triplane_head_backward_recorded_dw16(const lz_head_params* p, const float* state, const void* rec16, uint32_t M,
+                                                       const float* g_sigma, const float* g_rgb, const float* g_amb_aud, const float* g_amb_eye,
+                                                       const float* g_unc, const lz_head_bwd_out* out, const void* packed_bwd16, uint32_t k_sig0,
+                                                       float* dW_x3, float* dW_aud1, float* dW_sig0, float* dW_sig1, float* dW_c1h, void* workspace,
+                                                       lz_stream_t stream) {
+    LZ_REQUIRE(p && state && rec16 && g_sigma && g_rgb && g_amb_aud && g_unc && out && packed_bwd16 && workspace, LZ_ERR_BAD_ARGUMENT,
+               "triplane_head_backward_recorded_dw16: null tensor");
+    LZ_REQUIRE(dW_x3 && dW_aud1 && dW_sig0 && dW_sig1 && dW_c1h, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded_dw16: null weight-gradient output");
+    LZ_REQUIRE(p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded_dw16: incomplete lz_head_params");
+    LZ_REQUIRE(p->precision == 0 && !p->testing, LZ_ERR_UNSUPPORTED, "triplane_head_backward_recorded_dw16: training mode, f32 packed weights for the skinny rows");
+    LZ_REQUIRE(k_sig0 == 68 || k_sig0 == 69, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded_dw16: sigma_net.0 takes 68 or 69 inputs");
+    const lz_head_bwd_out& o = *out;
+    LZ_REQUIRE(o.denc && o.small, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded_dw16: incomplete lz_head_bwd_out");
+    LZ_REQUIRE((((uintptr_t)rec16 | (uintptr_t)state | (uintptr_t)packed_bwd16) & 15u) == 0, LZ_ERR_BAD_ARGUMENT,
+               "triplane_head_backward_recorded_dw16: rec / state / fragments must be 16-byte aligned");
+    if (M == 0) {   // no sample: the weight gradients are zero
+        hipStream_t st = lz_st(stream);
+        (void)hipMemsetAsync(dW_x3, 0, 112 * 36 * 4, st); (void)hipMemsetAsync(dW_aud1, 0, 32 * 64 * 4, st); (void)hipMemsetAsync(dW_sig0, 0, 64 * k_sig0 * 4, st);
+        (void)hipMemsetAsync(dW_sig1, 0, 64 * 64 * 4, st); (void)hipMemsetAsync(dW_c1h, 0, 65 * 84 * 4, st);
+        return LZ_OK;
+    }
+    LzHeadBwdArgs a;
+    lz_fill_head_args(p, a.fwd);
+    a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_amb_aud = g_amb_aud; a.g_amb_eye = g_amb_eye; a.g_unc = g_unc;
+    a.o = o;
+    a.o.rec = const_cast<float*>(static_cast<const float*>(rec16));   // read only: the X half
+    a.wb16 = packed_bwd16;
+    const uint32_t grid = lz_rec_grid(M, LZ_BWD_WG);
+    LZ_REQUIRE(grid <= LZ_DW_MAX_PARTS, LZ_ERR_UNSUPPORTED, "triplane_head_backward_recorded_dw16: more workgroups than partial images");
+    hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, true, true>), dim3(grid), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M,
+                       static_cast<float*>(workspace));
+    LZ_CHECK_LAUNCH("triplane_head_backward_recorded_dw16");
+    return lz_head_grad_w_reduce_launch(static_cast<const float*>(workspace), grid, true, k_sig0, dW_x3, dW_aud1, dW_sig0, dW_sig1, dW_c1h, stream);
 }

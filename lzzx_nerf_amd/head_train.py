@@ -121,7 +121,21 @@ class _FusedHeadTrain(Function):
         # `mod.packed` is shared by every forward of this module: re-pack from the weights THIS forward saw
         call("lz_head_pack_weights", *[ptr(t) for t in w], int(mod.has_eye), int(mod.has_ind), ptr(mod.packed), stream())
         p = mod._params(emb, enc_a_f, ind_f, eye_f)
-        if ctx.state is not None:
+        k_sig0, k_col0 = w[4].shape[1], w[7].shape[1]   # 68 without the eye column, 80 without an individual code
+        shapes = dict(x3=(112, 36), aud1=(32, 64), sig0=(64, k_sig0), sig1=(64, 64), c1h=(65, 84))
+        red = {n: torch.empty(sh, **kw) for n, sh in shapes.items()}
+        if mod._gw_ws is None or mod._gw_ws.device != dev:
+            mod._gw_ws = torch.empty(_lib.load().lz_triplane_head_grad_w_workspace() // 4, **kw)
+        fused_dw = ctx.state is not None and mod.fuse_dw and rec.dtype == torch.float16
+        if fused_dw:
+            # the whole backward of the all-f16 arrangement in one kernel: data-gradient chain + the five weight-gradient products
+            call("lz_head_pack_weights_bwd_f16", ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[4]), ptr(w[5]), ptr(w[6]), ptr(w[7]), int(mod.has_eye),
+                 int(mod.has_ind), ptr(mod.packed_bwd16), stream())
+            call("lz_triplane_head_backward_recorded_dw16", C.byref(p), ptr(ctx.state), ptr(rec), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae),
+                 ptr(g_un), C.byref(o), ptr(mod.packed_bwd16), k_sig0, *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")],
+                 ptr(mod._gw_ws), stream())
+            ctx.state = None
+        elif ctx.state is not None:
             wb16 = None
             if mod.backward_f16:   # transposed half fragments of the weights THIS forward saw
                 call("lz_head_pack_weights_bwd_f16", ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[4]), ptr(w[5]), ptr(w[6]), ptr(w[7]), int(mod.has_eye),
@@ -134,13 +148,9 @@ class _FusedHeadTrain(Function):
             call("lz_triplane_head_backward", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
                  C.byref(o), stream())
         # weight gradients of the wide layers: ONE pass over the records (the skinny ones came out of the backward kernel)
-        k_sig0, k_col0 = w[4].shape[1], w[7].shape[1]   # 68 without the eye column, 80 without an individual code
-        shapes = dict(x3=(112, 36), aud1=(32, 64), sig0=(64, k_sig0), sig1=(64, 64), c1h=(65, 84))
-        red = {n: torch.empty(sh, **kw) for n, sh in shapes.items()}
-        if mod._gw_ws is None or mod._gw_ws.device != dev:
-            mod._gw_ws = torch.empty(_lib.load().lz_triplane_head_grad_w_workspace() // 4, **kw)
-        call("lz_triplane_head_grad_w_f16" if rec.dtype == torch.float16 else "lz_triplane_head_grad_w", ptr(rec), M, k_sig0,
-             *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")], ptr(mod._gw_ws), stream())
+        if not fused_dw:
+            call("lz_triplane_head_grad_w_f16" if rec.dtype == torch.float16 else "lz_triplane_head_grad_w", ptr(rec), M, k_sig0,
+                 *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")], ptr(mod._gw_ws), stream())
         ctx.rec = None
         # geo = s2 . Wg^T and d geo = G_c1 . Wc[:, geo] never left the kernel: both weight gradients follow from R = sum G_c1^T s2
         x3, c1h = red["x3"], red["c1h"]
@@ -167,7 +177,7 @@ class _FusedHeadTrain(Function):
 
 class FusedTriplaneTrainHead(nn.Module):
     def __init__(self, state_dict=None, bound=1.0, exp_eye=True, ind_dim=4, record=True, record_dtype="f32", forward_dtype="f32",
-                 backward_dtype="f32"):
+                 backward_dtype="f32", fuse_dw=True):
         super().__init__()
         if record_dtype not in ("f32", "f16") or forward_dtype not in ("f32", "f16") or backward_dtype not in ("f32", "f16"):
             raise ValueError("record_dtype / forward_dtype / backward_dtype must be 'f32' or 'f16'")
@@ -189,6 +199,9 @@ class FusedTriplaneTrainHead(nn.Module):
         # reference's autocast backward; "f32" keeps the f32 chain (more accurate than autocast, 4 x the matrix instructions).
         # forward_dtype = backward_dtype = "f16" is the whole step in the arithmetic of the reference's `-O` mode.
         self.backward_f16 = backward_dtype == "f16"
+        # fuse_dw (only with backward_dtype="f16", whose half weight image leaves room in LDS): the weight gradients of the wide layers are
+        # reduced inside the backward kernel (lz_triplane_head_backward_recorded_dw16) instead of in a second pass over the records
+        self.fuse_dw = bool(fuse_dw) and self.backward_f16
         mk = lambda: GridEncoder(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
                                  desired_resolution=512 * bound)
         self.encoder_xy, self.encoder_yz, self.encoder_xz = mk(), mk(), mk()                       # network.py:131-133

@@ -695,6 +695,58 @@ def test_fused_train_head_tiny_batches_all_arrangements(params, golden, M):
                 assert float((g[k] - g_ref[k]).abs().max()) / scale < (2e-3 if kw else 1e-5), (kw, k)
 
 
+@pytest.mark.parametrize("M", [1, 17, 16 * 8 + 5, 16 * 8 * 3, 16 * 8 * 256 + 16 * 3 + 9, 120001])
+@pytest.mark.parametrize("exp_eye,ind_dim", [(True, 4), (False, 0)])
+def test_fused_weight_gradients_in_the_backward_kernel_equal_the_two_pass_arrangement(params, golden, M, exp_eye, ind_dim):
+    """fuse_dw (the default of the all-f16 arrangement): the weight gradients of the wide layers reduced inside the backward kernel
+    (lz_triplane_head_backward_recorded_dw16: G / X tiles transposed through LDS, 95 accumulator tiles shared by the workgroup's waves)
+    against backward + lz_triplane_head_grad_w_f16 over the records.  Same operand rounding (half), same f32 products, another summation
+    order: outputs and the data-gradient side (tables) bit for bit, weight gradients to f32 reassociation.  Batch sizes: less than one
+    slice, ragged last slice, a ragged last ROUND of a workgroup (8 slices per round), one round per workgroup, many rounds."""
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    rng = np.random.default_rng(41)
+    p = dict(params)
+    p["sigma_net.net.0.weight"] = np.ascontiguousarray(params["sigma_net.net.0.weight"][:, :68 + int(exp_eye)])
+    p["color_net.net.0.weight"] = np.ascontiguousarray(params["color_net.net.0.weight"][:, :80 + ind_dim])
+    for n in ("xy", "yz", "xz"):
+        p[f"encoder_{n}.embeddings"] = params[f"encoder_{n}.embeddings"] * np.float32(30.0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    xyz = dev(rng.uniform(-1, 1, (M, 3)).astype(np.float32))
+    d = torch.nn.functional.normalize(dev(rng.normal(size=(M, 3)).astype(np.float32)), dim=-1)
+    gout = [dev(rng.normal(size=sh).astype(np.float32)) for sh in ((M,), (M, 3), (M, 1), (M, 1), (M, 1))]
+    gout[0] *= 1e-2
+
+    def run(fuse):
+        net = FusedTriplaneTrainHead(p, bound=1.0, exp_eye=exp_eye, ind_dim=ind_dim, forward_dtype="f16", backward_dtype="f16", fuse_dw=fuse).cuda()
+        assert net.fuse_dw == fuse
+        enc_a = dev(golden["net_enc_a"]).requires_grad_(True)
+        ind = dev(golden["net_ind"]).requires_grad_(True) if ind_dim else None
+        outs = net(xyz, d, enc_a, ind, dev(golden["net_eye"]) if exp_eye else None)
+        live = [k for k in range(5) if outs[k].requires_grad]
+        torch.autograd.backward([outs[k] for k in live], [gout[k] for k in live])
+        g = {k: v.grad for k, v in net.named_parameters()}
+        g["enc_a"] = enc_a.grad
+        if ind is not None:
+            g["ind"] = ind.grad
+        return [o.detach() for o in outs], g
+
+    o2, g2 = run(False)
+    o1, g1 = run(True)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    for k in g2:
+        if g2[k] is None:
+            assert g1[k] is None, k
+            continue
+        assert torch.isfinite(g1[k]).all(), k
+        if "embeddings" in k:                       # the chain is the same instruction sequence: d enc_x, hence the table scatter inputs, equal
+            assert float((g1[k] - g2[k]).abs().max()) <= 2e-4 * float(g2[k].abs().max()) + 1e-30, k      # scatter-add order only
+            continue
+        scale = float(g2[k].abs().max()) + 1e-30
+        assert float((g1[k] - g2[k]).abs().max()) / scale < 2e-5, (k, float((g1[k] - g2[k]).abs().max()) / scale)
+        assert exp_eye is False and k.startswith("eye_att_net") or float(g1[k].abs().max()) > 0, k
+
+
 @pytest.mark.parametrize("M,k_sig0", [(1, 69), (3, 68), (15, 69), (16, 69), (1000, 68), (70001, 69)])
 def test_head_grad_w_f16_products_match_float64(M, k_sig0):
     """lz_triplane_head_grad_w_f16 on random half records built here from the documented layout (LZ_R16_*: 16-column tiles interleaved in
