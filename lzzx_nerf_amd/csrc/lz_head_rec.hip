@@ -447,6 +447,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
     for (int t = 0; t < 3; t++) acc_x3[t] = lz_f4{0, 0, 0, 0};
     acc_sig1[0] = acc_sig1[1] = acc_aud1[0] = lz_f4{0, 0, 0, 0};
+    lz_f4 acc_c2t = lz_f4{0, 0, 0, 0};   // FUSE, waves 4 .. 7: color_net.1's weight gradient, columns 16 (wave & 3) .. + 15 (rows 0 .. 2 of the tile)
     // a 16 x 16 half tile in LDS: [row][16 halves], row = rho(sample) so that the four rows one lane group of the transposing read
     // takes are samples kg, 4 + kg, 8 + kg, 12 + kg -- the k-slot order both operands of lz_k_head_grad_w16 use
     const int rho = 4 * (s & 3) + (s >> 2);
@@ -496,17 +497,24 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         };
         // one segment: barrier (every area of this buffer is written), then this wave's tiles of the product over the 8 areas
         // NG = G tiles of the segment (the X tiles follow them in the area)
-        auto mma16 = [](const lz_bh4& g, const lz_bh4& x, lz_f4& acc) { acc = __builtin_amdgcn_mfma_f32_16x16x16f16(g, x, acc, 0, 0, 0); };
+        // v_mfma_f32_16x16x32_f16: the contraction runs over the 32 samples of TWO areas (k slots 0..3 of a lane from area a, 4..7 from
+        // area a + 1: any assignment of samples to k slots works as long as both operands use the same one)
+        typedef _Float16 lz_bh8 __attribute__((ext_vector_type(8)));
+        auto tr2 = [&](const float* ar, int tile) -> lz_bh8 {
+            const lz_bh4 lo = tr(ar, tile), hi = tr(ar + AREA, tile);
+            return lz_bh8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto mma32 = [](const lz_bh8& g, const lz_bh8& x, lz_f4& acc) { acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(g, x, acc, 0, 0, 0); };
         auto seg_c1h = [&]() {
             __syncthreads();
             if (wave < 6) {
                 const float* buf = fuse + (seg & 1u) * (8 * AREA);
 #pragma unroll 2
-                for (int a = 0; a < 8; a++) {
+                for (int a = 0; a < 8; a += 2) {
                     const float* ar = buf + a * AREA;
-                    const lz_bh4 x = tr(ar, 5 + wave);
+                    const lz_bh8 x = tr2(ar, 5 + wave);
 #pragma unroll
-                    for (int t = 0; t < 5; t++) mma16(tr(ar, t), x, acc_c1h[t]);
+                    for (int t = 0; t < 5; t++) mma32(tr2(ar, t), x, acc_c1h[t]);
                 }
             }
             seg++;
@@ -516,11 +524,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             const float* buf = fuse + (seg & 1u) * (8 * AREA);
             const int u = wave & 3, t0 = 2 * (wave >> 2);
 #pragma unroll 2
-            for (int a = 0; a < 8; a++) {
+            for (int a = 0; a < 8; a += 2) {
                 const float* ar = buf + a * AREA;
-                const lz_bh4 x = tr(ar, 4 + u);
-                mma16(tr(ar, t0), x, acc_sig1[0]);
-                mma16(tr(ar, t0 + 1), x, acc_sig1[1]);
+                const lz_bh8 x = tr2(ar, 4 + u);
+                mma32(tr2(ar, t0), x, acc_sig1[0]);
+                mma32(tr2(ar, t0 + 1), x, acc_sig1[1]);
             }
             seg++;
         };
@@ -530,11 +538,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             if (u < 5) {
                 const float* buf = fuse + (seg & 1u) * (8 * AREA);
 #pragma unroll 2
-                for (int a = 0; a < 8; a++) {
+                for (int a = 0; a < 8; a += 2) {
                     const float* ar = buf + a * AREA;
-                    const lz_bh4 x = tr(ar, 4 + u);
+                    const lz_bh8 x = tr2(ar, 4 + u);
 #pragma unroll
-                    for (int t = 0; t < 4; t++) mma16(tr(ar, t), x, acc_sig0[t]);
+                    for (int t = 0; t < 4; t++) mma32(tr2(ar, t), x, acc_sig0[t]);
                 }
             }
             seg++;
@@ -543,9 +551,10 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             __syncthreads();
             const float* buf = fuse + (seg & 1u) * (8 * AREA);
 #pragma unroll 2
-            for (int a = 0; a < 8; a++) {
+            for (int a = 0; a < 8; a += 2) {
                 const float* ar = buf + a * AREA;
-                mma16(tr(ar, wave >> 2), tr(ar, 2 + (wave & 3)), acc_aud1[0]);
+                mma32(tr2(ar, wave >> 2), tr2(ar, 2 + (wave & 3)), acc_aud1[0]);
+                if (wave >= 4) mma32(tr2(ar, 6), tr2(ar, 7 + (wave & 3)), acc_c2t);
             }
             seg++;
         };
@@ -554,11 +563,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             if (wave >= 1) {
                 const float* buf = fuse + (seg & 1u) * (8 * AREA);
 #pragma unroll 2
-                for (int a = 0; a < 8; a++) {
+                for (int a = 0; a < 8; a += 2) {
                     const float* ar = buf + a * AREA;
-                    const lz_bh4 g = tr(ar, wave - 1);
+                    const lz_bh8 g = tr2(ar, wave - 1);
 #pragma unroll
-                    for (int u = 0; u < 3; u++) mma16(g, tr(ar, 7 + u), acc_x3[u]);
+                    for (int u = 0; u < 3; u++) mma32(g, tr2(ar, 7 + u), acc_x3[u]);
                 }
             }
             seg++;
@@ -604,9 +613,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         for (int c = 0; c < 3; c++) {
             const float sg = lz_sigmoidf(l_clr[c]);
             dc[c] = (c == 0 ? g_r0 : (c == 1 ? g_r1 : g_r2)) * 1.002f * sg * (1.0f - sg);
-            if (valid) {
+            if constexpr (!FUSE) {   // FUSE: color_net.1's weight gradient is one more product on the matrix cores (aud1 segment)
+                if (valid) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) acc_c2[c][k] = lz_fmaf(dc[c], c1[k], acc_c2[c][k]);
+                    for (int k = 0; k < 16; k++) acc_c2[c][k] = lz_fmaf(dc[c], c1[k], acc_c2[c][k]);
+                }
             }
         }
 
@@ -721,6 +732,9 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 g_put(0, datt[0], datt[1], datt[2], datt[3]);
                 g_put(1, datt[4], datt[5], datt[6], datt[7]);
                 x_put(2, xa[0], false); x_put(3, xa[0], true); x_put(4, xa[1], false); x_put(5, xa[1], true);             // X_A1: 4 tiles
+                // color_net.1 (3 x 64): G = d loss / d (colour pre-activation) in columns 0 .. 2 of a tile, X = its input c1 (the state row's pairs)
+                g_put(6, q == 0 ? dc[0] : 0.0f, q == 0 ? dc[1] : 0.0f, q == 0 ? dc[2] : 0.0f, 0.0f);
+                x_put(7, l_c0, false); x_put(8, l_c0, true); x_put(9, l_c1, false); x_put(10, l_c1, true);
                 xa[0] = x_load(LZ_R16_X_SIG0 / 2); xa[1] = x_load(LZ_R16_X_SIG0 / 2 + 1);                                  // enc_x again, for x3
                 seg_aud1();
             } else {
@@ -818,6 +832,10 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
             for (int u = 0; u < 3; u++) put_tile(LZ_DW_T_X3 + (wave - 1) * 3 + u, acc_x3[u]);
         }
+        if (wave >= 4 && lane < 16) {   // rows 0 .. 2 of the tile sit in registers 0 .. 2 of lanes 0 .. 15 (column = lane): dW_color1[c][16 u + lane]
+#pragma unroll
+            for (int c = 0; c < 3; c++) atomicAdd(O.small + 84 + 64 * c + 16 * (wave & 3) + lane, acc_c2t[c]);
+        }
     }
     // per-lane sums -> 16 sample lanes -> the workgroup's waves in LDS -> one atomic per value (layout of lz_head_bwd_out.small)
     constexpr int NRED = 32 + 4 + 16 + 32 + 192;
@@ -836,12 +854,14 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
     for (int k = 0; k < 4; k++) put(acc_e2[k], 36 + 4 * q + k);
 #pragma unroll
     for (int k = 0; k < 8; k++) put(acc_u2[k], 52 + 16 * (k >> 2) + 4 * q + (k & 3));
+    if constexpr (!FUSE) {
 #pragma unroll
-    for (int c = 0; c < 3; c++)
+        for (int c = 0; c < 3; c++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) put(acc_c2[c][k], 84 + 64 * c + 16 * (k >> 2) + 4 * q + (k & 3));
+            for (int k = 0; k < 16; k++) put(acc_c2[c][k], 84 + 64 * c + 16 * (k >> 2) + 4 * q + (k & 3));
+    }
     __syncthreads();
-    if (threadIdx.x < NRED) {
+    if (threadIdx.x < (FUSE ? 84 : NRED)) {
         float v = 0.0f;
         for (int w = 0; w < LZ_BWD_WG / 64; w++) v += red[w * NRED + threadIdx.x];
         if (v != 0.0f) atomicAdd(O.small + threadIdx.x, v);

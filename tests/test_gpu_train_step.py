@@ -743,7 +743,10 @@ def test_fused_weight_gradients_in_the_backward_kernel_equal_the_two_pass_arrang
             assert float((g1[k] - g2[k]).abs().max()) <= 2e-4 * float(g2[k].abs().max()) + 1e-30, k      # scatter-add order only
             continue
         scale = float(g2[k].abs().max()) + 1e-30
-        assert float((g1[k] - g2[k]).abs().max()) / scale < 2e-5, (k, float((g1[k] - g2[k]).abs().max()) / scale)
+        # color_net.1: the two-pass arrangement sums f32 dY x half input per lane, the fused one rounds dY to half like every other
+        # weight-gradient operand (autocast's dW GEMM has half operands): half rounding of one factor
+        tol = 2e-3 if k == "color_net.net.1.weight" else 2e-5
+        assert float((g1[k] - g2[k]).abs().max()) / scale < tol, (k, float((g1[k] - g2[k]).abs().max()) / scale)
         assert exp_eye is False and k.startswith("eye_att_net") or float(g1[k].abs().max()) > 0, k
 
 
