@@ -65,10 +65,12 @@ __device__ __forceinline__ void lz_dump_pair_f(float* __restrict__ rowq, int pai
 // what ReLU left: halves >= +0, so "positive" is "bit pattern not zero" -- an unsigned 16-bit min with 1 per packed pair, then the
 // eight 0 / 1 halves are folded into one byte (10 instructions; a compare + select + or per half costs 17)
 __device__ __forceinline__ uint32_t lz_mask_h8(const lz_h8& b) {
-    typedef unsigned short lz_us8 __attribute__((ext_vector_type(8)));
-    const lz_us8 one = {1, 1, 1, 1, 1, 1, 1, 1};
-    // whole-vector operations only: a bit_cast of a single vector ELEMENT to a 2-vector was miscompiled here (see lz_head_rec.hip)
-    const lz_u4 q = __builtin_bit_cast(lz_u4, __builtin_elementwise_min(__builtin_bit_cast(lz_us8, b), one));   // halves 2 d, 2 d + 1 of dword d -> 0 / 1
+    // v_pk_min_u16 spelled out: the compiler expands the vector min against the constant into a compare, a select and a pack per half
+    // (76 compares and 96 selects per slice in the ISA of round 2), four times the instructions of the packed form
+    const lz_u4 w = __builtin_bit_cast(lz_u4, b);   // whole-vector cast only: a bit_cast of a single vector ELEMENT to a 2-vector was miscompiled here (see lz_head_rec.hip)
+    uint32_t q[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) asm("v_pk_min_u16 %0, %1, %2" : "=v"(q[d]) : "v"(w[d]), "v"(0x00010001u));       // halves 2 d, 2 d + 1 of dword d -> 0 / 1
     const uint32_t m = q[0] | (q[1] << 2) | (q[2] << 4) | (q[3] << 6);                                          // bits 2 d and 16 + 2 d
     return (m | (m >> 15)) & 0xffu;
 }
