@@ -46,6 +46,7 @@ FLOP_PER_SAMPLE = 46368          # 23 184 MAC per sample, inference h
 ISSUED_FLOP_PER_ROW = 361 * 2048 // 16   # the head issues 361 v_mfma_f32_16x16x4_f32 (2048 FLOP each) per 16-row slice
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
+GRID_PMC_SUMMARY = "r3_grid_pmc_summary.json"   # tools/profile_grid.sh over the CURRENT kernels (a summary of an older round describes code that no longer exists)
 
 
 # kernels behind each grid_roofline case and the batch size tools/grid_bench.py profiled them at (tools/profile_grid.sh)
@@ -59,8 +60,8 @@ def _grid_traffic(tag, B):
     """HBM-side bytes per launch at batch size B from the committed PMC summary (KiB per launch at the profiled batch size, scaled
     per sample; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 -- calibrated there for wide streaming reads, so an
     upper bound for the gather-dominated kernels).  None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_grid_pmc_summary.json")
-    if not os.path.exists(path):
+    path = os.path.join(ROOT, "profiles", GRID_PMC_SUMMARY)
+    if not os.path.exists(path) or tag not in _GRID_PMC:
         return None
     try:
         pmc = json.load(open(path))
@@ -92,9 +93,13 @@ def grid_roofline(device):
             ("hashgrid_D3_L16_C2_f32_ray_ordered", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23, "fwd_rays"),
             ("hashgrid_D3_L16_C2_f32_march_order", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 4 + 128, 1 << 23, "fwd_march"),
             ("hashgrid_D3_L16_C2_f16", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 2 + 64, 1 << 23, "fwd16"),
+            ("hashgrid_D3_L16_C2_f16_ray_ordered", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 2 + 64, 1 << 23, "fwd_rays16"),
+            ("hashgrid_D3_L16_C2_f16_march_order", dict(desired_resolution=2048), 12 + 16 * 8 * 2 * 2 + 64, 1 << 23, "fwd_march16"),
             ("triplane_plane_D2_L12_C1_f32_backward", tri, 8 + 48 + 12 * 4 * 4 * 2, 1 << 22, "bwd")):
         enc = GridEncoder(**kw).to(device)
         enc.embeddings.data.uniform_(-1, 1, generator=g)
+        half = mode.endswith("16")
+        mode = mode[:-2] if half and mode != "fwd16" else mode
         if mode == "fwd_march":   # BASELINE cfg2 as the INFERENCE loop hands it to the encoder (renderer.py:513-521): per iteration every
             # alive ray contributes n_step = 8 consecutive samples, rays in pixel order -> [iteration][ray][8 steps]; 16 iterations of the
             # 256 x 256 frame = 2^23 samples (all rays kept alive: the densest case)
@@ -114,7 +119,7 @@ def grid_roofline(device):
             x = (((ro[:, None, :] + rd[:, None, :] * t[None, :, None]).clamp(-1, 1) + 1) / 2).reshape(-1, 3).contiguous()
         else:
             x = torch.rand(B, enc.input_dim, device=device, generator=g)
-        emb = enc.embeddings.data.half() if mode == "fwd16" else enc.embeddings.data
+        emb = enc.embeddings.data.half() if half else enc.embeddings.data
         if mode == "bwd":
             from lzzx_nerf_amd._util import call, ptr, stream
             grad = torch.rand(B, enc.output_dim, device=device, generator=g)
@@ -343,6 +348,8 @@ def parse_args():
     ap.add_argument("--steps-per-pass", type=int, default=0, help="fused mode: samples per ray and pass (0 = auto by ray count)")
     ap.add_argument("--no-side-legs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-sample", action="store_true",
+                    help="time the CPU baseline on every 4th pixel of the cfg3 frame (median of 3) instead of the whole frame (median of 5)")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="skip the 8 extra 2M-row head launches that measure the sustained shader clock (tools/profile_bench.sh: the kernel "
                          "trace then holds only warm-up + timed frames, so its average head duration is directly bench's avg_launch_ms_all)")
@@ -353,6 +360,9 @@ def parse_args():
     ap.add_argument("--no-occupancy", action="store_true")
     ap.add_argument("--no-dense192", action="store_true")
     ap.add_argument("--no-cfg5", action="store_true")
+    ap.add_argument("--gather-via", default="collective", choices=["collective", "peer"],
+                    help="N > 1, --shard frame: 'collective' = one RCCL all_gather_into_tensor per frame; 'peer' = every rank copies its tile "
+                         "straight into each peer's frame buffer (one xGMI hop per tile, IPC-mapped buffers, device-side flag wait)")
     ap.add_argument("--gather", default="f32", choices=["f32", "rgb24"],
                     help="what the per-step all-gather moves: f32 RGB tiles, or the video pipe's RGB24 quantised on device (4x fewer bytes)")
     args = ap.parse_args()
@@ -365,7 +375,7 @@ def parse_args():
 class FrameJob:
     """one rank's share of the per-step work: ray generation for its pixels -> render -> (tile all-gather)"""
 
-    def __init__(self, renderer, H, W, pose, intr, cond, max_steps, rank, world, shard, tiles, gather, device, shard_of=0):
+    def __init__(self, renderer, H, W, pose, intr, cond, max_steps, rank, world, shard, tiles, gather, device, shard_of=0, via="collective"):
         from lzzx_nerf_amd import dist as D
         self.r, self.H, self.W, self.intr, self.cond, self.max_steps, self.gather_fmt = renderer, H, W, intr, cond, max_steps, gather
         self.pose = torch.from_numpy(np.ascontiguousarray(pose)).to(device)
@@ -374,7 +384,7 @@ class FrameJob:
             self.sf = D.ShardedFrame(H, W, 0, shard_of, tiles, device)
             self.sf.gatherer = None
         elif world > 1 and shard == "frame":
-            self.sf = D.ShardedFrame(H, W, rank, world, tiles, device, dtype=torch.uint8 if gather == "rgb24" else torch.float32)
+            self.sf = D.ShardedFrame(H, W, rank, world, tiles, device, dtype=torch.uint8 if gather == "rgb24" else torch.float32, via=via)
         else:
             self.sf = D.ShardedFrame(H, W, 0, 1, device=device)
             if world > 1:         # clip mode: every rank contributes a whole frame to the gathered batch
@@ -429,9 +439,10 @@ def cpu_baseline(args, P, golden, bits_np, gpu_image_of, renderer_counts_of):
     """SURVEY 8(d) / BASELINE.md 3: the reference has no CPU renderer, so the baseline is the CPU checker's kernels (C, OpenMP) arranged
     exactly like run_cuda_for_inference (renderer.py:495-548) with the reference's pure-torch MLP arrangement on CPU tensors
     (oracle.head.head_forward_torch: F.linear stacks, fp32, torch intra-op threads = all cores).  cfg1 = whole 64x64 / 32-step frames,
-    median of 5 after a warm-up; cfg3 = a bounded sample of the 512x512 / 192-step frame (every 4th pixel in both directions, 16 384
-    rays, reference schedule), median of 3 -- a whole cfg3 frame is minutes of CPU time.  Also yields PSNR / sample-count parity of the
-    GPU image against the bit-pinned checker on every 8th pixel."""
+    median of 5 after a warm-up; cfg3 = the WHOLE 512x512 / 192-step frame (262 144 rays, 23.9 M samples, reference schedule), median of 5
+    after one warm-up (about 70 s on the 16 cores of a GPU box) -- `--cpu-baseline-sample` times every 4th pixel in both
+    directions instead (16 384 rays, median of 3: the bounded sample of rounds 1-2).  Also yields PSNR / sample-count parity of the GPU
+    image against the bit-pinned checker on every 8th pixel."""
     from oracle import oracle as O
     from oracle.head import TriplaneSpec, head_forward_torch
     from oracle.render import render_inference
@@ -464,12 +475,15 @@ def cpu_baseline(args, P, golden, bits_np, gpu_image_of, renderer_counts_of):
     log(f"cpu baseline: cfg1 {cfg1['s_per_frame']} s/frame; cfg3 sample")
     res["cfg1_64x64x32"] = cfg1
     H = W = args.size
-    stride = max(1, H // 128)
-    cfg3, sel = run(H, W, stride, args.max_steps, 3, bits_np)
-    res["cfg3_sample"] = cfg3
+    stride = max(1, H // 128) if args.cpu_baseline_sample else 1
+    reps = 3 if args.cpu_baseline_sample else 5
+    cfg3, sel = run(H, W, stride, args.max_steps, reps, bits_np)
+    res["cfg3_sample" if args.cpu_baseline_sample else "cfg3_whole_frame"] = cfg3
+    log(f"cpu baseline: cfg3 {cfg3['s_per_frame']} s/frame ({cfg3['rays']} rays)")
+    what = f"on every {stride}th pixel in both directions = " if stride > 1 else "whole = "
     base = dict(value=cfg3["samples_per_s"], unit="samples/s", cores=cores, kind="port",
-                sample=f"cfg3 frame ({H}x{W}, max_steps {args.max_steps}) on every {stride}th pixel in both directions = {cfg3['rays']} rays, "
-                       f"{cfg3['samples']} samples, median of 3 after a warm-up: {cfg3['s_per_frame']} s; checker kernels (C, OpenMP) arranged like "
+                sample=f"cfg3 frame ({H}x{W}, max_steps {args.max_steps}) {what}{cfg3['rays']} rays, "
+                       f"{cfg3['samples']} samples, median of {reps} after a warm-up: {cfg3['s_per_frame']} s; checker kernels (C, OpenMP) arranged like "
                        "run_cuda_for_inference (renderer.py:495-548) + the reference's torch-CPU MLP arrangement (network.py:73-94), fp32, "
                        f"torch.set_num_threads({cores})",
                 legs=res, cfg1_samples_per_s=cfg1["samples_per_s"], cfg1_s_per_frame=cfg1["s_per_frame"])
@@ -503,36 +517,46 @@ PMC_SUMMARY = "r2_final_pmc_summary.json"   # written by tools/profile_bench.sh 
 F16_SLICE_MFMAS = 59    # v_mfma_f32_16x16x32_f16 per 16-row slice of lz_k_triplane_head_f16
 
 
+F16_PMC_SUMMARY = "r3_f16_head_pmc_summary.json"   # tools/profile_bench.sh f16 over the current kernel
+F16_MFMA_PEAK_TFLOPS = 2500.0                      # dense f16 (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
+
+
 def f16_head_roofline(samples, rows, steps, head_total_ms, n_launch, launches_with_work, dt, fused=True):
-    """roofline object of the f16 head / fused f16 frame kernel.  Its matrix work is 7 % of the f32 kernel's (59 MFMAs x 16 cycles per
-    16-row slice), so the dense f16 MFMA peak does not bound it.  The PMC passes (profiles/r2_f16_head_pmc_summary.json, rocprofv3
-    --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_MFMA_MOPS_F16 over this same command) show what does: vector-instruction ISSUE.  A wave64 VALU
-    instruction occupies its SIMD's issue port for 4 cycles and an MFMA for 8 of its 16 (MI355X_MICROARCH.md, cycle constants), and
-    4 x (SQ_INSTS_VALU - N_mfma) + 8 x N_mfma per SIMD equals the elapsed cycles of the kernel: the port is saturated.  So the bound
-    reported here is that instruction stream at the nominal 2.4 GHz; `frac` = achieved / that."""
+    """roofline object of the f16 head / fused f16 frame kernel: ALGORITHMIC FLOP/s (46 368 FLOP per marched sample, the network's own
+    count) against the dense f16 MFMA peak -- `frac` is that quotient, nothing else.  The kernel's matrix work is small (59
+    v_mfma_f32_16x16x32_f16 per 16-row slice); what holds it is vector-instruction ISSUE (gathers' index arithmetic, conversions, the
+    march): the PMC passes (profiles/r3_f16_head_pmc_summary.json, rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_MFMA_MOPS_F16 over this
+    same command) give the instructions per slice, and with 4 issue cycles per wave64 VALU instruction and 8 per MFMA
+    (MI355X_MICROARCH.md, cycle constants) the `valu_issue` block prices that stream -- a labelled DIAGNOSTIC of where the time goes,
+    not a roofline: fewer instructions raise it."""
     t = head_total_ms * 1e-3
     sps = samples * steps / t
-    r = dict(bound="valu-issue", achieved=round(sps / 1e9, 4), peak=None, unit="Gsample/s", frac=None, traffic=None,
+    tflops = FLOP_PER_SAMPLE * sps / 1e12
+    r = dict(bound="mfma", achieved=round(tflops, 2), peak=F16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tflops / F16_MFMA_PEAK_TFLOPS, 4), traffic=None,
              kernel="lz_k_frame<1, S, ROWS> (march + f16 head + composite, one persistent launch per frame)" if fused else "lz_k_triplane_head_f16",
              avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5), avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5),
              launches=n_launch, head_time_share=round(t / dt, 4), head_ms_per_step=round(head_total_ms / steps, 4), rows_per_frame=rows,
-             samples_per_s=round(sps, 1),
-             mfma_frac_of_dense_f16_peak=round(FLOP_PER_SAMPLE * sps / 1e12 / 2500.0, 5),
+             samples_per_s=round(sps, 1), flop_per_sample=FLOP_PER_SAMPLE,
              matrix_pipe_busy_frac=round(F16_SLICE_MFMAS * 16 * (rows / 16) * steps / (t * 2.4e9 * 1024), 4))
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_f16_head_pmc_summary.json")))
-        k = "lz_k_frame<1, 1, 2>" if fused else "lz_k_triplane_head_f16"
+        pmc = json.load(open(os.path.join(ROOT, "profiles", F16_PMC_SUMMARY)))
+        k = next(kk for kk in pmc["SQ_INSTS_VALU"] if kk.startswith("lz_k_frame<1,")) if fused else "lz_k_triplane_head_f16"
         n_mfma = pmc["SQ_INSTS_VALU_MFMA_MOPS_F16"][k]["avg_per_launch"] / 32.0       # MOPS counts 512-FLOP units: 32 per 16x16x32 MFMA
         slices = n_mfma / F16_SLICE_MFMAS
         valu = pmc["SQ_INSTS_VALU"][k]["avg_per_launch"] - n_mfma
         cyc = (4.0 * valu + 8.0 * n_mfma) / slices                                      # issue-port cycles per 16-row slice
-        peak = 1024 * 2.4e9 / cyc * 16 * (samples / max(rows, 1))                        # samples/s the chip's 1024 SIMDs can issue at 2.4 GHz
-        r.update(peak=round(peak / 1e9, 4), frac=round(sps / peak, 4), valu_insts_per_slice=round(valu / slices, 1),
-                 issue_cycles_per_slice=round(cyc, 1), vmem_reads_per_slice=round(pmc["SQ_INSTS_VMEM_RD"][k]["avg_per_launch"] / slices, 1),
-                 lds_insts_per_slice=round(pmc["SQ_INSTS_LDS"][k]["avg_per_launch"] / slices, 1),
-                 pmc="profiles/r2_f16_head_pmc_summary.json")
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
-        r["note"] = "PMC summary absent: VALU-issue bound not priced"
+        bound = 1024 * 2.4e9 / cyc * 16 * (samples / max(rows, 1))                       # samples/s the chip's 1024 SIMDs could issue at 2.4 GHz
+        fetch, write = pmc.get("FETCH_SIZE", {}).get(k), pmc.get("WRITE_SIZE", {}).get(k)
+        if fetch and write:   # KiB per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
+            r["traffic"] = round((2 * fetch["avg_per_launch"] + write["avg_per_launch"]) * 1024)
+            r["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE of " + F16_PMC_SUMMARY + ")"
+        r["valu_issue"] = dict(note="diagnostic, not the roofline: the kernel's own instruction stream priced at the nominal clock",
+                               valu_insts_per_slice=round(valu / slices, 1), mfma_per_slice=F16_SLICE_MFMAS, issue_cycles_per_slice=round(cyc, 1),
+                               samples_per_s_if_issue_port_saturated=round(bound, 1), fraction_of_that=round(sps / bound, 4),
+                               vmem_reads_per_slice=round(pmc["SQ_INSTS_VMEM_RD"][k]["avg_per_launch"] / slices, 1),
+                               lds_insts_per_slice=round(pmc["SQ_INSTS_LDS"][k]["avg_per_launch"] / slices, 1), pmc="profiles/" + F16_PMC_SUMMARY)
+    except (OSError, KeyError, ValueError, ZeroDivisionError, StopIteration):
+        r["note"] = "PMC summary absent: instruction counts not reported"
     return r
 
 
@@ -864,7 +888,8 @@ def main():
         enc_a = enc_a0
         if k > 0:
             enc_a = enc_a0 + 0.5 * torch.randn(enc_a0.shape, device=device, generator=torch.Generator(device=device).manual_seed(100 + k))
-        return FrameJob(r, H, W, orbit_pose(k), intr, (enc_a, ind, eye), args.max_steps, rank, world, shard, tiles, args.gather, device, shard_of)
+        return FrameJob(r, H, W, orbit_pose(k), intr, (enc_a, ind, eye), args.max_steps, rank, world, shard, tiles, args.gather, device, shard_of,
+                        via=args.gather_via)
 
     log(f"rank {rank}/{world}: setup done")
     if args.train_only:
@@ -964,7 +989,8 @@ def main():
     if world == 1:
         par = "single GPU" if args.shard_of <= 1 else f"rank 0's tile of a frame ray-sharded x{args.shard_of} ({args.tiles} row tiles), no collective"
     elif args.shard == "frame":
-        par = f"one frame ray-sharded x{world} ({args.tiles} row tiles), 1 all-gather/frame ({args.gather} tiles), overlapped with the next frame"
+        how = "1 all-gather/frame" if args.gather_via == "collective" else "direct one-hop tile writes into every peer's frame buffer (no collective)"
+        par = f"one frame ray-sharded x{world} ({args.tiles} row tiles), {how} ({args.gather} tiles), overlapped with the next frame"
     else:
         par = f"clip of {world} frames, rank r renders frame r, 1 all-gather/step ({args.gather} tiles)"
     result = {

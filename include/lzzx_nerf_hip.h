@@ -510,6 +510,10 @@ typedef struct {
 
 /* rays_alive <- 0..N-1, rays_t <- nears, accumulators <- 0, state <- pre-state (list of N survivors, no steps taken),
  * workspace <- workgroup sizes */
+/* start of every ray with `perturb` (renderer.py:344,521 -> raymarching.cu:873, first iteration only): t0 = near + clamp(near * dt_gamma,
+ * dt_min, dt_max) * noise, evaluated as the reference's fused multiply-add; hand t0 to lz_loop_begin in place of `nears` */
+int lz_perturb_starts(const float* nears, const float* noises, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, uint32_t N,
+                      float* t0, lz_stream_t stream);
 int lz_loop_begin(uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap, const float* nears,
                   int32_t* rays_alive, float* rays_t,
                   float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum, float* unc_sum,
@@ -599,10 +603,19 @@ typedef struct {
     uint32_t N, max_steps, C, H;
     uint32_t steps_per_pass;       /* samples a ray marches per pass = the n_step of the schedule it equals: 0 = auto (1 for large
                                       frames; 2..16 when there are too few rays to fill the chip), or 1, 2, 4, 8, 16 */
+    const float* noises;           /* [N] or NULL: `perturb` of the reference's inference loop (renderer.py:521 passes it on the first
+                                      iteration only): every ray starts at near + clamp(near * dt_gamma, dt_min, dt_max) * noise
+                                      (raymarching.cu:873) */
 } lz_frame_fused;
 struct lz_timing;
 /* `timing` (may be NULL): bracket the persistent kernel with one event pair on the launch stream (lz_timing_create) */
 int lz_frame_render(const lz_frame_fused* f, struct lz_timing* timing, lz_stream_t stream);
+
+/* Multi-GPU tile hand-off without a collective (lzzx_nerf_amd/dist.py: PeerTileGatherer): every rank copies its rendered tile straight
+ * into each peer's frame buffer (one xGMI hop), then raises its flag there; lz_wait_flags makes `stream` wait, ON THE DEVICE, until all `n`
+ * flags (int32, written by the peers' copies) have reached `want` -- a BOUNDED spin (`max_polls` polls of ~1 us each): on expiry it sets
+ * *timed_out = 1 and returns, so a dead peer costs a wrong frame and an error flag, never a hung GPU. */
+int lz_wait_flags(const int32_t* flags, uint32_t n, int32_t want, uint32_t max_polls, int32_t* timed_out, lz_stream_t stream);
 
 /* image = clamp(image + (1 - weights_sum) * bg, 0, 1) (renderer.py:559-561); bg: device [N,3] or NULL -> bg_scalar */
 int lz_final_blend(const float* image, const float* weights_sum, const float* bg, float bg_scalar, uint32_t N,

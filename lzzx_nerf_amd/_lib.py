@@ -52,7 +52,7 @@ class FrameFused(C.Structure):
                 ("order", vp), ("state", vp), ("keys", vp), ("weights_sum", vp), ("depth", vp), ("image", vp), ("amb_aud_sum", vp),
                 ("amb_eye_sum", vp), ("unc_sum", vp), ("out", vp), ("bg", vp), ("out_rgb24", vp), ("ray_counts", vp),
                 ("bg_scalar", f32), ("bound", f32), ("dt_gamma", f32), ("T_thresh", f32), ("min_near", f32),
-                ("N", u32), ("max_steps", u32), ("C", u32), ("H", u32), ("steps_per_pass", u32)]
+                ("N", u32), ("max_steps", u32), ("C", u32), ("H", u32), ("steps_per_pass", u32), ("noises", vp)]
 
 
 # name -> argtypes, in the order of include/lzzx_nerf_hip.h
@@ -94,6 +94,8 @@ SIGNATURES = {
     "lz_bg_coords": [u32, u32, vp, vp],
     "lz_head_pack_weights": [vp] * 11 + [i32, i32, vp, vp],
     "lz_triplane_head_forward": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, vp, vp],
+    "lz_perturb_starts": [vp, vp, f32, u32, u32, u32, u32, vp, vp],
+    "lz_wait_flags": [vp, u32, i32, u32, vp, vp],
     "lz_loop_begin": [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_march": [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_composite": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -51,6 +51,7 @@ struct LzFrameK {
     float* out; const float* bg; uint8_t* out_rgb24; int* ray_counts;
     float bg_scalar, bound, dt_gamma, T_thresh, min_near;
     uint32_t N, max_steps, C, H;
+    const float* noises;
 };
 
 __device__ __forceinline__ void lzf_write_pixel(const LzFrameK& F, int ray, float ws, float d, float r, float g, float b, float a0, float a1,
@@ -90,6 +91,7 @@ __global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
         LzMarch m;
         m.init(o, d, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
         float t = near, x, y, z, dt = 0.0f;
+        if (F.noises) t = lz_fmaf(lz_clampf(t * F.dt_gamma, m.dt_min, m.dt_max), F.noises[n], t);   // perturb: raymarching.cu:873, first iteration only
         bool found = false;
         while (t < far) {
             if (m.probe(t, x, y, z, dt)) { found = true; break; }
@@ -537,6 +539,7 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     K.unc_sum = f->unc_sum; K.out = f->out; K.bg = f->bg; K.out_rgb24 = f->out_rgb24; K.ray_counts = f->ray_counts;
     K.bg_scalar = f->bg_scalar; K.bound = f->bound; K.dt_gamma = f->dt_gamma; K.T_thresh = f->T_thresh; K.min_near = f->min_near;
     K.N = f->N; K.max_steps = f->max_steps; K.C = f->C; K.H = f->H;
+    K.noises = f->noises;
     hipError_t rc = hipMemsetAsync(f->state, 0, LZ_FRAME_STATE_INTS * sizeof(int32_t), st);
     if (rc != hipSuccess) { lz_set_error("frame_render: memset: %s", hipGetErrorString(rc)); return (int)rc; }
     const uint32_t nb = lz_div_up(f->N, 256);

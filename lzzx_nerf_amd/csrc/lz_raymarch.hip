@@ -1234,6 +1234,27 @@ lz_k_loop_begin(uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t
     if (unc_sum) unc_sum[n] = 0;
 }
 
+__global__ void __launch_bounds__(256)
+lz_k_perturb_starts(const float* __restrict__ nears, const float* __restrict__ noises, float dt_gamma, float dt_min, float dt_max, uint32_t N,
+                    float* __restrict__ t0) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float t = nears[n];
+    t0[n] = lz_fmaf(lz_clampf(t * dt_gamma, dt_min, dt_max), noises[n], t);   // raymarching.cu:873, `t += a * b` contracted by nvcc
+}
+
+extern "C" int lz_perturb_starts(const float* nears, const float* noises, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, uint32_t N,
+                                 float* t0, lz_stream_t stream) {
+    if (N == 0) return LZ_OK;
+    LZ_REQUIRE(nears && noises && t0, LZ_ERR_BAD_ARGUMENT, "perturb_starts: null tensor");
+    LZ_REQUIRE(C >= 1 && C <= 8 && H > 0 && max_steps > 0, LZ_ERR_BAD_ARGUMENT, "perturb_starts: cascade in [1, 8], grid size and max_steps positive");
+    const float dt_max = 2 * LZ_SQRT3F * (float)(1 << (C - 1)) / (float)H;            // LzMarch::init
+    const float dt_min = lz_fminf(dt_max, 2 * LZ_SQRT3F / (float)max_steps);
+    hipLaunchKernelGGL(lz_k_perturb_starts, dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), nears, noises, dt_gamma, dt_min, dt_max, N, t0);
+    LZ_CHECK_LAUNCH("perturb_starts");
+    return LZ_OK;
+}
+
 extern "C" int lz_loop_begin(uint32_t N, uint32_t max_steps, uint32_t sample_budget, uint32_t n_step_cap, const float* nears,
                              int32_t* rays_alive, float* rays_t, float* weights_sum,
                              float* depth, float* image, float* amb0_sum, float* amb1_sum, float* unc_sum, lz_loop_state* state,

@@ -36,6 +36,29 @@ extern "C" int lz_timing_create(uint32_t n_pairs, lz_timing** out) {
     return LZ_OK;
 }
 
+// one wave: lane r polls flag r (system-scope loads: the writers are other devices / processes) with a sleep between polls; every lane
+// leaves after at most max_polls polls, so the kernel always ends
+__global__ void __launch_bounds__(64) lz_k_wait_flags(const int32_t* flags, uint32_t n, int32_t want, uint32_t max_polls, int32_t* timed_out) {
+    for (uint32_t r = threadIdx.x; r < n; r += 64) {
+        uint32_t polls = 0;
+        while (__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+            if (++polls >= max_polls) {
+                __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+}
+
+extern "C" int lz_wait_flags(const int32_t* flags, uint32_t n, int32_t want, uint32_t max_polls, int32_t* timed_out, lz_stream_t stream) {
+    LZ_REQUIRE(flags && timed_out, LZ_ERR_BAD_ARGUMENT, "wait_flags: null");
+    LZ_REQUIRE(n >= 1 && n <= 4096 && max_polls >= 1, LZ_ERR_BAD_ARGUMENT, "wait_flags: 1 <= n <= 4096, max_polls >= 1");
+    hipLaunchKernelGGL(lz_k_wait_flags, dim3(1), dim3(64), 0, lz_st(stream), flags, n, want, max_polls, timed_out);
+    LZ_CHECK_LAUNCH("wait_flags");
+    return LZ_OK;
+}
+
 extern "C" int lz_timing_destroy(lz_timing* t) {
     if (!t) return LZ_OK;
     for (auto& e : t->ev) (void)hipEventDestroy(e);

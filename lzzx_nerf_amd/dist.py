@@ -126,6 +126,106 @@ class TileGatherer:
                     o.record_stream(cur)
 
 
+class PeerTileGatherer:
+    """The same hand-off WITHOUT a collective (at ~390 KB per rank a ring all-gather is 7 dependent hops on point-to-point
+    xGMI links; here every tile crosses exactly ONE hop).  Every rank owns two frame buffers [sum n_local, C] (double buffering, as
+    TileGatherer) and exports them to its peers (CUDA / HIP IPC handles, exchanged once with all_gather_object); a frame then is
+
+        for every peer p:  p.frame[k & 1][my_offset : my_offset + n_local] <- my tile        (W device-to-device copies, side stream)
+                           p.flags[k & 1][me] <- k + 1                                       (a 4-byte copy BEHIND the data, same stream)
+        wait on the device until my flags[k & 1][:] have all reached k + 1                   (lz_wait_flags: bounded spin, never hangs)
+
+    `gather(tile)` returns this rank's own frame buffer of frame k, complete once `wait()` has run; valid until the second-next call.
+    A buffer is reused two frames later: a peer may only overwrite it after this rank has finished reading frame k - 2, which the
+    caller guarantees by calling `wait()` (and consuming the frame) before the second-next `gather` -- the flags of frame k - 1 that the
+    peer waited for were written by this rank after that.  `timed_out` (device int32) is 1 if a wait ever expired.
+
+    CPU tensors (the gloo tests) take the same OFFSET / double-buffer / flag bookkeeping with the peer writes carried by a gloo
+    all_gather: the indexing is what those tests pin; the transport needs the GPUs."""
+
+    MAX_POLLS = 2_000_000   # ~2 s of polling before a wait gives up
+
+    def __init__(self, n_local, channels, dtype, device, sizes=None, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.sizes = list(sizes) if sizes is not None else [n_local] * self.world
+        if self.sizes[self.rank] != n_local:
+            raise ValueError("PeerTileGatherer: sizes[rank] must equal n_local")
+        self.offsets = [sum(self.sizes[:r]) for r in range(self.world)]
+        self.total, self.n_local, self.channels = sum(self.sizes), n_local, channels
+        self.cuda = torch.device(device).type == "cuda"
+        self.k = 0
+        self.frame = [torch.zeros(self.total, channels, dtype=dtype, device=device) for _ in range(2)]
+        self.flags = [torch.zeros(max(self.world, 1), dtype=torch.int32, device=device) for _ in range(2)]
+        self.timed_out = torch.zeros(1, dtype=torch.int32, device=device)
+        self.comm = None
+        self.peer_frame = self.peer_flags = None
+        if self.world > 1 and self.cuda:
+            self.comm = torch.cuda.Stream(device=device)
+            self._tick = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(2)]
+            self._open_peers(device)
+
+    def _open_peers(self, device):
+        """export my four buffers, import everyone's (same-process tensors for my own rank)"""
+        mine = [t.untyped_storage()._share_cuda_() for t in self.frame + self.flags]
+        meta = [(tuple(t.shape), t.dtype) for t in self.frame + self.flags]
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, (mine, meta), group=self.group)
+        self.peer_frame, self.peer_flags = [], []
+        for r, (handles, metas) in enumerate(everyone):
+            if r == self.rank:
+                ts = self.frame + self.flags
+            else:
+                ts = []
+                for h, (shape, dt) in zip(handles, metas):
+                    st = torch.UntypedStorage._new_shared_cuda(*h)
+                    ts.append(torch.empty(0, dtype=dt, device=st.device).set_(st, 0, shape))
+            self.peer_frame.append(ts[:2])
+            self.peer_flags.append(ts[2:])
+        dist.barrier(group=self.group)   # nobody proceeds (or frees) before every import has succeeded
+
+    def gather(self, tile):
+        if self.world == 1:
+            return tile
+        i, want = self.k & 1, self.k + 1
+        self.k += 1
+        lo = self.offsets[self.rank]
+        if self.comm is None:   # CPU: the same bookkeeping, the transport emulated by an all_gather into the offsets
+            parts = [torch.empty(sz, self.channels, dtype=tile.dtype) for sz in self.sizes]
+            if all(sz == self.sizes[0] for sz in self.sizes):
+                dist.all_gather(parts, tile.contiguous(), group=self.group)
+            else:
+                mx = max(self.sizes)
+                pad = torch.zeros(mx, self.channels, dtype=tile.dtype)
+                pad[: tile.shape[0]] = tile
+                padded = [torch.empty_like(pad) for _ in range(self.world)]
+                dist.all_gather(padded, pad, group=self.group)
+                parts = [p[:sz] for p, sz in zip(padded, self.sizes)]
+            for r, part in enumerate(parts):          # what rank r's peer write leaves in MY buffer
+                self.frame[i][self.offsets[r]: self.offsets[r] + self.sizes[r]] = part
+                self.flags[i][r] = want
+            return self.frame[i]
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)                              # the tile is rendered
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ready)
+            self._tick[i].fill_(want)
+            for d in range(self.world):                # start with my right-hand neighbour: the W ranks hit W different links at a time
+                p = (self.rank + 1 + d) % self.world
+                self.peer_frame[p][i][lo: lo + self.n_local].copy_(tile, non_blocking=True)
+                self.peer_flags[p][i][self.rank: self.rank + 1].copy_(self._tick[i], non_blocking=True)
+            from ._util import call, ptr
+            call("lz_wait_flags", ptr(self.flags[i]), self.world, want, self.MAX_POLLS, ptr(self.timed_out), self.comm.cuda_stream)
+        tile.record_stream(self.comm)
+        return self.frame[i]
+
+    def wait(self):
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+
+
 class ShardedFrame:
     """BASELINE cfg4: ONE H x W frame whose rays are sharded over the ranks (row tiles, contiguous or interleaved stripes), every
     rank renders its tile with a full model replica, ONE all-gather per frame makes every rank hold the frame.
@@ -137,7 +237,7 @@ class ShardedFrame:
     """
 
     def __init__(self, H, W, rank, world, tiles="contiguous", device="cuda", channels=3, dtype=torch.float32, group=None,
-                 steps_per_pass=None):
+                 steps_per_pass=None, via="collective"):
         """steps_per_pass: pin the fused renderer's samples-per-ray-and-pass S (`configure(renderer)`).  The fused frame is the
         reference loop under the schedule n_step = S, and S is otherwise chosen from the ray count -- a rank's tile (N / world rays)
         gets a larger S than the whole frame.  Pixels are schedule-independent for every ray that ends before `max_steps`; a ray
@@ -148,7 +248,10 @@ class ShardedFrame:
         self.pixels = tile_pixels(H, W, rank, world, tiles, device)
         self.sizes = [len(tile_rows(H, r, world, tiles)) * W for r in range(world)]
         self.n_local = self.sizes[rank]
-        self.gatherer = TileGatherer(self.n_local, channels, dtype, device, self.sizes, group) if world > 1 else None
+        if via not in ("collective", "peer"):
+            raise ValueError("via must be 'collective' (one RCCL all-gather) or 'peer' (direct one-hop tile writes)")
+        cls = PeerTileGatherer if via == "peer" else TileGatherer
+        self.gatherer = cls(self.n_local, channels, dtype, device, self.sizes, group) if world > 1 else None
 
     def rays(self, pose, intrinsics):
         from .utils import frame_rays

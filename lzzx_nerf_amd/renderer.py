@@ -165,14 +165,23 @@ class TriplaneRenderer:
 
     @torch.no_grad()
     def render(self, rays_o, rays_d, enc_a, ind_code=None, eye=None, dt_gamma=1.0 / 256, max_steps=16, T_thresh=1e-4,
-               bg_color=1.0, count_samples=False, sync_free=True, rgb24=False):
+               bg_color=1.0, count_samples=False, sync_free=True, rgb24=False, perturb=False, noises=None):
         """rays_o, rays_d: [N,3] (or [1,N,3]) f32 cuda.  Returns dict(image [N,3] blended+clamped, weights_sum, depth,
         amb_aud_sum, amb_eye_sum, uncertainty_sum, state (device int32[8]), ray_counts if requested).
+        perturb: the reference's inference loop passes `perturb` to march_rays on its FIRST iteration only (renderer.py:344,521), where
+        every ray's start moves by clamp(near * dt_gamma, dt_min, dt_max) * U[0,1) (raymarching.cu:873).  `noises` [N] supplies the
+        draws (tests; default torch.rand like raymarching.py:298).
         sync_free: the host never waits for the newest work, only for the chunk `lookahead` chunks back (the GPU
         queue never drains); the returned tensors are ready in stream order."""
         rays_o = rays_o.reshape(-1, 3).float().contiguous()
         rays_d = rays_d.reshape(-1, 3).float().contiguous()
         N = rays_o.shape[0]
+        if perturb and noises is None:
+            noises = torch.rand(N, dtype=torch.float32, device=rays_o.device)
+        if noises is not None:
+            noises = noises.reshape(-1).to(rays_o.device, torch.float32).contiguous()
+            if noises.numel() != N:
+                raise RuntimeError("noises must hold one value per ray")
         if N > MAX_RAYS_PER_PASS and self.mode != "fused":
             # rays are independent: larger batches are rendered in passes of <= 2^20 rays (the device loop scans at most 4096
             # workgroup counts per iteration) and concatenated; pixels do not depend on the split
@@ -181,7 +190,7 @@ class TriplaneRenderer:
                 hi = min(lo + MAX_RAYS_PER_PASS, N)
                 bg = bg_color[lo:hi] if torch.is_tensor(bg_color) and bg_color.dim() > 1 and bg_color.shape[0] == N else bg_color
                 o = self.render(rays_o[lo:hi], rays_d[lo:hi], enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg, count_samples,
-                                sync_free, rgb24)
+                                sync_free, rgb24, noises=None if noises is None else noises[lo:hi])
                 outs.append({k: v.clone() for k, v in o.items()})
             res = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0] if k not in ("state",)}
             st = torch.stack([o["state"] for o in outs])
@@ -191,13 +200,17 @@ class TriplaneRenderer:
             res["state"][6] = st[:, 6].max()
             return res
         if self.mode == "fused":
-            return self._render_fused(rays_o, rays_d, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg_color, count_samples, rgb24)
+            return self._render_fused(rays_o, rays_d, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg_color, count_samples, rgb24, noises)
         b = self._buffers(N, rays_o.device)
         self._rays_o, self._rays_d = rays_o, rays_d
         call("lz_near_far_from_aabb", ptr(rays_o), ptr(rays_d), ptr(self.aabb), N, self.min_near, ptr(b.nears), ptr(b.fars), stream())
         if count_samples:
             b.ray_counts.zero_()
-        call("lz_loop_begin", N, int(max_steps), N * self.budget_factor, self.n_step_cap, ptr(b.nears), ptr(b.rays_alive[0]), ptr(b.rays_t), ptr(b.weights_sum), ptr(b.depth),
+        starts = b.nears
+        if noises is not None:   # the loop's first march starts every ray at its perturbed t (the kernel copies `starts` into rays_t)
+            starts = torch.empty_like(b.nears)
+            call("lz_perturb_starts", ptr(b.nears), ptr(noises), float(dt_gamma), int(max_steps), int(self.cascade), int(self.grid_size), N, ptr(starts), stream())
+        call("lz_loop_begin", N, int(max_steps), N * self.budget_factor, self.n_step_cap, ptr(starts), ptr(b.rays_alive[0]), ptr(b.rays_t), ptr(b.weights_sum), ptr(b.depth),
              ptr(b.image), ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ptr(b.state), ptr(b.workspace), stream())
         cur, it = 0, 0
         pending_q = []
@@ -263,7 +276,7 @@ class TriplaneRenderer:
             self._fbuf = fb
         return fb
 
-    def _render_fused(self, rays_o, rays_d, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg_color, count_samples, rgb24):
+    def _render_fused(self, rays_o, rays_d, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg_color, count_samples, rgb24, noises=None):
         N, dev = rays_o.shape[0], rays_o.device
         b = self._fused_buffers(N, dev)
         h = self.head
@@ -289,8 +302,9 @@ class TriplaneRenderer:
         f.bound, f.dt_gamma, f.T_thresh, f.min_near = self.bound, float(dt_gamma), float(T_thresh), self.min_near
         f.N, f.max_steps, f.C, f.H = N, int(max_steps), int(self.cascade), int(self.grid_size)
         f.steps_per_pass = int(self.steps_per_pass)
+        f.noises = None if noises is None else noises.data_ptr()
         call("lz_frame_render", C.byref(f), self._timing, stream())   # timing: one event pair around the persistent kernel
-        self._keep = (enc_a, ind_code, eye, bg, rays_o, rays_d)
+        self._keep = (enc_a, ind_code, eye, bg, rays_o, rays_d, noises)
         res = dict(image=b["out"], image_raw=b["image"], weights_sum=b["weights_sum"], depth=b["depth"], amb_aud_sum=b["amb_aud_sum"],
                    amb_eye_sum=b["amb_eye_sum"], uncertainty_sum=b["unc_sum"], state=b["state"], nears=b["nears"], fars=b["fars"])
         if count_samples:

@@ -20,9 +20,10 @@ def default_aabb(bound):
 
 def render_inference(spec, P, rays_o, rays_d, bitfield, enc_a, ind_code, eye, cascade=1, grid_size=128, aabb=None,
                      min_near=0.05, dt_gamma=1.0 / 256, max_steps=16, T_thresh=1e-4, bg_color=1.0, stats=None,
-                     budget_factor=1, n_step_cap=8, head=None):
+                     budget_factor=1, n_step_cap=8, head=None, noises=None):
     """head: the per-sample network, default the bit-pinned checker `head_forward`; bench.py's cpu_baseline passes
-    `head_forward_torch` (the reference's torch-CPU MLP arrangement)"""
+    `head_forward_torch` (the reference's torch-CPU MLP arrangement).  noises [N]: `perturb` -- handed to march_rays on the first
+    iteration only, like renderer.py:521 (`perturb if step == 0 else False`)"""
     if head is None:
         head = head_forward
     rays_o = np.ascontiguousarray(rays_o, dtype=F32).reshape(-1, 3)
@@ -49,7 +50,7 @@ def render_inference(spec, P, rays_o, rays_d, bitfield, enc_a, ind_code, eye, ca
             break
         n_step = max(min(budget_factor * N // n_alive, n_step_cap), 1)           # renderer.py:513 (factor 1, cap 8)
         xyzs, dirs, deltas = O.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, bitfield,
-                                          cascade, grid_size, nears, fars, 128, None, dt_gamma, max_steps)
+                                          cascade, grid_size, nears, fars, 128, noises if step == 0 else None, dt_gamma, max_steps)
         sigmas, rgbs, amb_aud, amb_eye, unc = head(spec, P, xyzs, dirs, enc_a, ind_code, eye, testing=True)
         if amb_eye is None:
             amb_eye = np.zeros_like(amb_aud)

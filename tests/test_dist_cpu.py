@@ -150,7 +150,7 @@ def test_gradient_bucket_single_process():
 
 # ---- BASELINE cfg4 on CPU: one frame ray-sharded over the ranks through the product's ShardedFrame (tile lists, staging, ONE
 # all-gather, re-assembly); the renderer under it is the CPU checker (the HIP renderer needs a GPU), on real rays of a real scene ----
-def _frame_worker(rank, world, port, tiles, out_dir):
+def _frame_worker(rank, world, port, tiles, out_dir, via="collective"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       OMP_NUM_THREADS="2", OMP_WAIT_POLICY="passive")   # the checker's OpenMP teams would oversubscribe the host
     torch.set_num_threads(2)
@@ -167,8 +167,11 @@ def _frame_worker(rank, world, port, tiles, out_dir):
     bits, _ = ellipsoid_bitfield()
     render = lambda ro, rd: render_inference(TriplaneSpec(1.0), P, ro, rd, bits, golden["net_enc_a"], golden["net_ind"], golden["net_eye"],
                                              max_steps=24)["image"]
-    sf = D.ShardedFrame(H, W, rank, world, tiles, device="cpu")
+    sf = D.ShardedFrame(H, W, rank, world, tiles, device="cpu", via=via)
     assert sf.pixels.numel() == sf.n_local and sum(sf.sizes) == H * W
+    if via == "peer":
+        g = sf.gatherer
+        assert isinstance(g, D.PeerTileGatherer) and g.offsets == [sum(sf.sizes[:r]) for r in range(world)] and g.total == H * W
     r = O.get_rays_batched(pose[None], intr, H, W, sf.pixels.numpy())
     ok = True
     for k in range(3):     # three frames through the double-buffered gatherer
@@ -180,15 +183,24 @@ def _frame_worker(rank, world, port, tiles, out_dir):
             ref = torch.from_numpy(render(full["rays_o"][0], full["rays_d"][0]))
             ok = ok and float(ref.min()) < 0.99     # the ellipsoid is in view: not an all-background frame
         ok = ok and torch.equal(frame, ref + k)
+        if via == "peer":   # every writer raised its flag in this frame's buffer; the other buffer still holds the previous frame
+            g = sf.gatherer
+            ok = ok and bool((g.flags[k & 1] == k + 1).all()) and int(g.timed_out) == 0
+            if k >= 1:
+                ok = ok and torch.equal(sf.assemble(g.frame[(k - 1) & 1]), ref + (k - 1))
     np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array([int(ok)]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tiles", [(2, "contiguous"), (2, "interleaved"), (3, "interleaved")])
-def test_frame_ray_sharded_equals_unsharded(tmp_path, world, tiles):
+@pytest.mark.parametrize("world,tiles,via", [(2, "contiguous", "collective"), (2, "interleaved", "collective"), (3, "interleaved", "collective"),
+                                             (2, "interleaved", "peer"), (3, "interleaved", "peer"), (3, "contiguous", "peer")])
+def test_frame_ray_sharded_equals_unsharded(tmp_path, world, tiles, via):
+    """via="peer": the collective-free hand-off (dist.PeerTileGatherer: every rank writes its tile at its offset of every peer's frame
+    buffer, double-buffered, a flag per writer) -- on CPU the peer writes ride a gloo all_gather, so this pins the offsets / ragged
+    sizes / buffer rotation / flag bookkeeping; the IPC transport itself needs GPUs (tests/test_gpu_cfg4.py rehearses it on one card)"""
     port = _free_port()
-    mp.spawn(_frame_worker, args=(world, port, tiles, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_frame_worker, args=(world, port, tiles, str(tmp_path), via), nprocs=world, join=True)
     for r in range(world):
         assert int(np.load(tmp_path / f"ok_{r}.npy")[0]) == 1
 

@@ -118,6 +118,47 @@ def test_bench_self_spawns_two_ranks_and_prints_the_contract_line(tmp_path):
     assert "tiles_contiguous" in r and "roofline" in r
 
 
+def test_peer_tile_hand_off_two_ranks_on_one_card(tmp_path):
+    """--gather-via peer (dist.PeerTileGatherer): two processes on the one GPU of a test box export their frame buffers over HIP IPC, copy
+    their tiles straight into each other's buffer, raise flags and wait for them on the device (lz_wait_flags) -- the whole transport
+    except that both ends sit on the same card.  The gathered frame must equal each rank's own tile where they overlap, for every
+    frame of the double-buffered sequence, and no wait may have timed out."""
+    script = tmp_path / "peer2.py"
+    script.write_text('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["LZ_ROOT"])
+from lzzx_nerf_amd import dist as D
+rank, world = D.init_from_env(backend="gloo")
+torch.cuda.set_device(0)
+H, W = 64, 48
+sf = D.ShardedFrame(H, W, rank, world, "interleaved", device="cuda", via="peer")
+ok = True
+for k in range(5):
+    tile = torch.full((sf.n_local, 3), float(10 * k + rank), device="cuda") + sf.pixels[:, None].float() * 1e-3
+    gathered = sf.gather(tile)
+    sf.wait()
+    frame = sf.assemble(gathered)
+    torch.cuda.synchronize()
+    for r in range(world):
+        px = D.tile_pixels(H, W, r, world, "interleaved", "cuda")
+        want = torch.full((px.numel(), 3), float(10 * k + r), device="cuda") + px[:, None].float() * 1e-3
+        ok = ok and torch.equal(frame[px], want)
+    dist.barrier()          # a rank may only overwrite a peer's buffer of frame k after the peer has read frame k - 2: keep the ranks within one frame
+ok = ok and int(sf.gatherer.timed_out) == 0
+print("peer ok" if ok else "peer MISMATCH", rank, flush=True)
+dist.barrier()
+dist.destroy_process_group()
+''')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LZ_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "peer ok" in so, (so[-500:], se[-2000:])
+
+
 def test_rccl_backend_runs_the_two_collectives_world_1(tmp_path):
     """One GPU is all a test box has, so the N-way exchange itself cannot run here; what can: the RCCL backend ("nccl" on ROCm) initialises
     on this image and executes, on the device and on a side stream behind an event exactly as TileGatherer issues it, the two collectives

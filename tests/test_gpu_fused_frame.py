@@ -232,3 +232,38 @@ def test_fold_geo_frame_and_head(params, golden, scene, H, W, kw):
     assert float((o0[1] - o1[1]).abs().max()) < 2e-6
     with pytest.raises(RuntimeError):
         folded.forward(xyz, d, *cond, testing=False)
+
+
+@pytest.mark.parametrize("scene,S,kw", [("ellipsoid", 1, dict(max_steps=64)), ("ones", 1, dict(max_steps=48)), ("ellipsoid", 4, dict(max_steps=64))])
+def test_perturb_on_the_fast_paths_equals_the_reference_loop_with_the_same_noise(params, golden, scene, S, kw):
+    """perturb (renderer.py:344,521: march_rays gets it on the FIRST iteration only; raymarching.cu:873: every ray starts at
+    near + clamp(near dt_gamma, dt_min, dt_max) * noise): loop mode and the fused frame, with recorded draws, against the checker's loop
+    handed the same draws -- pixels, depth, sums and per-ray sample counts bit for bit; and it does move the samples."""
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    head, bits, ro, rd, cond = setup(params, golden, 56, 48, scene)
+    N = ro.shape[0]
+    noise = np.random.default_rng(77).uniform(0, 1, N).astype(np.float32)
+    st = {}
+    ref = render_inference(TriplaneSpec(1.0), params, ro.cpu().numpy(), rd.cpu().numpy(), bits, golden["net_enc_a"], golden["net_ind"],
+                           golden["net_eye"], stats=st, budget_factor=S, n_step_cap=S, noises=noise, **kw)
+    plain = render_inference(TriplaneSpec(1.0), params, ro.cpu().numpy(), rd.cpu().numpy(), bits, golden["net_enc_a"], golden["net_ind"],
+                             golden["net_eye"], budget_factor=S, n_step_cap=S, **kw)
+    assert not np.array_equal(ref["image"], plain["image"])
+    fr = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
+    fr.steps_per_pass = S
+    fused = {k: v.clone() for k, v in fr.render(ro, rd, *cond, count_samples=True, noises=dev(noise), **kw).items()}
+    loop = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=S, n_step_cap=S).render(ro, rd, *cond, count_samples=True, noises=dev(noise), **kw)
+    for name, out in (("fused", fused), ("loop", loop)):
+        assert np.array_equal(out["image"].cpu().numpy(), ref["image"]), name
+        assert np.array_equal(out["depth"].cpu().numpy(), ref["depth"]), name
+        assert np.array_equal(out["weights_sum"].cpu().numpy(), ref["weights_sum"]), name
+        assert np.array_equal(out["ray_counts"].cpu().numpy().astype(np.int64), st["samples_per_ray"]), name
+    # the reference's schedule (1, 8): perturbed starts shift where a ray ends, so only rays that end before the cap keep their pixels --
+    # all of them here (max_steps exceeds the longest chord)
+    ref18 = TriplaneRenderer(head, dev(bits), bound=1.0).render(ro, rd, *cond, noises=dev(noise), **kw)
+    assert torch.equal(ref18["image"], fused["image"])
+    # perturb=True draws its own noise (torch.rand like raymarching.py:298): another image, same background for the rays that miss
+    own = fr.render(ro, rd, *cond, perturb=True, **kw)["image"]
+    assert not torch.equal(own, fused["image"])
+    with pytest.raises(RuntimeError, match="one value per ray"):
+        fr.render(ro, rd, *cond, noises=dev(noise[:5]), **kw)
