@@ -31,6 +31,7 @@
 #define LZF_WG 1024
 #define LZF_WAVES (LZF_WG / 64)
 #define LZF_BINS 256
+#define LZF_LUT 256          // Morton bit-spread table in LDS, for grids up to 256^3 (the reference hard-codes 128, renderer.py:94)
 #define LZF_MARCH_PROBES 2   // empty cells a slot may cross per march attempt (S = 1); measured on cfg5 (f16 / f32 ms): 1 -> 1.80 / 4.30, 2 -> 1.82 / 4.29, 3 -> 1.83 / 4.34, 6 -> 1.84 / 4.38, 12 -> 1.96 / 4.49, unbounded -> 2.39 / 4.81
 // device state words (LZ_FRAME_STATE_INTS int32, zeroed per frame by lz_frame_render).  Words 3, 5, 6 and 72 sit where the
 // multi-launch loop keeps done / total_samples / iterations / rows (lz_loop_state, LZ_LOOP_STAT_ROWS), so a caller reads both alike.
@@ -244,7 +245,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                   SF_OA0 = FL::OA0, SF_OA1 = FL::OA1, SF_OU = FL::OU, SF_IT = FL::IT, SF_RD = FL::RD;
     (void)SF_RD; (void)SF_X; (void)SF_Y; (void)SF_Z; (void)SF_TS; (void)SF_IT; (void)SF_OSIG; (void)SF_OR; (void)SF_OG; (void)SF_OB; (void)SF_OA0; (void)SF_OA1; (void)SF_OU;
     constexpr int SLOT_WORDS = LZF_WAVES * NF * NS;
-    __shared__ __align__(16) float lds[HD::LDS_WORDS + SLOT_WORDS + 4];
+    __shared__ __align__(16) float lds[HD::LDS_WORDS + SLOT_WORDS + 4 + LZF_LUT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
     typename HD::Ctx ctx;
@@ -254,6 +255,10 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     int* wg_stat = reinterpret_cast<int*>(lds + HD::LDS_WORDS + SLOT_WORDS);   // [0] samples, [1] slices, [2] waves done
     if (lane < NS) sloti[SF_RAY * NS + lane] = -1;
     if (threadIdx.x < 4) wg_stat[threadIdx.x] = 0;
+    // bit-spread table of the Morton code (lz_expand_bits) for the march: three LDS reads per probe instead of 24 vector instructions
+    uint32_t* mlut = reinterpret_cast<uint32_t*>(lds + HD::LDS_WORDS + SLOT_WORDS + 4);
+    const bool use_lut = F.H <= LZF_LUT;
+    if (use_lut && threadIdx.x < LZF_LUT) mlut[threadIdx.x] = lz_expand_bits(threadIdx.x);
     __syncthreads();
     const int n_queue = F.state[LZF_Q_SIZE];
     LzMarch m;   // the frame-constant part of LzMarch (init() below sets the per-ray part)
@@ -295,6 +300,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 if (leader && ray >= 0 && kk == 0) {
                     m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, slot[SF_RD * 16 + s], slot[(SF_RD + 1) * 16 + s], slot[(SF_RD + 2) * 16 + s],
                            F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+                    if (use_lut) m.morton_lut = mlut;
                     float t = slot[SF_T * 16 + s];
                     const float far = slot[SF_FAR * 16 + s];
                     while (t < far && kk < S) {
@@ -411,6 +417,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 if (slot_lane && ray >= 0 && !have) {
                     m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, slot[SF_RD * NS + sl], slot[(SF_RD + 1) * NS + sl], slot[(SF_RD + 2) * NS + sl],
                            F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+                    if (use_lut) m.morton_lut = mlut;
                     float t = slot[SF_T * NS + sl], dt = 0.0f;
                     const float far = slot[SF_FAR * NS + sl];
                     // at most LZF_MARCH_PROBES empty cells per attempt: a ray crossing empty space (behind the object, between two blobs) keeps

@@ -97,17 +97,18 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
         oobc[d] = IN_RANGE ? false : (c01[d] < 0 || c01[d] > 1);
         cc[d] = IN_RANGE ? c01[d] : lz_fminf(lz_fmaxf(c01[d], 0.0f), 1.0f);
     }
-    // per (coordinate, level): cell, fraction, 1 - fraction (gridencoder.cu:128-133).  p >= 0.5, so p - floor(p) is the reference's
-    // p - (float)(uint32_t)floor(p) without the two conversions.
+    // per (coordinate, level): cell, fraction, 1 - fraction (gridencoder.cu:128-133).  p >= 0.5, so the reference's
+    // p - (float)(uint32_t)floor(p) is p - floor(p), an exact subtraction -- which is what v_fract_f32 returns for p >= 0 -- and the
+    // cell is the truncating conversion of p itself.
     uint32_t cell[3][3];
     float fr[3][3], om[3][3];
 #pragma unroll
     for (int mrec = 0; mrec < 3; mrec++)
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            const float p = lz_fmaf(cc[d], lv_scale[mrec], 0.5f), fl = floorf(p);
-            cell[mrec][d] = (uint32_t)fl;
-            fr[mrec][d] = p - fl;
+            const float p = lz_fmaf(cc[d], lv_scale[mrec], 0.5f);
+            cell[mrec][d] = (uint32_t)p;
+            fr[mrec][d] = __builtin_amdgcn_fractf(p);
             om[mrec][d] = 1 - fr[mrec][d];
         }
     // row terms per (row coordinate, level): y for the xy plane, z for yz and xz (network.py:211: xy = (x, y), yz = (y, z), xz = (x, z))

@@ -69,8 +69,9 @@ struct LzMarch {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
     float bound, rbound, dt_gamma, dt_min, dt_max, rH, H3, fC, fH, halfH;
     uint32_t H;
-    bool pow2H;
+    bool pow2H, one_cascade;
     const uint8_t* grid;
+    const uint32_t* morton_lut;   // optional (LDS): lz_expand_bits(v) for v < H, set by kernels that stage one (lz_frame.hip); null = compute
 
     __device__ __forceinline__ void init(const float* o, const float* d, float bound_, float dt_gamma_, uint32_t max_steps,
                                          uint32_t C, uint32_t H_, const uint8_t* grid_) {
@@ -83,10 +84,12 @@ struct LzMarch {
         ox = o[0]; oy = o[1]; oz = o[2];
         dx = d[0]; dy = d[1]; dz = d[2];
         rdx = rdx_; rdy = rdy_; rdz = rdz_;
+        morton_lut = nullptr;
         bound = bound_; rbound = 1 / bound_; dt_gamma = dt_gamma_;
         rH = 1 / (float)H_;
         H3 = (float)(H_ * H_ * H_);
         H = H_; fC = (float)C; fH = (float)H_; grid = grid_;
+        one_cascade = C == 1;      // then both mip rules clamp to level 0 (raymarching.cu:42-54: min(max_cascade - 1, .)): nothing to evaluate
         pow2H = (H_ & (H_ - 1u)) == 0u && H_ >= 2u;
         halfH = 0.5f * (float)H_;
         dt_max = 2 * LZ_SQRT3F * (float)(1 << (C - 1)) / (float)H_;
@@ -100,12 +103,19 @@ struct LzMarch {
         y = lz_clampf(lz_fmaf(tt0, dy, oy), -bound, bound);
         z = lz_clampf(lz_fmaf(tt0, dz, oz), -bound, bound);
         dt = lz_clampf(tt0 * dt_gamma, dt_min, dt_max);
-        const int lp = lz_mip_from_pos(x, y, z, fC), ld = lz_mip_from_dt(dt, fH, fC);
-        const int level = lp > ld ? lp : ld;
-        const float lb = lz_scalbnf(1.0f, level);
-        const float mip_bound = lz_fminf(lb, bound);
-        // 1 / mip_bound without a division per probe: the reciprocal of 2^level is exact, the one of `bound` is hoisted to init()
-        const float mip_rbound = (lb <= bound) ? lz_scalbnf(1.0f, -level) : rbound;
+        int level = 0;
+        float mip_bound, mip_rbound;
+        if (one_cascade) {          // wave-uniform; the same values the general branch yields for level = 0, without its ~20 instructions
+            mip_bound = lz_fminf(1.0f, bound);
+            mip_rbound = (1.0f <= bound) ? 1.0f : rbound;
+        } else {
+            const int lp = lz_mip_from_pos(x, y, z, fC), ld = lz_mip_from_dt(dt, fH, fC);
+            level = lp > ld ? lp : ld;
+            const float lb = lz_scalbnf(1.0f, level);
+            mip_bound = lz_fminf(lb, bound);
+            // 1 / mip_bound without a division per probe: the reciprocal of 2^level is exact, the one of `bound` is hoisted to init()
+            mip_rbound = (lb <= bound) ? lz_scalbnf(1.0f, -level) : rbound;
+        }
         const float hm1 = (float)(H - 1);
         // raymarching.cu:415-417 evaluates 0.5 * (x * mip_rbound + 1) * H in double and narrows.  For a power-of-two H (the reference
         // hard-codes 128, renderer.py:94) the two multiplications are exact in float as well, so both evaluations give the same bits
@@ -120,7 +130,9 @@ struct LzMarch {
             ny = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
             nz = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
         }
-        const uint32_t index = (uint32_t)((float)level * H3 + (float)lz_morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        const uint32_t mort = morton_lut ? (morton_lut[nx] | (morton_lut[ny] << 1) | (morton_lut[nz] << 2))      // three LDS reads for 24 vector instructions
+                                         : lz_morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+        const uint32_t index = (uint32_t)((float)level * H3 + (float)mort);
         const int occ = grid[index / 8] & (1 << (index % 8));
         if (occ) return 1;
         const float tx = lz_fmaf(lz_fmaf(((float)nx + 0.5f + 0.5f * lz_signf(dx)) * rH, 2.0f, -1.0f), mip_bound, -x) * rdx;
