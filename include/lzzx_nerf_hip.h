@@ -461,12 +461,14 @@ int lz_triplane_head_grad_w(const float* rec, uint32_t M, uint32_t k_sig0, float
  * use, f32 accumulation, same outputs */
 int lz_triplane_head_grad_w_f16(const void* rec16, uint32_t M, uint32_t k_sig0, float* dW_x3, float* dW_aud1, float* dW_sig0,
                                 float* dW_sig1, float* dW_c1h, void* workspace, lz_stream_t stream);
-/* The all-f16 arrangement (f16 recording forward + f16 data gradient: the reference's `-O` arithmetic) with the weight gradients of the
- * wide layers reduced INSIDE the backward kernel: = lz_triplane_head_backward_recorded(record_f16 = 1, packed_bwd16) followed by
- * lz_triplane_head_grad_w_f16, without the G half of the records ever being written or the records read a second time.  The waves of a
- * workgroup transpose their G / X tiles through LDS (ds_read_b64_tr_b16) and share the 95 accumulator tiles.  rec16: the f16 records of
- * lz_triplane_head_forward_record_f16 (read only: the X half); out->rec is ignored; same operand rounding, f32 accumulation in a
- * different (fixed) order. */
+/* The backward over f16 records with the weight gradients of the wide layers reduced INSIDE the kernel: =
+ * lz_triplane_head_backward_recorded(record_f16 = 1, packed_bwd16) followed by lz_triplane_head_grad_w_f16, without the G half of the
+ * records ever being written or the records read a second time.  The waves of a workgroup transpose their G / X tiles through LDS
+ * (ds_read_b64_tr_b16) and share the 95 accumulator tiles.  packed_bwd16 non-null: data gradient on the f16 matrix cores (with the f16
+ * recording forward: the whole step in the reference's `-O` arithmetic); NULL: the f32 data-gradient chain through p->packed.  rec16: the
+ * f16 records of lz_triplane_head_forward_record(record_f16 = 1) / _forward_record_f16 (read only: the X half); out->rec is ignored;
+ * same operand rounding as the two-pass arrangement, f32 accumulation in a different (fixed) order; color_net.1's weight gradient is one
+ * of the products here (its dY rounded to half like the others). */
 int lz_triplane_head_backward_recorded_dw16(const lz_head_params* p, const float* state, const void* rec16, uint32_t M, const float* g_sigma,
                                             const float* g_rgb, const float* g_amb_aud, const float* g_amb_eye, const float* g_unc,
                                             const lz_head_bwd_out* out, const void* packed_bwd16, uint32_t k_sig0, float* dW_x3,

@@ -341,15 +341,18 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 //     after da1        x3    7 x 3 = 21   w >= 1: row t = w - 1, columns 0..2
 // -- at most 15 tiles = 60 accumulator registers per wave.  At the end a workgroup writes its partial tiles in the layout of
 // lz_k_head_grad_w16 and the same lz_k_head_grad_w_reduce sums them over the workgroups.
+// With the f32 data-gradient chain (B16 = false: the 97 KB f32 weight image stays in LDS) only ONE buffer fits: every segment then
+// ends with a second barrier (all reads done) before the next one may write.
 #define LZ_FUSE_AREA_TILES 11                                 // largest segment: c1h, 5 G + 6 X tiles
-#define LZ_FUSE_LDS_FLOATS (2 * 8 * LZ_FUSE_AREA_TILES * 128)   // two buffers x 8 areas x 11 tiles x 512 bytes = 88 KB
+#define LZ_FUSE_LDS_FLOATS(NBUF) ((NBUF) * 8 * LZ_FUSE_AREA_TILES * 128)   // buffers x 8 areas x 11 tiles x 512 bytes = 44 KB each
 template <bool H16, bool B16, bool FUSE = false>
 __global__ void __launch_bounds__(LZ_BWD_WG, LZ_BWD_WG / 256)
 lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, uint32_t M, float* __restrict__ parts) {
-    static_assert(!FUSE || (H16 && B16), "the fused weight-gradient products run on half operands");
+    static_assert(!FUSE || H16, "the fused weight-gradient products run on half operands (f16 records)");
     constexpr int NFRAG = LZ_FRAGS_ALL;
     constexpr int WV = B16 ? LZ_BFRAGS * 128 : NFRAG * 64, TAB = WV + LZ_WV_FLOATS;
-    __shared__ __align__(16) float wl[TAB + LZ_LVTAB_WORDS + (FUSE ? LZ_FUSE_LDS_FLOATS : 0)];
+    constexpr uint32_t NBUF = B16 ? 2u : 1u;          // FUSE: LDS buffers of G / X tiles
+    __shared__ __align__(16) float wl[TAB + LZ_LVTAB_WORDS + (FUSE ? LZ_FUSE_LDS_FLOATS(NBUF) : 0)];
     const LzHeadArgs& P = A.fwd;
     const lz_head_bwd_out& O = A.o;
     const uint32_t n_slices = (M + 15) / 16;
@@ -475,14 +478,14 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         // FUSE helpers (all lanes take part in every LDS access: the transposing read needs EXEC all ones)
         float* const my_area0 = fuse + wave * AREA;
         auto g_put = [&](int tile, float v0, float v1, float v2, float v3) {     // this lane's four columns 4 q .. 4 q + 3 of a G tile
-            float* ar = my_area0 + (seg & 1u) * (8 * AREA);
+            float* ar = my_area0 + (seg & (NBUF - 1u)) * (8 * AREA);
             lz_v2u w = {__float_as_uint(lz_pack_h2(v0, v1)), __float_as_uint(lz_pack_h2(v2, v3))};
             if (!valid) w = lz_v2u{0u, 0u};
             *reinterpret_cast<lz_v2u*>(ar + tile * 128 + rho * 8 + 2 * q) = w;
         };
         auto x_load = [&](int pair) -> lz_v4 { return ld4(rb + 256 * pair + 4 * q); };     // X half of the record: dword j = {tile 2 p, tile 2 p + 1} column 4 q + j
         auto x_put = [&](int tile, const lz_v4& d, bool odd) {                               // one tile of the pair, de-interleaved
-            float* ar = my_area0 + (seg & 1u) * (8 * AREA);
+            float* ar = my_area0 + (seg & (NBUF - 1u)) * (8 * AREA);
             const uint32_t sel = odd ? 0x07060302u : 0x05040100u;
             lz_v2u w = {__builtin_amdgcn_perm(__float_as_uint(d[1]), __float_as_uint(d[0]), sel),
                         __builtin_amdgcn_perm(__float_as_uint(d[3]), __float_as_uint(d[2]), sel)};
@@ -508,7 +511,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         auto seg_c1h = [&]() {
             __syncthreads();
             if (wave < 6) {
-                const float* buf = fuse + (seg & 1u) * (8 * AREA);
+                const float* buf = fuse + (seg & (NBUF - 1u)) * (8 * AREA);
 #pragma unroll 2
                 for (int a = 0; a < 8; a += 2) {
                     const float* ar = buf + a * AREA;
@@ -518,10 +521,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 }
             }
             seg++;
+            if constexpr (NBUF == 1) __syncthreads();   // single buffer: every wave has read before anyone writes the next segment
         };
         auto seg_sig1 = [&]() {
             __syncthreads();
-            const float* buf = fuse + (seg & 1u) * (8 * AREA);
+            const float* buf = fuse + (seg & (NBUF - 1u)) * (8 * AREA);
             const int u = wave & 3, t0 = 2 * (wave >> 2);
 #pragma unroll 2
             for (int a = 0; a < 8; a += 2) {
@@ -531,12 +535,13 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 mma32(tr2(ar, t0 + 1), x, acc_sig1[1]);
             }
             seg++;
+            if constexpr (NBUF == 1) __syncthreads();   // single buffer: every wave has read before anyone writes the next segment
         };
         auto seg_sig0 = [&]() {
             __syncthreads();
             const int u = (wave + 2) & 7;                    // waves 6, 7, 0, 1, 2 own columns 0 .. 4
             if (u < 5) {
-                const float* buf = fuse + (seg & 1u) * (8 * AREA);
+                const float* buf = fuse + (seg & (NBUF - 1u)) * (8 * AREA);
 #pragma unroll 2
                 for (int a = 0; a < 8; a += 2) {
                     const float* ar = buf + a * AREA;
@@ -546,10 +551,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 }
             }
             seg++;
+            if constexpr (NBUF == 1) __syncthreads();   // single buffer: every wave has read before anyone writes the next segment
         };
         auto seg_aud1 = [&]() {
             __syncthreads();
-            const float* buf = fuse + (seg & 1u) * (8 * AREA);
+            const float* buf = fuse + (seg & (NBUF - 1u)) * (8 * AREA);
 #pragma unroll 2
             for (int a = 0; a < 8; a += 2) {
                 const float* ar = buf + a * AREA;
@@ -557,11 +563,12 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 if (wave >= 4) mma32(tr2(ar, 6), tr2(ar, 7 + (wave & 3)), acc_c2t);
             }
             seg++;
+            if constexpr (NBUF == 1) __syncthreads();   // single buffer: every wave has read before anyone writes the next segment
         };
         auto seg_x3 = [&]() {
             __syncthreads();
             if (wave >= 1) {
-                const float* buf = fuse + (seg & 1u) * (8 * AREA);
+                const float* buf = fuse + (seg & (NBUF - 1u)) * (8 * AREA);
 #pragma unroll 2
                 for (int a = 0; a < 8; a += 2) {
                     const float* ar = buf + a * AREA;
@@ -571,6 +578,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 }
             }
             seg++;
+            if constexpr (NBUF == 1) __syncthreads();   // single buffer: every wave has read before anyone writes the next segment
         };
         lz_v4 xa[3];
         if constexpr (FUSE) {
@@ -976,7 +984,7 @@ extern "C" int lz_triplane_head_backward_recorded_dw16(const lz_head_params* p, 
                                                        const float* g_unc, const lz_head_bwd_out* out, const void* packed_bwd16, uint32_t k_sig0,
                                                        float* dW_x3, float* dW_aud1, float* dW_sig0, float* dW_sig1, float* dW_c1h, void* workspace,
                                                        lz_stream_t stream) {
-    LZ_REQUIRE(p && state && rec16 && g_sigma && g_rgb && g_amb_aud && g_unc && out && packed_bwd16 && workspace, LZ_ERR_BAD_ARGUMENT,
+    LZ_REQUIRE(p && state && rec16 && g_sigma && g_rgb && g_amb_aud && g_unc && out && workspace, LZ_ERR_BAD_ARGUMENT,
                "triplane_head_backward_recorded_dw16: null tensor");
     LZ_REQUIRE(dW_x3 && dW_aud1 && dW_sig0 && dW_sig1 && dW_c1h, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded_dw16: null weight-gradient output");
     LZ_REQUIRE(p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_recorded_dw16: incomplete lz_head_params");
@@ -1000,8 +1008,12 @@ extern "C" int lz_triplane_head_backward_recorded_dw16(const lz_head_params* p, 
     a.wb16 = packed_bwd16;
     const uint32_t grid = lz_rec_grid(M, LZ_BWD_WG);
     LZ_REQUIRE(grid <= LZ_DW_MAX_PARTS, LZ_ERR_UNSUPPORTED, "triplane_head_backward_recorded_dw16: more workgroups than partial images");
-    hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, true, true>), dim3(grid), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M,
-                       static_cast<float*>(workspace));
+    if (packed_bwd16)   // data gradient on the f16 matrix cores: two LDS buffers of G / X tiles
+        hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, true, true>), dim3(grid), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M,
+                           static_cast<float*>(workspace));
+    else                // f32 data-gradient chain (its 97 KB weight image leaves room for one buffer)
+        hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, false, true>), dim3(grid), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M,
+                           static_cast<float*>(workspace));
     LZ_CHECK_LAUNCH("triplane_head_backward_recorded_dw16");
     return lz_head_grad_w_reduce_launch(static_cast<const float*>(workspace), grid, true, k_sig0, dW_x3, dW_aud1, dW_sig0, dW_sig1, dW_c1h, stream);
 }

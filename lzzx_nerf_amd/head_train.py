@@ -128,11 +128,14 @@ class _FusedHeadTrain(Function):
             mod._gw_ws = torch.empty(_lib.load().lz_triplane_head_grad_w_workspace() // 4, **kw)
         fused_dw = ctx.state is not None and mod.fuse_dw and rec.dtype == torch.float16
         if fused_dw:
-            # the whole backward of the all-f16 arrangement in one kernel: data-gradient chain + the five weight-gradient products
-            call("lz_head_pack_weights_bwd_f16", ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[4]), ptr(w[5]), ptr(w[6]), ptr(w[7]), int(mod.has_eye),
-                 int(mod.has_ind), ptr(mod.packed_bwd16), stream())
+            # the whole backward over half records in one kernel: data-gradient chain (f16 or f32 matrix path) + the weight-gradient products
+            wb16 = None
+            if mod.backward_f16:
+                call("lz_head_pack_weights_bwd_f16", ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[4]), ptr(w[5]), ptr(w[6]), ptr(w[7]), int(mod.has_eye),
+                     int(mod.has_ind), ptr(mod.packed_bwd16), stream())
+                wb16 = ptr(mod.packed_bwd16)
             call("lz_triplane_head_backward_recorded_dw16", C.byref(p), ptr(ctx.state), ptr(rec), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae),
-                 ptr(g_un), C.byref(o), ptr(mod.packed_bwd16), k_sig0, *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")],
+                 ptr(g_un), C.byref(o), wb16, k_sig0, *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")],
                  ptr(mod._gw_ws), stream())
             ctx.state = None
         elif ctx.state is not None:
@@ -199,9 +202,10 @@ class FusedTriplaneTrainHead(nn.Module):
         # reference's autocast backward; "f32" keeps the f32 chain (more accurate than autocast, 4 x the matrix instructions).
         # forward_dtype = backward_dtype = "f16" is the whole step in the arithmetic of the reference's `-O` mode.
         self.backward_f16 = backward_dtype == "f16"
-        # fuse_dw (only with backward_dtype="f16", whose half weight image leaves room in LDS): the weight gradients of the wide layers are
-        # reduced inside the backward kernel (lz_triplane_head_backward_recorded_dw16) instead of in a second pass over the records
-        self.fuse_dw = bool(fuse_dw) and self.backward_f16
+        # fuse_dw (with half records): the weight gradients of the wide layers are reduced inside the backward kernel
+        # (lz_triplane_head_backward_recorded_dw16) instead of in a second pass over the records, and the G half of the records is
+        # never written.  Two LDS buffers of operand tiles with the f16 data gradient, one (an extra barrier per segment) with the f32 chain
+        self.fuse_dw = bool(fuse_dw) and self.record_f16
         mk = lambda: GridEncoder(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
                                  desired_resolution=512 * bound)
         self.encoder_xy, self.encoder_yz, self.encoder_xz = mk(), mk(), mk()                       # network.py:131-133

@@ -696,13 +696,15 @@ def test_fused_train_head_tiny_batches_all_arrangements(params, golden, M):
 
 
 @pytest.mark.parametrize("M", [1, 17, 16 * 8 + 5, 16 * 8 * 3, 16 * 8 * 256 + 16 * 3 + 9, 120001])
-@pytest.mark.parametrize("exp_eye,ind_dim", [(True, 4), (False, 0)])
-def test_fused_weight_gradients_in_the_backward_kernel_equal_the_two_pass_arrangement(params, golden, M, exp_eye, ind_dim):
+@pytest.mark.parametrize("exp_eye,ind_dim,arr", [(True, 4, dict(forward_dtype="f16", backward_dtype="f16")), (False, 0, dict(forward_dtype="f16", backward_dtype="f16")),
+                                                 (True, 4, dict(record_dtype="f16")), (True, 4, dict(forward_dtype="f16"))])
+def test_fused_weight_gradients_in_the_backward_kernel_equal_the_two_pass_arrangement(params, golden, M, exp_eye, ind_dim, arr):
     """fuse_dw (the default of the all-f16 arrangement): the weight gradients of the wide layers reduced inside the backward kernel
     (lz_triplane_head_backward_recorded_dw16: G / X tiles transposed through LDS, 95 accumulator tiles shared by the workgroup's waves)
     against backward + lz_triplane_head_grad_w_f16 over the records.  Same operand rounding (half), same f32 products, another summation
     order: outputs and the data-gradient side (tables) bit for bit, weight gradients to f32 reassociation.  Batch sizes: less than one
-    slice, ragged last slice, a ragged last ROUND of a workgroup (8 slices per round), one round per workgroup, many rounds."""
+    slice, ragged last slice, a ragged last ROUND of a workgroup (8 slices per round), one round per workgroup, many rounds.
+    Arrangements: the all-f16 step (two LDS buffers), and the two with the f32 data-gradient chain (f32 or f16 forward; one LDS buffer)."""
     from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
     rng = np.random.default_rng(41)
     p = dict(params)
@@ -717,7 +719,7 @@ def test_fused_weight_gradients_in_the_backward_kernel_equal_the_two_pass_arrang
     gout[0] *= 1e-2
 
     def run(fuse):
-        net = FusedTriplaneTrainHead(p, bound=1.0, exp_eye=exp_eye, ind_dim=ind_dim, forward_dtype="f16", backward_dtype="f16", fuse_dw=fuse).cuda()
+        net = FusedTriplaneTrainHead(p, bound=1.0, exp_eye=exp_eye, ind_dim=ind_dim, fuse_dw=fuse, **arr).cuda()
         assert net.fuse_dw == fuse
         enc_a = dev(golden["net_enc_a"]).requires_grad_(True)
         ind = dev(golden["net_ind"]).requires_grad_(True) if ind_dim else None
