@@ -513,7 +513,7 @@ def log(msg):
 
 
 REF_SCHEDULE = (1, 8)   # renderer.py:513
-PMC_SUMMARY = "r2_final_pmc_summary.json"   # written by tools/profile_bench.sh from rocprofv3 --pmc passes of this same command
+PMC_SUMMARY = "r3_final_pmc_summary.json"   # written by tools/profile_bench.sh from rocprofv3 --pmc passes of this same command
 F16_SLICE_MFMAS = 59    # v_mfma_f32_16x16x32_f16 per 16-row slice of lz_k_triplane_head_f16
 
 
