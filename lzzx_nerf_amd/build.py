@@ -18,7 +18,9 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 SO = os.path.join(LIBDIR, "liblzzx_nerf_hip.so")
 SOURCES = ["lz_grid.hip", "lz_encoders.hip", "lz_raymarch.hip", "lz_head.hip", "lz_head_bwd.hip", "lz_head_rec.hip", "lz_head_rec16.hip", "lz_head_gradw.hip", "lz_head_f16.hip", "lz_frame.hip", "lz_render.hip", "lz_linear.hip", "lz_torso.hip", "lz_audio.hip"]
 # -ffp-contract=off: every FMA in the kernels is explicit, so results are bit-identical to the CPU checker
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+         "-Rpass-analysis=kernel-resource-usage"]   # the remarks are parsed into lib/kernel_resources.json (registers, spills, LDS per kernel)
+RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
 
 
 def _hipcc():
@@ -26,6 +28,24 @@ def _hipcc():
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
             return c
     return "hipcc"
+
+
+def parse_resources(stderr):
+    """clang's kernel-resource-usage remarks -> {mangled kernel: {vgprs, agprs, sgpr_spill, vgpr_spill, scratch, occupancy, lds}}"""
+    import re
+    out, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill",
+            "VGPRs Spill": "vgpr_spill", "LDS Size [bytes/block]": "lds"}
+    for line in stderr.splitlines():
+        m = re.search(r"remark: (?:.*?:\d+:\d+: )?\s*(Function Name|[A-Za-z ]+(?:\[[a-z/A-Z]+\])?): (\S+)", line)
+        if not m:
+            continue
+        k, v = m.group(1).strip(), m.group(2)
+        if k == "Function Name":
+            cur = out.setdefault(v, {})
+        elif cur is not None and k in keys:
+            cur[keys[k]] = int(v)
+    return out
 
 
 def _deps():
@@ -48,18 +68,24 @@ def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
 
+    resources = {}
+
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
+        resources[src] = parse_resources(r.stderr)
         if verbose and r.stderr:
-            print(r.stderr, file=sys.stderr)
+            print("\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l), file=sys.stderr)
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    import json
+    with open(RESOURCES, "w") as f:   # a register spill in a kernel tuned to a register limit is a 1.5x slowdown that no parity test sees:
+        json.dump(resources, f, indent=1, sort_keys=True)   # tests/test_cabi.py checks this report
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)

@@ -52,32 +52,15 @@ __device__ __forceinline__ void lz_level_table_fill(int* tab, const int* __restr
 
 typedef float lz_gf2 __attribute__((ext_vector_type(2)));
 
-// The gather in two halves, so that a caller can put other work -- and its STORES -- between the loads and their use: on gfx9 one in-order
-// counter covers vector loads and stores, so a load can be waited for without draining the stores issued AFTER it, but not those before.
-// lz_head_gather_issue computes the table addresses of a sample and issues its 36 loads; lz_head_gather_finish forms the bilinear
-// weights (recomputed from the coordinates: cheaper than 18 live registers) and accumulates.  lz_head_gather = issue + finish.
-struct LzGatherInflight {
-    float gv[9][4];   // the 36 table values of this lane's nine features, in flight
-    float c01[3];     // the sample's coordinates in [0, 1]
-    float p[3][3];    // positions per (level record, coordinate): used by a finish that follows at once (KEEP_P), dead otherwise
-};
-
-__device__ __forceinline__ void lz_gather_unit_coords(float px, float py, float pz, float bound, float two_bound, float (&c01)[3]) {
-    // (x + bound) / (2 bound), grid.py:143.  When 2 bound is a power of two (bound 1, 2, 4 ...: every scene of the reference) the
-    // division equals the multiplication by its exact reciprocal bit for bit, and an IEEE division is ~11 VALU instructions
-    const uint32_t tb_bits = __float_as_uint(two_bound);
-    const bool pow2 = (tb_bits & 0x007fffffu) == 0u && tb_bits > 0x00800000u && tb_bits < 0x7f000000u;   // wave-uniform
-    if (pow2) {
-        const float inv = __uint_as_float(0x7f000000u - tb_bits);    // 2^-k for two_bound = 2^k
-        c01[0] = (px + bound) * inv; c01[1] = (py + bound) * inv; c01[2] = (pz + bound) * inv;
-    } else {
-        c01[0] = (px + bound) / two_bound; c01[1] = (py + bound) / two_bound; c01[2] = (pz + bound) / two_bound;
-    }
-}
-
-template <bool IN_RANGE = false>
-__device__ __forceinline__ void lz_head_gather_issue(const float* const (&emb)[3], const int* __restrict__ tab, float px, float py, float pz, int q,
-                                                     float bound, float two_bound, LzGatherInflight& g) {
+// tab: the table above; emb: the three planes' tables; (px, py, pz): the sample
+// IN_RANGE drops the range clamps / out-of-range selects for a caller that guarantees |x|, |y|, |z| <= bound -- the fused f16 frame kernel,
+// whose march clamps every sample (raymarching.cu:866-889) and which is bound by VALU issue; the host checks that the march's bound does
+// not exceed the head's.  An identity on the values -- but mind what it exposes: with the select gone, `(_Float16)encx[i]` sat directly
+// behind the last fma of the interpolation and the compiler folded the two into v_fma_mixlo_f16 (one rounding instead of f32-then-half):
+// 28 pixels of a 96 x 96 frame moved by 2e-7 against the loop until the conversions went through h_round (lz_head_f16_slice.h).
+template <bool IN_RANGE = false, bool PACK = false>
+__device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], const int* __restrict__ tab, float px, float py, float pz, int q,
+                                               float bound, float two_bound, float (&encx)[9]) {
     // the three grid levels this lane touches (level = 4 m + q); read per slice from LDS so that they do not occupy registers during the
     // matrix phase
     uint32_t lv_off[3], lv_strd[3], lv_hmul[3], lv_mask[3];
@@ -91,19 +74,42 @@ __device__ __forceinline__ void lz_head_gather_issue(const float* const (&emb)[3
         lv_hmul[mrec] = (uint32_t)tab[LZ_LVTAB_HMUL + level];
         lv_mask[mrec] = (uint32_t)tab[LZ_LVTAB_MASK + level];
     }
-    lz_gather_unit_coords(px, py, pz, bound, two_bound, g.c01);
+    // (x + bound) / (2 bound), grid.py:143.  When 2 bound is a power of two (bound 1, 2, 4 ...: every scene of the reference) the
+    // division equals the multiplication by its exact reciprocal bit for bit, and an IEEE division is ~11 VALU instructions
+    const uint32_t tb_bits = __float_as_uint(two_bound);
+    const bool pow2 = (tb_bits & 0x007fffffu) == 0u && tb_bits > 0x00800000u && tb_bits < 0x7f000000u;   // wave-uniform
+    float c01[3];
+    if (pow2) {
+        const float inv = __uint_as_float(0x7f000000u - tb_bits);    // 2^-k for two_bound = 2^k
+        c01[0] = (px + bound) * inv; c01[1] = (py + bound) * inv; c01[2] = (pz + bound) * inv;
+    } else {
+        c01[0] = (px + bound) / two_bound; c01[1] = (py + bound) / two_bound; c01[2] = (pz + bound) / two_bound;
+    }
     // Branch-free: out-of-range coordinates are clamped for ADDRESSING only and the feature is zeroed by a select
-    // (gridencoder.cu:98-122), so all 36 gathers of a sample are independent loads, IN FLIGHT TOGETHER (one L2 round trip per slice
-    // instead of one per read).
+    // (gridencoder.cu:98-122), so all 36 gathers of a sample are independent loads.  Two passes so that the 36 table reads are IN
+    // FLIGHT TOGETHER (one L2 round trip per slice instead of one per read): pass 1 computes fractions + table indices and issues
+    // every load, the empty asm pins all 36 results as live at one point (so the compiler cannot sink a load next to its use),
+    // pass 2 forms the bilinear weights and accumulates in corner order.
+    bool oobc[3];
+    float cc[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        oobc[d] = IN_RANGE ? false : (c01[d] < 0 || c01[d] > 1);
+        cc[d] = IN_RANGE ? c01[d] : lz_fminf(lz_fmaxf(c01[d], 0.0f), 1.0f);
+    }
+    // per (coordinate, level): cell, fraction, 1 - fraction (gridencoder.cu:128-133).  p >= 0.5, so the reference's
+    // p - (float)(uint32_t)floor(p) is p - floor(p), an exact subtraction -- which is what v_fract_f32 returns for p >= 0 -- and the
+    // cell is the truncating conversion of p itself.
     uint32_t cell[3][3];
+    float fr[3][3], om[3][3];
 #pragma unroll
     for (int mrec = 0; mrec < 3; mrec++)
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            const float cc = IN_RANGE ? g.c01[d] : lz_fminf(lz_fmaxf(g.c01[d], 0.0f), 1.0f);
-            const float p = lz_fmaf(cc, lv_scale[mrec], 0.5f);
-            cell[mrec][d] = (uint32_t)p;   // p >= 0.5: the truncating conversion is the floor (gridencoder.cu:128-133)
-            g.p[mrec][d] = p;
+            const float p = lz_fmaf(cc[d], lv_scale[mrec], 0.5f);
+            cell[mrec][d] = (uint32_t)p;
+            fr[mrec][d] = __builtin_amdgcn_fractf(p);
+            om[mrec][d] = 1 - fr[mrec][d];
         }
     // row terms per (row coordinate, level): y for the xy plane, z for yz and xz (network.py:211: xy = (x, y), yz = (y, z), xz = (x, z))
     uint32_t rowH[2][3][2], rowD[2][3][2];     // [row coordinate: 0 = y, 1 = z][level record][lower / upper corner]
@@ -117,6 +123,7 @@ __device__ __forceinline__ void lz_head_gather_issue(const float* const (&emb)[3
             rowD[rc][mrec][0] = __umul24(g1, lv_strd[mrec]) + lv_off[mrec];        // v_mad_u32_u24
             rowD[rc][mrec][1] = rowD[rc][mrec][0] + lv_strd[mrec];
         }
+    float gv[9][4];
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         constexpr int kPlaneOf[9] = {0, 0, 0, 1, 1, 1, 2, 2, 2};
@@ -129,45 +136,19 @@ __device__ __forceinline__ void lz_head_gather_issue(const float* const (&emb)[3
         for (int c = 0; c < 4; c++) {
             const uint32_t c0 = g0 + (c & 1);
             const uint32_t index = ((c0 ^ rowH[rc][mrec][c >> 1]) & lv_mask[mrec]) + rowD[rc][mrec][c >> 1];
-            g.gv[i][c] = *reinterpret_cast<const float*>(gb + (index << 2));
+            gv[i][c] = *reinterpret_cast<const float*>(gb + (index << 2));
         }
     }
-}
-
-// the empty asm pins all 36 results as live at one point (so the compiler cannot sink a load next to its use)
-__device__ __forceinline__ void lz_head_gather_pin(LzGatherInflight& g) {
-    float (&gv)[9][4] = g.gv;
     asm volatile("" ::"v"(gv[0][0]), "v"(gv[0][1]), "v"(gv[0][2]), "v"(gv[0][3]), "v"(gv[1][0]), "v"(gv[1][1]), "v"(gv[1][2]),
                  "v"(gv[1][3]), "v"(gv[2][0]), "v"(gv[2][1]), "v"(gv[2][2]), "v"(gv[2][3]), "v"(gv[3][0]), "v"(gv[3][1]),
                  "v"(gv[3][2]), "v"(gv[3][3]), "v"(gv[4][0]), "v"(gv[4][1]), "v"(gv[4][2]), "v"(gv[4][3]), "v"(gv[8][0]),
                  "v"(gv[8][1]), "v"(gv[8][2]), "v"(gv[8][3]), "v"(gv[7][0]), "v"(gv[7][1]), "v"(gv[7][2]), "v"(gv[7][3]));
     asm volatile("" ::"v"(gv[5][0]), "v"(gv[5][1]), "v"(gv[5][2]), "v"(gv[5][3]), "v"(gv[6][0]), "v"(gv[6][1]), "v"(gv[6][2]),
                  "v"(gv[6][3]));
-}
-
-// KEEP_P: the positions issue() computed are still in registers (finish follows at once); otherwise they are recomputed from the coordinates
-template <bool IN_RANGE = false, bool PACK = false, bool KEEP_P = false>
-__device__ __forceinline__ void lz_head_gather_finish(const int* __restrict__ tab, int q, const LzGatherInflight& g, float (&encx)[9]) {
-    const float (&gv)[9][4] = g.gv;
-    // per (coordinate, level): fraction, 1 - fraction (gridencoder.cu:128-133).  p >= 0.5, so the reference's
-    // p - (float)(uint32_t)floor(p) is p - floor(p), an exact subtraction -- which is what v_fract_f32 returns for p >= 0
-    bool oobc[3];
-    float fr[3][3], om[3][3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) oobc[d] = IN_RANGE ? false : (g.c01[d] < 0 || g.c01[d] > 1);
-#pragma unroll
-    for (int mrec = 0; mrec < 3; mrec++) {
-        const float scale = KEEP_P ? 0.0f : reinterpret_cast<const float*>(tab)[LZ_LVTAB_SCALE + 4 * mrec + q];
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const float cc = IN_RANGE ? g.c01[d] : lz_fminf(lz_fmaxf(g.c01[d], 0.0f), 1.0f);
-            fr[mrec][d] = __builtin_amdgcn_fractf(KEEP_P ? g.p[mrec][d] : lz_fmaf(cc, scale, 0.5f));
-            om[mrec][d] = 1 - fr[mrec][d];
-        }
-    }
     // bilinear weights in the reference's corner order, w = (1 * w0) * w1 with w_d = 1 - f_d or f_d (gridencoder.cu:141-152), fma chain
     if constexpr (PACK) {
-        // two features per packed instruction (v_pk_mul_f32 / v_pk_fma_f32 are IEEE per half: any pairing gives the same bits)
+        // features (i, i + 1) of a plane share the coordinates and differ in the level: two of them per packed instruction; the ninth
+        // (and each plane's third) pairs up across planes -- any pairing gives the same bits, the lanes of a packed op are independent
         constexpr int kPair[5][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 8}};
 #pragma unroll
         for (int pr = 0; pr < 5; pr++) {
@@ -180,8 +161,8 @@ __device__ __forceinline__ void lz_head_gather_finish(const int* __restrict__ ta
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const lz_gf2 w = ((c & 1) ? f0 : o0) * ((c >> 1) ? f1 : o1);
-                const lz_gf2 gg = {gv[ia][c], gv[ib][c]};
-                acc = __builtin_elementwise_fma(w, gg, acc);
+                const lz_gf2 g = {gv[ia][c], gv[ib][c]};
+                acc = __builtin_elementwise_fma(w, g, acc);
             }
             encx[ia] = acc[0];
             if (ib != ia) encx[ib] = acc[1];
@@ -208,20 +189,5 @@ __device__ __forceinline__ void lz_head_gather_finish(const int* __restrict__ ta
             encx[i] = oob ? 0.0f : encx[i];
         }
     }
-}
-
-// tab: the table above; emb: the three planes' tables; (px, py, pz): the sample
-// IN_RANGE drops the range clamps / out-of-range selects for a caller that guarantees |x|, |y|, |z| <= bound -- the fused f16 frame kernel,
-// whose march clamps every sample (raymarching.cu:866-889) and which is bound by VALU issue; the host checks that the march's bound does
-// not exceed the head's.  An identity on the values -- but mind what it exposes: with the select gone, `(_Float16)encx[i]` sat directly
-// behind the last fma of the interpolation and the compiler folded the two into v_fma_mixlo_f16 (one rounding instead of f32-then-half):
-// 28 pixels of a 96 x 96 frame moved by 2e-7 against the loop until the conversions went through h_round (lz_head_f16_slice.h).
-template <bool IN_RANGE = false, bool PACK = false>
-__device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], const int* __restrict__ tab, float px, float py, float pz, int q,
-                                               float bound, float two_bound, float (&encx)[9]) {
-    LzGatherInflight g;
-    lz_head_gather_issue<IN_RANGE>(emb, tab, px, py, pz, q, bound, two_bound, g);
-    lz_head_gather_pin(g);
-    lz_head_gather_finish<IN_RANGE, PACK, true>(tab, q, g, encx);
 }
 #endif

@@ -22,9 +22,8 @@ MARKS = {
     "lz_head_f16_slice.h": [("    float encx[9];\n    lz_head_gather<IN_RANGE", "gather"), ("    lz_h8 bx[2];", "bx"), ("    lz_h8 att16;   // [4 t + r]", "aud"),
                             ("    float eyeatt = 0.0f;", "eye"), ("    lz_h8 geo16[2];", "sigma"), ("    float rgb[3];\n    {\n        shfn.prepare();", "colour"),
                             ("    out.sigma = sigma;", "end")],
-    "lz_head_gather.h": [("    uint32_t cell[3][3];", "g_pos"), ("    uint32_t rowH[2][3][2]", "g_rows"),
-                         ("#pragma unroll\n    for (int i = 0; i < 9; i++) {\n        constexpr int kPlaneOf", "g_loads"), ("    lz_head_gather_pin(g);\n", "g_pin"),
-                         ("    if constexpr (PACK) {", "g_interp")],
+    "lz_head_gather.h": [("    bool oobc[3];", "g_pos"), ("    uint32_t rowH[2][3][2]", "g_rows"), ("    float gv[9][4];", "g_loads"),
+                         ('    asm volatile("" ::"v"(gv[0][0])', "g_pin"), ("    if constexpr (PACK) {", "g_interp")],
     "lz_frame.hip": [("            int ray = slot_lane ? sloti[SF_RAY * NS + sl] : -1;\n            bool have = false;", "F_refill_march"),
                      ("            typename HD::Out o;\n#pragma unroll 1", "F_head"), ("            __builtin_amdgcn_wave_barrier();     // the parked outputs", "F_composite")],
 }
