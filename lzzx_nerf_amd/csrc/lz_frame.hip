@@ -79,7 +79,9 @@ __device__ __forceinline__ void lzf_write_pixel(const LzFrameK& F, int ray, floa
 // ---- pass 1: near / far, first occupied cell, sort key, histogram -------------------------------------------------------------
 __global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
     __shared__ int hist[LZF_BINS];
+    __shared__ uint32_t mlut[LZF_LUT];                       // Morton bit-spread table for the march (as in lz_k_frame)
     hist[threadIdx.x] = 0;
+    mlut[threadIdx.x] = lz_expand_bits(threadIdx.x);
     __syncthreads();
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n < F.N) {
@@ -91,6 +93,7 @@ __global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
         F.fars[n] = far;
         LzMarch m;
         m.init(o, d, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+        if (F.H <= LZF_LUT) m.morton_lut = mlut;
         float t = near, x, y, z, dt = 0.0f;
         if (F.noises) t = lz_fmaf(lz_clampf(t * F.dt_gamma, m.dt_min, m.dt_max), F.noises[n], t);   // perturb: raymarching.cu:873, first iteration only
         bool found = false;

@@ -41,6 +41,12 @@ __device__ __forceinline__ int lz_mip_from_dt(float dt, float H, float max_casca
     return (int)lz_fminf(max_cascade - 1, lz_fmaxf(0, (float)lz_frexp_exp(mx)));
 }
 
+// bit-spread table for the Morton code of the march (LzMarch::morton_lut): every thread of the workgroup writes its share, caller barriers
+#define LZ_MORTON_LUT 256
+__device__ __forceinline__ void lz_morton_lut_stage(uint32_t* lut) {
+    for (uint32_t i = threadIdx.x; i < LZ_MORTON_LUT; i += blockDim.x) lut[i] = lz_expand_bits(i);
+}
+
 // slab intersection with the aabb (raymarching.cu:91-145); a miss yields near = far = FLT_MAX
 __device__ __forceinline__ void lz_near_far_ray(float ox, float oy, float oz, float dx, float dy, float dz, const float* __restrict__ aabb,
                                                 float min_near, float& near_out, float& far_out) {

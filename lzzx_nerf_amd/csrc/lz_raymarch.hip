@@ -434,10 +434,14 @@ lz_k_march_train_count(const float* __restrict__ rays_o, const float* __restrict
                        float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                        const float* __restrict__ nears, const float* __restrict__ fars, const float* __restrict__ noises,
                        int* __restrict__ counts) {
+    __shared__ uint32_t mlut[LZ_MORTON_LUT];     // Morton bit-spread table: three LDS reads per probe instead of 24 vector instructions
+    lz_morton_lut_stage(mlut);
+    __syncthreads();
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     LzMarch m;
     m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
+    if (H <= LZ_MORTON_LUT) m.morton_lut = mlut;
     const float far = fars[n];
     float t = nears[n];
     t = lz_fmaf(lz_clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
@@ -526,6 +530,9 @@ lz_k_march_train_write(const float* __restrict__ rays_o, const float* __restrict
                        const int* __restrict__ offsets, const int* __restrict__ counts_next, const int* __restrict__ base,
                        const int* __restrict__ total, float* __restrict__ xyzs, float* __restrict__ dirs,
                        float* __restrict__ deltas, int* __restrict__ rays) {
+    __shared__ uint32_t mlut[LZ_MORTON_LUT];
+    lz_morton_lut_stage(mlut);
+    __syncthreads();
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     // offsets[] holds the exclusive scan; the ray's own count is the difference to its successor
@@ -541,6 +548,7 @@ lz_k_march_train_write(const float* __restrict__ rays_o, const float* __restrict
     if (point_index + num_steps > M) return;
     LzMarch m;
     m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
+    if (H <= LZ_MORTON_LUT) m.morton_lut = mlut;
     const float far = fars[n];
     float t = nears[n];
     t = lz_fmaf(lz_clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
@@ -637,6 +645,9 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
                 const float* __restrict__ noises, int* __restrict__ ray_counts, uint32_t N, uint32_t sample_budget, uint32_t n_step_cap) {
     __shared__ uint32_t wsum[4];
     __shared__ int rsum[8];
+    __shared__ uint32_t mlut[LZ_MORTON_LUT];
+    lz_morton_lut_stage(mlut);
+    __syncthreads();
     uint32_t n_list = n_alive_h, n_step = n_step_h, prefix = 0;
     if (STATE) {
         const lz_loop_state S = *state;
@@ -688,6 +699,7 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
     if (index >= 0) {
         LzMarch m;
         m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
+        if (H <= LZ_MORTON_LUT) m.morton_lut = mlut;
         float* px = xyzs + (size_t)row * n_step * 3;
         float* pd = dirs + (size_t)row * n_step * 3;
         float* pl = deltas + (size_t)row * n_step * 2;
