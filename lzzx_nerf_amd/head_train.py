@@ -27,15 +27,26 @@ _REC16, _STATE16 = 704, 128   # record_dtype="f16": halves per record (LZ_BWD_RE
 _ORDER = ["aud0", "aud1", "eye0", "eye1", "sig0", "sig1", "sig2", "col0", "col1", "unc0", "unc1"]
 
 
+def _color0_output_gradient(rec, M):
+    """[M, 64] f32: the (ReLU-masked) gradient of color_net.0's output from the per-sample records -- slot G_C1H of the blocked layouts
+    (csrc/lz_head_bwd_common.h: f32 [slice][tile][sample 16][16 dwords]; f16: tiles interleaved in pairs, dword j of pair g =
+    {tile 2 g column j | tile 2 g + 1 column j << 16}, include/lzzx_nerf_hip.h LZ_BWD_G_C1H / LZ_R16_G_C1H)"""
+    n = rec.shape[0] // 16
+    if rec.dtype == torch.float16:
+        t = rec.view(n, _REC16 // 32, 16, 16, 2)[:, 19:21]          # pairs 19, 20 = tiles 38..41: [slice, pair, sample, column, half]
+        g = t.permute(0, 2, 1, 4, 3).reshape(n * 16, 64).float()       # feature = 32 pair + 16 half + column
+    else:
+        t = rec.view(n, _REC // 16, 16, 16)[:, 36:40]                # tiles 36..39: [slice, tile, sample, column]
+        g = t.permute(0, 2, 1, 3).reshape(n * 16, 64)
+    return g[:M]
+
+
 class _FusedHeadTrain(Function):
     @staticmethod
     def forward(ctx, mod, xyzs, dirs, enc_a, ind_code, eye, e_xy, e_yz, e_xz, *weights):
         dev = xyzs.device
-        if xyzs.requires_grad or dirs.requires_grad:
-            # the reference reaches sample positions through dy_dx when opt.train_camera is set (grid.py:60-84); this fused
-            # head has no such path, and silently dropping the gradient would train a wrong camera
-            raise RuntimeError("FusedTriplaneTrainHead does not propagate gradients to xyzs / dirs (train_camera): "
-                               "use the operator path (encoding.get_encoder + MLP) for that")
+        # opt.train_camera (renderer.py:129-132, 225-230): rays_o / rays_d carry gradients, march_rays_train hands them on to xyzs / dirs
+        # and the reference reaches them through the encoders' dy_dx (grid.py:44-84, sphere_harmonics.py:27-58).  Same here, see backward
         xyzs, dirs = xyzs.detach().float().contiguous(), dirs.detach().float().contiguous()
         M = xyzs.shape[0]
         w = [t.detach().float().contiguous() for t in weights]
@@ -104,7 +115,9 @@ class _FusedHeadTrain(Function):
             enc_a_shape, ind_shape = ctx.shapes
             g_enc_a = torch.zeros(enc_a_shape, **kw) if ctx.needs_input_grad[3] else None
             g_ind = torch.zeros(ind_shape, **kw) if (ind_shape is not None and ctx.needs_input_grad[4] and mod.has_ind) else None
-            return (None, None, None, g_enc_a, g_ind, None) + tuple(torch.zeros_like(t) for t in emb) + tuple(torch.zeros_like(t) for t in w)
+            g_x = torch.zeros(0, 3, **kw) if ctx.needs_input_grad[1] else None
+            g_d = torch.zeros(0, 3, **kw) if ctx.needs_input_grad[2] else None
+            return (None, g_x, g_d, g_enc_a, g_ind, None) + tuple(torch.zeros_like(t) for t in emb) + tuple(torch.zeros_like(t) for t in w)
         z = lambda g, shape: (torch.zeros(shape, **kw) if g is None else g.float().contiguous())
         g_sig, g_rgb, g_aa, g_ae, g_un = z(g_sig, (M,)), z(g_rgb, (M, 3)), z(g_aa, (M, 1)), z(g_ae, (M, 1)), z(g_un, (M, 1))
         if not ctx.recompute and ctx.rec is None:
@@ -126,7 +139,9 @@ class _FusedHeadTrain(Function):
         red = {n: torch.empty(sh, **kw) for n, sh in shapes.items()}
         if mod._gw_ws is None or mod._gw_ws.device != dev:
             mod._gw_ws = torch.empty(_lib.load().lz_triplane_head_grad_w_workspace() // 4, **kw)
-        fused_dw = ctx.state is not None and mod.fuse_dw and rec.dtype == torch.float16
+        need_x, need_d = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        # d loss / d dirs starts from color_net.0's output gradient, which only the two-pass arrangements leave behind (record slot G_C1H)
+        fused_dw = ctx.state is not None and mod.fuse_dw and rec.dtype == torch.float16 and not need_d
         if fused_dw:
             # the whole backward over half records in one kernel: data-gradient chain (f16 or f32 matrix path) + the weight-gradient products
             wb16 = None
@@ -154,6 +169,13 @@ class _FusedHeadTrain(Function):
         if not fused_dw:
             call("lz_triplane_head_grad_w_f16" if rec.dtype == torch.float16 else "lz_triplane_head_grad_w", ptr(rec), M, k_sig0,
                  *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")], ptr(mod._gw_ws), stream())
+        g_dirs = None
+        if need_d:
+            # d SH = G_c0 . W_color0[:, SH columns]; then the SH encoder's own input gradient (shencoder.cu:358-382) from its Jacobian
+            d_sh = (_color0_output_gradient(rec, M) @ w[7][:, :16]).contiguous()
+            sh, jac, g_dirs = torch.empty(M, 16, **kw), torch.empty(M, 48, **kw), torch.zeros(M, 3, **kw)
+            call("lz_sh_encode_forward", ptr(dirs), ptr(sh), M, 3, 4, ptr(jac), stream())
+            call("lz_sh_encode_backward", ptr(d_sh), ptr(dirs), M, 3, 4, ptr(jac), ptr(g_dirs), stream())
         ctx.rec = None
         # geo = s2 . Wg^T and d geo = G_c1 . Wc[:, geo] never left the kernel: both weight gradients follow from R = sum G_c1^T s2
         x3, c1h = red["x3"], red["c1h"]
@@ -166,16 +188,27 @@ class _FusedHeadTrain(Function):
         # table gradients: LDS-accumulated scatter per plane, inputs mapped exactly like the forward ((x + bound) / (2 bound))
         x01 = torch.empty(3, M, 2, **kw)
         call("lz_triplane_plane_coords", ptr(xyzs), M, mod.bound, ptr(x01), stream())
-        demb = []
+        demb, dx01 = [], []
         for c, e, g in zip(x01, emb, denc):
             ge = torch.zeros_like(e)
-            call("lz_grid_encode_backward", ptr(g), ptr(c), ptr(e), ptr(mod.offsets), ptr(ge), M, 2, 1, 12, mod.S, mod.H, None, None, 0, 0,
+            jac = gin = None
+            if need_x:
+                # the grid encoder's dy_dx (gridencoder.cu:179-222) is recomputed here instead of being held from the forward (96 B per
+                # sample and plane); kernel_input_backward (:316-342) then runs inside lz_grid_encode_backward as on the operator path
+                jac, gin, feat = torch.empty(M, 24, **kw), torch.zeros(M, 2, **kw), torch.empty(12, M, 1, **kw)
+                call("lz_grid_encode_forward", ptr(c), ptr(e), ptr(mod.offsets), ptr(feat), M, 2, 1, 12, mod.S, mod.H, ptr(jac), 0, 0, 0, 0, stream())
+                dx01.append(gin)
+            call("lz_grid_encode_backward", ptr(g), ptr(c), ptr(e), ptr(mod.offsets), ptr(ge), M, 2, 1, 12, mod.S, mod.H, ptr(jac), ptr(gin), 0, 0,
                  0, 3 if M >= 16384 else 0, stream())
             demb.append(ge)
+        g_xyzs = None
+        if need_x:
+            # planes xy = (x, y), yz = (y, z), xz = (x, z) (network.py:211) behind x01 = (x + bound) / (2 bound) (grid.py:143)
+            g_xyzs = torch.stack([dx01[0][:, 0] + dx01[2][:, 0], dx01[0][:, 1] + dx01[1][:, 0], dx01[1][:, 1] + dx01[2][:, 1]], 1) / (2 * mod.bound)
         enc_a_shape, ind_shape = ctx.shapes
         g_enc_a = d_enc_a.view(enc_a_shape) if ctx.needs_input_grad[3] else None
         g_ind = d_ind.view(ind_shape) if (ind_shape is not None and ctx.needs_input_grad[4] and mod.has_ind) else None
-        return (None, None, None, g_enc_a, g_ind, None, demb[0], demb[1], demb[2]) + tuple(dws[n] for n in _ORDER)
+        return (None, g_xyzs, g_dirs, g_enc_a, g_ind, None, demb[0], demb[1], demb[2]) + tuple(dws[n] for n in _ORDER)
 
 
 class FusedTriplaneTrainHead(nn.Module):

@@ -800,3 +800,123 @@ def test_head_grad_w_f16_products_match_float64(M, k_sig0):
         got = out[n].double()
         assert torch.isfinite(got).all(), n
         assert float((got - want[n]).abs().max()) <= 2e-5 * float(want[n].abs().max()) + 1e-6, n
+
+
+@pytest.mark.parametrize("arr", [dict(), dict(record=False), dict(record_dtype="f16"), dict(forward_dtype="f16", backward_dtype="f16"),
+                                 dict(forward_dtype="f16")])
+def test_fused_train_head_camera_gradients(params, golden, arr):
+    """opt.train_camera (renderer.py:129-132, 225-230): rays carry gradients, march_rays_train hands them to xyzs / dirs, and the reference
+    reaches them through the encoders' dy_dx (grid.py:44-84, gridencoder.cu:179-222, 316-342; sphere_harmonics.py:27-58).  The fused
+    training head returns both input gradients in every arrangement (with fuse_dw the call falls back to the two-pass arrangement, whose
+    record keeps color_net.0's output gradient): against the float64 model of the whole step, differentiated with respect to the sample
+    positions (bilinear weights) and, through the checker's SH Jacobian, the directions -- and on to rays_o / rays_d through the
+    march_rays_train backward (raymarching.cu:535-583)."""
+    from lzzx_nerf_amd import raymarching as R
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    H = W = 24
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    bits = ellipsoid_bitfield()[0]
+    spec = TriplaneSpec(1.0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    enc_a, eye, ind = golden["net_enc_a"], golden["net_eye"], golden["net_ind"]
+    net = FusedTriplaneTrainHead({k: v for k, v in params.items()}, bound=1.0, **arr).cuda()
+    half = "forward_dtype" in arr or "record_dtype" in arr
+    aabb = dev(np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32))
+    ro_t, rd_t = dev(ro).requires_grad_(True), dev(rd).requires_grad_(True)
+    nears, fars = R.near_far_from_aabb(ro_t.detach(), rd_t.detach(), aabb, 0.05)
+    ctr = torch.zeros(2, dtype=torch.int32, device="cuda")
+    xyzs, dirs, deltas, rays = R.march_rays_train(ro_t, rd_t, 1.0, dev(bits), 1, 128, nears, fars, ctr, -1, False, 128, True, 1 / 256, 32)
+    assert xyzs.requires_grad and dirs.requires_grad
+    xyzs.retain_grad()
+    dirs.retain_grad()
+    scale = 1024.0 if half else 1.0          # the half arrangements expect a GradScaler in front (bench.py does the same)
+    sigma, rgb, aa, ae, unc = net(xyzs, dirs, dev(enc_a), dev(ind), dev(eye))
+    ws, a0s, a1s, us, dep, img = R.composite_rays_train_triplane(sigma, rgb, aa[:, 0], ae[:, 0], unc[:, 0], deltas, rays)
+    target = torch.linspace(0, 1, H * W * 3, device="cuda").reshape(-1, 3)
+    loss = ((img - target) ** 2).mean() + 0.1 * ws.mean() + 1e-3 * a0s.mean() + 1e-3 * a1s.mean() + 1e-2 * us.mean()
+    (loss * scale).backward()
+    gx, gd = xyzs.grad / scale, dirs.grad / scale
+    # ---------------- float64 model (as in test_fused_train_head_gradients), inputs as leaves ----------------
+    dd = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()
+    E = [dd(params[f"encoder_{n}.embeddings"]) for n in ("xy", "yz", "xz")]
+    Wc = {k: dd(v) for k, v in params.items() if k.endswith(".weight")}
+    sc, rs = O.grid_level_params(12, np.float32(np.log2(spec.per_level_scale)), 64)
+    xc = dd(xyzs.detach().cpu().numpy()).requires_grad_(True)
+    x01 = (xc + 1) / 2
+
+    def mlpc(h, name, n):
+        for i in range(n):
+            h = h @ Wc[f"{name}.net.{i}.weight"].T
+            if i < n - 1:
+                h = torch.relu(h)
+        return h
+
+    enc_xc = torch.cat([_grid64(x01[:, [0, 1]], E[0], spec.offsets, sc, rs), _grid64(x01[:, [1, 2]], E[1], spec.offsets, sc, rs),
+                        _grid64(x01[:, [0, 2]], E[2], spec.offsets, sc, rs)], -1)
+    attc = mlpc(enc_xc, "aud_ch_att_net", 2)
+    eyec = torch.sigmoid(mlpc(enc_xc, "eye_att_net", 2))
+    hc = mlpc(torch.cat([enc_xc, dd(enc_a) * attc, dd(eye) * eyec], -1), "sigma_net", 3)
+    sigc = torch.exp(hc[:, 0])
+    sh_np, jac_np = O.sh_encode_forward(dirs.detach().cpu().numpy(), 4, True)
+    shc = dd(sh_np).requires_grad_(True)
+    rgbc = torch.sigmoid(mlpc(torch.cat([shc, hc[:, 1:], dd(ind).repeat(xc.shape[0], 1)], -1), "color_net", 2)) * 1.002 - 0.001
+    uncc = torch.log(1 + torch.exp(mlpc(enc_xc.detach(), "unc_net", 2)))[:, 0]
+    dl = dd(deltas.detach().cpu().numpy())
+    rays_np = rays.cpu().numpy()
+    N = rays_np.shape[0]
+    imgs, wss, a0c, a1c, usc = [None] * N, [None] * N, [None] * N, [None] * N, [None] * N
+    zero = torch.zeros((), dtype=torch.float64)
+    for n in range(N):
+        i, o, c = [int(v) for v in rays_np[n]]
+        T, r, w_, a0_, a1_, u_ = 1.0, torch.zeros(3, dtype=torch.float64), zero, zero, zero, zero
+        for s in range(o, o + c):
+            alpha = 1 - torch.exp(-sigc[s] * dl[s, 0])
+            wgt = alpha * T
+            r = r + wgt * rgbc[s]
+            w_ = w_ + wgt
+            a0_ = a0_ + attc[s].norm()
+            a1_ = a1_ + eyec[s].abs().sum()
+            u_ = u_ + wgt * uncc[s]
+            T = T * (1 - alpha)
+            if float(T.detach()) < 1e-4:
+                break
+        imgs[i], wss[i], a0c[i], a1c[i], usc[i] = r, w_, a0_, a1_, u_
+    lossc = ((torch.stack(imgs) - target.cpu().double()) ** 2).mean() + 0.1 * torch.stack(wss).mean() + 1e-3 * torch.stack(a0c).mean() + \
+        1e-3 * torch.stack(a1c).mean() + 1e-2 * torch.stack(usc).mean()
+    lossc.backward()
+    want_x = xc.grad.numpy()
+    want_d = np.einsum("bk,bdk->bd", shc.grad.numpy(), jac_np.astype(np.float64).reshape(-1, 3, 16))
+    assert np.abs(want_x).max() > 0 and np.abs(want_d).max() > 0
+
+    f16_forward = "forward_dtype" in arr
+
+    def close(got, want, name, tol):
+        a = got.detach().cpu().double().numpy()
+        err, l2 = np.max(np.abs(a - want)) / np.abs(want).max(), np.linalg.norm(a - want) / np.linalg.norm(want)
+        p95 = np.percentile(np.abs(a - want), 95) / np.abs(want).max()
+        # a half forward flips the ReLU mask of a unit whose pre-activation is within half rounding of zero: one sample's gradient then
+        # differs by that unit's whole contribution (sums over samples -- the weight gradients -- average it out, a per-sample gradient
+        # does not; ~200 flips among 3 200 x 64 colour units give the measured l2 of 0.03), so those arrangements are held in the l2
+        # norm and on 95 % of the entries
+        if f16_forward:
+            assert l2 < 6e-2 and p95 < 1e-2, (name, err, l2, p95)
+        else:
+            assert err < tol, (name, err, l2)
+
+    # positions: the finest level turns a table difference into a slope of ~511 per unit, and f32 rounding of pos = x * scale + 0.5 moves
+    # the corner weights of the gradient's other factor by ~3e-5 of a cell
+    close(gx, want_x, "xyzs", 3e-2 if half else 2e-3)
+    close(gd, want_d, "dirs", 3e-2 if half else 2e-3)
+    # and on through the march: d rays_o = sum over the ray's samples of d xyz, d rays_d = sum of d xyz * deltas[:, 1] + d dirs -- the
+    # reference multiplies by the stored step difference, not by t (raymarching.cu:570-572); mirrored
+    assert ro_t.grad is not None and rd_t.grad is not None and float(ro_t.grad.abs().sum()) > 0 and float(rd_t.grad.abs().sum()) > 0
+    go = np.zeros((N, 3)), np.zeros((N, 3))
+    dl_np = dl.numpy()
+    for n in range(N):
+        i, o, c = [int(v) for v in rays_np[n]]
+        for s in range(o, o + c):
+            go[0][i] += want_x[s]
+            go[1][i] += dl_np[s, 1] * want_x[s] + want_d[s]
+    close(ro_t.grad / scale, go[0], "rays_o", 3e-2 if half else 2e-3)
+    close(rd_t.grad / scale, go[1], "rays_d", 3e-2 if half else 2e-3)
