@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "liblzzx_nerf_hip.so")
+# LZZX_NERF_HIP_SO: another build of the same library (an experiment variant of lzzx_nerf_amd/build.py --variant); same ABI check applies
+SO_PATH = os.environ.get("LZZX_NERF_HIP_SO") or os.path.join(_HERE, "lib", "liblzzx_nerf_hip.so")
 
 vp, u32, f32, i32 = C.c_void_p, C.c_uint32, C.c_float, C.c_int
 

@@ -92,5 +92,44 @@ def build(force=False, verbose=False):
     return SO
 
 
+def build_variant(name, extra_flags, only=None):
+    """Experiment builds (tools/*): the sources in `only` (default: all) recompiled with `extra_flags` (-D switches), the rest taken from
+    the regular build's objects, linked into lib/variants/<name>.so; run with LZZX_NERF_HIP_SO=<that path> (lzzx_nerf_amd/_lib.py)."""
+    build()
+    vdir = os.path.join(LIBDIR, "variants")
+    odir = os.path.join(OBJDIR, "variants", name)
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(odir, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+
+    def one(src):
+        if only is not None and src not in only:
+            return os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(odir, src.replace(".hip", ".o"))
+        r = subprocess.run([hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
+        res = parse_resources(r.stderr)
+        for k, v in res.items():
+            if v.get("vgpr_spill", 0) or v.get("scratch", 0):
+                print("variant %s: %s spills (vgpr_spill %d, scratch %d)" % (name, k, v.get("vgpr_spill", 0), v.get("scratch", 0)), file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, SOURCES))
+    so = os.path.join(vdir, name + ".so")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr)
+    return so
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:   # python -m lzzx_nerf_amd.build --variant NAME [--only a.hip,b.hip] -- -DFOO=1 ...
+        i = sys.argv.index("--variant")
+        only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
+        extra = sys.argv[sys.argv.index("--") + 1:] if "--" in sys.argv else []
+        print(build_variant(sys.argv[i + 1], extra, only))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

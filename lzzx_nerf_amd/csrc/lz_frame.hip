@@ -212,13 +212,13 @@ template <> struct LzfHead<0> {
     __device__ static __forceinline__ void stage(const Args& P, float* lds, int q, Ctx& c) { lz_head_stage<false>(P, lds, LZF_WG, q, c); }
     template <typename ShFn>
     __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
-        lz_head_slice<false>(c, lane, x, y, z, f, o);
+        lz_head_slice<false, false, false, true>(c, lane, x, y, z, f, o);
     }
 };
 template <> struct LzfHead<2> : LzfHead<0> {   // f32 with the geo projection folded into colour_net.0 (lz_head_slice.h: FOLD)
     template <typename ShFn>
     __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
-        lz_head_slice<false, true>(c, lane, x, y, z, f, o);
+        lz_head_slice<false, true, false, true>(c, lane, x, y, z, f, o);
     }
 };
 template <> struct LzfHead<1> {
@@ -272,6 +272,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
         const int j = s % S, lead = s - j;              // slot s = step j of the ray whose state sits at slot `lead`
         const int max_passes = ((int)F.max_steps + S - 1) / S;
         for (;;) {
+            if constexpr (PREC != 1) __builtin_amdgcn_s_setprio(2);   // see the S = 1 loop
             // ---------------- refill + march (group leaders): up to S samples per ray into the staging fields ----------------
             const bool leader = (q == 0) && j == 0;
             int ray = leader ? sloti[SF_RAY * 16 + s] : -1;
@@ -390,6 +391,9 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
         const bool slot_lane = lane < NS;
         const int sl = lane;                       // this lane's slot (slot lanes only)
         for (;;) {
+            // f32 heads: refill, march and the gather's address work run at a raised wave priority and the slice drops it once its loads are
+            // issued (lz_head_gather<YIELD>): a wave that is about to wait on memory gets there first, the matrix phases fill the time
+            if constexpr (PREC != 1) __builtin_amdgcn_s_setprio(2);
             // ---------------- refill + march: every slot ends with a sample, crossing empty space, or empty with the queue dry ----------------
             int ray = slot_lane ? sloti[SF_RAY * NS + sl] : -1;
             bool have = false;

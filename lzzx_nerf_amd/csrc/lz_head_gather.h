@@ -58,7 +58,10 @@ typedef float lz_gf2 __attribute__((ext_vector_type(2)));
 // not exceed the head's.  An identity on the values -- but mind what it exposes: with the select gone, `(_Float16)encx[i]` sat directly
 // behind the last fma of the interpolation and the compiler folded the two into v_fma_mixlo_f16 (one rounding instead of f32-then-half):
 // 28 pixels of a 96 x 96 frame moved by 2e-7 against the loop until the conversions went through h_round (lz_head_f16_slice.h).
-template <bool IN_RANGE = false, bool PACK = false>
+// YIELD: the caller runs this wave at a raised priority (s_setprio) through its march / address work so that the 36 loads leave early; the
+// priority drops once they are issued and the matrix phase behind them yields to the other waves' address work (fused f32 frame kernel:
+// 9.17 -> 8.99 ms; dropping it before the address arithmetic instead: 9.06; no effect on the issue-bound f16 kernel)
+template <bool IN_RANGE = false, bool PACK = false, bool YIELD = false>
 __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], const int* __restrict__ tab, float px, float py, float pz, int q,
                                                float bound, float two_bound, float (&encx)[9]) {
     // the three grid levels this lane touches (level = 4 m + q); read per slice from LDS so that they do not occupy registers during the
@@ -139,6 +142,7 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
             gv[i][c] = *reinterpret_cast<const float*>(gb + (index << 2));
         }
     }
+    if constexpr (YIELD) __builtin_amdgcn_s_setprio(0);
     asm volatile("" ::"v"(gv[0][0]), "v"(gv[0][1]), "v"(gv[0][2]), "v"(gv[0][3]), "v"(gv[1][0]), "v"(gv[1][1]), "v"(gv[1][2]),
                  "v"(gv[1][3]), "v"(gv[2][0]), "v"(gv[2][1]), "v"(gv[2][2]), "v"(gv[2][3]), "v"(gv[3][0]), "v"(gv[3][1]),
                  "v"(gv[3][2]), "v"(gv[3][3]), "v"(gv[4][0]), "v"(gv[4][1]), "v"(gv[4][2]), "v"(gv[4][3]), "v"(gv[8][0]),

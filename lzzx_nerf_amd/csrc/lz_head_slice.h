@@ -83,14 +83,14 @@ __device__ __forceinline__ LzShFromDir<DirFn> lz_sh_from_dir(DirFn f) { return L
 // W_c0[:, geo] (Wg s2) = (W_c0[:, geo] Wg) s2: the host packs the 64 x 64 product into colour_net.0's geo columns (head.py: fold_geo) and
 // the slice hands s2 to the colour net directly -- 64 of the 361 MFMAs per slice are never issued.  sigma (the VALU row of sigma_net.2 on
 // s2) is unchanged bit for bit; rgb moves by the reassociation, a few 1e-7.
-template <bool TRAIN_UNC, bool FOLD = false, bool IN_RANGE = false, typename ShFn>
+template <bool TRAIN_UNC, bool FOLD = false, bool IN_RANGE = false, bool YIELD = false, typename ShFn>
 __device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, float px, float py, float pz, ShFn shfn, LzHeadOut& out) {
     static_assert(!(TRAIN_UNC && FOLD), "the folded colour net is an inference arrangement");
     constexpr int WV = LzHeadLds<TRAIN_UNC>::WV;
     const int q = lane >> 4;
     // ---------------- gather: enc_x features f = 4i + q of sample s -> B operands (lz_head_gather.h) ----------------
     float encx[LZ_T][9];
-    lz_head_gather<IN_RANGE>(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx[0]);
+    lz_head_gather<IN_RANGE, false, YIELD>(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx[0]);
     __builtin_amdgcn_sched_barrier(0);  // the tile's 36 reads in flight at a time: bounds the register footprint
 
     // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
