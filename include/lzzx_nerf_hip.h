@@ -608,7 +608,20 @@ typedef struct {
     const float* noises;           /* [N] or NULL: `perturb` of the reference's inference loop (renderer.py:521 passes it on the first
                                       iteration only): every ray starts at near + clamp(near * dt_gamma, dt_min, dt_max) * noise
                                       (raymarching.cu:873) */
+    const float* occupied_aabb;    /* [6] or NULL: lz_occupied_bounds of `grid`.  The march is then confined to that box: the stretch in
+                                      front of it is walked with the march's own step t += clamp(t * dt_gamma, dt_min, dt_max) and no cell
+                                      test, and a ray ends where it leaves the box -- the same samples (no cell outside the box is
+                                      occupied, and the t sequence of a ray does not depend on what the cells hold), without the ~130
+                                      instructions per empty cell crossed */
+    float* t_end;                  /* [N] scratch, required with occupied_aabb: where each ray's march ends */
 } lz_frame_fused;
+/* World-space bounds {xmin, ymin, zmin, xmax, ymax, zmax} of the occupied cells of a density bitfield (bit index = level * H^3 +
+ * morton(x, y, z), raymarching.cu:267-300), every level's cells dilated by `margin` cells of their own size and by at least four
+ * of the march's longest steps (4 dt_max, raymarching.cu:866); a side that reaches the rim
+ * of the outermost level is open (-/+FLT_MAX: the march clamps positions to the bound before the cell test); an empty bitfield gives a box
+ * at +FLT_MAX that no ray reaches.  workspace: 48 int32.  Two small launches, no host round trip; run it when the bitfield changes. */
+int lz_occupied_bounds(const uint8_t* bitfield, uint32_t C, uint32_t H, float bound, uint32_t margin, int32_t* workspace,
+                       float* aabb6, lz_stream_t stream);
 struct lz_timing;
 /* `timing` (may be NULL): bracket the persistent kernel with one event pair on the launch stream (lz_timing_create) */
 int lz_frame_render(const lz_frame_fused* f, struct lz_timing* timing, lz_stream_t stream);

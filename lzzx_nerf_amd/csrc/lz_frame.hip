@@ -53,6 +53,8 @@ struct LzFrameK {
     float bg_scalar, bound, dt_gamma, T_thresh, min_near;
     uint32_t N, max_steps, C, H;
     const float* noises;
+    const float* occ;     // [6] or null: bounds of the occupied cells (lz_occupied_bounds); the march is confined to them
+    float* t_end;         // [N] with occ: where a ray's march ends (far, clipped to occ); the persistent kernel reads it instead of fars
 };
 
 __device__ __forceinline__ void lzf_write_pixel(const LzFrameK& F, int ray, float ws, float d, float r, float g, float b, float a0, float a1,
@@ -96,6 +98,20 @@ __global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
         if (F.H <= LZF_LUT) m.morton_lut = mlut;
         float t = near, x, y, z, dt = 0.0f;
         if (F.noises) t = lz_fmaf(lz_clampf(t * F.dt_gamma, m.dt_min, m.dt_max), F.noises[n], t);   // perturb: raymarching.cu:873, first iteration only
+        if (F.occ) {
+            // No cell outside the (dilated) bounds of the occupied ones can yield a sample, and every step of the reference's march --
+            // the sample step and the empty-cell skip alike -- is t += clamp(t * dt_gamma, dt_min, dt_max) (raymarching.cu:907, 919-926):
+            // the t sequence of a ray does not depend on what the cells hold.  So the stretch in front of the bounds is walked with that
+            // one addition per step instead of a cell test per step (~130 instructions), and the march ends where the ray leaves them.
+            float on, of;
+            lz_near_far_ray(o[0], o[1], o[2], d[0], d[1], d[2], F.occ, near, on, of);
+            if (on == on && of == of) {          // (a NaN from an axis-parallel ray: no clipping)
+                const float stop = lz_fminf(on, far);
+                while (t < stop) t += lz_clampf(t * F.dt_gamma, m.dt_min, m.dt_max);
+                far = lz_fminf(far, of);
+            }
+            F.t_end[n] = far;
+        }
         bool found = false;
         while (t < far) {
             if (m.probe(t, x, y, z, dt)) { found = true; break; }
@@ -291,7 +307,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             ray = F.order[idx];
                             sloti[SF_RAY * 16 + s] = ray;
                             slot[SF_T * 16 + s] = F.rays_t[ray];
-                            slot[SF_FAR * 16 + s] = F.fars[ray];
+                            slot[SF_FAR * 16 + s] = (F.occ ? F.t_end[ray] : F.fars[ray]);
 #pragma unroll
                             for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
                             sloti[SF_CNT * 16 + s] = 0;
@@ -412,7 +428,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             ray = F.order[idx];
                             sloti[SF_RAY * NS + sl] = ray;
                             slot[SF_T * NS + sl] = F.rays_t[ray];
-                            slot[SF_FAR * NS + sl] = F.fars[ray];
+                            slot[SF_FAR * NS + sl] = (F.occ ? F.t_end[ray] : F.fars[ray]);
 #pragma unroll
                             for (int f = SF_WS; f <= SF_U; f++) slot[f * NS + sl] = 0.0f;
                             sloti[SF_CNT * NS + sl] = 0;
@@ -524,6 +540,80 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     }
 }
 
+// ---- bounds of the occupied cells (once per bitfield; lz_frame_fused.occupied_aabb) ---------------------------------------------------
+// ws [C][6] int32, preset to -1: per cascade level max(H - 1 - x), max(H - 1 - y), max(H - 1 - z), max(x), max(y), max(z) over the set
+// bits (bit index = level * H^3 + morton(x, y, z), raymarching.cu:267-300, 890-895)
+__global__ void __launch_bounds__(256) lz_k_occupied_cells(const uint8_t* __restrict__ bits, uint32_t C, uint32_t H, int* __restrict__ ws) {
+    __shared__ int lm[8 * 6];
+    if (threadIdx.x < 48) lm[threadIdx.x] = -1;
+    __syncthreads();
+    const uint32_t H3 = H * H * H;
+    const uint64_t n_bytes = ((uint64_t)C * H3 + 7) / 8;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_bytes; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = bits[b];
+        while (v) {
+            const int k = __ffs((int)v) - 1;
+            v &= v - 1u;
+            const uint64_t index = b * 8 + (uint32_t)k;
+            const uint32_t level = (uint32_t)(index / H3), mort = (uint32_t)(index % H3);
+            if (level >= C) break;
+            const int x = (int)lz_morton3_inv(mort), y = (int)lz_morton3_inv(mort >> 1), z = (int)lz_morton3_inv(mort >> 2);
+            int* l = lm + level * 6;
+            atomicMax(l + 0, (int)H - 1 - x); atomicMax(l + 1, (int)H - 1 - y); atomicMax(l + 2, (int)H - 1 - z);
+            atomicMax(l + 3, x); atomicMax(l + 4, y); atomicMax(l + 5, z);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 * C && lm[threadIdx.x] >= 0) atomicMax(ws + threadIdx.x, lm[threadIdx.x]);
+}
+// world-space box: cell n of level l spans ((n .. n + 1) / H * 2 - 1) * min(2^l, bound) (raymarching.cu:409-417); `margin` cells of the
+// level's own size (and never less than four of the march's longest steps) on every side.  A side that reaches the rim of the outermost level is open (positions are clamped to the bound
+// before the cell test, so the rim cells also stand for everything outside).  No occupied cell: a box at +FLT_MAX that no ray reaches.
+__global__ void lz_k_occupied_box(const int* __restrict__ ws, uint32_t C, uint32_t H, float bound, int margin, float* __restrict__ box) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    bool any = false;
+    // never less than four of the march's longest steps (dt_max = 2 sqrt(3) 2^(C - 1) / H, raymarching.cu:866): the march reaches the
+    // first occupied cell through at least that many ordinary cell tests
+    const float steps4 = 4.0f * (2 * LZ_SQRT3F * (float)(1u << (C - 1)) / (float)H);
+    for (uint32_t l = 0; l < C; l++) {
+        const float mb = lz_fminf(lz_scalbnf(1.0f, (int)l), bound);
+        const float pad = lz_fmaxf((float)margin * (2.0f * mb / (float)H), steps4);
+        for (int a = 0; a < 3; a++) {
+            const int mn_r = ws[l * 6 + a], mx = ws[l * 6 + 3 + a];
+            if (mx < 0) continue;
+            any = true;
+            const int c0 = (int)H - 1 - mn_r, c1 = mx + 1;
+            float w0 = ((float)c0 / (float)H * 2.0f - 1.0f) * mb - pad, w1 = ((float)c1 / (float)H * 2.0f - 1.0f) * mb + pad;
+            if (l == C - 1 && w0 <= -mb) w0 = -FLT_MAX;
+            if (l == C - 1 && w1 >= mb) w1 = FLT_MAX;
+            lo[a] = lz_fminf(lo[a], w0);
+            hi[a] = lz_fmaxf(hi[a], w1);
+        }
+    }
+    for (int a = 0; a < 3; a++) {
+        box[a] = any ? lo[a] : FLT_MAX;
+        box[3 + a] = any ? hi[a] : FLT_MAX;
+    }
+}
+
+extern "C" int lz_occupied_bounds(const uint8_t* bitfield, uint32_t C, uint32_t H, float bound, uint32_t margin, int32_t* workspace, float* aabb6,
+                                  lz_stream_t stream) {
+    LZ_REQUIRE(bitfield && workspace && aabb6, LZ_ERR_BAD_ARGUMENT, "occupied_bounds: null tensor");
+    LZ_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024 && bound > 0.0f && margin <= 64, LZ_ERR_BAD_ARGUMENT,
+               "occupied_bounds: cascade in [1, 8], grid size in [1, 1024], bound > 0, margin <= 64");
+    hipStream_t st = lz_st(stream);
+    hipError_t rc = hipMemsetAsync(workspace, 0xff, 48 * sizeof(int32_t), st);
+    if (rc != hipSuccess) { lz_set_error("occupied_bounds: memset: %s", hipGetErrorString(rc)); return (int)rc; }
+    const uint64_t n_bytes = ((uint64_t)C * H * H * H + 7) / 8;
+    uint32_t nb = (uint32_t)lz_div_up(n_bytes, (uint64_t)256 * 16);
+    nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+    hipLaunchKernelGGL(lz_k_occupied_cells, dim3(nb), dim3(256), 0, st, bitfield, C, H, workspace);
+    hipLaunchKernelGGL(lz_k_occupied_box, dim3(1), dim3(64), 0, st, workspace, C, H, bound, (int)margin, aabb6);
+    LZ_CHECK_LAUNCH("occupied_bounds");
+    return LZ_OK;
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 static void lzf_level_tables(const lz_head_params* p, float* scale, uint32_t* res) {
     for (int l = 0; l < 12; l++) {  // gridencoder.cu:125-126 on the host, same libm call as the CPU checker
@@ -554,6 +644,8 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     K.bg_scalar = f->bg_scalar; K.bound = f->bound; K.dt_gamma = f->dt_gamma; K.T_thresh = f->T_thresh; K.min_near = f->min_near;
     K.N = f->N; K.max_steps = f->max_steps; K.C = f->C; K.H = f->H;
     K.noises = f->noises;
+    K.occ = f->occupied_aabb; K.t_end = f->t_end;
+    LZ_REQUIRE(!f->occupied_aabb || f->t_end, LZ_ERR_BAD_ARGUMENT, "frame_render: occupied_aabb needs the t_end scratch buffer");
     hipError_t rc = hipMemsetAsync(f->state, 0, LZ_FRAME_STATE_INTS * sizeof(int32_t), st);
     if (rc != hipSuccess) { lz_set_error("frame_render: memset: %s", hipGetErrorString(rc)); return (int)rc; }
     const uint32_t nb = lz_div_up(f->N, 256);

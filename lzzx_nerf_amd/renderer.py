@@ -95,6 +95,24 @@ class TriplaneRenderer:
         self._timing = None       # lz_timing handle: native loop records a HIP event pair around every head launch
         self.chunk = 8       # iterations enqueued per C call
         self.lookahead = 2   # chunks the host keeps queued ahead of the one whose result it inspects (ring holds lookahead + 2)
+        # fused mode: confine every ray's march to the bounds of the occupied cells (lz_occupied_bounds, recomputed when the bitfield
+        # tensor changes): same samples, bit for bit, without a cell test per empty cell in front of / behind the object
+        self.clip_to_occupancy = True
+        self.occupancy_margin = 8      # cells; see occupied_bounds()
+        self._occ = None
+
+    def occupied_bounds(self):
+        """device tensor [6]: world-space box of the occupied cells of `self.bitfield`, dilated by `occupancy_margin` cells of each level's own size and by
+        at least four of the march's longest steps (dt_max = sqrt(3) cells of the outermost level), so that the march walks its last steps
+        in front of the first occupied cell with its ordinary cell tests.  Cached per (tensor, version): an in-place update of the bitfield (occupancy.update_density_grid) recomputes it."""
+        bf = self.bitfield
+        key = (bf.data_ptr(), bf._version, self.occupancy_margin)
+        if self._occ is None or self._occ[0] != key:
+            box = torch.empty(6, dtype=torch.float32, device=bf.device)
+            ws = torch.empty(48, dtype=torch.int32, device=bf.device)
+            call("lz_occupied_bounds", ptr(bf), int(self.cascade), int(self.grid_size), self.bound, int(self.occupancy_margin), ptr(ws), ptr(box), stream())
+            self._occ = (key, box, ws)
+        return self._occ[1]
 
     def timing_start(self, n_pairs):
         """bracket every head launch of the following render() calls with HIP events (bench.py's roofline leg)"""
@@ -272,7 +290,7 @@ class TriplaneRenderer:
                       order=torch.empty(N, dtype=torch.int32, device=device), state=torch.zeros(1024, dtype=torch.int32, device=device),
                       keys=torch.empty(N, dtype=torch.uint8, device=device), weights_sum=torch.empty(N, **f), depth=torch.empty(N, **f),
                       image=torch.empty(N, 3, **f), amb_aud_sum=torch.empty(N, **f), amb_eye_sum=torch.empty(N, **f), unc_sum=torch.empty(N, **f),
-                      out=torch.empty(N, 3, **f), out_rgb24=None, ray_counts=None)
+                      out=torch.empty(N, 3, **f), out_rgb24=None, ray_counts=None, t_end=torch.empty(N, **f))
             self._fbuf = fb
         return fb
 
@@ -303,6 +321,8 @@ class TriplaneRenderer:
         f.N, f.max_steps, f.C, f.H = N, int(max_steps), int(self.cascade), int(self.grid_size)
         f.steps_per_pass = int(self.steps_per_pass)
         f.noises = None if noises is None else noises.data_ptr()
+        if self.clip_to_occupancy:
+            f.occupied_aabb, f.t_end = p(self.occupied_bounds()), p(b["t_end"])
         call("lz_frame_render", C.byref(f), self._timing, stream())   # timing: one event pair around the persistent kernel
         self._keep = (enc_a, ind_code, eye, bg, rays_o, rays_d, noises)
         res = dict(image=b["out"], image_raw=b["image"], weights_sum=b["weights_sum"], depth=b["depth"], amb_aud_sum=b["amb_aud_sum"],

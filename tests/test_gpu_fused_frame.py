@@ -267,3 +267,118 @@ def test_perturb_on_the_fast_paths_equals_the_reference_loop_with_the_same_noise
     assert not torch.equal(own, fused["image"])
     with pytest.raises(RuntimeError, match="one value per ray"):
         fr.render(ro, rd, *cond, noises=dev(noise[:5]), **kw)
+
+
+def _bitfield_from_cells(cells, grid_size=128, cascade=1):
+    """cells: list of (level, x, y, z) -> bitfield through the checker's morton3D (bit index = level * H^3 + morton, raymarching.cu:267-300)"""
+    from oracle import oracle as O
+    bits = np.zeros(cascade * grid_size ** 3 // 8, np.uint8)
+    c = np.asarray(cells, np.int64).reshape(-1, 4)
+    idx = c[:, 0] * grid_size ** 3 + O.morton3D(c[:, 1:].astype(np.int32)).astype(np.int64)
+    np.bitwise_or.at(bits, idx // 8, (1 << (idx % 8)).astype(np.uint8))
+    return bits
+
+
+def _blob(level, centre, radius, grid_size=128):
+    g = np.arange(grid_size)
+    x, y, z = np.meshgrid(g, g, g, indexing="ij")
+    m = (x - centre[0]) ** 2 + (y - centre[1]) ** 2 + (z - centre[2]) ** 2 <= radius ** 2
+    return [(level, int(a), int(b), int(c)) for a, b, c in zip(x[m], y[m], z[m])]
+
+
+@pytest.mark.parametrize("case", ["ellipsoid", "two_cascades", "rim", "empty", "ones"])
+def test_occupied_bounds_match_numpy(case):
+    """lz_occupied_bounds: the world-space box of the set bits of a density bitfield, per level ((n .. n + 1) / H * 2 - 1) * min(2^level,
+    bound) (raymarching.cu:409-417), dilated by max(margin cells of the level, 4 dt_max); open towards the rim of the outermost level"""
+    from lzzx_nerf_amd._util import call, ptr, stream
+    H, margin = 128, 8
+    if case == "ellipsoid":
+        C, bound, bits = 1, 1.0, ellipsoid_bitfield()[0]
+    elif case == "two_cascades":
+        C, bound = 2, 2.0
+        cells = _blob(0, (40, 64, 90), 5) + _blob(1, (70, 60, 64), 3)
+        bits = _bitfield_from_cells(cells, H, C)
+    elif case == "rim":
+        C, bound = 1, 1.0
+        cells = _blob(0, (3, 64, 120), 3)
+        bits = _bitfield_from_cells(cells, H, C)
+    elif case == "empty":
+        C, bound, bits = 1, 1.0, np.zeros(H ** 3 // 8, np.uint8)
+    else:
+        C, bound, bits = 1, 1.0, np.full(H ** 3 // 8, 255, np.uint8)
+    box, ws = torch.empty(6, device="cuda"), torch.empty(48, dtype=torch.int32, device="cuda")
+    call("lz_occupied_bounds", ptr(dev(bits)), C, H, bound, margin, ptr(ws), ptr(box), stream())
+    got = box.cpu().numpy()
+    from oracle import oracle as O
+    FMAX = np.finfo(np.float32).max
+    idx = np.nonzero(np.unpackbits(bits, bitorder="little"))[0]
+    if len(idx) == 0:
+        assert np.all(got == FMAX)
+        return
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    dt_max = 2 * np.sqrt(3) * 2 ** (C - 1) / H
+    for l in range(C):
+        sel = idx[(idx // H ** 3) == l] % H ** 3
+        if len(sel) == 0:
+            continue
+        xyz = O.morton3D_invert(sel.astype(np.int32)).astype(np.int64)
+        mb = min(2.0 ** l, bound)
+        pad = max(margin * 2 * mb / H, 4 * dt_max)
+        w0 = (xyz.min(0) / H * 2 - 1) * mb - pad
+        w1 = ((xyz.max(0) + 1) / H * 2 - 1) * mb + pad
+        if l == C - 1:
+            w0 = np.where(w0 <= -mb, -np.inf, w0)
+            w1 = np.where(w1 >= mb, np.inf, w1)
+        lo, hi = np.minimum(lo, w0), np.maximum(hi, w1)
+    want = np.concatenate([lo, hi])
+    for g, w in zip(got, want):
+        if np.isinf(w):
+            assert abs(g) == FMAX and np.sign(g) == np.sign(w)
+        else:
+            assert abs(g - w) < 1e-5, (got, want)
+    if case == "rim":
+        assert got[0] == -FMAX and got[5] == FMAX and abs(got[1]) < 1
+    if case == "ones":
+        assert np.all(np.abs(got) == FMAX)
+
+
+@pytest.mark.parametrize("scene,precision,kw", [
+    ("ellipsoid", "f32", dict(max_steps=192)),
+    ("ellipsoid", "f16", dict(max_steps=192)),
+    ("blobs", "f32", dict(max_steps=128)),
+    ("blobs", "f32", dict(max_steps=1024, perturb=True)),     # the reference's inference cap: dt_min = 0.22 cells, ~600 steps across the box
+    ("rim", "f32", dict(max_steps=96)),
+    ("empty", "f32", dict(max_steps=64)),
+])
+def test_march_confined_to_the_occupied_bounds_changes_no_sample(params, golden, scene, precision, kw):
+    """TriplaneRenderer(mode="fused").clip_to_occupancy (lz_frame_fused.occupied_aabb): the stretch of a ray in front of the occupied
+    cells is walked with the march's own step and no cell test, the ray ends where it leaves their bounds.  Every output, the per-ray
+    sample counts and the sample total equal the unclipped kernel's and the multi-launch loop's (whose march tests every cell), bit for bit."""
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    H = W = 160
+    head, bits, ro, rd, cond = setup(params, golden, H, W, "ellipsoid", precision=precision)
+    if scene == "blobs":        # two separate objects, one off-centre near a face of the box: empty space in front, between and behind
+        bits = _bitfield_from_cells(_blob(0, (40, 52, 30), 9) + _blob(0, (84, 70, 100), 13) + _blob(0, (64, 64, 64), 2))
+    elif scene == "rim":        # occupied cells on the rim of the grid: the box is open on those sides
+        bits = _bitfield_from_cells(_blob(0, (60, 64, 2), 6) + _blob(0, (70, 60, 126), 5))
+    elif scene == "empty":
+        bits = np.zeros(128 ** 3 // 8, np.uint8)
+    noises = None
+    if kw.pop("perturb", False):
+        noises = torch.rand(ro.shape[0], device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    outs = []
+    for clip in (True, False):
+        r = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
+        r.clip_to_occupancy = clip
+        r.steps_per_pass = 1
+        o = r.render(ro, rd, *cond, count_samples=True, noises=noises, **kw)
+        outs.append({k: v.clone() for k, v in o.items()})
+    loop = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=1, n_step_cap=1).render(ro, rd, *cond, count_samples=True, noises=noises, **kw)
+    for other in (outs[1], loop):
+        for k in KEYS + ("ray_counts",):
+            assert torch.equal(outs[0][k], other[k]), k
+        assert int(outs[0]["state"][5]) == int(other["state"][5])
+    if scene != "empty":
+        assert int(outs[0]["state"][5]) > 1000
+    else:
+        assert int(outs[0]["state"][5]) == 0 and float(outs[0]["image"].min()) == 1.0
