@@ -722,6 +722,38 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             del xyz, dirs_d, deltas, rays_tbl, outd, comp
         except Exception as exc:   # an optional leg must never take the headline line down
             err("dense192", exc)
+    log("leg: cfg2 render")
+    if not args.no_grid_roofline:
+        try:
+            # BASELINE cfg2 end to end: 256 x 256 rays, max_steps 128, generic hash-grid NeRF (D3 L16 C2 T19) through the operator API
+            # with the reference's own inference loop (host sync per iteration and all) -- what a caller of the drop-in operators gets
+            from lzzx_nerf_amd.synthetic import GenericHashgridNeRF, synthetic_camera as cam2
+            from lzzx_nerf_amd.utils import frame_rays as fr2
+            pose2, intr2 = cam2(256, 256)
+            ro2, rd2 = fr2(torch.from_numpy(np.ascontiguousarray(pose2)).to(device), intr2, 256, 256)
+            aabb2 = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32, device=device)
+            bits2 = torch.full((128 ** 3 // 8,), 255, dtype=torch.uint8, device=device)
+            legs2 = {}
+            for tag, half in (("f32_tables", False), ("f16_tables", True)):
+                g2 = GenericHashgridNeRF(device, half_tables=half)
+                for _ in range(2):
+                    out2 = g2.render(ro2, rd2, aabb2, bits2, max_steps=128)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    out2 = g2.render(ro2, rd2, aabb2, bits2, max_steps=128)
+                torch.cuda.synchronize()
+                ms2 = (time.perf_counter() - t0) / 5 * 1e3
+                legs2[tag] = dict(ms_per_frame=round(ms2, 3), rays_per_s=round(65536 / ms2 * 1e3, 1), sample_rows_per_frame=int(out2[3]),
+                                  sample_rows_per_s=round(out2[3] / ms2 * 1e3, 1), iterations_per_frame=int(out2[4]),
+                                  image_mean=float(out2[0].mean()))
+                del g2
+            result["cfg2_hashgrid_render"] = dict(
+                workload="cfg2: 256x256 rays, max_steps 128, all-ones occupancy, get_encoder('hashgrid') defaults (D3 L16 C2 T2^19) + SH(4) + "
+                         "bias-free MLPs 32-64-16 / 31-64-3 (MFMA Linear kernels), the reference's inference loop on the operator API "
+                         "(march_rays / composite_rays / boolean-mask compaction with its host sync per iteration)", **legs2)
+        except Exception as exc:
+            err("cfg2_hashgrid_render", exc)
     log("leg: if not args.no_grid_roofline:")
     if not args.no_grid_roofline:
         try:

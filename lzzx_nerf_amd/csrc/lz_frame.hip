@@ -228,13 +228,13 @@ template <> struct LzfHead<0> {
     __device__ static __forceinline__ void stage(const Args& P, float* lds, int q, Ctx& c) { lz_head_stage<false>(P, lds, LZF_WG, q, c); }
     template <typename ShFn>
     __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
-        lz_head_slice<false, false, false, true>(c, lane, x, y, z, f, o);
+        lz_head_slice<false, false, true, true>(c, lane, x, y, z, f, o);
     }
 };
 template <> struct LzfHead<2> : LzfHead<0> {   // f32 with the geo projection folded into colour_net.0 (lz_head_slice.h: FOLD)
     template <typename ShFn>
     __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
-        lz_head_slice<false, true, false, true>(c, lane, x, y, z, f, o);
+        lz_head_slice<false, true, true, true>(c, lane, x, y, z, f, o);
     }
 };
 template <> struct LzfHead<1> {
@@ -548,20 +548,40 @@ __global__ void __launch_bounds__(256) lz_k_occupied_cells(const uint8_t* __rest
     if (threadIdx.x < 48) lm[threadIdx.x] = -1;
     __syncthreads();
     const uint32_t H3 = H * H * H;
-    const uint64_t n_bytes = ((uint64_t)C * H3 + 7) / 8;
-    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_bytes; b += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t v = bits[b];
-        while (v) {
-            const int k = __ffs((int)v) - 1;
-            v &= v - 1u;
-            const uint64_t index = b * 8 + (uint32_t)k;
-            const uint32_t level = (uint32_t)(index / H3), mort = (uint32_t)(index % H3);
-            if (level >= C) break;
-            const int x = (int)lz_morton3_inv(mort), y = (int)lz_morton3_inv(mort >> 1), z = (int)lz_morton3_inv(mort >> 2);
-            int* l = lm + level * 6;
-            atomicMax(l + 0, (int)H - 1 - x); atomicMax(l + 1, (int)H - 1 - y); atomicMax(l + 2, (int)H - 1 - z);
-            atomicMax(l + 3, x); atomicMax(l + 4, y); atomicMax(l + 5, z);
+    const uint64_t n_bytes = ((uint64_t)C * H3 + 7) / 8, n_chunks = (n_bytes + 15) / 16;
+    // a thread takes 16 consecutive bytes at a time and keeps the extremes of the level it is in in registers: six LDS atomics per chunk
+    // and level, not per set bit (a dense grid has 2 M of them)
+    for (uint64_t ch = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < n_chunks; ch += (uint64_t)gridDim.x * blockDim.x) {
+        int cur = -1, m[6] = {-1, -1, -1, -1, -1, -1};
+        auto flush = [&]() {
+            if (cur >= 0 && m[3] >= 0) {
+#pragma unroll
+                for (int a = 0; a < 6; a++) atomicMax(lm + cur * 6 + a, m[a]);
+            }
+        };
+        for (uint32_t j = 0; j < 16; j++) {
+            const uint64_t b = ch * 16 + j;
+            if (b >= n_bytes) break;
+            uint32_t v = bits[b];
+            while (v) {
+                const int k = __ffs((int)v) - 1;
+                v &= v - 1u;
+                const uint64_t index = b * 8 + (uint32_t)k;
+                const int level = (int)(index / H3);
+                if (level >= (int)C) break;
+                if (level != cur) {
+                    flush();
+                    cur = level;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) m[a] = -1;
+                }
+                const uint32_t mort = (uint32_t)(index % H3);
+                const int x = (int)lz_morton3_inv(mort), y = (int)lz_morton3_inv(mort >> 1), z = (int)lz_morton3_inv(mort >> 2);
+                m[0] = max(m[0], (int)H - 1 - x); m[1] = max(m[1], (int)H - 1 - y); m[2] = max(m[2], (int)H - 1 - z);
+                m[3] = max(m[3], x); m[4] = max(m[4], y); m[5] = max(m[5], z);
+            }
         }
+        flush();
     }
     __syncthreads();
     if (threadIdx.x < 6 * C && lm[threadIdx.x] >= 0) atomicMax(ws + threadIdx.x, lm[threadIdx.x]);
@@ -606,7 +626,7 @@ extern "C" int lz_occupied_bounds(const uint8_t* bitfield, uint32_t C, uint32_t 
     hipError_t rc = hipMemsetAsync(workspace, 0xff, 48 * sizeof(int32_t), st);
     if (rc != hipSuccess) { lz_set_error("occupied_bounds: memset: %s", hipGetErrorString(rc)); return (int)rc; }
     const uint64_t n_bytes = ((uint64_t)C * H * H * H + 7) / 8;
-    uint32_t nb = (uint32_t)lz_div_up(n_bytes, (uint64_t)256 * 16);
+    uint32_t nb = (uint32_t)lz_div_up(n_bytes, (uint64_t)256 * 16);   // one 16-byte chunk per thread
     nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
     hipLaunchKernelGGL(lz_k_occupied_cells, dim3(nb), dim3(256), 0, st, bitfield, C, H, workspace);
     hipLaunchKernelGGL(lz_k_occupied_box, dim3(1), dim3(64), 0, st, workspace, C, H, bound, (int)margin, aabb6);
@@ -673,10 +693,10 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
         case 8: LZF_LAUNCH(PREC, 8); break;                                     \
         default: LZF_LAUNCH(PREC, 16); break;                                   \
     }
+    // the heads' gathers run without range clamps here (lz_head_gather<IN_RANGE>): every sample the march emits is clamped to ITS bound
+    LZ_REQUIRE(f->bound > 0.0f && f->bound <= p->bound, LZ_ERR_BAD_ARGUMENT,
+               "frame_render: the march's bound must not exceed the head's (the reference uses one `bound` for both, renderer.py:94, network.py:100)");
     if (p->precision == 1) {
-        // the f16 head's gather runs without range clamps here (lz_head_gather<IN_RANGE>): every sample the march emits is clamped to ITS bound
-        LZ_REQUIRE(f->bound > 0.0f && f->bound <= p->bound, LZ_ERR_BAD_ARGUMENT,
-                   "frame_render: the march's bound must not exceed the head's (the reference uses one `bound` for both, renderer.py:94, network.py:100)");
         LzHead16Args a;
         a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
         a.offsets = p->offsets; a.packed = reinterpret_cast<const lz_h8*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code;

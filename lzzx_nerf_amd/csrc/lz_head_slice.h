@@ -90,7 +90,7 @@ __device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, flo
     const int q = lane >> 4;
     // ---------------- gather: enc_x features f = 4i + q of sample s -> B operands (lz_head_gather.h) ----------------
     float encx[LZ_T][9];
-    lz_head_gather<IN_RANGE, false, YIELD>(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx[0]);
+    lz_head_gather<IN_RANGE, true, YIELD>(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx[0]);
     __builtin_amdgcn_sched_barrier(0);  // the tile's 36 reads in flight at a time: bounds the register footprint
 
     // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
@@ -174,7 +174,7 @@ __device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, flo
     }
     // ---------------- sigma net: [enc_x 36 | enc_a * att 32 | eye * eye_att 1] -> 64 -> 64 -> 65 ----------------
     float geo[LZ_T][16];
-    float sigma[LZ_T];
+    float sig_pre[LZ_T];      // row 0 of sigma_net.2, before the exp (evaluated with the colours' sigmoids at the end)
     {
         float b1[LZ_T][18];
 #pragma unroll
@@ -233,7 +233,7 @@ __device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, flo
                     for (int r = 0; r < 4; r++) geo[j][4 * ft + r] = acc3[ft][j][r];   // geo_feat, no activation (network.py:304)
         }
 #pragma unroll
-        for (int j = 0; j < LZ_T; j++) sigma[j] = lz_expf(lz_lane_dot<4>(hc.wl + WV + LZ_WV_SIG, q, b3[j]));     // row 0 of sigma_net.2 on the VALU
+        for (int j = 0; j < LZ_T; j++) sig_pre[j] = lz_lane_dot<4>(hc.wl + WV + LZ_WV_SIG, q, b3[j]);     // row 0 of sigma_net.2 on the VALU
     }
     // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
     float rgb[LZ_T][3];
@@ -263,12 +263,26 @@ __device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, flo
             for (int ft = 0; ft < 4; ft++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) b2[j][4 * ft + r] = lz_relu(acc1[ft][j][r]);
+        // colour_net.1 (64 -> 3) on the VALU (network.py:275), then the four transcendentals of a sample -- sigma = exp(h0) (network.py:302)
+        // and three sigmoids (:310) -- ONE per lane instead of four per lane: after the lane-partial sums every lane of a sample holds all
+        // four pre-activations, so lane q evaluates the q-th (q < 3: sigmoid = 1 / (1 + exp(-x)), q == 3: exp) with the same lz_expf on
+        // the same argument -- the same bits -- and the sample's lanes fetch each other's result (~120 vector instructions per slice less;
+        // the exp is a 30-instruction polynomial because its bits are part of the parity contract)
 #pragma unroll
-        for (int j = 0; j < LZ_T; j++)
+        for (int j = 0; j < LZ_T; j++) {
+            float d[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++)   // colour_net.1 (64 -> 3) on the VALU; network.py:275
-                rgb[j][c] = lz_sigmoidf(lz_lane_dot<4>(hc.wl + WV + LZ_WV_C2 + 64 * c, q, b2[j])) * 1.002f - 0.001f;
-    }    out.sigma = sigma[0];
+            for (int c = 0; c < 3; c++) d[c] = lz_lane_dot<4>(hc.wl + WV + LZ_WV_C2 + 64 * c, q, b2[j]);
+            const float arg = q == 0 ? -d[0] : (q == 1 ? -d[1] : (q == 2 ? -d[2] : sig_pre[j]));
+            const float e = lz_expf(arg);
+            const float v = q == 3 ? e : (1.0f / (1.0f + e)) * 1.002f - 0.001f;
+            const int s0 = lane & 15;
+#pragma unroll
+            for (int c = 0; c < 3; c++) rgb[j][c] = __shfl(v, s0 + 16 * c, 64);
+            sig_pre[j] = __shfl(v, s0 + 48, 64);      // now sigma itself
+        }
+    }
+    out.sigma = sig_pre[0];
     out.rgb[0] = rgb[0][0]; out.rgb[1] = rgb[0][1]; out.rgb[2] = rgb[0][2];
     out.ambaud = ambaud[0];
     out.eyeatt = eyeatt[0];

@@ -74,3 +74,67 @@ def ellipsoid_bitfield_device(device, grid_size=128, semi=(0.35, 0.45, 0.35), bo
 def ones_bitfield(grid_size=128, cascade=1):
     """occupancy variant (ii): every cell occupied -- the dense deterministic workload of the headline"""
     return np.full(cascade * grid_size ** 3 // 8, 255, np.uint8)
+
+
+class GenericHashgridNeRF:
+    """BASELINE cfg2's workload: a generic (non-triplane) NeRF through the OPERATOR API only -- `get_encoder('hashgrid')` defaults (D 3,
+    L 16, C 2, T 2^19, desired resolution 2048: encoding.py:6-8), SH(4) directions, two small bias-free MLPs on the MFMA Linear
+    kernels (lzzx_nerf_amd.linear.MLP, the drop-in for network.py:73-94) -- rendered with the reference's inference loop as its callers
+    write it (renderer.py:495-561: march_rays -> network -> composite_rays -> `rays_alive[rays_alive >= 0]`, n_step schedule), host
+    sync per iteration included.  tests/test_gpu_cfg2_render.py checks the same arrangement against the CPU checker."""
+
+    def __init__(self, device, seed=3, half_tables=False):
+        import torch
+
+        from .encoding import get_encoder
+        from .linear import MLP
+        self.enc, dim = get_encoder("hashgrid")
+        self.sh, dim_sh = get_encoder("spherical_harmonics")
+        g = torch.Generator().manual_seed(seed)
+        self.enc = self.enc.to(device)
+        self.enc.embeddings.data.copy_(torch.rand(self.enc.embeddings.shape, generator=g) * 2 - 1)
+        self.half_tables = half_tables
+        self.sigma_net, self.color_net = MLP(dim, 16, 64, 2).to(device), MLP(dim_sh + 15, 3, 64, 2).to(device)
+        for m in (self.sigma_net, self.color_net):
+            for lin in m.net:
+                k = lin.weight.shape[1]
+                lin.weight.data.copy_((torch.rand(lin.weight.shape, generator=g) * 2 - 1) / k ** 0.5)
+        self.sigma_net.net[1].weight.data[0] *= 6.0   # sharper density: rays terminate, the schedule and the compaction are exercised
+
+    def net(self, xyzs, dirs, bound):
+        import torch
+        if self.half_tables:       # what grid.py:28,38-39 does under autocast with an even level_dim: half tables, half features
+            with torch.autocast("cuda", dtype=torch.float16):
+                feat = self.enc(xyzs, bound=bound).float()
+        else:
+            feat = self.enc(xyzs, bound=bound)
+        h = self.sigma_net(feat)
+        sigma = torch.exp(h[:, 0])
+        rgb = torch.sigmoid(self.color_net(torch.cat([self.sh(dirs), h[:, 1:]], -1)))
+        return sigma, rgb
+
+    def render(self, rays_o, rays_d, aabb, bitfield, bound=1.0, max_steps=128, T_thresh=1e-4, dt_gamma=1 / 256, min_near=0.05):
+        """-> (image [N,3] blended on white, depth [N], weights_sum [N], marched sample rows, iterations)"""
+        import torch
+
+        from . import raymarching as R
+        with torch.no_grad():
+            N, dev = rays_o.shape[0], rays_o.device
+            nears, fars = R.near_far_from_aabb(rays_o, rays_d, aabb, min_near)
+            ws, dep, img = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
+            alive = torch.arange(N, dtype=torch.int32, device=dev)
+            t = nears.clone()
+            step = rows = iters = 0
+            while step < max_steps:
+                n_alive = alive.shape[0]
+                if n_alive <= 0:
+                    break
+                n_step = max(min(N // n_alive, 8), 1)
+                xyzs, dirs, dl = R.march_rays(n_alive, n_step, alive, t, rays_o, rays_d, bound, bitfield, 1, 128, nears, fars, 128, False, dt_gamma, max_steps)
+                sigma, rgb = self.net(xyzs, dirs, bound)
+                R.composite_rays(n_alive, n_step, alive, t, sigma, rgb, dl, ws, dep, img, T_thresh)
+                alive = alive[alive >= 0]        # the reference's compaction: a device -> host sync per iteration (renderer.py:542)
+                step += n_step
+                rows += n_alive * n_step
+                iters += 1
+            return torch.clamp(img + (1 - ws)[:, None], 0, 1), dep, ws, rows, iters
