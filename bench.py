@@ -263,18 +263,32 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
         opt.step()
         return loss
 
-    k_steps = args.steps if n_rays <= 65536 else max(3, args.steps // 3)
+    k_steps = args.steps if n_rays <= 65536 else max(5, args.steps // 2)
     for _ in range(max(args.warmup, 2)):
         step()
     torch.cuda.synchronize()
     overflow = int(ctr[0].item()) > mean_count[0]     # rays dropped because the buffer was too small (raymarching.cu:457)? must be False
     if world > 1:
         torch.distributed.barrier()
+    ms0 = torch.cuda.memory_stats(device)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(k_steps + 1)]   # step boundaries on the stream (no sync inside the loop)
+    import gc
+    gc.collect()
+    gc.disable()       # as timeit does: a generation-2 collection in the middle of a step is a host stall of tens of milliseconds
     t0 = time.perf_counter()
-    for _ in range(k_steps):
+    marks[0].record()
+    for i in range(k_steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / k_steps
+    gc.enable()
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(k_steps))
+    ms1 = torch.cuda.memory_stats(device)
+    # hipMalloc / hipFree calls of torch's caching allocator inside the timed region (each is a device-wide stall of milliseconds at these
+    # buffer sizes): must be 0 for the number to mean anything
+    dev_allocs = int(ms1.get("segment.all.allocated", 0) - ms0.get("segment.all.allocated", 0))
+    dev_frees = int(ms1.get("segment.all.freed", 0) - ms0.get("segment.all.freed", 0))
     n_samples[0] = int(ctr[0].item())      # samples of the last step (after the timed region)
     if world > 1:
         red = torch.tensor([dt, float(n_samples[0])], dtype=torch.float64, device=device)
@@ -288,6 +302,8 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
                          "march_rays_train -> head (see 'mlp') -> composite_rays_train_triplane -> MSE -> backward (weight gradients + grid "
                          "scatter-add) -> Adam; sample buffers sized by mean_count like the reference's steady state (no D2H copy in the step)",
                 rays=n_rays, samples_per_step=int(n_samples[0]), steps=k_steps, sample_buffer_overflow=overflow,
+                device_allocations_in_timed_region=dev_allocs, device_frees_in_timed_region=dev_frees,
+                ms_per_step_median=round(per_step[len(per_step) // 2], 3), ms_per_step_min=round(per_step[0], 3), ms_per_step_max=round(per_step[-1], 3),
                 ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
                 loss=float(loss.detach()), dtype=train_dtype(args), mlp={"fused": "fused head forward + backward kernels, " + ("activations recomputed in the backward (csrc/lz_head.hip, lz_head_bwd.hip)" if args.train_recompute else "forward records, backward starts from the record (csrc/lz_head_rec.hip" + (", lz_head_rec16.hip" if args.train_forward == "f16" else "") + "), " + ("f16" if "f16" in (args.train_forward, args.train_backward) else args.train_records) + " records"), "lz": "csrc/lz_linear.hip (MFMA f32)",
                      "torch": "torch/rocBLAS"}[args.train_mlp])
@@ -411,11 +427,15 @@ def timed(job, steps, warmup, world, device, timing=True):
     barrier()
     if timing:
         job.r.timing_start(steps * job.max_steps + 16)   # HIP event pair around every head launch, on the launch stream
+    import gc
+    gc.collect()
+    gc.disable()       # as timeit does
     t0 = time.perf_counter()
     for _ in range(steps):
         out, tiles = job.step()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     head_ms = job.r.timing_stop() if timing else []
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
