@@ -382,3 +382,42 @@ def test_march_confined_to_the_occupied_bounds_changes_no_sample(params, golden,
         assert int(outs[0]["state"][5]) > 1000
     else:
         assert int(outs[0]["state"][5]) == 0 and float(outs[0]["image"].min()) == 1.0
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_fused_frame_two_cascades_with_occupancy_bounds(params, golden, precision):
+    """bound = 2 (two cascade levels, renderer.py:93; tables sized for desired_resolution 512 * bound, network.py:131): the fused frame with
+    the march confined to the occupied bounds of BOTH levels (a blob in the inner level, a larger one in the outer level only) against
+    the unclipped kernel and the multi-launch loop -- mip_from_pos / mip_from_dt, per-level dilation and the union of the level boxes"""
+    from lzzx_nerf_amd.gridencoder import GridEncoder
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    from lzzx_nerf_amd.utils import frame_rays
+    bound = 2.0
+    enc = GridEncoder(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14, desired_resolution=512 * bound)
+    g = torch.Generator().manual_seed(21)
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    for n in ("xy", "yz", "xz"):
+        sd[f"encoder_{n}.embeddings"] = torch.rand(enc.embeddings.shape, generator=g) * 2 - 1
+        sd[f"encoder_{n}.offsets"] = enc.offsets.clone()
+    head = FusedTriplaneHead(sd, bound=bound, precision=precision)
+    H = W = 96
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = frame_rays(dev(pose), intr, H, W)
+    cond = (dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]))
+    # level 0 spans [-1, 1]^3, level 1 [-2, 2]^3: a blob around the origin in level 0 and a shell part only level 1 sees
+    cells = _blob(0, (64, 64, 64), 14) + _blob(1, (64, 64, 64), 9) + _blob(1, (80, 64, 100), 6)
+    bits = _bitfield_from_cells(cells, 128, 2)
+    aabb = torch.tensor([-bound, -bound / 2, -bound, bound, bound / 2, bound], device="cuda")
+    outs = []
+    for clip in (True, False):
+        r = TriplaneRenderer(head, dev(bits), bound=bound, cascade=2, aabb=aabb, mode="fused")
+        r.clip_to_occupancy = clip
+        r.steps_per_pass = 1
+        outs.append({k: v.clone() for k, v in r.render(ro, rd, *cond, count_samples=True, max_steps=256).items()})
+    loop = TriplaneRenderer(head, dev(bits), bound=bound, cascade=2, aabb=aabb, budget_factor=1, n_step_cap=1).render(ro, rd, *cond, count_samples=True, max_steps=256)
+    for other in (outs[1], loop):
+        for k in KEYS + ("ray_counts",):
+            assert torch.equal(outs[0][k], other[k]), k
+        assert int(outs[0]["state"][5]) == int(other["state"][5])
+    assert int(outs[0]["state"][5]) > 5000
