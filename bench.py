@@ -754,24 +754,38 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             aabb2 = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32, device=device)
             bits2 = torch.full((128 ** 3 // 8,), 255, dtype=torch.uint8, device=device)
             legs2 = {}
-            for tag, half in (("f32_tables", False), ("f16_tables", True)):
-                g2 = GenericHashgridNeRF(device, half_tables=half)
+
+            def time2(f):
                 for _ in range(2):
-                    out2 = g2.render(ro2, rd2, aabb2, bits2, max_steps=128)
+                    o = f()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(5):
-                    out2 = g2.render(ro2, rd2, aabb2, bits2, max_steps=128)
+                    o = f()
                 torch.cuda.synchronize()
-                ms2 = (time.perf_counter() - t0) / 5 * 1e3
-                legs2[tag] = dict(ms_per_frame=round(ms2, 3), rays_per_s=round(65536 / ms2 * 1e3, 1), sample_rows_per_frame=int(out2[3]),
-                                  sample_rows_per_s=round(out2[3] / ms2 * 1e3, 1), iterations_per_frame=int(out2[4]),
-                                  image_mean=float(out2[0].mean()))
+                return (time.perf_counter() - t0) / 5 * 1e3, o
+            for tag, half in (("f32_tables", False), ("f16_tables", True)):
+                g2 = GenericHashgridNeRF(device, half_tables=half)
+                ms2, out2 = time2(lambda: g2.render(ro2, rd2, aabb2, bits2, max_steps=128))
+                leg = dict(reference_loop=dict(ms_per_frame=round(ms2, 3), rays_per_s=round(65536 / ms2 * 1e3, 1), sample_rows_per_frame=int(out2[3]),
+                                               iterations_per_frame=int(out2[4]), note="renderer.py:495-561 on the operators: boolean-mask compaction, a host sync per iteration"))
+                img_ref = out2[0].clone()
+                from lzzx_nerf_amd.renderer import NetworkRenderer
+                for name, graph in (("device_loop", False), ("device_loop_hipgraph", True)):
+                    nr = NetworkRenderer(lambda x, d: g2.net(x, d, 1.0), bits2, bound=1.0, aabb=aabb2, graph=graph)
+                    ms3, o3 = time2(lambda: nr.render(ro2, rd2, max_steps=128))
+                    st3 = o3["state"].cpu().numpy()
+                    leg[name] = dict(ms_per_frame=round(ms3, 3), rays_per_s=round(65536 / ms3 * 1e3, 1), samples_per_frame=int(st3[5]),
+                                     samples_per_s=round(int(st3[5]) / ms3 * 1e3, 1), iterations_per_frame=int(st3[6]), rows_evaluated_per_frame=int(st3[6]) * 4 * 65536,
+                                     image_equal_to_reference_loop=bool(torch.equal(o3["image"], img_ref)))
+                    del nr
+                legs2[tag] = leg
                 del g2
             result["cfg2_hashgrid_render"] = dict(
                 workload="cfg2: 256x256 rays, max_steps 128, all-ones occupancy, get_encoder('hashgrid') defaults (D3 L16 C2 T2^19) + SH(4) + "
-                         "bias-free MLPs 32-64-16 / 31-64-3 (MFMA Linear kernels), the reference's inference loop on the operator API "
-                         "(march_rays / composite_rays / boolean-mask compaction with its host sync per iteration)", **legs2)
+                         "bias-free MLPs 32-64-16 / 31-64-3 (MFMA Linear kernels); reference_loop = the reference's inference loop on the operator API, "
+                         "device_loop = renderer.NetworkRenderer (loop state on the device, the network on the whole 4 N row budget per iteration, no "
+                         "host round trip), device_loop_hipgraph = the same with two iterations captured as one hipGraph and replayed", **legs2)
         except Exception as exc:
             err("cfg2_hashgrid_render", exc)
     log("leg: if not args.no_grid_roofline:")

@@ -332,3 +332,112 @@ class TriplaneRenderer:
         if rgb24:
             res["image_rgb24"] = b["out_rgb24"]
         return res
+
+
+class NetworkRenderer(TriplaneRenderer):
+    """The device-resident inference loop around ANY per-sample network (BASELINE cfg2: a generic hash-grid NeRF on the operator API):
+    run_cuda_for_inference's iteration (renderer.py:503-548) as lz_loop_march -> net -> lz_loop_composite with the loop state in device
+    memory, like TriplaneRenderer(mode="loop") -- but the network is a Python callable over torch tensors,
+
+        net(xyzs [rows, 3], dirs [rows, 3]) -> (sigma [rows], rgb [rows, 3])
+
+    evaluated every iteration on the WHOLE row budget (rows = budget_factor * N, static shapes): rows behind the iteration's n_alive *
+    n_step samples hold older samples whose results nobody reads.  That costs a few useless rows (the budget is what the schedule
+    fills while most rays are alive) and buys an iteration without a host round trip -- the reference syncs on `rays_alive[rays_alive >=
+    0]` every iteration -- and with static shapes, so that a pair of iterations (the alive list ping-pongs) is captured ONCE as a hipGraph
+    (torch.cuda.CUDAGraph over torch's kernels and this library's launches on the capturing stream) and replayed: the ~25 launches of an
+    iteration cost one graph launch.  Pixels and per-ray sample counts equal the reference loop's on the same operators (rays are
+    independent, compositing resumes exactly; tests/test_gpu_cfg2_render.py)."""
+
+    def __init__(self, net, density_bitfield, bound=1.0, cascade=None, grid_size=128, aabb=None, min_near=0.05, budget_factor=4, n_step_cap=4,
+                 graph=True):
+        super().__init__(None, density_bitfield, bound=bound, cascade=cascade, grid_size=grid_size, aabb=aabb, min_near=min_near,
+                         budget_factor=budget_factor, n_step_cap=n_step_cap, mode="loop")
+        self.net = net
+        self.use_graph = bool(graph)
+        self._graph = None        # (key, CUDAGraph) of two iterations
+
+    def _pair(self, b, N, dt_gamma, max_steps, T_thresh, count_samples):
+        st, ws = ptr(b.state), ptr(b.workspace)
+        for cur in (0, 1):
+            nxt = 1 - cur
+            call("lz_loop_march", st, N, N * self.budget_factor, self.n_step_cap, ptr(b.rays_alive[cur]), ptr(b.rays_alive[nxt]), ws, ptr(b.rays_t),
+                 ptr(self._rays_o), ptr(self._rays_d), self.bound, float(dt_gamma), int(max_steps), int(self.cascade), int(self.grid_size),
+                 ptr(self.bitfield), ptr(b.nears), ptr(b.fars), ptr(b.xyzs), ptr(b.dirs), ptr(b.deltas), ptr(b.ray_counts) if count_samples else None,
+                 stream())
+            sigma, rgb = self.net(b.xyzs, b.dirs)
+            b.sigmas.copy_(sigma.reshape(-1))
+            b.rgbs.copy_(rgb.reshape(-1, 3))
+            call("lz_loop_composite", st, N, float(T_thresh), ptr(b.rays_alive[nxt]), ptr(b.rays_t), ptr(b.sigmas), ptr(b.rgbs), ptr(b.deltas),
+                 ptr(b.amb_aud), ptr(b.amb_eye), ptr(b.unc), ptr(b.weights_sum), ptr(b.depth), ptr(b.image), ptr(b.amb_aud_sum), ptr(b.amb_eye_sum),
+                 ptr(b.unc_sum), ws, stream())
+
+    @torch.no_grad()
+    def render(self, rays_o, rays_d, dt_gamma=1.0 / 256, max_steps=128, T_thresh=1e-4, bg_color=1.0, count_samples=False):
+        """-> dict(image [N,3] blended + clamped, image_raw, weights_sum, depth, state, ray_counts if requested); ready in stream order"""
+        rays_o = rays_o.reshape(-1, 3).float().contiguous()
+        rays_d = rays_d.reshape(-1, 3).float().contiguous()
+        N, dev = rays_o.shape[0], rays_o.device
+        if N > MAX_RAYS_PER_PASS:
+            raise RuntimeError("NetworkRenderer renders at most %d rays per call" % MAX_RAYS_PER_PASS)
+        fresh = self._buf is None or self._buf.N != N
+        b = self._buffers(N, dev)
+        if fresh:   # rows no march has written yet are evaluated too: give the network finite positions there
+            b.xyzs.zero_(); b.dirs.zero_(); b.deltas.zero_()
+            b.amb_aud.zero_(); b.amb_eye.zero_(); b.unc.zero_()
+            self._graph = None
+        # the graph holds the addresses of the ray tensors: keep them in buffers of our own
+        if getattr(b, "ro", None) is None:
+            b.ro, b.rd = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
+        b.ro.copy_(rays_o); b.rd.copy_(rays_d)
+        self._rays_o, self._rays_d = b.ro, b.rd
+        call("lz_near_far_from_aabb", ptr(b.ro), ptr(b.rd), ptr(self.aabb), N, self.min_near, ptr(b.nears), ptr(b.fars), stream())
+        if count_samples:
+            b.ray_counts.zero_()
+        call("lz_loop_begin", N, int(max_steps), N * self.budget_factor, self.n_step_cap, ptr(b.nears), ptr(b.rays_alive[0]), ptr(b.rays_t), ptr(b.weights_sum),
+             ptr(b.depth), ptr(b.image), ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ptr(b.state), ptr(b.workspace), stream())
+        key = (N, float(dt_gamma), int(max_steps), float(T_thresh), bool(count_samples))
+        if self.use_graph and (self._graph is None or self._graph[0] != key):
+            # capture two iterations.  The capture itself executes nothing, and torch wants the ops warmed up on a side stream first:
+            # run one pair for real there (it is simply the frame's first pair), then capture
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._pair(b, N, dt_gamma, max_steps, T_thresh, count_samples)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._pair(b, N, dt_gamma, max_steps, T_thresh, count_samples)
+            self._graph = (key, g)
+            done_pairs = 1
+        else:
+            done_pairs = 0
+        limit = (int(max_steps) + 2) // 2 + 1          # pairs: n_step >= 1, plus the iteration that commits the last state
+        pending = []
+        it = done_pairs
+        while it < limit:
+            n = min(max(self.chunk // 2, 1), limit - it)
+            for _ in range(n):
+                if self.use_graph:
+                    self._graph[1].replay()
+                else:
+                    self._pair(b, N, dt_gamma, max_steps, T_thresh, count_samples)
+            it += n
+            k = len(pending)
+            slot = b.state_ring[k % len(b.state_ring)]
+            slot.copy_(b.state[:8], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending.append((ev, slot))
+            if k >= self.lookahead:
+                ev_old, slot_old = pending[k - self.lookahead]
+                ev_old.synchronize()
+                if int(slot_old[3]) == 1:
+                    break
+        bg = bg_color.to(dev, torch.float32).expand(N, 3).contiguous() if torch.is_tensor(bg_color) else None
+        call("lz_final_blend", ptr(b.image), ptr(b.weights_sum), ptr(bg), 1.0 if bg is not None else float(bg_color), N, ptr(b.out), stream())
+        self._keep = bg
+        res = dict(image=b.out, image_raw=b.image, weights_sum=b.weights_sum, depth=b.depth, state=b.state)
+        if count_samples:
+            res["ray_counts"] = b.ray_counts
+        return res
