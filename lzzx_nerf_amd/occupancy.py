@@ -39,6 +39,10 @@ def update_density_grid(head, density_grid, density_bitfield, enc_a, eye=None, b
     workspace = torch.empty((n + 255) // 256, dtype=torch.float32, device=dev)
     call("lz_density_grid_update", ptr(sigma), float(density_scale), float(decay), float(density_thresh), cascade, G, ptr(density_grid),
          ptr(density_bitfield), ptr(stats), ptr(workspace), stream())
+    # both tensors were written through raw pointers: tell torch (version counters), so that whoever keys derived data on them --
+    # TriplaneRenderer.occupied_bounds() on the bitfield -- sees the change
+    torch.autograd.graph.increment_version(density_grid)
+    torch.autograd.graph.increment_version(density_bitfield)
     return stats[0], stats[1]
 
 

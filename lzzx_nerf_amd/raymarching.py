@@ -91,6 +91,7 @@ class _packbits(Function):
         if bitfield is None:
             bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
         call("lz_packbits", ptr(grid), N, float(thresh), ptr(bitfield), stream())
+        torch.autograd.graph.increment_version(bitfield)   # a caller-supplied bitfield was written through its raw pointer
         return bitfield
 
 

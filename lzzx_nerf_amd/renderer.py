@@ -104,7 +104,9 @@ class TriplaneRenderer:
     def occupied_bounds(self):
         """device tensor [6]: world-space box of the occupied cells of `self.bitfield`, dilated by `occupancy_margin` cells of each level's own size and by
         at least four of the march's longest steps (dt_max = sqrt(3) cells of the outermost level), so that the march walks its last steps
-        in front of the first occupied cell with its ordinary cell tests.  Cached per (tensor, version): an in-place update of the bitfield (occupancy.update_density_grid) recomputes it."""
+        in front of the first occupied cell with its ordinary cell tests.  Cached per (tensor, version): an in-place update of the bitfield through torch or through this package
+        (occupancy.update_density_grid, raymarching.packbits into a supplied bitfield: both bump the version) recomputes it; code that writes
+        the bitfield through its raw pointer by other means calls invalidate_occupancy()."""
         bf = self.bitfield
         key = (bf.data_ptr(), bf._version, self.occupancy_margin)
         if self._occ is None or self._occ[0] != key:
@@ -113,6 +115,10 @@ class TriplaneRenderer:
             call("lz_occupied_bounds", ptr(bf), int(self.cascade), int(self.grid_size), self.bound, int(self.occupancy_margin), ptr(ws), ptr(box), stream())
             self._occ = (key, box, ws)
         return self._occ[1]
+
+    def invalidate_occupancy(self):
+        """forget the cached bounds of the occupied cells (the next fused frame rescans the bitfield)"""
+        self._occ = None
 
     def timing_start(self, n_pairs):
         """bracket every head launch of the following render() calls with HIP events (bench.py's roofline leg)"""

@@ -421,3 +421,28 @@ def test_fused_frame_two_cascades_with_occupancy_bounds(params, golden, precisio
             assert torch.equal(outs[0][k], other[k]), k
         assert int(outs[0]["state"][5]) == int(other["state"][5])
     assert int(outs[0]["state"][5]) > 5000
+
+
+def test_occupied_bounds_follow_an_in_place_update_of_the_bitfield(params, golden):
+    """The renderer caches the bounds of the occupied cells per (bitfield tensor, version).  raymarching.packbits into a supplied bitfield and
+    occupancy.update_density_grid write through raw pointers and bump the tensor's version, so the next frame rescans: rendering after
+    such an update equals a fresh renderer on the new bitfield (a stale box would cut the object that moved out of it)."""
+    from lzzx_nerf_amd import raymarching as R
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    from oracle import oracle as O
+    head, bits0, ro, rd, cond = setup(params, golden, 96, 96, "ellipsoid")
+    bitfield = dev(bits0).clone()
+    r = TriplaneRenderer(head, bitfield, bound=1.0, mode="fused")
+    a = {k: v.clone() for k, v in r.render(ro, rd, *cond, max_steps=128, count_samples=True).items()}
+    box0 = r.occupied_bounds().clone()
+    # a different scene written into the SAME tensor: a blob well outside the first box
+    cells = np.asarray(_blob(0, (30, 50, 20), 8), np.int64)
+    grid = np.zeros((1, 128 ** 3), np.float32)
+    grid[0, O.morton3D(cells[:, 1:].astype(np.int32))] = 1.0
+    R.packbits(dev(grid), 0.5, bitfield)
+    b = {k: v.clone() for k, v in r.render(ro, rd, *cond, max_steps=128, count_samples=True).items()}
+    assert not torch.equal(box0, r.occupied_bounds())
+    fresh = TriplaneRenderer(head, bitfield.clone(), bound=1.0, mode="fused").render(ro, rd, *cond, max_steps=128, count_samples=True)
+    for k in KEYS + ("ray_counts",):
+        assert torch.equal(b[k], fresh[k]), k
+    assert int(b["state"][5]) > 500 and not torch.equal(a["image"], b["image"])
