@@ -899,7 +899,39 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
                 aenc(auds)
             torch.cuda.synchronize()
             result["audio_frontend"] = dict(ms=round((time.perf_counter() - t0) / 20 * 1e3, 4), windows=8, dim_in=1024, launches=2)
-            del aenc, auds
+            del aenc
+            # the whole frame the way run_cuda_for_inference orders it (renderer.py:406-570): rays -> audio window -> enc_a -> torso
+            # background -> head (the fused frame kernel over that background) -> blended frame + the video pipe's RGB24
+            from lzzx_nerf_amd.pipeline import TalkingHeadFrame
+            from lzzx_nerf_amd.utils import frame_rays as fr3
+            full_sd = dict(sd)
+            full_sd.update(sdt)
+            full_sd.update(sda)
+            lin1 = torch.linspace(-1, 1, H, device=device)
+            bgc = torch.stack(torch.meshgrid(lin1, lin1, indexing="xy"), -1).reshape(-1, 2).contiguous()
+            pose_d = job.pose
+            legs3 = {}
+            for prec in ("f32", "f16"):
+                thf = TalkingHeadFrame(full_sd, bits_dev, bound=1.0, precision=prec, device=device, mode="fused")
+
+                def whole():
+                    ro3, rd3 = fr3(pose_d, job.intr, H, W)
+                    return thf.render(ro3, rd3, auds, eye=eye, ind_code=ind, bg_coords=bgc, poses=pose_d[None], ind_code_torso=indt,
+                                      bg_color=1.0, max_steps=args.max_steps, rgb24=True)
+                for _ in range(3):
+                    whole()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    o3 = whole()
+                torch.cuda.synchronize()
+                ms3 = (time.perf_counter() - t0) / 10 * 1e3
+                legs3[prec] = dict(ms_per_frame=round(ms3, 4), frames_per_s=round(1e3 / ms3, 1), samples_per_frame=int(o3["state"][5]))
+                del thf
+            result["talking_head_frame"] = dict(
+                workload=f"{H}x{W} frame, max_steps {args.max_steps}: ray generation + encode_audio (8 HuBERT windows) + torso branch on every pixel + "
+                         "triplane head over the torso background (fused frame kernel) + blend + RGB24, random torso / audio weights", **legs3)
+            del auds, bgc
         except Exception as exc:   # an optional leg must never take the headline line down
             result.setdefault("leg_errors", {})["torso_audio"] = repr(exc)
     # ---- CPU baseline (rank 0, N = 1): bounded, next to the GPU numbers; also PSNR / sample-count parity against the pinned checker ----
