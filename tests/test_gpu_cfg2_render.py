@@ -161,3 +161,31 @@ def test_cfg2_device_resident_loop_equals_the_reference_loop(graph):
         assert torch.equal(got["depth"], want[1]) and torch.equal(got["weights_sum"], want[2])
         assert int(got["state"][3]) == 1 and int(got["ray_counts"].sum()) == int(got["state"][5]) > 10000
         assert float(want[2].max()) > 0.5 and float(want[2].min()) < 0.5
+
+
+def test_network_renderer_small_batches_and_recapture():
+    """NetworkRenderer edge cases: a handful of rays (one workgroup of the loop kernels), a ray count change between frames (buffers and the
+    captured graph are rebuilt), rays that all miss the box (no sample: background), and a budget of one row per ray (the reference's)."""
+    from lzzx_nerf_amd.renderer import NetworkRenderer
+    from lzzx_nerf_amd.synthetic import GenericHashgridNeRF
+    from lzzx_nerf_amd.utils import frame_rays
+    g = GenericHashgridNeRF(torch.device("cuda"))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    bits = dev(ellipsoid_bitfield()[0])
+    aabb = dev(np.array([-1, -1, -1, 1, 1, 1], F32))
+    pose, intr = synthetic_camera(40, 40)
+    ro, rd = frame_rays(dev(pose), intr, 40, 40)
+    r = NetworkRenderer(lambda x, d: g.net(x, d, 1.0), bits, bound=1.0, aabb=aabb, graph=True)
+    for sel in (slice(0, 1600), slice(780, 787), slice(0, 1600, 3)):
+        want = g.render(ro[sel].contiguous(), rd[sel].contiguous(), aabb, bits, max_steps=64)
+        got = r.render(ro[sel], rd[sel], max_steps=64)
+        assert torch.equal(got["image"], want[0]) and torch.equal(got["weights_sum"], want[2]), sel
+    up = torch.zeros_like(rd)
+    up[:, 1] = 1.0
+    up[:, 0] = up[:, 2] = 1e-3
+    out = r.render(ro + torch.tensor([0.0, 5.0, 0.0], device="cuda"), up, max_steps=64)
+    assert float(out["image"].min()) == 1.0 and int(out["state"][5]) == 0
+    r1 = NetworkRenderer(lambda x, d: g.net(x, d, 1.0), bits, bound=1.0, aabb=aabb, budget_factor=1, n_step_cap=8, graph=False)
+    want = g.render(ro, rd, aabb, bits, max_steps=64)
+    got = r1.render(ro, rd, max_steps=64, count_samples=True)
+    assert torch.equal(got["image"], want[0]) and int(got["state"][72]) == want[3]      # the reference's schedule: the same rows, too
