@@ -245,6 +245,11 @@ template <> struct LzfHead<1> {
     __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
         lz_head16_slice<true>(c, lane, x, y, z, f, o);
     }
+    // two slot rows through the head together (lz_head16_slice_rows: every weight fragment read from LDS once for both)
+    template <typename ShFn>
+    __device__ static __forceinline__ void slice2(const Ctx& c, int lane, const float (&x)[2], const float (&y)[2], const float (&z)[2], ShFn (&f)[2], Out (&o)[2]) {
+        lz_head16_slice_rows<true, 2>(c, lane, x, y, z, f, o);
+    }
 };
 
 // S = samples one ray marches per pass (1, 2, 4, 8 or 16; a slice holds 16 / S rays).  S = 1 is the layout described at the top of the file.
@@ -474,8 +479,34 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
             }
             // ---------------- head: one slice per row of 16 slots, exactly a slice of the stand-alone head kernel ----------------
             typename HD::Out o;
+            int row0 = 0;
+            if constexpr (PREC == 1 && ROWS >= 2) {
+#ifndef LZ_NO_ROW_PAIRS
+                if ((have_mask & 0xffffull) && ((have_mask >> 16) & 0xffffull)) {     // wave-uniform: rows 0 and 1 both carry samples
+                    float px2[2], py2[2], pz2[2];
+                    typename HD::ShSlot f2[2] = {typename HD::ShSlot{slot, s, NS}, typename HD::ShSlot{slot, 16 + s, NS}};
+                    typename HD::Out o2[2];
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        px2[r] = __shfl(x, 16 * r + s, 64); py2[r] = __shfl(y, 16 * r + s, 64); pz2[r] = __shfl(z, 16 * r + s, 64);
+                    }
+                    HD::slice2(ctx, lane, px2, py2, pz2, f2, o2);
+                    my_slices += 2;
+                    if (q == 0) {
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const int rs = 16 * r + s;
+                            slot[SF_OSIG * NS + rs] = o2[r].sigma;
+                            slot[SF_OR * NS + rs] = o2[r].rgb[0]; slot[SF_OG * NS + rs] = o2[r].rgb[1]; slot[SF_OB * NS + rs] = o2[r].rgb[2];
+                            slot[SF_OA0 * NS + rs] = o2[r].ambaud; slot[SF_OA1 * NS + rs] = o2[r].eyeatt; slot[SF_OU * NS + rs] = o2[r].unc;
+                        }
+                    }
+                    row0 = 2;
+                }
+#endif
+            }
 #pragma unroll 1
-            for (int row = 0; row < ROWS; row++) {
+            for (int row = row0; row < ROWS; row++) {
                 if (ROWS > 1 && !((have_mask >> (16 * row)) & 0xffffull)) continue;   // no sample in this row
                 const int rs = 16 * row + s;                   // the slot whose sample this lane works on
                 const float px = __shfl(x, rs, 64), py = __shfl(y, rs, 64), pz = __shfl(z, rs, 64);

@@ -172,98 +172,184 @@ __device__ __forceinline__ void lz_head16_stage(const LzHead16Args& P, lz_h8* wl
     hc.unc_const = lz_softplusf(0.0f);   // test mode (network.py:243-249, 278)
 }
 
-template <bool IN_RANGE = false, typename ShFn>   // SH(4) source: LzShFromDir (lz_head_slice.h) or the frame kernel's per-ray LDS copy
-__device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane, float px, float py, float pz, ShFn shfn, LzHead16Out& out) {
+// R row tiles (R x 16 samples) through the head TOGETHER: every A fragment is read from LDS once and feeds R MFMAs (the weights are 59 KB
+// per slice: with one row per call the LDS array is busy 56 % of the fused f16 frame kernel's cycles), and the R accumulation chains
+// interleave.  The gathers stay one row at a time (36 loads in flight, the row's enc_x parked as two half operands = 8 registers), so
+// the register peak is the gather's plus 8 per parked row.  Per row the arithmetic and its order are those of a single-row call.
+template <int LAYER, int R>
+__device__ __forceinline__ void h_layer_rows(const lz_h8* __restrict__ wl, int lane, const lz_h8 (&b)[R][H_KS[LAYER]], lz_f4 (&acc)[R][H_NT[LAYER]]) {
+    constexpr int KS = H_KS[LAYER], NT = H_NT[LAYER];
+    const lz_h8* frag = wl + h_frag_base(LAYER) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int ft = 0; ft < NT; ft++) {
+            const lz_h8 a = frag[(ks * NT + ft) * 64];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[r][ks], acc[r][ft], 0, 0, 0);
+        }
+}
+
+template <bool IN_RANGE = false, int R = 1, typename ShFn>   // SH(4) source: LzShFromDir (lz_head_slice.h) or the frame kernel's per-ray LDS copy
+__device__ __forceinline__ void lz_head16_slice_rows(const LzHead16Ctx& hc, int lane, const float (&px)[R], const float (&py)[R], const float (&pz)[R],
+                                                     ShFn (&shfn)[R], LzHead16Out (&out)[R]) {
     const int q = lane >> 4;
+    const lz_f4 z4 = lz_f4{0, 0, 0, 0};
     // ---------------- gather (f32, the same code as lz_k_triplane_head: lz_head_gather.h): lane q holds enc_x features 4 i + q
-    float encx[9];
-    lz_head_gather<IN_RANGE, true>(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx);
     // enc_x as two half B operands (slot j of k-step ks <-> i = 8 ks + j); slot (1, q = 0, 1) is filled in for the sigma net
-    lz_h8 bx[2];
-    {   // h_round2: every f32 feature exists first, then its half (no v_fma_mixlo_f16 with the interpolation's last fma)
+    lz_h8 bx[R][2];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        float encx[9];
+        lz_head_gather<IN_RANGE, true>(hc.emb, hc.tab, px[r], py[r], pz[r], q, hc.bound, hc.two_bound, encx);
+        // h_round2: every f32 feature exists first, then its half (no v_fma_mixlo_f16 with the interpolation's last fma)
         const lz_u4v w0 = {h_round2(encx[0], encx[1]), h_round2(encx[2], encx[3]), h_round2(encx[4], encx[5]), h_round2(encx[6], encx[7])};
         const lz_u4v w1 = {h_round2(encx[8], 0.0f), 0u, 0u, 0u};
-        bx[0] = __builtin_bit_cast(lz_h8, w0);
-        bx[1] = __builtin_bit_cast(lz_h8, w1);
+        bx[r][0] = __builtin_bit_cast(lz_h8, w0);
+        bx[r][1] = __builtin_bit_cast(lz_h8, w1);
     }
 
     // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
-    lz_h8 att16;   // [4 t + r] = feature 16 t + 4 q + r
+    lz_h8 att16[R];   // [4 t + r] = feature 16 t + 4 q + r
     {
-        lz_f4 a1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-        h_layer<H_A1>(hc.wl, lane, bx, a1);
-        const lz_h8 b2[2] = {h_pair(a1[0], a1[1], true), h_pair(a1[2], a1[3], true)};
-        lz_f4 a2[2] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-        h_layer<H_A2>(hc.wl, lane, b2, a2);
-        att16 = h_pair(a2[0], a2[1], false);
+        lz_f4 a1[R][4];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) a1[r][t] = z4;
+        h_layer_rows<H_A1, R>(hc.wl, lane, bx, a1);
+        lz_h8 b2[R][2];
+        lz_f4 a2[R][2];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            b2[r][0] = h_pair(a1[r][0], a1[r][1], true);
+            b2[r][1] = h_pair(a1[r][2], a1[r][3], true);
+            a2[r][0] = z4; a2[r][1] = z4;
+        }
+        h_layer_rows<H_A2, R>(hc.wl, lane, b2, a2);
+#pragma unroll
+        for (int r = 0; r < R; r++) att16[r] = h_pair(a2[r][0], a2[r][1], false);
     }
     // ambient_aud = || att ||_2 in f32 (norm is an autocast-to-f32 op): lane partial over its 8 features, then over q
-    float ss = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) ss = lz_fmaf((float)att16[k], (float)att16[k], ss);
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    const float ambaud = h_sqrt32(ss);
+    for (int r = 0; r < R; r++) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) ss = lz_fmaf((float)att16[r][k], (float)att16[r][k], ss);
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        out[r].ambaud = h_sqrt32(ss);
+    }
     // ---------------- eye attention: 36 -> 16 -> 1, sigmoid (half) ----------------
-    float eyeatt = 0.0f;
+    float eyeatt[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) eyeatt[r] = 0.0f;
     if (hc.has_eye) {
-        lz_f4 e1[1] = {lz_f4{0, 0, 0, 0}};
-        h_layer<H_E1>(hc.wl, lane, bx, e1);
-        const lz_f4 z = lz_f4{0, 0, 0, 0};
-        const lz_h8 be[1] = {h_pair(e1[0], z, true)};
-        lz_f4 e2[1] = {lz_f4{0, 0, 0, 0}};
-        h_layer<H_E2>(hc.wl, lane, be, e2);
-        eyeatt = (float)(_Float16)h_sigmoid((float)(_Float16)e2[0][0]);   // valid on lanes q == 0
+        lz_f4 e1[R][1];
+#pragma unroll
+        for (int r = 0; r < R; r++) e1[r][0] = z4;
+        h_layer_rows<H_E1, R>(hc.wl, lane, bx, e1);
+        lz_h8 be[R][1];
+        lz_f4 e2[R][1];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            be[r][0] = h_pair(e1[r][0], z4, true);
+            e2[r][0] = z4;
+        }
+        h_layer_rows<H_E2, R>(hc.wl, lane, be, e2);
+#pragma unroll
+        for (int r = 0; r < R; r++) eyeatt[r] = (float)(_Float16)h_sigmoid((float)(_Float16)e2[r][0][0]);   // valid on lanes q == 0
     }
     // ---------------- sigma net: [enc_x 36 | enc_a * att 32 | eye * eye_att 1] -> 64 -> 64 -> 65 ----------------
-    lz_h8 geo16[2];
-    float sigma;
+    lz_h8 geo16[R][2];
     {
-        lz_h8 b1[3];
-        b1[0] = bx[0];
-        b1[1] = bx[1];
-        b1[1][1] = (hc.has_eye && q == 0) ? h_round(hc.eye_v * eyeatt) : (_Float16)0.0f;
-        b1[2] = h_encw(hc.tab, q, att16);
-        lz_f4 s1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-        h_layer<H_S1>(hc.wl, lane, b1, s1);
-        const lz_h8 b2[2] = {h_pair(s1[0], s1[1], true), h_pair(s1[2], s1[3], true)};
-        lz_f4 s2[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-        h_layer<H_S2>(hc.wl, lane, b2, s2);
-        const lz_h8 b3[2] = {h_pair(s2[0], s2[1], true), h_pair(s2[2], s2[3], true)};
-        lz_f4 s3[5] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-        h_layer<H_S3>(hc.wl, lane, b3, s3);
-        geo16[0] = h_pair(s3[0], s3[1], false);   // geo_feat, no activation (network.py:304)
-        geo16[1] = h_pair(s3[2], s3[3], false);
-        sigma = h_exp32((float)(_Float16)s3[4][0]);   // exp is an autocast-to-f32 op: half -> f32 in, f32 out; lanes q == 0
+        lz_h8 b1[R][3];
+        lz_f4 s1[R][4];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            b1[r][0] = bx[r][0];
+            b1[r][1] = bx[r][1];
+            b1[r][1][1] = (hc.has_eye && q == 0) ? h_round(hc.eye_v * eyeatt[r]) : (_Float16)0.0f;
+            b1[r][2] = h_encw(hc.tab, q, att16[r]);
+#pragma unroll
+            for (int t = 0; t < 4; t++) s1[r][t] = z4;
+        }
+        h_layer_rows<H_S1, R>(hc.wl, lane, b1, s1);
+        lz_h8 b2[R][2];
+        lz_f4 s2[R][4];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            b2[r][0] = h_pair(s1[r][0], s1[r][1], true);
+            b2[r][1] = h_pair(s1[r][2], s1[r][3], true);
+#pragma unroll
+            for (int t = 0; t < 4; t++) s2[r][t] = z4;
+        }
+        h_layer_rows<H_S2, R>(hc.wl, lane, b2, s2);
+        lz_h8 b3[R][2];
+        lz_f4 s3[R][5];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            b3[r][0] = h_pair(s2[r][0], s2[r][1], true);
+            b3[r][1] = h_pair(s2[r][2], s2[r][3], true);
+#pragma unroll
+            for (int t = 0; t < 5; t++) s3[r][t] = z4;
+        }
+        h_layer_rows<H_S3, R>(hc.wl, lane, b3, s3);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            geo16[r][0] = h_pair(s3[r][0], s3[r][1], false);   // geo_feat, no activation (network.py:304)
+            geo16[r][1] = h_pair(s3[r][2], s3[r][3], false);
+            out[r].sigma = h_exp32((float)(_Float16)s3[r][4][0]);   // exp is an autocast-to-f32 op: half -> f32 in, f32 out; lanes q == 0
+        }
     }
     // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
-    float rgb[3];
     {
-        shfn.prepare();
-        lz_h8 b1[3];
-        {
-            uint32_t shw[2];
-            h_sh_pk(shfn, q, shw);                                                  // SH 4 q + j, j < 4
-            const lz_u4v w = {shw[0], shw[1], q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16] : 0u, q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16 + 1] : 0u};
-            b1[0] = __builtin_bit_cast(lz_h8, w);
-        }
-        b1[1] = geo16[0];
-        b1[2] = geo16[1];
-        lz_f4 c1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-        h_layer<H_C1>(hc.wl, lane, b1, c1);
-        const lz_h8 b2[2] = {h_pair(c1[0], c1[1], true), h_pair(c1[2], c1[3], true)};
-        lz_f4 c2[1] = {lz_f4{0, 0, 0, 0}};
-        h_layer<H_C2>(hc.wl, lane, b2, c2);
+        lz_h8 b1[R][3];
+        lz_f4 c1[R][4];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
-            const _Float16 sg = (_Float16)h_sigmoid((float)(_Float16)c2[0][c]);
-            const _Float16 t1 = h_round((float)sg * 1.002f);
-            rgb[c] = (float)h_round((float)t1 - 0.001f);
+        for (int r = 0; r < R; r++) {
+            shfn[r].prepare();
+            uint32_t shw[2];
+            h_sh_pk(shfn[r], q, shw);                                                  // SH 4 q + j, j < 4
+            const lz_u4v w = {shw[0], shw[1], q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16] : 0u, q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16 + 1] : 0u};
+            b1[r][0] = __builtin_bit_cast(lz_h8, w);
+            b1[r][1] = geo16[r][0];
+            b1[r][2] = geo16[r][1];
+#pragma unroll
+            for (int t = 0; t < 4; t++) c1[r][t] = z4;
         }
-    }    out.sigma = sigma;
-    out.rgb[0] = rgb[0]; out.rgb[1] = rgb[1]; out.rgb[2] = rgb[2];
-    out.ambaud = ambaud;
-    out.eyeatt = eyeatt;
-    out.unc = hc.unc_const;
+        h_layer_rows<H_C1, R>(hc.wl, lane, b1, c1);
+        lz_h8 b2[R][2];
+        lz_f4 c2[R][1];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            b2[r][0] = h_pair(c1[r][0], c1[r][1], true);
+            b2[r][1] = h_pair(c1[r][2], c1[r][3], true);
+            c2[r][0] = z4;
+        }
+        h_layer_rows<H_C2, R>(hc.wl, lane, b2, c2);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
+                const _Float16 sg = (_Float16)h_sigmoid((float)(_Float16)c2[r][0][c]);
+                const _Float16 t1 = h_round((float)sg * 1.002f);
+                out[r].rgb[c] = (float)h_round((float)t1 - 0.001f);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        out[r].eyeatt = eyeatt[r];
+        out[r].unc = hc.unc_const;
+    }
+}
+
+template <bool IN_RANGE = false, typename ShFn>
+__device__ __forceinline__ void lz_head16_slice(const LzHead16Ctx& hc, int lane, float px, float py, float pz, ShFn shfn, LzHead16Out& out) {
+    const float x[1] = {px}, y[1] = {py}, z[1] = {pz};
+    ShFn f[1] = {shfn};
+    LzHead16Out o[1];
+    lz_head16_slice_rows<IN_RANGE, 1>(hc, lane, x, y, z, f, o);
+    out = o[0];
 }
 #endif
