@@ -541,6 +541,13 @@ F16_PMC_SUMMARY = "r3_f16_head_pmc_summary.json"   # tools/profile_bench.sh f16 
 F16_MFMA_PEAK_TFLOPS = 2500.0                      # dense f16 (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 
 
+def _pmc_per_launch(rec):
+    """counter value per launch from a tools/summarize_pmc.py record: the mean over all launches but the largest one (the profiled command's
+    first, cold launch now and then reads several times the others' WRITE_SIZE), the plain mean when there are fewer than three"""
+    n = rec["launches"]
+    return (rec["sum"] - rec["max"]) / (n - 1) if n >= 3 else rec["avg_per_launch"]
+
+
 def f16_head_roofline(samples, rows, steps, head_total_ms, n_launch, launches_with_work, dt, fused=True):
     """roofline object of the f16 head / fused f16 frame kernel: ALGORITHMIC FLOP/s (46 368 FLOP per marched sample, the network's own
     count) against the dense f16 MFMA peak -- `frac` is that quotient, nothing else.  The kernel's matrix work is small (59
@@ -568,7 +575,7 @@ def f16_head_roofline(samples, rows, steps, head_total_ms, n_launch, launches_wi
         bound = 1024 * 2.4e9 / cyc * 16 * (samples / max(rows, 1))                       # samples/s the chip's 1024 SIMDs could issue at 2.4 GHz
         fetch, write = pmc.get("FETCH_SIZE", {}).get(k), pmc.get("WRITE_SIZE", {}).get(k)
         if fetch and write:   # KiB per launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
-            r["traffic"] = round((2 * fetch["avg_per_launch"] + write["avg_per_launch"]) * 1024)
+            r["traffic"] = round((2 * _pmc_per_launch(fetch) + _pmc_per_launch(write)) * 1024)
             r["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE of " + F16_PMC_SUMMARY + ")"
         r["valu_issue"] = dict(note="diagnostic, not the roofline: the kernel's own instruction stream priced at the nominal clock",
                                valu_insts_per_slice=round(valu / slices, 1), mfma_per_slice=F16_SLICE_MFMAS, issue_cycles_per_slice=round(cyc, 1),
@@ -1077,8 +1084,8 @@ def main():
         try:
             pmc = json.load(open(pmc_path))
             k = "lz_k_frame<0, 1, 1>" if args.mode == "fused" else "lz_k_triplane_head<false>"
-            roofline["traffic"] = round((2 * pmc["FETCH_SIZE"][k]["avg_per_launch"] + pmc["WRITE_SIZE"][k]["avg_per_launch"]) * 1024)
-            roofline["traffic_unit"] = f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, averaged over all launches of profiles/{PMC_SUMMARY})"
+            roofline["traffic"] = round((2 * _pmc_per_launch(pmc["FETCH_SIZE"][k]) + _pmc_per_launch(pmc["WRITE_SIZE"][k])) * 1024)
+            roofline["traffic_unit"] = f"bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, mean over the launches of profiles/{PMC_SUMMARY} without the largest)"
             # fused: 24 B/ray in + ~68 B/ray out, plus the packed weights every workgroup stages into its LDS once (256 x 94 KB)
             roofline["algorithmic_bytes_per_launch"] = (round(92 * job.n_rays + min(256, (job.n_rays + 63) // 64) * 94080) if args.mode == "fused" else
                                                         round(52 * my_rows * args.steps / max(n_launch, 1)))
