@@ -308,9 +308,10 @@ __device__ __forceinline__ void lz_head16_slice_rows(const LzHead16Ctx& hc, int 
         lz_f4 c1[R][4];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            shfn[r].prepare();
+            ShFn f = shfn[r];              // a local copy: the polynomial values of LzShFromDir stay in registers (an array of them would not)
+            f.prepare();
             uint32_t shw[2];
-            h_sh_pk(shfn[r], q, shw);                                                  // SH 4 q + j, j < 4
+            h_sh_pk(f, q, shw);                                                        // SH 4 q + j, j < 4
             const lz_u4v w = {shw[0], shw[1], q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16] : 0u, q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16 + 1] : 0u};
             b1[r][0] = __builtin_bit_cast(lz_h8, w);
             b1[r][1] = geo16[r][0];
