@@ -300,6 +300,9 @@ typedef struct {
     uint32_t G;
     float density_thresh;        /* min(density_thresh_torso, mean_density_torso), renderer.py:603 */
 } lz_torso_params;
+/* enc_anchor [42] of a frame (network.py:179-183): anchor_points [3,4] warped by the inverse of the head pose [4,4] (row-major c2w),
+ * (x / w / z, y / w / z) per anchor, frequency-encoded with degree 3 -- one launch instead of torch.inverse's library kernels */
+int lz_torso_anchor_encode(const float* pose, const float* anchor_points, float* enc_anchor, lz_stream_t stream);
 /* bg_coords [N,2] in [-1,1] -> alpha [N], color [N,3], deform [N,2] (may be NULL); unmasked pixels get zeros */
 int lz_torso_forward(const lz_torso_params* p, const float* bg_coords, uint32_t N, float* alpha, float* color, float* deform,
                      lz_stream_t stream);

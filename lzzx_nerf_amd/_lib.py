@@ -114,6 +114,7 @@ SIGNATURES = {
     "lz_triplane_head_backward": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, C.POINTER(HeadBwdOut), vp],
     "lz_head_pack_weights_f16": [vp] * 9 + [i32, i32, vp, vp],
     "lz_torso_forward": [C.POINTER(TorsoParams), vp, u32, vp, vp, vp, vp],
+    "lz_torso_anchor_encode": [vp, vp, vp, vp],
     "lz_audio_encode": [C.POINTER(AudioParams), vp, vp, vp, vp],
     "lz_mark_untrained_grid": [vp, u32, f32, f32, f32, f32, u32, u32, f32, vp, vp, vp],
     "lz_density_grid_points": [vp, u32, u32, f32, vp, vp],

@@ -181,6 +181,61 @@ lz_k_torso_forward(LzTorsoArgs A, const float* __restrict__ bg_coords, uint32_t 
     if (deform_out) { deform_out[(size_t)n * 2] = dx[0]; deform_out[(size_t)n * 2 + 1] = dx[1]; }
 }
 
+// ---- the frame-constant anchor encoding (network.py:179-183) as one launch -------------------------------------------------------------
+// wrapped = anchor_points @ inverse(pose^T): row i is pose^-1 . a_i; (x / w / z, y / w / z) per anchor; frequency encoding of the 6 values,
+// degree 3 (lz_k_freq_forward's formula and order).  The 4 x 4 inverse is a Gauss-Jordan elimination with partial pivoting in double by
+// one thread -- torch runs an LU factorisation in f32 through a dozen library launches for it; the results agree to a few f32 ulp.
+__global__ void __launch_bounds__(64) lz_k_torso_anchor_encode(const float* __restrict__ pose, const float* __restrict__ anchors, float* __restrict__ enc) {
+    __shared__ float w6[6];
+    if (threadIdx.x == 0) {
+        double a[4][8];
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) { a[r][c] = (double)pose[r * 4 + c]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+        for (int col = 0; col < 4; col++) {
+            int piv = col;
+            for (int r = col + 1; r < 4; r++)
+                if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+            if (piv != col)
+                for (int c = 0; c < 8; c++) { const double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
+            const double inv = 1.0 / a[col][col];
+            for (int c = 0; c < 8; c++) a[col][c] *= inv;
+            for (int r = 0; r < 4; r++) {
+                if (r == col) continue;
+                const double f = a[r][col];
+                for (int c = 0; c < 8; c++) a[r][c] -= f * a[col][c];
+            }
+        }
+        for (int i = 0; i < 3; i++) {
+            double w[4];
+            for (int r = 0; r < 4; r++) {
+                w[r] = 0.0;
+                for (int c = 0; c < 4; c++) w[r] += a[r][4 + c] * (double)anchors[i * 4 + c];
+            }
+            w6[2 * i] = (float)(w[0] / w[3] / w[2]);
+            w6[2 * i + 1] = (float)(w[1] / w[3] / w[2]);
+        }
+    }
+    __syncthreads();
+    const uint32_t c = threadIdx.x;
+    if (c < 42) {
+        float v;
+        if (c < 6) v = w6[c];
+        else {
+            const uint32_t col = c / 6 - 1, d = c % 6, freq = col / 2;
+            const float phase = (float)(col % 2) * (3.141592653589793f / 2);
+            v = lz_sinf(lz_scalbnf(w6[d], (int)freq) + phase);
+        }
+        enc[c] = v;
+    }
+}
+
+extern "C" int lz_torso_anchor_encode(const float* pose, const float* anchor_points, float* enc_anchor, lz_stream_t stream) {
+    LZ_REQUIRE(pose && anchor_points && enc_anchor, LZ_ERR_BAD_ARGUMENT, "torso_anchor_encode: null tensor");
+    hipLaunchKernelGGL(lz_k_torso_anchor_encode, dim3(1), dim3(64), 0, lz_st(stream), pose, anchor_points, enc_anchor);
+    LZ_CHECK_LAUNCH("torso_anchor_encode");
+    return LZ_OK;
+}
+
 extern "C" int lz_torso_forward(const lz_torso_params* p, const float* bg_coords, uint32_t N, float* alpha, float* color, float* deform,
                                 lz_stream_t stream) {
     if (N == 0) return LZ_OK;

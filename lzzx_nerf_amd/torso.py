@@ -34,9 +34,13 @@ class FusedTorso:
 
     def encode_anchor(self, poses):
         """network.py:179-183: anchor points warped by the inverse head pose, perspective-divided, frequency-encoded -> [1, 42]"""
-        wrapped = self.anchor_points[None, ...] @ poses.to(self.device, torch.float32).permute(0, 2, 1).inverse()
-        wrapped = (wrapped[:, :, :2] / wrapped[:, :, 3, None] / wrapped[:, :, 2, None]).view(1, -1)
-        return self.anchor_encoder(wrapped.contiguous())
+        pose = poses.to(self.device, torch.float32).reshape(-1, 4, 4)
+        if pose.shape[0] != 1:
+            raise RuntimeError("encode_anchor: one head pose per frame (the reference's forward_torso asserts the same, network.py:179)")
+        pose = pose.contiguous()
+        enc = torch.empty(1, 42, dtype=torch.float32, device=self.device)
+        call("lz_torso_anchor_encode", ptr(pose), ptr(self.anchor_points), ptr(enc), stream())   # one launch; torch.inverse alone is a dozen
+        return enc
 
     @torch.no_grad()
     def forward(self, bg_coords, poses=None, ind_code=None, density_grid=None, density_thresh=0.0, enc_anchor=None):

@@ -130,7 +130,8 @@ def test_no_kernel_spills_registers():
         "_Z10lz_k_frameILi1ELi1ELi2EEvN7LzfHeadIXT_EE4ArgsE8LzFrameK": 2,
         "_Z10lz_k_frameILi1ELi1ELi3EEvN7LzfHeadIXT_EE4ArgsE8LzFrameK": 4,
     }
-    scratch_ok = {"_Z15lz_k_sh_forwardILi", "_Z25lz_k_grid_backward_lds_fxILj3E"}   # dynamically indexed local arrays off the hot path (SH degree >= 5 tables, D = 3 LDS backward)
+    # dynamically indexed local arrays off the hot path (SH degree >= 5 tables, D = 3 LDS backward, the one-thread 4 x 4 pivoted inverse)
+    scratch_ok = {"_Z15lz_k_sh_forwardILi", "_Z25lz_k_grid_backward_lds_fxILj3E", "_Z24lz_k_torso_anchor_encode"}
     n = 0
     for src, kernels in res.items():
         for name, r in kernels.items():
