@@ -879,7 +879,7 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
                 ta, tc, _ = torso(bgc, ind_code=indt, enc_anchor=enc_anchor)
             torch.cuda.synchronize()
             result["torso_branch"] = dict(ms=round((time.perf_counter() - t0) / 20 * 1e3, 4), pixels=H * W, launches=1,
-                                          note="all pixels queried (no 2-D occupancy mask); 5.4 kMAC per pixel on the VALU")
+                                          note="all pixels queried (no 2-D occupancy mask); 5.4 kMAC per pixel on v_mfma_f32_16x16x4_f32, 16 pixels per wave pass")
             del torso, bgc
             # encode_audio (AudioNet on 8 HuBERT windows [8, 1024, 16] + AudioAttNet) as one launch, random weights
             from lzzx_nerf_amd.audio import FusedAudioEncoder
