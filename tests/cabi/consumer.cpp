@@ -99,6 +99,10 @@ int main() {
                                                    nullptr, nullptr, nullptr, st) != 0);
     CHECK(lz_near_far_from_aabb(nullptr, nullptr, nullptr, 4, 0.05f, nullptr, nullptr, st) != 0);
     CHECK(lz_packbits(nullptr, 8, 0.5f, nullptr, st) != 0);
+    CHECK(lz_occupied_bounds(nullptr, 1, 128, 1.0f, 8, nullptr, nullptr, st) != 0);
+    CHECK(lz_occupied_bounds(d_bits, 9, 128, 1.0f, 8, d_idx, d_near, st) != 0);          // cascade out of range
+    CHECK(lz_torso_anchor_encode(nullptr, nullptr, nullptr, st) != 0);
+    CHECK(lz_frame_render(nullptr, nullptr, st) != 0);
     CHECK(lz_last_error()[0] != 0);
     HIP_OK(hipStreamSynchronize(st));                     // nothing was launched: the stream is still healthy
     LZ_OK_(lz_packbits(d_grid, G, 0.5f, d_bits, st));
