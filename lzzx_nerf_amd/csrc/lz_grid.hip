@@ -973,10 +973,39 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
     float gkeep[kKeep ? LZ_GRID_FX_KEEP : 1];
     const bool kept = kKeep && blockDim.x == 1024 && (b1 - b0) <= LZ_GRID_FX_KEEP * 1024u;   // workgroup-uniform
     float gm = 0.0f;
+    // kept path: which sample of a 1024-sample block a thread takes.  Consecutive samples are one ray's (march order) and project onto the
+    // SAME cell of a plane the ray is normal to (a camera looking along z: the xy plane) -- a wave of 64 consecutive samples then issues
+    // 64-way same-address LDS atomics, which retire at about one lane per cycle: 0.78 ms for the xy plane against 0.30 ms for the other
+    // two of a cfg3 step.  The spread map deals a wave 16 groups of 4 consecutive samples, 64 samples apart (<= 4 lanes per ray segment),
+    // at the price of 16-byte pieces instead of whole lines per load instruction: xy plane 0.83 -> 0.42 ms, the others 0.30 -> 0.40.  So
+    // the workgroup looks first: on its first 1024 samples, how many lanes sit in the same cell of THIS level as their neighbour?  More
+    // than half -> spread.  The sums are exact integers: the same bits under either map.
+    uint32_t tperm = threadIdx.x;
+    if constexpr (kKeep && D == 2) {
+        __shared__ int run_votes;
+        if (threadIdx.x == 0) run_votes = 0;
+        __syncthreads();
+        const uint32_t bb = b0 + threadIdx.x < b1 ? b0 + threadIdx.x : b1 - 1;
+        const float sx = lz_fmaf(inputs[(size_t)bb * 2], scale_l, align_corners ? 0.0f : 0.5f);
+        const float sy = lz_fmaf(inputs[(size_t)bb * 2 + 1], scale_l, align_corners ? 0.0f : 0.5f);
+        const int cx = (int)floorf(sx), cy = (int)floorf(sy);
+        const bool same = cx == __shfl_down(cx, 1, 64) && cy == __shfl_down(cy, 1, 64) && (threadIdx.x & 63u) != 63u;
+        const int cnt = __popcll(__ballot(same));
+        if ((threadIdx.x & 63u) == 0u && cnt) atomicAdd(&run_votes, cnt);
+        __syncthreads();
+#ifndef LZ_GRID_FX_GROUP
+#define LZ_GRID_FX_GROUP 4     /* consecutive samples a wave keeps together: 4 -> xy plane 0.46 ms, the others unchanged (tools: build.py --variant) */
+#endif
+        if (LZ_GRID_FX_GROUP < 64 && run_votes * 2 > (int)blockDim.x) {
+            constexpr uint32_t G = LZ_GRID_FX_GROUP;
+            const uint32_t l = threadIdx.x & 63u, w = threadIdx.x >> 6;
+            tperm = (l / G) * (16u * G) + w * G + (l % G);
+        }
+    }
     if (kept) {
 #pragma unroll
         for (uint32_t k = 0; k < (kKeep ? LZ_GRID_FX_KEEP : 1); k++) {
-            const uint32_t b = b0 + threadIdx.x + k * 1024u;
+            const uint32_t b = b0 + tperm + k * 1024u;
             gkeep[k] = b < b1 ? grad[sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C] : 0.0f;
             gm = fmaxf(gm, lz_abs_nan_inf(gkeep[k]));
         }
@@ -1078,7 +1107,7 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
     if (kept) {
 #pragma unroll
         for (uint32_t k = 0; k < (kKeep ? LZ_GRID_FX_KEEP : 1); k++) {
-            const uint32_t b = b0 + threadIdx.x + k * 1024u;
+            const uint32_t b = b0 + tperm + k * 1024u;
             if (b < b1) {
                 float gcur[C];
                 gcur[0] = gkeep[k];

@@ -1100,3 +1100,37 @@ def test_composite_reference_named_entry_points():
     call("lz_composite_rays", n_alive, n_step, 1e-2, ptr(al2), ptr(rt2), ptr(sig), ptr(rgb), ptr(deltas), ptr(w2), ptr(d2), ptr(im2), stream())
     for a, b in zip((al, rt, w_, d_, im_), (al2, rt2, w2, d2, im2)):
         assert torch.equal(a, b)
+
+
+def test_grid_backward_level_resident_on_runs_of_equal_cells():
+    """march-ordered samples of rays normal to a plane fall into the SAME cell in long runs; lz_k_grid_backward_lds_fx then deals the lanes of
+    a wave samples that lie 64 apart (its workgroups vote on their first 1024 samples) so that the LDS atomics do not all hit one address.
+    The fixed-point sums are exact integers, so the result must not depend on the map: runs of 1 .. 200 equal positions (plus jitter far
+    below a cell of the coarse levels) against the checker and against the same call on a shuffled copy of the samples."""
+    from lzzx_nerf_amd.gridencoder import GridEncoder
+    from lzzx_nerf_amd._util import call, ptr, stream
+    D, L, C, H, T, res = 2, 12, 1, 64, 14, 512
+    enc = GridEncoder(input_dim=D, num_levels=L, level_dim=C, base_resolution=H, log2_hashmap_size=T, desired_resolution=res).cuda()
+    rng = np.random.default_rng(5)
+    B = 60000
+    lens = rng.integers(1, 200, size=2000)
+    base = rng.uniform(0.05, 0.95, (len(lens), D)).astype(np.float32)
+    x = np.repeat(base, lens, axis=0)[:B]
+    x = (x + rng.uniform(-2e-4, 2e-4, x.shape)).astype(np.float32)
+    assert x.shape[0] == B
+    g = rng.normal(size=(B, L * C)).astype(np.float32)
+    off = host(enc.offsets)
+    ge, _ = O.grid_encode_backward(g, x, tuple(enc.embeddings.shape), off, enc.per_level_scale, H, None, 0)
+    S = float(np.float32(np.log2(enc.per_level_scale)))
+    outs = []
+    perm = rng.permutation(B)
+    for xs, gs in ((x, g), (x[perm], g[perm])):
+        gemb = torch.zeros_like(enc.embeddings.data)
+        gl = dev(np.ascontiguousarray(gs.reshape(B, L, C).transpose(1, 0, 2)))      # level-major, as the fused training head hands it over
+        call("lz_grid_encode_backward", ptr(gl), ptr(dev(xs)), ptr(enc.embeddings.data), ptr(enc.offsets), ptr(gemb), B, D, C, L, S, H,
+             None, None, 0, 0, 0, 3, stream())
+        outs.append(host(gemb))
+    scale = np.abs(ge).max()
+    assert np.max(np.abs(outs[0] - ge)) < 1e-4 * scale
+    # same terms, exact accumulation inside a workgroup; only the f32 flush of the per-chunk sums can differ in its last bits
+    assert np.max(np.abs(outs[0] - outs[1])) < 2e-6 * scale
