@@ -523,7 +523,13 @@ lz_k_exclusive_scan_1wg(int* __restrict__ data, uint32_t N, int* __restrict__ co
 }
 
 // pass 2: re-march and write (raymarching.cu:445-517); rays rows in ray order
-__global__ void __launch_bounds__(256)
+#ifndef LZ_MT_WG
+#define LZ_MT_WG 256
+#endif
+#ifndef LZ_MT_STAGE
+#define LZ_MT_STAGE 8    // rows a lane parks before the wave stores them (40 KB of LDS per workgroup)
+#endif
+__global__ void __launch_bounds__(LZ_MT_WG)
 lz_k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
                        float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                        const float* __restrict__ nears, const float* __restrict__ fars, const float* __restrict__ noises,
@@ -533,39 +539,75 @@ lz_k_march_train_write(const float* __restrict__ rays_o, const float* __restrict
     __shared__ uint32_t mlut[LZ_MORTON_LUT];
     lz_morton_lut_stage(mlut);
     __syncthreads();
+    // A lane walks its ray; its rows are NOT stored one by one -- 64 lanes x (12 + 12 + 8) bytes into 64 different rays' rows per step were
+    // 190 MB of scattered dword stores per cfg3 step, 0.23 ms against 0.045 ms for the same walk without stores (the count pass).  A lane
+    // parks up to LZ_MT_STAGE rows (x y z dt t) in LDS; when a lane's buffer is full (and at the end) the wave writes every ray's parked
+    // rows cooperatively: consecutive lanes -> consecutive floats of a ray's rows, 96-byte pieces instead of 4-byte ones.
+    constexpr int STG = LZ_MT_STAGE;
+    __shared__ float stage[LZ_MT_WG / 64][64][STG][5];
+    __shared__ float sdir[LZ_MT_WG / 64][64][3];
+    __shared__ uint32_t srow[LZ_MT_WG / 64][64], scnt[LZ_MT_WG / 64][64];
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    // offsets[] holds the exclusive scan; the ray's own count is the difference to its successor
-    const uint32_t off = (uint32_t)offsets[n];
-    const uint32_t nxt = (n + 1 < N) ? (uint32_t)counts_next[n + 1] : (uint32_t)(total[0] - base[0]);
-    const uint32_t num_steps = nxt - off;
-    const uint32_t point_index = (uint32_t)base[0] + off;
-    const uint32_t ray_index = (uint32_t)base[1] + n;
-    rays[(size_t)ray_index * 3] = (int)n;
-    rays[(size_t)ray_index * 3 + 1] = (int)point_index;
-    rays[(size_t)ray_index * 3 + 2] = (int)num_steps;
-    if (num_steps == 0) return;
-    if (point_index + num_steps > M) return;
-    LzMarch m;
-    m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
-    if (H <= LZ_MORTON_LUT) m.morton_lut = mlut;
-    const float far = fars[n];
-    float t = nears[n];
-    t = lz_fmaf(lz_clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
-    float* px = xyzs + (size_t)point_index * 3;
-    float* pd = dirs + (size_t)point_index * 3;
-    float* pl = deltas + (size_t)point_index * 2;
-    uint32_t step = 0;
-    float x, y, z, dt;
-    while (t < far && step < num_steps) {
-        if (m.probe(t, x, y, z, dt)) {
-            px[0] = x; px[1] = y; px[2] = z;
-            pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
-            t += dt;
-            pl[0] = dt; pl[1] = t;
-            px += 3; pd += 3; pl += 2; step++;
-        }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool active = n < N;
+    uint32_t num_steps = 0, point_index = 0;
+    if (active) {
+        // offsets[] holds the exclusive scan; the ray's own count is the difference to its successor
+        const uint32_t off = (uint32_t)offsets[n];
+        const uint32_t nxt = (n + 1 < N) ? (uint32_t)counts_next[n + 1] : (uint32_t)(total[0] - base[0]);
+        num_steps = nxt - off;
+        point_index = (uint32_t)base[0] + off;
+        const uint32_t ray_index = (uint32_t)base[1] + n;
+        rays[(size_t)ray_index * 3] = (int)n;
+        rays[(size_t)ray_index * 3 + 1] = (int)point_index;
+        rays[(size_t)ray_index * 3 + 2] = (int)num_steps;
+        if (num_steps == 0 || point_index + num_steps > M) active = false;     // nothing marched / dropped for lack of room (raymarching.cu:457)
     }
+    LzMarch m;
+    const uint32_t nc = n < N ? n : N - 1;
+    m.init(rays_o + (size_t)nc * 3, rays_d + (size_t)nc * 3, bound, dt_gamma, max_steps, C, H, grid);
+    if (H <= LZ_MORTON_LUT) m.morton_lut = mlut;
+    const float far = fars[nc];
+    float t = nears[nc];
+    t = lz_fmaf(lz_clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[nc], t);
+    sdir[wv][lane][0] = m.dx; sdir[wv][lane][1] = m.dy; sdir[wv][lane][2] = m.dz;
+    srow[wv][lane] = point_index;
+    uint32_t step = 0, nb = 0;
+    auto flush = [&]() {
+        scnt[wv][lane] = nb;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int idx = lane; idx < 64 * STG * 3; idx += 64) {
+            const int r = idx / (STG * 3), j = idx - r * (STG * 3);
+            if ((uint32_t)j < scnt[wv][r] * 3u) {
+                const size_t dst = (size_t)srow[wv][r] * 3 + j;
+                xyzs[dst] = stage[wv][r][j / 3][j % 3];
+                dirs[dst] = sdir[wv][r][j % 3];
+            }
+        }
+#pragma unroll 1
+        for (int idx = lane; idx < 64 * STG * 2; idx += 64) {
+            const int r = idx / (STG * 2), j = idx - r * (STG * 2);
+            if ((uint32_t)j < scnt[wv][r] * 2u) deltas[(size_t)srow[wv][r] * 2 + j] = stage[wv][r][j >> 1][3 + (j & 1)];
+        }
+        __builtin_amdgcn_wave_barrier();
+        srow[wv][lane] += nb;
+        nb = 0;
+    };
+    float x, y, z, dt;
+    for (;;) {
+        const bool can = active && t < far && step < num_steps;
+        if (!__ballot(can)) break;
+        if (can && m.probe(t, x, y, z, dt)) {
+            t += dt;
+            float* row = stage[wv][lane][nb];
+            row[0] = x; row[1] = y; row[2] = z; row[3] = dt; row[4] = t;
+            nb++;
+            step++;
+        }
+        if (__ballot(nb == (uint32_t)STG)) flush();
+    }
+    flush();
 }
 
 extern "C" int lz_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
@@ -583,7 +625,7 @@ extern "C" int lz_march_rays_train(const float* rays_o, const float* rays_d, con
     hipStream_t st = lz_st(stream);
     hipLaunchKernelGGL(lz_k_march_train_count, dim3(lz_div_up(N, 256)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, counts);
     hipLaunchKernelGGL(lz_k_exclusive_scan_1wg, dim3(1), dim3(1024), 0, st, counts, N, counter, base);
-    hipLaunchKernelGGL(lz_k_march_train_write, dim3(lz_div_up(N, 256)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, noises, counts, counts, base, counter, xyzs, dirs, deltas, rays);
+    hipLaunchKernelGGL(lz_k_march_train_write, dim3(lz_div_up(N, LZ_MT_WG)), dim3(LZ_MT_WG), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, noises, counts, counts, base, counter, xyzs, dirs, deltas, rays);
     LZ_CHECK_LAUNCH("march_rays_train");
     return LZ_OK;
 }
