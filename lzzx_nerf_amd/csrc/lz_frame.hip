@@ -710,8 +710,10 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     // 16-sample rows in flight (N * S / 16) reach that number otherwise (f->steps_per_pass overrides: 1, 2, 4, 8 or 16)
     uint32_t S = f->steps_per_pass;
     if (S == 0) {
+        // (the f16 head's passes are a quarter as long: it wants the rows in flight once over, not twice -- 32 768 rays: 0.45 ms at S = 2, 0.47 at 4)
+        const uint64_t want = (uint64_t)n_cu * LZF_WAVES * 16 * (p->precision == 1 ? 1 : 2);
         S = 1;
-        while (S < 16 && (uint64_t)f->N * S < (uint64_t)n_cu * LZF_WAVES * 16 * 2) S *= 2;
+        while (S < 16 && (uint64_t)f->N * S < want) S *= 2;
     }
     LZ_REQUIRE(S == 1 || S == 2 || S == 4 || S == 8 || S == 16, LZ_ERR_BAD_ARGUMENT, "frame_render: steps_per_pass must be 0 (auto), 1, 2, 4, 8 or 16");
     if (timing) (void)lz_timing_mark(timing, 0, stream);    // the event pair brackets the persistent kernel alone
@@ -742,7 +744,9 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
         static const bool force_rows = getenv("LZ_FRAME_ROWS") != nullptr;
         if (S == 1 && max_rows >= 3 && (uint64_t)f->N >= (uint64_t)n_cu * LZF_WAVES * 48 * (force_rows ? 1 : 2)) {
             hipLaunchKernelGGL((lz_k_frame<1, 1, 3>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
-        } else if (S == 1 && max_rows >= 2 && (uint64_t)f->N >= (uint64_t)n_cu * LZF_WAVES * 32) {
+        } else if (S == 1 && max_rows >= 2 && (uint64_t)f->N * 2 >= (uint64_t)n_cu * LZF_WAVES * 32 * (force_rows ? 2 : 3)) {
+            // two rows once the rays fill them 1.5 times over: with exactly one ray per slot nothing is ever refilled and the frame ends on
+            // emptying slices (one rank's tile of a frame sharded two ways, 131 072 rays: 1.30 ms with two rows, 1.17 with one)
             hipLaunchKernelGGL((lz_k_frame<1, 1, 2>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
         } else {
             LZF_SWITCH(1)
