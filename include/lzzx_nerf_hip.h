@@ -579,13 +579,26 @@ int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterations, lz_ti
 
 /* One inference frame as ONE persistent kernel (csrc/lz_frame.hip): near/far + first occupied cell + longest-rays-first queue
  * (2 small launches), then march -> head -> composite per ray slot with refill from the queue; no per-sample buffers, no host round
- * trip.  Equals the reference loop (renderer.py:406-570) under the schedule n_step = S (= steps_per_pass, 1 for whole frames).
- * Pixels do not depend on the schedule for any ray that ends (leaves the box / T < T_thresh) before max_steps; a ray still alive at
- * the cap stops at ceil(max_steps / S) * S samples -- the reference's loop tests the cap once per iteration (renderer.py:503-548), so
- * under ITS varying n_step such a ray gets up to max_steps + 7.  Callers that compare tiles of one frame on such rays pin S.
+ * trip.  Pixels, depth and sums of a ray do not depend on the iteration schedule except through the CAP: the reference's loop
+ * (renderer.py:406-570) tests `step < max_steps` once per iteration and advances step += n_step, n_step = max(min(N // n_alive, 8), 1)
+ * (:503,513,546), so every ray still alive at the cap has received the same frame-wide count C_eff = sum of n_step, in [max_steps,
+ * max_steps + 7].
+ *   cap_mode 1 (LZ_FRAME_CAP_REFERENCE): reproduces that.  Phase 1 stops rays at exactly max_steps and leaves, per ray, the last chunk
+ *     boundary it can survive; a histogram of those replays n_alive / n_step / C_eff on the device (no host round trip); phase 2
+ *     continues the rays that stood at the cap to C_eff samples.  Equal to the reference loop pixel for pixel whatever steps_per_pass is;
+ *     with ray_counts also count for count (a ray cut by T_thresh inside a chunk counts the chunk's marched samples, raymarching.py:347-398).
+ *     Ranks that render tiles of ONE frame set N_total and defer_finish, all-reduce (sum) cap_ws[0 .. max_steps] after lz_frame_render and
+ *     then call lz_frame_finish: their tiles equal the unsharded reference frame.  Needs ray_last, cap_ws; max_steps <= 4096.
+ *   cap_mode 0 (LZ_FRAME_CAP_PER_RAY): a ray alive at the cap stops at ceil(max_steps / S) * S samples, S = steps_per_pass: the loop under
+ *     the schedule n_step = S.  No histogram, no second phase, no exchange between ranks -- and not the reference's pixels on rays that
+ *     reach the cap (every ray that leaves the box or falls under T_thresh before max_steps is unaffected).
  * All pointers are device pointers; the caller owns every buffer.  state words after the call (stream order):
- *   [1] rays that had at least one sample, [3] 1, [5] marched samples, [6] 1, [72] sample rows evaluated by the head (16 per slice)
- *   -- words 3 / 5 / 6 / 72 as in lz_loop_state / LZ_LOOP_STAT_ROWS. */
+ *   [1] rays that had at least one sample, [3] 1, [5] composited samples (with ray_counts under cap_mode 1: marched samples = the sum of
+ *   ray_counts), [6] 1, [72] sample rows evaluated by the head (16 per slice) -- words 3 / 5 / 6 / 72 as in lz_loop_state /
+ *   LZ_LOOP_STAT_ROWS; cap_mode 1 adds [9] rays phase 2 continued, [10] C_eff, [11] iterations of the reference's loop. */
+#define LZ_FRAME_CAP_PER_RAY 0
+#define LZ_FRAME_CAP_REFERENCE 1
+#define LZ_FRAME_CAP_WS_INTS(max_steps) (2 * (max_steps) + 16)
 #define LZ_FRAME_STATE_INTS 1024
 typedef struct {
     lz_head_params head;           /* testing = 1; precision 0 (f32) or 1 (f16) */
@@ -617,6 +630,13 @@ typedef struct {
                                       occupied, and the t sequence of a ray does not depend on what the cells hold), without the ~130
                                       instructions per empty cell crossed */
     float* t_end;                  /* [N] scratch, required with occupied_aabb: where each ray's march ends */
+    uint32_t cap_mode;             /* LZ_FRAME_CAP_PER_RAY | LZ_FRAME_CAP_REFERENCE (see above) */
+    uint32_t N_total;              /* cap_mode 1: rays of the whole frame this call renders a tile of = the N of renderer.py:513 (0 = N) */
+    uint32_t defer_finish;         /* cap_mode 1: 1 = lz_frame_render stops behind the histogram; the caller (all-reduces it and) calls
+                                      lz_frame_finish with the same struct */
+    int32_t* ray_last;             /* cap_mode 1: [N] scratch */
+    int32_t* cap_ws;               /* cap_mode 1: LZ_FRAME_CAP_WS_INTS(max_steps) int32, zeroed by lz_frame_render; words [0 .. max_steps] =
+                                      histogram over the rays of the last chunk boundary each can survive (bin max_steps: alive at the cap) */
 } lz_frame_fused;
 /* World-space bounds {xmin, ymin, zmin, xmax, ymax, zmax} of the occupied cells of a density bitfield (bit index = level * H^3 +
  * morton(x, y, z), raymarching.cu:267-300), every level's cells dilated by `margin` cells of their own size and by at least four
@@ -628,6 +648,8 @@ int lz_occupied_bounds(const uint8_t* bitfield, uint32_t C, uint32_t H, float bo
 struct lz_timing;
 /* `timing` (may be NULL): bracket the persistent kernel with one event pair on the launch stream (lz_timing_create) */
 int lz_frame_render(const lz_frame_fused* f, struct lz_timing* timing, lz_stream_t stream);
+/* cap_mode 1 with defer_finish: schedule replay from cap_ws, phase 2, marched counts (see above); lz_frame_render calls it itself otherwise */
+int lz_frame_finish(const lz_frame_fused* f, lz_stream_t stream);
 
 /* Multi-GPU tile hand-off without a collective (lzzx_nerf_amd/dist.py: PeerTileGatherer): every rank copies its rendered tile straight
  * into each peer's frame buffer (one xGMI hop), then raises its flag there; lz_wait_flags makes `stream` wait, ON THE DEVICE, until all `n`

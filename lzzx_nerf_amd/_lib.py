@@ -53,7 +53,8 @@ class FrameFused(C.Structure):
                 ("order", vp), ("state", vp), ("keys", vp), ("weights_sum", vp), ("depth", vp), ("image", vp), ("amb_aud_sum", vp),
                 ("amb_eye_sum", vp), ("unc_sum", vp), ("out", vp), ("bg", vp), ("out_rgb24", vp), ("ray_counts", vp),
                 ("bg_scalar", f32), ("bound", f32), ("dt_gamma", f32), ("T_thresh", f32), ("min_near", f32),
-                ("N", u32), ("max_steps", u32), ("C", u32), ("H", u32), ("steps_per_pass", u32), ("noises", vp), ("occupied_aabb", vp), ("t_end", vp)]
+                ("N", u32), ("max_steps", u32), ("C", u32), ("H", u32), ("steps_per_pass", u32), ("noises", vp), ("occupied_aabb", vp), ("t_end", vp),
+                ("cap_mode", u32), ("N_total", u32), ("defer_finish", u32), ("ray_last", vp), ("cap_ws", vp)]
 
 
 # name -> argtypes, in the order of include/lzzx_nerf_hip.h
@@ -107,6 +108,7 @@ SIGNATURES = {
     "lz_timing_mark": [vp, i32, vp],
     "lz_timing_elapsed_ms": [vp, C.POINTER(f32), u32, C.POINTER(u32)],
     "lz_frame_render": [C.POINTER(FrameFused), vp, vp],
+    "lz_frame_finish": [C.POINTER(FrameFused), vp],
     "lz_occupied_bounds": [vp, u32, u32, f32, u32, vp, vp, vp],
     "lz_final_blend": [vp, vp, vp, f32, u32, vp, vp],
     "lz_final_blend_rgb24": [vp, vp, vp, f32, u32, vp, vp, vp],
@@ -139,7 +141,7 @@ PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_dev
          "lz_triplane_head_grad_w_workspace": ([], C.c_size_t)}
 
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
-ABI_VERSION = 8   # lz_abi_version() of the library this binding table describes (include/lzzx_nerf_hip.h)
+ABI_VERSION = 9   # lz_abi_version() of the library this binding table describes (include/lzzx_nerf_hip.h)
 
 _lib = None
 

@@ -22,6 +22,22 @@
 //     ray ids; lz_k_frame is the persistent kernel: 3 launches + 1 memset per frame, no host round trip, no per-sample HBM traffic
 //     (compulsory: 24 B/ray in, ~50 B/ray out).
 //   * No inter-workgroup communication; a wave leaves when the queue is dry and its slots are empty, so the grid always drains.
+//
+// The cap (cap_mode 1, the default of the Python renderer).  The reference tests `step < max_steps` once per ITERATION and advances
+// step += n_step with n_step = max(min(N // n_alive, 8), 1) (renderer.py:503-548), so every ray still alive at the cap has received the
+// same GLOBAL count C_eff = sum of n_step, somewhere in [max_steps, max_steps + 7] -- a property of the whole frame, not of the ray.
+// A ray is alive at the iteration that starts at sample boundary B exactly when B <= L, L = min(samples the box holds, tau - 1), tau =
+// the sample at which T < T_thresh fired (compositing kills a ray whose chunk was cut short, raymarching.cu:2193-2238).  So:
+//     phase 1   the persistent kernel as above with the cap at exactly max_steps; every ray leaves its L in ray_last (max_steps =
+//               still alive), rays at the cap park their accumulators in the output arrays and their t in rays_t;
+//     lz_k_frame_cap_hist   histogram of L over the rays (LDS per workgroup), parked rays compacted into the queue;
+//     [ranks rendering tiles of ONE frame all-reduce the max_steps + 1 histogram words here: lz_frame_finish]
+//     lz_k_frame_schedule   replays n_alive / n_step from the histogram: C_eff, the chunk boundaries;
+//     phase 2   the persistent kernel again over the parked rays, from their parked state, up to C_eff samples (no work, one early-out
+//               launch, when no ray reached the cap -- the 192-step headline frame);
+//     lz_k_frame_counts (only with ray_counts)   a ray cut by T_thresh inside a chunk was still MARCHED to the end of that chunk by the
+//               reference (raymarching.py:347-398): its count grows by the box samples behind tau up to the chunk's end.
+// cap_mode 0 keeps the per-ray cap ceil(max_steps / S) * S (no histogram, no second phase).
 #include <stdlib.h>
 
 #include "lz_march.h"
@@ -41,6 +57,13 @@
 #define LZF_SAMPLES 5     // marched = composited samples
 #define LZF_ITER 6        // 1: one persistent launch
 #define LZF_ROWS 72       // sample rows handed to the head (16 per slice)
+// cap_mode 1 (the reference's cap, see "the cap" below)
+#define LZF_P_HEAD 8      // phase 2: queue cursor over the rays phase 1 parked at max_steps
+#define LZF_P_SIZE 9      // rays parked by phase 1 that phase 2 continues (0 when C_eff == max_steps)
+#define LZF_CEFF 10       // C_eff: samples a ray alive at the cap receives under the reference's schedule
+#define LZF_SCHED_K 11    // iterations the reference's loop runs
+#define LZF_TICKET 12     // workgroups of lz_k_frame_cap_hist that have flushed
+#define LZF_CAP_MAX_STEPS 4096   // LDS histogram / schedule tables of the cap kernels
 #define LZF_HIST 128      // [256] rays per key
 #define LZF_CURSOR 384    // [256] scatter cursors
 
@@ -55,6 +78,10 @@ struct LzFrameK {
     const float* noises;
     const float* occ;     // [6] or null: bounds of the occupied cells (lz_occupied_bounds); the march is confined to them
     float* t_end;         // [N] with occ: where a ray's march ends (far, clipped to occ); the persistent kernel reads it instead of fars
+    // ---- the cap (cap_mode 1) ----
+    int* ray_last;        // [N]: L of every ray = the last chunk boundary it can survive, min(box samples, tau - 1), max_steps = parked at the cap
+    int* cap_ws;          // [0 .. max_steps] histogram of L (what ranks all-reduce), then the schedule tables (lz_k_frame_schedule)
+    uint32_t cap_mode, phase2, N_total;
 };
 
 __device__ __forceinline__ void lzf_write_pixel(const LzFrameK& F, int ray, float ws, float d, float r, float g, float b, float a0, float a1,
@@ -126,6 +153,7 @@ __global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
             atomicAdd(&hist[key], 1);
         } else {
             lzf_write_pixel(F, (int)n, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0);   // no sample on this ray: background
+            if (F.cap_mode) F.ray_last[n] = 0;     // alive in the reference's first iteration only
         }
         F.keys[n] = (uint8_t)key;
     }
@@ -221,6 +249,44 @@ __device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* 
     }
 }
 
+// a slot takes a ray: fresh accumulators (phase 1), or the ones phase 1 parked in the output arrays when the ray reached max_steps (phase 2)
+__device__ __forceinline__ void lzf_slot_take(const LzFrameK& F, bool ph2, int ray, float* slot, int* sloti, int sl, int ns) {
+    if (ph2) {
+        slot[SF_WS * ns + sl] = F.weights_sum[ray];
+        slot[SF_D * ns + sl] = F.depth[ray];
+        slot[SF_R * ns + sl] = F.image[(size_t)ray * 3];
+        slot[SF_G * ns + sl] = F.image[(size_t)ray * 3 + 1];
+        slot[SF_B * ns + sl] = F.image[(size_t)ray * 3 + 2];
+        slot[SF_A0 * ns + sl] = F.amb0_sum[ray];
+        slot[SF_A1 * ns + sl] = F.amb1_sum[ray];
+        slot[SF_U * ns + sl] = F.unc_sum[ray];
+        sloti[SF_CNT * ns + sl] = (int)F.max_steps;
+    } else {
+#pragma unroll
+        for (int f = SF_WS; f <= SF_U; f++) slot[f * ns + sl] = 0.0f;
+        sloti[SF_CNT * ns + sl] = 0;
+    }
+}
+// a ray leaves its slot.  kind: how it ended -- LZF_END_BOX no further sample in the box (`composited` = all it has), LZF_END_T the
+// compositing cut it at its `composited`-th sample (T < T_thresh), LZF_END_CAP alive after `composited` = cap samples.  cap_mode 1
+// records L for the schedule (phase 1), parks a capped ray's t for phase 2, and flags the count of a T-cut ray (negative, its t kept)
+// for lz_k_frame_counts; `report` is the count written otherwise.
+enum { LZF_END_BOX = 0, LZF_END_T = 1, LZF_END_CAP = 2 };
+__device__ __forceinline__ void lzf_ray_end(const LzFrameK& F, bool ph2, int ray, int kind, int composited, int report, float t, float ws, float d,
+                                            float r, float g, float b, float a0, float a1, float u) {
+    if (F.cap_mode) {
+        report = composited;
+        if (kind == LZF_END_T) {
+            if (F.ray_counts) { report = -composited; F.rays_t[ray] = t; }
+            if (!ph2) F.ray_last[ray] = composited - 1;
+        } else if (!ph2) {
+            F.ray_last[ray] = composited;          // LZF_END_CAP: composited == max_steps, the bin of the rays phase 2 continues
+            if (kind == LZF_END_CAP) F.rays_t[ray] = t;
+        }
+    }
+    lzf_write_pixel(F, ray, ws, d, r, g, b, a0, a1, u, report);
+}
+
 template <int PREC> struct LzfHead;
 template <> struct LzfHead<0> {
     using Args = LzHeadArgs; using Ctx = LzHeadCtx; using Out = LzHeadOut; using ShSlot = LzShFromSlot;
@@ -272,6 +338,9 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     __shared__ __align__(16) float lds[HD::LDS_WORDS + SLOT_WORDS + 4 + LZF_LUT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
+    // phase 2 of the reference's cap continues the rays phase 1 parked at max_steps; none parked (or C_eff == max_steps): nothing to stage
+    const bool ph2 = F.phase2 != 0;
+    if (ph2 && F.state[LZF_P_SIZE] <= 0) return;
     typename HD::Ctx ctx;
     HD::stage(P, lds, q, ctx);
     float* slot = lds + HD::LDS_WORDS + wave * NF * NS;      // this wave's slots: slot[field * 16 + s]
@@ -284,14 +353,18 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     const bool use_lut = F.H <= LZF_LUT;
     if (use_lut && threadIdx.x < LZF_LUT) mlut[threadIdx.x] = lz_expand_bits(threadIdx.x);
     __syncthreads();
-    const int n_queue = F.state[LZF_Q_SIZE];
+    const int n_queue = F.state[ph2 ? LZF_P_SIZE : LZF_Q_SIZE];
+    int* const q_head = F.state + (ph2 ? LZF_P_HEAD : LZF_Q_HEAD);
+    // samples at which a ray still alive is stopped: the per-ray cap ceil(max_steps / S) * S (cap_mode 0), or exactly max_steps in phase 1 and
+    // the schedule's C_eff in phase 2 (cap_mode 1)
+    const int cap = ph2 ? F.state[LZF_CEFF] : (F.cap_mode ? (int)F.max_steps : (((int)F.max_steps + S - 1) / S) * S);
+    const int cnt_base = ph2 ? (int)F.max_steps : 0;      // samples a ray brings along when it takes a slot
     LzMarch m;   // the frame-constant part of LzMarch (init() below sets the per-ray part)
     bool dry = n_queue <= 0;
     int my_samples = 0, my_slices = 0;
 
     if constexpr (S > 1) {
         const int j = s % S, lead = s - j;              // slot s = step j of the ray whose state sits at slot `lead`
-        const int max_passes = ((int)F.max_steps + S - 1) / S;
         for (;;) {
             if constexpr (PREC != 1) __builtin_amdgcn_s_setprio(2);   // see the S = 1 loop
             // ---------------- refill + march (group leaders): up to S samples per ray into the staging fields ----------------
@@ -304,7 +377,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 if (mask) {
                     const int first = __ffsll((long long)mask) - 1, take = __popcll(mask);
                     int base = 0;
-                    if (lane == first) base = atomicAdd(F.state + LZF_Q_HEAD, take);
+                    if (lane == first) base = atomicAdd(q_head, take);
                     base = __shfl(base, first, 64);
                     if (need) {
                         const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
@@ -313,10 +386,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             sloti[SF_RAY * 16 + s] = ray;
                             slot[SF_T * 16 + s] = F.rays_t[ray];
                             slot[SF_FAR * 16 + s] = (F.occ ? F.t_end[ray] : F.fars[ray]);
-#pragma unroll
-                            for (int f = SF_WS; f <= SF_U; f++) slot[f * 16 + s] = 0.0f;
-                            sloti[SF_CNT * 16 + s] = 0;
-                            sloti[SF_IT * 16 + s] = 0;
+                            lzf_slot_take(F, ph2, ray, slot, sloti, s, 16);
                             lzf_store_sh<PREC>(F, ray, slot, s, 16, SF_RD);
                         }
                     }
@@ -328,7 +398,8 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                     if (use_lut) m.morton_lut = mlut;
                     float t = slot[SF_T * 16 + s];
                     const float far = slot[SF_FAR * 16 + s];
-                    while (t < far && kk < S) {
+                    const int want = min(S, cap - sloti[SF_CNT * 16 + s]);      // >= 1: a ray at the cap has left its slot
+                    while (t < far && kk < want) {
                         float x, y, z, dt;
                         if (m.probe(t, x, y, z, dt)) {
                             const int sl = s + kk;
@@ -340,22 +411,23 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                         }
                     }
                     if (kk == 0) {     // the ray left the box without another sample
-                        lzf_write_pixel(F, ray, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s],
-                                        slot[SF_B * 16 + s], slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s], sloti[SF_CNT * 16 + s]);
-                        my_samples += sloti[SF_CNT * 16 + s];
+                        const int c0 = sloti[SF_CNT * 16 + s];
+                        lzf_ray_end(F, ph2, ray, LZF_END_BOX, c0, c0, t, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s],
+                                    slot[SF_B * 16 + s], slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s]);
+                        my_samples += c0 - cnt_base;
                         ray = -1;
                         sloti[SF_RAY * 16 + s] = -1;
                     }
                 }
                 if (!__ballot(leader && ray < 0 && !dry)) break;
             }
-            if (leader) sloti[SF_IT * 16 + s] = (sloti[SF_IT * 16 + s] & 0xffff) | (kk << 16);   // low half: passes done, high half: samples of this pass
+            if (leader) sloti[SF_IT * 16 + s] = kk;      // samples of this pass
             if (!__ballot(kk > 0)) {
                 if (dry) break;
                 continue;
             }
             // ---------------- head: slot s evaluates sample j of its ray when the leader staged one ----------------
-            const int lkk = sloti[SF_IT * 16 + lead] >> 16;
+            const int lkk = sloti[SF_IT * 16 + lead];
             const bool live = sloti[SF_RAY * 16 + lead] >= 0 && j < lkk;
             const float px = live ? slot[SF_X * 16 + s] : 0.0f, py = live ? slot[SF_Y * 16 + s] : 0.0f, pz = live ? slot[SF_Z * 16 + s] : 0.0f;
             typename HD::Out o;
@@ -388,12 +460,15 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                     if (T < F.T_thresh) break;
                     step++;
                 }
-                const int cnt = sloti[SF_CNT * 16 + s] + kk;                 // marched samples (renderer semantics: the chunk was marched)
-                const int passes = (sloti[SF_IT * 16 + s] & 0xffff) + 1;
-                const bool survives = step == kk && kk == S;                 // composited the whole chunk and the chunk was full
-                if (!survives || passes >= max_passes) {
-                    lzf_write_pixel(F, ray, ws, d, r, g, b, a0, a1, u, cnt);
-                    my_samples += cnt;
+                const int c0 = sloti[SF_CNT * 16 + s];
+                const int cnt = c0 + kk;                                     // marched samples (renderer semantics: the chunk was marched)
+                const bool cut = step < kk;                                  // T < T_thresh at sample c0 + step + 1
+                const bool short_chunk = kk < min(S, cap - c0);              // the box held fewer samples than the chunk wanted
+                if (cut || short_chunk || cnt >= cap) {
+                    const int kind = cut ? LZF_END_T : (short_chunk ? LZF_END_BOX : LZF_END_CAP);
+                    const int composited = cut ? c0 + step + 1 : cnt;
+                    lzf_ray_end(F, ph2, ray, kind, composited, cnt, t, ws, d, r, g, b, a0, a1, u);
+                    my_samples += (F.cap_mode ? composited : cnt) - cnt_base;
                     sloti[SF_RAY * 16 + s] = -1;
                 } else {
                     slot[SF_T * 16 + s] = t;
@@ -401,7 +476,6 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                     slot[SF_R * 16 + s] = r; slot[SF_G * 16 + s] = g; slot[SF_B * 16 + s] = b;
                     slot[SF_A0 * 16 + s] = a0; slot[SF_A1 * 16 + s] = a1; slot[SF_U * 16 + s] = u;
                     sloti[SF_CNT * 16 + s] = cnt;
-                    sloti[SF_IT * 16 + s] = passes;
                 }
             }
         }
@@ -425,7 +499,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 if (mask) {
                     const int leader = __ffsll((long long)mask) - 1, take = __popcll(mask);
                     int base = 0;
-                    if (lane == leader) base = atomicAdd(F.state + LZF_Q_HEAD, take);
+                    if (lane == leader) base = atomicAdd(q_head, take);
                     base = __shfl(base, leader, 64);
                     if (need) {
                         const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
@@ -434,9 +508,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             sloti[SF_RAY * NS + sl] = ray;
                             slot[SF_T * NS + sl] = F.rays_t[ray];
                             slot[SF_FAR * NS + sl] = (F.occ ? F.t_end[ray] : F.fars[ray]);
-#pragma unroll
-                            for (int f = SF_WS; f <= SF_U; f++) slot[f * NS + sl] = 0.0f;
-                            sloti[SF_CNT * NS + sl] = 0;
+                            lzf_slot_take(F, ph2, ray, slot, sloti, sl, NS);
                             lzf_store_sh<PREC>(F, ray, slot, sl, NS, SF_RD);
                         }
                     }
@@ -462,9 +534,10 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                         slot[SF_T * NS + sl] = t;
                         x = y = z = 0.0f;
                     } else {        // the ray left the box (renderer.py: the march writes no row, compositing kills the ray on delta == 0)
-                        lzf_write_pixel(F, ray, slot[SF_WS * NS + sl], slot[SF_D * NS + sl], slot[SF_R * NS + sl], slot[SF_G * NS + sl],
-                                        slot[SF_B * NS + sl], slot[SF_A0 * NS + sl], slot[SF_A1 * NS + sl], slot[SF_U * NS + sl], sloti[SF_CNT * NS + sl]);
-                        my_samples += sloti[SF_CNT * NS + sl];
+                        const int c0 = sloti[SF_CNT * NS + sl];
+                        lzf_ray_end(F, ph2, ray, LZF_END_BOX, c0, c0, t, slot[SF_WS * NS + sl], slot[SF_D * NS + sl], slot[SF_R * NS + sl], slot[SF_G * NS + sl],
+                                    slot[SF_B * NS + sl], slot[SF_A0 * NS + sl], slot[SF_A1 * NS + sl], slot[SF_U * NS + sl]);
+                        my_samples += c0 - cnt_base;
                         ray = -1;
                         sloti[SF_RAY * NS + sl] = -1;
                         x = y = z = 0.0f;
@@ -542,9 +615,9 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 const float a1 = slot[SF_A1 * NS + sl] + am1;
                 const float u = lz_fmaf(w, un, slot[SF_U * NS + sl]);
                 const int cnt = sloti[SF_CNT * NS + sl] + 1;
-                if (T < F.T_thresh || cnt >= (int)F.max_steps) {
-                    lzf_write_pixel(F, ray, ws, d, r, g, b, a0, a1, u, cnt);
-                    my_samples += cnt;
+                if (T < F.T_thresh || cnt >= cap) {
+                    lzf_ray_end(F, ph2, ray, T < F.T_thresh ? LZF_END_T : LZF_END_CAP, cnt, cnt, t, ws, d, r, g, b, a0, a1, u);
+                    my_samples += cnt - cnt_base;
                     sloti[SF_RAY * NS + sl] = -1;
                 } else {
                     slot[SF_T * NS + sl] = t;
@@ -569,6 +642,107 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
             if (b) atomicAdd(F.state + LZF_ROWS, 16 * b);
         }
     }
+}
+
+// ---- the reference's cap (cap_mode 1): histogram of L, schedule replay, marched counts ------------------------------------------------
+// cap_ws: [0 .. max_steps] histogram of L (bin max_steps = rays alive at the cap); behind it the schedule tables, see lzf_ws_*
+__host__ __device__ __forceinline__ int lzf_ws_chunk_end(int max_steps) { return max_steps + 1; }     // [max_steps + 9]: index c = 1-based sample
+
+// one lane per ray: LDS histogram of ray_last per workgroup, flushed with one atomic per non-empty bin; the rays parked at the cap are
+// compacted into the queue (order[]; phase 1 has consumed it) with one global atomic per workgroup
+__global__ void __launch_bounds__(256) lz_k_frame_cap_hist(LzFrameK F) {
+    extern __shared__ int ch_lds[];                      // [max_steps + 1] bins, then 2 words
+    const int bins = (int)F.max_steps + 1;
+    int* cnt = ch_lds + bins;                            // [0] parked rays of this workgroup, [1] their base in the queue
+    for (int i = threadIdx.x; i < bins + 2; i += blockDim.x) ch_lds[i] = 0;
+    __syncthreads();
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    int L = -1, rank = 0;
+    if (n < F.N) {
+        L = F.ray_last[n];
+        L = L < 0 ? 0 : (L > (int)F.max_steps ? (int)F.max_steps : L);
+        if (L == (int)F.max_steps) rank = atomicAdd(&cnt[0], 1);
+        else atomicAdd(&ch_lds[L], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt[0] > 0) {
+        cnt[1] = atomicAdd(F.state + LZF_P_SIZE, cnt[0]);
+        atomicAdd(F.cap_ws + F.max_steps, cnt[0]);
+    }
+    __syncthreads();
+    if (L == (int)F.max_steps) F.order[cnt[1] + rank] = (int)n;
+    for (int i = threadIdx.x; i < bins - 1; i += blockDim.x) {
+        const int h = ch_lds[i];
+        if (h) atomicAdd(F.cap_ws + i, h);
+    }
+}
+
+// one workgroup: suffix sums of the histogram (rays alive at boundary B = rays with L >= B), then the reference's loop on the counts alone
+// (renderer.py:503-548): n_alive -> n_step = max(min(N // n_alive, 8), 1) -> step += n_step while step < max_steps.  Writes C_eff, the
+// iteration count, chunk_end[c] = the boundary that closes the chunk of sample c (1-based), and empties phase 2's queue when C_eff ==
+// max_steps (the parked rays are complete as they are).
+__global__ void __launch_bounds__(1024) lz_k_frame_schedule(LzFrameK F) {
+    extern __shared__ int sc_lds[];                      // 2 x [max_steps + 2]: alive-at-boundary counts, ping-pong for the scan
+    const int ms = (int)F.max_steps;
+    int* alive = sc_lds;
+    int* other = sc_lds + ms + 2;
+    for (int i = threadIdx.x; i <= ms; i += blockDim.x) alive[i] = F.cap_ws[i];
+    __syncthreads();
+    for (int off = 1; off <= ms; off <<= 1) {            // suffix scan (Hillis-Steele)
+        for (int i = threadIdx.x; i <= ms; i += blockDim.x) other[i] = alive[i] + ((i + off <= ms) ? alive[i + off] : 0);
+        __syncthreads();
+        int* sw = alive; alive = other; other = sw;
+    }
+    if (threadIdx.x == 0) {
+        int* chunk_end = F.cap_ws + lzf_ws_chunk_end(ms);
+        const long long N = F.N_total ? (long long)F.N_total : (long long)F.N;
+        int B = 0, K = 0;
+        while (B < ms) {
+            const long long na = alive[B];
+            if (na <= 0) break;
+            long long q = N / na;
+            const int n_step = (int)(q > 8 ? 8 : (q < 1 ? 1 : q));
+            for (int c = B + 1; c <= B + n_step; c++) chunk_end[c] = B + n_step;
+            B += n_step;
+            K++;
+        }
+        F.state[LZF_CEFF] = B;
+        F.state[LZF_SCHED_K] = K;
+        if (B <= ms) F.state[LZF_P_SIZE] = 0;
+    }
+}
+
+// one lane per ray, only with ray_counts: a ray the compositing cut at sample tau (count flagged negative, t behind that sample in rays_t)
+// was marched by the reference to the end of the chunk holding tau: count = min(box samples, chunk_end[tau])
+__global__ void __launch_bounds__(256) lz_k_frame_counts(LzFrameK F) {
+    __shared__ uint32_t mlut[LZF_LUT];
+    __shared__ int extra_sum;
+    mlut[threadIdx.x] = lz_expand_bits(threadIdx.x);
+    if (threadIdx.x == 0) extra_sum = 0;
+    __syncthreads();
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    int extra = 0;
+    if (n < F.N) {
+        const int c = F.ray_counts[n];
+        if (c < 0) {
+            const int tau = -c;
+            const int end = F.cap_ws[lzf_ws_chunk_end((int)F.max_steps) + tau];
+            LzMarch m;
+            m.init(F.rays_o + (size_t)n * 3, F.rays_d + (size_t)n * 3, F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+            if (F.H <= LZF_LUT) m.morton_lut = mlut;
+            float t = F.rays_t[n], x, y, z, dt;
+            const float far = F.occ ? F.t_end[n] : F.fars[n];
+            while (t < far && tau + extra < end) {
+                if (m.probe(t, x, y, z, dt)) { t += dt; extra++; }
+            }
+            F.ray_counts[n] = tau + extra;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) extra += __shfl_xor(extra, off, 64);
+    if ((threadIdx.x & 63) == 0 && extra) atomicAdd(&extra_sum, extra);
+    __syncthreads();
+    if (threadIdx.x == 0 && extra_sum) atomicAdd(F.state + LZF_SAMPLES, extra_sum);
 }
 
 // ---- bounds of the occupied cells (once per bitfield; lz_frame_fused.occupied_aabb) ---------------------------------------------------
@@ -674,19 +848,7 @@ static void lzf_level_tables(const lz_head_params* p, float* scale, uint32_t* re
     }
 }
 
-extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_stream_t stream) {
-    LZ_REQUIRE(f, LZ_ERR_BAD_ARGUMENT, "frame_render: null");
-    const lz_head_params* p = &f->head;
-    LZ_REQUIRE(f->rays_o && f->rays_d && f->grid && f->aabb && f->nears && f->fars && f->rays_t && f->order && f->state && f->keys &&
-                   f->weights_sum && f->depth && f->image && f->amb_aud_sum && f->amb_eye_sum && f->unc_sum && f->out,
-               LZ_ERR_BAD_ARGUMENT, "frame_render: incomplete lz_frame_fused");
-    LZ_REQUIRE(p->emb_xy && p->emb_yz && p->emb_xz && p->offsets && p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT, "frame_render: incomplete lz_head_params");
-    LZ_REQUIRE(p->testing, LZ_ERR_UNSUPPORTED, "frame_render: inference only (head.testing must be 1)");
-    LZ_REQUIRE(p->precision >= 0 && p->precision <= 2, LZ_ERR_BAD_ARGUMENT, "frame_render: precision must be 0 (f32), 1 (f16) or 2 (f32, folded geo)");
-    LZ_REQUIRE(f->C >= 1 && f->C <= 8 && f->H > 0, LZ_ERR_BAD_ARGUMENT, "frame_render: cascade must be in [1, 8]");
-    if (f->N == 0) return LZ_OK;
-    hipStream_t st = lz_st(stream);
-    LzFrameK K;
+static int lzf_fill(const lz_frame_fused* f, LzFrameK& K) {
     K.rays_o = f->rays_o; K.rays_d = f->rays_d; K.grid = f->grid; K.aabb = f->aabb;
     K.nears = f->nears; K.fars = f->fars; K.rays_t = f->rays_t;
     K.order = f->order; K.state = f->state; K.keys = f->keys;
@@ -696,12 +858,35 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     K.N = f->N; K.max_steps = f->max_steps; K.C = f->C; K.H = f->H;
     K.noises = f->noises;
     K.occ = f->occupied_aabb; K.t_end = f->t_end;
-    LZ_REQUIRE(!f->occupied_aabb || f->t_end, LZ_ERR_BAD_ARGUMENT, "frame_render: occupied_aabb needs the t_end scratch buffer");
-    hipError_t rc = hipMemsetAsync(f->state, 0, LZ_FRAME_STATE_INTS * sizeof(int32_t), st);
-    if (rc != hipSuccess) { lz_set_error("frame_render: memset: %s", hipGetErrorString(rc)); return (int)rc; }
-    const uint32_t nb = lz_div_up(f->N, 256);
-    hipLaunchKernelGGL(lz_k_frame_prepare, dim3(nb), dim3(256), 0, st, K);
-    hipLaunchKernelGGL(lz_k_frame_scatter, dim3(nb), dim3(256), 0, st, K);
+    K.ray_last = f->ray_last; K.cap_ws = f->cap_ws; K.cap_mode = f->cap_mode; K.phase2 = 0; K.N_total = f->N_total;
+    return LZ_OK;
+}
+
+static int lzf_check(const lz_frame_fused* f, const char* who) {
+    const lz_head_params* p = &f->head;
+    LZ_REQUIRE(f->rays_o && f->rays_d && f->grid && f->aabb && f->nears && f->fars && f->rays_t && f->order && f->state && f->keys &&
+                   f->weights_sum && f->depth && f->image && f->amb_aud_sum && f->amb_eye_sum && f->unc_sum && f->out,
+               LZ_ERR_BAD_ARGUMENT, "%s: incomplete lz_frame_fused", who);
+    LZ_REQUIRE(p->emb_xy && p->emb_yz && p->emb_xz && p->offsets && p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT, "%s: incomplete lz_head_params", who);
+    LZ_REQUIRE(p->testing, LZ_ERR_UNSUPPORTED, "%s: inference only (head.testing must be 1)", who);
+    LZ_REQUIRE(p->precision >= 0 && p->precision <= 2, LZ_ERR_BAD_ARGUMENT, "%s: precision must be 0 (f32), 1 (f16) or 2 (f32, folded geo)", who);
+    LZ_REQUIRE(f->C >= 1 && f->C <= 8 && f->H > 0, LZ_ERR_BAD_ARGUMENT, "%s: cascade must be in [1, 8]", who);
+    LZ_REQUIRE(!f->occupied_aabb || f->t_end, LZ_ERR_BAD_ARGUMENT, "%s: occupied_aabb needs the t_end scratch buffer", who);
+    LZ_REQUIRE(f->cap_mode == LZ_FRAME_CAP_PER_RAY || f->cap_mode == LZ_FRAME_CAP_REFERENCE, LZ_ERR_BAD_ARGUMENT, "%s: cap_mode must be 0 (per ray) or 1 (the reference's schedule)", who);
+    if (f->cap_mode == LZ_FRAME_CAP_REFERENCE) {
+        LZ_REQUIRE(f->ray_last && f->cap_ws, LZ_ERR_BAD_ARGUMENT, "%s: cap_mode 1 needs the ray_last and cap_ws buffers", who);
+        LZ_REQUIRE(f->max_steps <= LZF_CAP_MAX_STEPS, LZ_ERR_UNSUPPORTED, "%s: cap_mode 1 supports max_steps <= %d", who, LZF_CAP_MAX_STEPS);
+        LZ_REQUIRE(f->N_total == 0 || f->N_total >= f->N, LZ_ERR_BAD_ARGUMENT, "%s: N_total is the ray count of the whole frame (>= N)", who);
+    }
+    // the heads' gathers run without range clamps here (lz_head_gather<IN_RANGE>): every sample the march emits is clamped to ITS bound
+    LZ_REQUIRE(f->bound > 0.0f && f->bound <= p->bound, LZ_ERR_BAD_ARGUMENT,
+               "%s: the march's bound must not exceed the head's (the reference uses one `bound` for both, renderer.py:94, network.py:100)", who);
+    return LZ_OK;
+}
+
+// the persistent kernel over the queue (phase 1) or over the rays parked at the cap (K.phase2)
+static int lzf_launch_persistent(const lz_frame_fused* f, const LzFrameK& K, hipStream_t st) {
+    const lz_head_params* p = &f->head;
     const int n_cu = lz_cu_count();   // of the current device, per call (cached per device)
     // one workgroup per CU (the weights fill most of its LDS); fewer when there are not enough rays for one slot row per wave
     uint32_t grid = lz_div_up(f->N, 16 * 4);   // at least 4 waves' worth of slots per workgroup
@@ -716,7 +901,6 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
         while (S < 16 && (uint64_t)f->N * S < want) S *= 2;
     }
     LZ_REQUIRE(S == 1 || S == 2 || S == 4 || S == 8 || S == 16, LZ_ERR_BAD_ARGUMENT, "frame_render: steps_per_pass must be 0 (auto), 1, 2, 4, 8 or 16");
-    if (timing) (void)lz_timing_mark(timing, 0, stream);    // the event pair brackets the persistent kernel alone
 #define LZF_LAUNCH(PREC, SS) hipLaunchKernelGGL((lz_k_frame<PREC, SS, 1>), dim3(grid), dim3(LZF_WG), 0, st, a, K)
 #define LZF_SWITCH(PREC)                                                        \
     switch (S) {                                                                \
@@ -726,9 +910,6 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
         case 8: LZF_LAUNCH(PREC, 8); break;                                     \
         default: LZF_LAUNCH(PREC, 16); break;                                   \
     }
-    // the heads' gathers run without range clamps here (lz_head_gather<IN_RANGE>): every sample the march emits is clamped to ITS bound
-    LZ_REQUIRE(f->bound > 0.0f && f->bound <= p->bound, LZ_ERR_BAD_ARGUMENT,
-               "frame_render: the march's bound must not exceed the head's (the reference uses one `bound` for both, renderer.py:94, network.py:100)");
     if (p->precision == 1) {
         LzHead16Args a;
         a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
@@ -761,7 +942,51 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     }
 #undef LZF_SWITCH
 #undef LZF_LAUNCH
+    return LZ_OK;
+}
+
+extern "C" int lz_frame_finish(const lz_frame_fused* f, lz_stream_t stream) {
+    LZ_REQUIRE(f, LZ_ERR_BAD_ARGUMENT, "frame_finish: null");
+    int rc = lzf_check(f, "frame_finish");
+    if (rc != LZ_OK) return rc;
+    LZ_REQUIRE(f->cap_mode == LZ_FRAME_CAP_REFERENCE, LZ_ERR_BAD_ARGUMENT, "frame_finish: only after lz_frame_render with cap_mode 1");
+    if (f->N == 0) return LZ_OK;
+    hipStream_t st = lz_st(stream);
+    LzFrameK K;
+    lzf_fill(f, K);
+    hipLaunchKernelGGL(lz_k_frame_schedule, dim3(1), dim3(1024), 2 * (f->max_steps + 2) * sizeof(int), st, K);
+    K.phase2 = 1;
+    rc = lzf_launch_persistent(f, K, st);
+    if (rc != LZ_OK) return rc;
+    if (f->ray_counts) hipLaunchKernelGGL(lz_k_frame_counts, dim3(lz_div_up(f->N, 256)), dim3(256), 0, st, K);
+    LZ_CHECK_LAUNCH("frame_finish");
+    return LZ_OK;
+}
+
+extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_stream_t stream) {
+    LZ_REQUIRE(f, LZ_ERR_BAD_ARGUMENT, "frame_render: null");
+    int rc = lzf_check(f, "frame_render");
+    if (rc != LZ_OK) return rc;
+    if (f->N == 0) return LZ_OK;
+    hipStream_t st = lz_st(stream);
+    LzFrameK K;
+    lzf_fill(f, K);
+    hipError_t hrc = hipMemsetAsync(f->state, 0, LZ_FRAME_STATE_INTS * sizeof(int32_t), st);
+    if (hrc != hipSuccess) { lz_set_error("frame_render: memset: %s", hipGetErrorString(hrc)); return (int)hrc; }
+    const bool ref_cap = f->cap_mode == LZ_FRAME_CAP_REFERENCE;
+    if (ref_cap) {
+        hrc = hipMemsetAsync(f->cap_ws, 0, LZ_FRAME_CAP_WS_INTS(f->max_steps) * sizeof(int32_t), st);
+        if (hrc != hipSuccess) { lz_set_error("frame_render: memset: %s", hipGetErrorString(hrc)); return (int)hrc; }
+    }
+    const uint32_t nb = lz_div_up(f->N, 256);
+    hipLaunchKernelGGL(lz_k_frame_prepare, dim3(nb), dim3(256), 0, st, K);
+    hipLaunchKernelGGL(lz_k_frame_scatter, dim3(nb), dim3(256), 0, st, K);
+    if (timing) (void)lz_timing_mark(timing, 0, stream);    // the event pair brackets the persistent kernel alone
+    rc = lzf_launch_persistent(f, K, st);
+    if (rc != LZ_OK) return rc;
     if (timing) (void)lz_timing_mark(timing, 1, stream);
+    if (ref_cap) hipLaunchKernelGGL(lz_k_frame_cap_hist, dim3(nb), dim3(256), (f->max_steps + 3) * sizeof(int), st, K);
     LZ_CHECK_LAUNCH("frame_render");
+    if (ref_cap && !f->defer_finish) return lz_frame_finish(f, stream);
     return LZ_OK;
 }

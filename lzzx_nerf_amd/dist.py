@@ -237,12 +237,19 @@ class ShardedFrame:
     """
 
     def __init__(self, H, W, rank, world, tiles="contiguous", device="cuda", channels=3, dtype=torch.float32, group=None,
-                 steps_per_pass=None, via="collective"):
-        """steps_per_pass: pin the fused renderer's samples-per-ray-and-pass S (`configure(renderer)`).  The fused frame is the
-        reference loop under the schedule n_step = S, and S is otherwise chosen from the ray count -- a rank's tile (N / world rays)
-        gets a larger S than the whole frame.  Pixels are schedule-independent for every ray that ends before `max_steps`; a ray
-        that reaches the cap receives ceil(max_steps / S) * S samples (the reference's loop tests the cap once per iteration,
-        renderer.py:503-548), so only a pinned S makes tiles and the unsharded frame agree on such rays too."""
+                 steps_per_pass=None, via="collective", cap="reference"):
+        """cap (`configure(renderer)` applies it to a fused TriplaneRenderer): the reference stops every ray that is still alive at
+        `max_steps` after the same FRAME-WIDE count C_eff = the sum of its loop's n_step = max(min(N // n_alive, 8), 1)
+        (renderer.py:503-548) -- N and n_alive being those of the whole frame.
+          "reference": the tiles reproduce that: every rank histograms its rays' last surviving chunk boundary, the max_steps + 1 int32
+            words are summed over the ranks (ONE small all-reduce between the two phases of the frame kernel) and every rank replays the
+            same schedule; the assembled frame equals the unsharded reference frame on every ray, whatever S each rank picked.
+          "per_ray": no exchange; a ray at the cap stops at ceil(max_steps / S) * S samples, so only a pinned `steps_per_pass` makes
+            tiles agree with each other (and none of them with the reference on those rays).
+        steps_per_pass: pin the fused renderer's samples-per-ray-and-pass S (launch shape; otherwise chosen from the tile's ray count)."""
+        if cap not in ("reference", "per_ray"):
+            raise ValueError("cap must be 'reference' or 'per_ray'")
+        self.cap, self.group = cap, group
         self.H, self.W, self.rank, self.world, self.tiles = H, W, rank, world, tiles
         self.steps_per_pass = steps_per_pass
         self.pixels = tile_pixels(H, W, rank, world, tiles, device)
@@ -257,10 +264,22 @@ class ShardedFrame:
         from .utils import frame_rays
         return frame_rays(pose, intrinsics, self.H, self.W, self.pixels)
 
+    def sum_over_ranks(self, hist):
+        """in-place sum of a small device tensor over the ranks of the frame (the cap histogram); a no-op for one rank"""
+        if self.world > 1 and dist.is_initialized():
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=self.group)
+        return hist
+
     def configure(self, renderer):
-        """apply the pinned schedule (if any) to a TriplaneRenderer; returns it"""
+        """apply the cap rule and the pinned launch shape (if any) to a TriplaneRenderer; returns it"""
         if self.steps_per_pass is not None:
             renderer.steps_per_pass = int(self.steps_per_pass)
+        renderer.cap = self.cap
+        if self.cap == "reference" and self.world > 1:
+            renderer.frame_rays_total = self.H * self.W
+            renderer.cap_exchange = self.sum_over_ranks
+        else:
+            renderer.frame_rays_total = renderer.cap_exchange = None
         return renderer
 
     def gather(self, tile):

@@ -58,21 +58,32 @@ class TriplaneRenderer:
     """
 
     def __init__(self, head: FusedTriplaneHead, density_bitfield, bound=1.0, cascade=None, grid_size=128, aabb=None,
-                 min_near=0.05, density_scale=1, budget_factor=1, n_step_cap=8, mode="loop"):
+                 min_near=0.05, density_scale=1, budget_factor=1, n_step_cap=8, mode="loop", cap="reference"):
         """mode "loop": the reference's iteration structure, 3 launches per iteration (march, head, composite), schedule
-        (budget_factor, n_step_cap).  mode "fused": the whole frame as one persistent kernel (csrc/lz_frame.hip) -- the loop under
-        the schedule n_step = S (`steps_per_pass`; 0 = chosen from the ray count: 1 for a whole frame, up to 16 for small tiles) with
-        on-the-fly refill of finished ray slots; same pixels, depth and sums, bit for bit, as the loop run with (budget_factor,
-        n_step_cap) = (S, S).
-        Cap semantics: the reference tests `step < max_steps` once per ITERATION (renderer.py:503-548), so a ray that is still alive
-        at the cap has received ceil(max_steps / n_step) * n_step samples -- up to max_steps + 7 under the reference's own varying
-        n_step.  Fused mode stops such a ray at ceil(max_steps / S) * S samples (exactly max_steps for S = 1).  Every ray that leaves
-        the box or falls under T_thresh before the cap -- all rays of a bounded scene with max_steps >= the longest chord / dt_min,
-        e.g. the 512^2 / 192-step headline frame -- is schedule-independent; for the others pin S (dist.ShardedFrame(steps_per_pass=))
-        when tiles of one frame must agree with each other."""
+        (budget_factor, n_step_cap).  mode "fused": the whole frame as one persistent kernel (csrc/lz_frame.hip) with on-the-fly refill of
+        finished ray slots; `steps_per_pass` (0 = chosen from the ray count: 1 for a whole frame, up to 16 for small tiles) is its launch shape.
+        Cap semantics: the reference tests `step < max_steps` once per ITERATION (renderer.py:503-548) with n_step = max(min(N // n_alive, 8), 1),
+        so every ray still alive at the cap has received the same frame-wide C_eff = sum of n_step samples, in [max_steps, max_steps + 7]
+        (the deployed max_steps = 16 binds on most foreground rays).
+          cap = "reference" (default): fused mode reproduces exactly that -- phase 1 to max_steps, a device-side replay of the schedule from
+            a histogram over the rays, phase 2 to C_eff -- and equals the loop under the reference schedule (1, 8) bit for bit: pixels, depth,
+            sums and, with count_samples, per-ray marched counts.  A tile of a larger frame passes the frame's ray count and a histogram
+            exchange (dist.ShardedFrame.configure does both) and then equals the unsharded frame.
+          cap = "per_ray": a ray alive at the cap stops at ceil(max_steps / S) * S samples, S = steps_per_pass -- the loop under the
+            schedule (budget_factor, n_step_cap) = (S, S); one launch less, no exchange between ranks, NOT the reference's pixels on rays
+            that reach the cap.
+        Every ray that leaves the box or falls under T_thresh before max_steps -- all rays of the 512^2 / 192-step headline frame -- is
+        the same under both."""
         if mode not in ("loop", "fused"):
             raise ValueError("mode must be 'loop' or 'fused'")
+        if cap not in ("reference", "per_ray"):
+            raise ValueError("cap must be 'reference' or 'per_ray'")
         self.mode = mode
+        self.cap = cap
+        # fused mode, cap "reference", when this renderer draws a TILE of a frame: the frame's ray count (the N of renderer.py:513) and a
+        # callable that sums the [max_steps + 1] int32 histogram over the ranks in place (dist.ShardedFrame.configure sets both)
+        self.frame_rays_total = None
+        self.cap_exchange = None
         self.steps_per_pass = 0    # fused mode: samples per ray and pass (0 = auto by ray count; 1, 2, 4, 8, 16 = the schedule n_step it equals)
         import math
         self.head = head
@@ -296,11 +307,25 @@ class TriplaneRenderer:
                       order=torch.empty(N, dtype=torch.int32, device=device), state=torch.zeros(1024, dtype=torch.int32, device=device),
                       keys=torch.empty(N, dtype=torch.uint8, device=device), weights_sum=torch.empty(N, **f), depth=torch.empty(N, **f),
                       image=torch.empty(N, 3, **f), amb_aud_sum=torch.empty(N, **f), amb_eye_sum=torch.empty(N, **f), unc_sum=torch.empty(N, **f),
-                      out=torch.empty(N, 3, **f), out_rgb24=None, ray_counts=None, t_end=torch.empty(N, **f))
+                      out=torch.empty(N, 3, **f), out_rgb24=None, ray_counts=None, t_end=torch.empty(N, **f),
+                      ray_last=torch.empty(N, dtype=torch.int32, device=device), cap_ws=None)
             self._fbuf = fb
         return fb
 
     def _render_fused(self, rays_o, rays_d, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg_color, count_samples, rgb24, noises=None):
+        ctx = self.fused_begin(rays_o, rays_d, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg_color, count_samples, rgb24, noises)
+        if ctx["deferred"] and self.cap_exchange is not None:
+            self.cap_exchange(ctx["hist"])
+        return self.fused_finish(ctx)
+
+    def fused_begin(self, rays_o, rays_d, enc_a, ind_code=None, eye=None, dt_gamma=1.0 / 256, max_steps=16, T_thresh=1e-4, bg_color=1.0,
+                    count_samples=False, rgb24=False, noises=None):
+        """Fused mode in two calls, for callers that render tiles of ONE frame under cap = "reference": fused_begin enqueues phase 1 and the
+        histogram of the rays' last surviving chunk boundary -- ctx["hist"], int32 [max_steps + 1] on the device; the caller sums it over all
+        tiles of the frame, in place -- and fused_finish(ctx) enqueues the schedule replay, phase 2 and returns the result dict.  With
+        frame_rays_total unset (a whole frame) and for cap = "per_ray" everything happens in fused_begin."""
+        rays_o = rays_o.reshape(-1, 3).float().contiguous()
+        rays_d = rays_d.reshape(-1, 3).float().contiguous()
         N, dev = rays_o.shape[0], rays_o.device
         b = self._fused_buffers(N, dev)
         h = self.head
@@ -329,13 +354,32 @@ class TriplaneRenderer:
         f.noises = None if noises is None else noises.data_ptr()
         if self.clip_to_occupancy:
             f.occupied_aabb, f.t_end = p(self.occupied_bounds()), p(b["t_end"])
+        deferred = False
+        if self.cap == "reference":
+            need = 2 * int(max_steps) + 16            # LZ_FRAME_CAP_WS_INTS
+            if b["cap_ws"] is None or b["cap_ws"].numel() < need:
+                b["cap_ws"] = torch.zeros(need, dtype=torch.int32, device=dev)
+            f.cap_mode, f.ray_last, f.cap_ws = 1, p(b["ray_last"]), p(b["cap_ws"])
+            if self.frame_rays_total is not None:
+                if int(self.frame_rays_total) < N:
+                    raise ValueError("frame_rays_total is the ray count of the whole frame (>= the rays of this call)")
+                f.N_total, f.defer_finish = int(self.frame_rays_total), 1
+                deferred = True
         call("lz_frame_render", C.byref(f), self._timing, stream())   # timing: one event pair around the persistent kernel
-        self._keep = (enc_a, ind_code, eye, bg, rays_o, rays_d, noises)
+        keep = (enc_a, ind_code, eye, bg, rays_o, rays_d, noises)
+        self._keep = keep
+        return dict(f=f, b=b, keep=keep, deferred=deferred, count_samples=count_samples, rgb24=rgb24,
+                    hist=b["cap_ws"][: int(max_steps) + 1] if deferred else None)
+
+    def fused_finish(self, ctx):
+        b = ctx["b"]
+        if ctx["deferred"]:
+            call("lz_frame_finish", C.byref(ctx["f"]), stream())
         res = dict(image=b["out"], image_raw=b["image"], weights_sum=b["weights_sum"], depth=b["depth"], amb_aud_sum=b["amb_aud_sum"],
                    amb_eye_sum=b["amb_eye_sum"], uncertainty_sum=b["unc_sum"], state=b["state"], nears=b["nears"], fars=b["fars"])
-        if count_samples:
+        if ctx["count_samples"]:
             res["ray_counts"] = b["ray_counts"]
-        if rgb24:
+        if ctx["rgb24"]:
             res["image_rgb24"] = b["out_rgb24"]
         return res
 

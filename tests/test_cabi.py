@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(_lib.ALL_SYMBOLS) == _declared()
     bound = _lib.load()
-    assert bound.lz_abi_version() == _lib.ABI_VERSION == 8
+    assert bound.lz_abi_version() == _lib.ABI_VERSION == 9
     assert bound.lz_head_packed_size() == 24576 and bound.lz_head_packed_size_f16() == 60416
 
 

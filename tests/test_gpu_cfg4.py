@@ -56,7 +56,7 @@ def test_frame_as_8_ray_shards_equals_unsharded(params, golden, tiles):
 
 
 def test_pinned_schedule_makes_tiles_agree_on_rays_that_reach_the_cap(params, golden):
-    """fused mode stops a ray that is still alive at the cap after ceil(max_steps / S) * S samples (the reference tests the cap once per
+    """cap = "per_ray": fused mode stops a ray that is still alive at the cap after ceil(max_steps / S) * S samples (the reference tests the cap once per
     iteration, renderer.py:503-548) and picks S from the ray count -- so a tile and the whole frame differ on such rays unless S is
     pinned (ShardedFrame(steps_per_pass=)).  All-ones occupancy, dt_gamma 0 and a 19-step cap: every ray that enters the box hits it."""
     from lzzx_nerf_amd import dist as D
@@ -71,7 +71,7 @@ def test_pinned_schedule_makes_tiles_agree_on_rays_that_reach_the_cap(params, go
     kw = dict(max_steps=19, dt_gamma=0.0, count_samples=True)
     world = 4
     for S, cap in ((1, 19), (4, 20), (8, 24)):
-        full_sf = D.ShardedFrame(H, W, 0, 1, device="cuda", steps_per_pass=S)
+        full_sf = D.ShardedFrame(H, W, 0, 1, device="cuda", steps_per_pass=S, cap="per_ray")
         r = full_sf.configure(TriplaneRenderer(head, bits, bound=1.0, mode="fused"))
         ro, rd = full_sf.rays(dev(pose), intr)
         ref = {k: v.clone() for k, v in r.render(ro, rd, *cond, **kw).items()}
@@ -80,7 +80,7 @@ def test_pinned_schedule_makes_tiles_agree_on_rays_that_reach_the_cap(params, go
         assert torch.equal(loop["image"], ref["image"]) and torch.equal(loop["ray_counts"], ref["ray_counts"])
         imgs, cnts = [], []
         for g in range(world):
-            sf = D.ShardedFrame(H, W, g, world, "interleaved", device="cuda", steps_per_pass=S)
+            sf = D.ShardedFrame(H, W, g, world, "interleaved", device="cuda", steps_per_pass=S, cap="per_ray")
             sf.gatherer = None
             rr = sf.configure(TriplaneRenderer(head, bits, bound=1.0, mode="fused"))
             o = rr.render(*sf.rays(dev(pose), intr), *cond, **kw)
@@ -89,7 +89,7 @@ def test_pinned_schedule_makes_tiles_agree_on_rays_that_reach_the_cap(params, go
         assert torch.equal(D.assemble_frame(torch.cat(imgs), H, W, world, "interleaved"), ref["image"]), S
         assert torch.equal(D.assemble_frame(torch.cat(cnts)[:, None], H, W, world, "interleaved")[:, 0], ref["ray_counts"]), S
     # unpinned: the 4 096-ray tile picks S > 1, the 16 384-ray frame may pick another -> counts at the cap differ, as documented
-    auto_tile = TriplaneRenderer(head, bits, bound=1.0, mode="fused").render(*D.ShardedFrame(H, W, 0, world, "interleaved", device="cuda").rays(dev(pose), intr), *cond, **kw)
+    auto_tile = TriplaneRenderer(head, bits, bound=1.0, mode="fused", cap="per_ray").render(*D.ShardedFrame(H, W, 0, world, "interleaved", device="cuda").rays(dev(pose), intr), *cond, **kw)
     assert int(auto_tile["ray_counts"].max()) in (19, 20, 24, 32)
 
 

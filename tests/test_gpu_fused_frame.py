@@ -1,7 +1,9 @@
 """The whole frame as one persistent kernel (csrc/lz_frame.hip, TriplaneRenderer(mode="fused")) against the multi-launch loop and the
-CPU checker.  The fused kernel is the reference loop (renderer.py:406-570) under the schedule n_step = 1, so against the loop /
-checker run with (budget_factor, n_step_cap) = (1, 1) EVERYTHING is bit-identical, per-ray sample counts included; against any other
-schedule the pixels and sums are (counts too unless T_thresh cuts a ray inside a chunk)."""
+CPU checker.
+  cap = "reference" (the default): the fused frame reproduces the reference loop's frame-wide cap C_eff (renderer.py:503-548) and is
+    bit-identical -- pixels, depth, sums, per-ray marched counts -- to the loop / checker under the REFERENCE schedule (budget_factor,
+    n_step_cap) = (1, 8), whatever steps_per_pass is and also as tiles of one frame (test_fused_reference_cap_*).
+  cap = "per_ray": the loop under the schedule n_step = S; against the loop / checker run with (S, S) everything is bit-identical."""
 import numpy as np
 import pytest
 import torch
@@ -29,9 +31,9 @@ def setup(params, golden, H, W, scene, precision="f32"):
     return head, bits, ro, rd, cond
 
 
-def both(head, bits, ro, rd, cond, loop_schedule=(1, 1), steps_per_pass=1, **kw):
+def both(head, bits, ro, rd, cond, loop_schedule=(1, 1), steps_per_pass=1, cap="per_ray", **kw):
     from lzzx_nerf_amd.renderer import TriplaneRenderer
-    fr = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
+    fr = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused", cap=cap)
     fr.steps_per_pass = steps_per_pass
     fused = fr.render(ro, rd, *cond, count_samples=True, **kw)
     fused = {k: v.clone() for k, v in fused.items()}
@@ -134,7 +136,7 @@ def test_fused_frame_auto_steps_per_pass_keeps_pixels(params, golden):
     from lzzx_nerf_amd import dist as D
     from lzzx_nerf_amd.renderer import TriplaneRenderer
     head, bits, ro, rd, cond = setup(params, golden, 512, 512, "ones")
-    r = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
+    r = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused", cap="per_ray")
     full = r.render(ro, rd, *cond, max_steps=192)["image"].clone()
     px = D.tile_pixels(512, 512, 3, 8, "interleaved", "cuda")
     tile = r.render(ro[px].contiguous(), rd[px].contiguous(), *cond, max_steps=192)
@@ -191,7 +193,7 @@ def test_fused_frame_two_cascades(golden, S):
     ro, rd = frame_rays(dev(pose), intr, H, W)
     cond = (dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]))
     from lzzx_nerf_amd.renderer import TriplaneRenderer
-    fr = TriplaneRenderer(head, dev(bits), bound=bound, mode="fused")
+    fr = TriplaneRenderer(head, dev(bits), bound=bound, mode="fused", cap="per_ray")
     fr.steps_per_pass = S
     fused = {k: v.clone() for k, v in fr.render(ro, rd, *cond, max_steps=96, count_samples=True).items()}
     loop = TriplaneRenderer(head, dev(bits), bound=bound, budget_factor=S, n_step_cap=S).render(ro, rd, *cond, max_steps=96, count_samples=True)
@@ -249,7 +251,7 @@ def test_perturb_on_the_fast_paths_equals_the_reference_loop_with_the_same_noise
     plain = render_inference(TriplaneSpec(1.0), params, ro.cpu().numpy(), rd.cpu().numpy(), bits, golden["net_enc_a"], golden["net_ind"],
                              golden["net_eye"], budget_factor=S, n_step_cap=S, **kw)
     assert not np.array_equal(ref["image"], plain["image"])
-    fr = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
+    fr = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused", cap="per_ray")
     fr.steps_per_pass = S
     fused = {k: v.clone() for k, v in fr.render(ro, rd, *cond, count_samples=True, noises=dev(noise), **kw).items()}
     loop = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=S, n_step_cap=S).render(ro, rd, *cond, count_samples=True, noises=dev(noise), **kw)
@@ -368,7 +370,7 @@ def test_march_confined_to_the_occupied_bounds_changes_no_sample(params, golden,
         noises = torch.rand(ro.shape[0], device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
     outs = []
     for clip in (True, False):
-        r = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
+        r = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused", cap="per_ray")
         r.clip_to_occupancy = clip
         r.steps_per_pass = 1
         o = r.render(ro, rd, *cond, count_samples=True, noises=noises, **kw)
@@ -411,7 +413,7 @@ def test_fused_frame_two_cascades_with_occupancy_bounds(params, golden, precisio
     aabb = torch.tensor([-bound, -bound / 2, -bound, bound, bound / 2, bound], device="cuda")
     outs = []
     for clip in (True, False):
-        r = TriplaneRenderer(head, dev(bits), bound=bound, cascade=2, aabb=aabb, mode="fused")
+        r = TriplaneRenderer(head, dev(bits), bound=bound, cascade=2, aabb=aabb, mode="fused", cap="per_ray")
         r.clip_to_occupancy = clip
         r.steps_per_pass = 1
         outs.append({k: v.clone() for k, v in r.render(ro, rd, *cond, count_samples=True, max_steps=256).items()})
@@ -446,3 +448,105 @@ def test_occupied_bounds_follow_an_in_place_update_of_the_bitfield(params, golde
     for k in KEYS + ("ray_counts",):
         assert torch.equal(b[k], fresh[k]), k
     assert int(b["state"][5]) > 500 and not torch.equal(a["image"], b["image"])
+
+
+# ---- cap = "reference": the fused frame under the reference's own schedule, also where max_steps binds ---------------------------------
+def _scene_bits(scene):
+    if scene == "ones":
+        return np.full(128 ** 3 // 8, 255, np.uint8)
+    if scene == "blobs":
+        return _bitfield_from_cells(_blob(0, (40, 52, 30), 9) + _blob(0, (84, 70, 100), 13) + _blob(0, (64, 64, 64), 2))
+    return ellipsoid_bitfield()[0]
+
+
+@pytest.mark.parametrize("S", [1, 0, 4])
+@pytest.mark.parametrize("scene,H,W,kw", [
+    ("ellipsoid", 64, 64, dict(max_steps=16)),                      # the reference's deployed cap (HubertInferenceMQ.py:69, train.py:35)
+    ("ellipsoid", 64, 64, dict(max_steps=32)),
+    ("blobs", 72, 56, dict(max_steps=16)),
+    ("blobs", 72, 56, dict(max_steps=32, T_thresh=0.5)),            # T_thresh cuts rays inside multi-step chunks: marched counts
+    ("ones", 40, 40, dict(max_steps=16, dt_gamma=0.0)),             # every ray that enters the box reaches the cap
+    ("ellipsoid", 64, 64, dict(max_steps=64, T_thresh=0.6)),        # the cap does not bind
+])
+def test_fused_reference_cap_equals_the_reference_schedule(params, golden, scene, H, W, kw, S):
+    """mode="fused", cap="reference" against the multi-launch loop under the reference's schedule (1, 8) and the checker's
+    render_inference(budget_factor=1, n_step_cap=8) = run_cuda_for_inference (renderer.py:503-548): image, depth, every sum and the
+    per-ray marched counts bit for bit, for steps_per_pass 1, auto and 4; C_eff and the iteration count the device replayed equal the
+    checker's schedule."""
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    head, _, ro, rd, cond = setup(params, golden, H, W, "ones")
+    bits = _scene_bits(scene)
+    fr = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused", cap="reference")
+    fr.steps_per_pass = S
+    fused = {k: v.clone() for k, v in fr.render(ro, rd, *cond, count_samples=True, **kw).items()}
+    loop = TriplaneRenderer(head, dev(bits), bound=1.0, budget_factor=1, n_step_cap=8).render(ro, rd, *cond, count_samples=True, **kw)
+    for k in KEYS:
+        assert torch.equal(fused[k], loop[k]), k
+    assert torch.equal(fused["ray_counts"], loop["ray_counts"])
+    assert int(fused["state"][5]) == int(loop["state"][5]) == int(fused["ray_counts"].sum())
+    st = {}
+    ref = render_inference(TriplaneSpec(1.0), params, ro.cpu().numpy(), rd.cpu().numpy(), bits, golden["net_enc_a"], golden["net_ind"],
+                           golden["net_eye"], stats=st, budget_factor=1, n_step_cap=8, **kw)
+    for k in ("image", "depth", "weights_sum", "amb_aud_sum", "amb_eye_sum", "uncertainty_sum"):
+        assert np.array_equal(fused[k].cpu().numpy(), ref[k]), k
+    assert np.array_equal(fused["ray_counts"].cpu().numpy().astype(np.int64), st["samples_per_ray"])
+    sched = st["schedule"]
+    c_eff = sum(n for _, n in sched)
+    assert int(fused["state"][11]) == len(sched) and int(fused["state"][10]) == c_eff
+    if kw["max_steps"] == 16 and scene != "blobs":
+        assert int(fused["ray_counts"].max()) == c_eff                        # rays stand at the cap and receive C_eff samples
+    if kw["max_steps"] == 16 and scene == "ellipsoid":
+        assert c_eff > 16                                                     # ... past max_steps
+        per_ray = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused", cap="per_ray")
+        per_ray.steps_per_pass = 1
+        other = per_ray.render(ro, rd, *cond, **kw)["image"]
+        assert int(((other - fused["image"]).abs().max(1).values > 1e-4).sum()) > 50   # what the per-ray cap gets wrong (VERDICT r3)
+
+
+def test_fused_reference_cap_f16_equals_loop_f16(params, golden):
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    head, _, ro, rd, cond = setup(params, golden, 96, 96, "ones", precision="f16")
+    bits = _scene_bits("ellipsoid")
+    for ms in (16, 24):
+        fused = {k: v.clone() for k, v in TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused").render(ro, rd, *cond, count_samples=True, max_steps=ms).items()}
+        loop = TriplaneRenderer(head, dev(bits), bound=1.0).render(ro, rd, *cond, count_samples=True, max_steps=ms)
+        for k in KEYS + ("ray_counts",):
+            assert torch.equal(fused[k], loop[k]), (ms, k)
+        assert int(fused["ray_counts"].max()) > ms
+
+
+@pytest.mark.parametrize("tiles", ["interleaved", "contiguous"])
+@pytest.mark.parametrize("max_steps", [16, 24])
+def test_fused_reference_cap_tiles_equal_the_unsharded_reference_frame(params, golden, tiles, max_steps):
+    """4 tiles of one frame, each rendered by its own fused renderer with its own steps_per_pass (auto: tiles pick a larger S than the
+    frame would), the histograms of the four first phases summed as ShardedFrame's all-reduce does: the assembled frame equals the
+    unsharded loop under the reference schedule -- pixels and counts -- although n_alive / N of renderer.py:513 are frame-wide."""
+    from lzzx_nerf_amd import dist as D
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    H = W = 64
+    head, _, ro, rd, cond = setup(params, golden, H, W, "ones")
+    bits = dev(_scene_bits("ellipsoid"))
+    ref = TriplaneRenderer(head, bits, bound=1.0).render(ro, rd, *cond, count_samples=True, max_steps=max_steps)
+    ref = {k: v.clone() for k, v in ref.items()}
+    world = 4
+    rs, ctxs, pxs = [], [], []
+    for g in range(world):
+        sf = D.ShardedFrame(H, W, g, world, tiles, device="cuda")
+        sf.gatherer = None
+        r = sf.configure(TriplaneRenderer(head, bits, bound=1.0, mode="fused"))
+        assert r.cap == "reference" and r.frame_rays_total == H * W
+        px = sf.pixels
+        ctxs.append(r.fused_begin(ro[px].contiguous(), rd[px].contiguous(), *cond, max_steps=max_steps, count_samples=True))
+        rs.append(r)
+        pxs.append(px)
+    total = torch.stack([c["hist"] for c in ctxs]).sum(0)
+    assert int(total.sum()) == H * W
+    imgs, cnts, deps = [], [], []
+    for r, c in zip(rs, ctxs):
+        c["hist"].copy_(total)                       # what dist.all_reduce leaves on every rank
+        o = r.fused_finish(c)
+        imgs.append(o["image"].clone()); cnts.append(o["ray_counts"].clone()); deps.append(o["depth"].clone())
+    assert torch.equal(D.assemble_frame(torch.cat(imgs), H, W, world, tiles), ref["image"])
+    assert torch.equal(D.assemble_frame(torch.cat(deps)[:, None], H, W, world, tiles)[:, 0], ref["depth"])
+    assert torch.equal(D.assemble_frame(torch.cat(cnts)[:, None], H, W, world, tiles)[:, 0], ref["ray_counts"])
+    assert int(ref["ray_counts"].max()) > max_steps
