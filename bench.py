@@ -362,6 +362,10 @@ def parse_args():
                     help="fused: the frame as one persistent kernel (csrc/lz_frame.hip; the loop under the schedule n_step = 1, same pixels); "
                          "loop: march / head / composite launches per iteration under --budget-factor / --n-step-cap")
     ap.add_argument("--steps-per-pass", type=int, default=0, help="fused mode: samples per ray and pass (0 = auto by ray count)")
+    ap.add_argument("--cap", default="reference", choices=["reference", "per_ray"],
+                    help="fused mode, rays still alive at max_steps: 'reference' = the reference loop's frame-wide count C_eff = sum of its n_step "
+                         "(renderer.py:503-548; ranks of a sharded frame sum a small histogram between the kernel's two phases), "
+                         "'per_ray' = stop at ceil(max_steps / S) * S (no exchange; not the reference's pixels on such rays)")
     ap.add_argument("--no-side-legs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-sample", action="store_true",
@@ -400,7 +404,9 @@ class FrameJob:
             self.sf = D.ShardedFrame(H, W, 0, shard_of, tiles, device)
             self.sf.gatherer = None
         elif world > 1 and shard == "frame":
-            self.sf = D.ShardedFrame(H, W, rank, world, tiles, device, dtype=torch.uint8 if gather == "rgb24" else torch.float32, via=via)
+            self.sf = D.ShardedFrame(H, W, rank, world, tiles, device, dtype=torch.uint8 if gather == "rgb24" else torch.float32, via=via,
+                                     cap=getattr(renderer, "cap", "reference"))
+            self.sf.configure(renderer)      # cap "reference": the frame's ray count + the histogram all-reduce between the two phases
         else:
             self.sf = D.ShardedFrame(H, W, 0, 1, device=device)
             if world > 1:         # clip mode: every rank contributes a whole frame to the gathered batch
@@ -616,7 +622,7 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
         k = steps or args.steps
         d2, hms, o2, _ = timed(j2, k, 2, 1, device)
         s2 = o2["state"].cpu().numpy()
-        return dict(mode=mode, schedule="n_step = 1, slots refilled on the fly (one persistent kernel)" if mode == "fused" else
+        return dict(mode=mode, schedule=f"one persistent kernel, slots refilled on the fly, cap = {args.cap}" if mode == "fused" else
                     f"n_step = max(min({budget_factor} * N // n_alive, {n_step_cap}), 1)", value=round(int(s2[5]) * k / d2, 1),
                     unit="samples/s", ms_per_step=round(d2 / k * 1e3, 4), rays_per_s=round(j2.sf.n_local * k / d2, 1),
                     samples_per_frame=int(s2[5]), iterations_per_frame=int(s2[6]), rows_per_frame=int(s2[72]),
@@ -648,6 +654,38 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             result["reference_schedule"] = leg
         except Exception as exc:
             err("reference_schedule", exc)
+    if args.mode == "fused" and not args.no_fat_schedule:
+        try:
+            # the reference's DEPLOYED cap (HubertInferenceMQ.py:69, train.py:35: max_steps = 16) on the head-like ellipsoid scene: dt_min =
+            # dt_max, 16 steps cross 0.43 units, so the cap binds on most foreground rays and the reference hands each of them C_eff =
+            # sum of n_step > 16 samples.  The fused frame against the multi-launch loop under the reference's schedule: pixels and counts.
+            from lzzx_nerf_amd.synthetic import ellipsoid_bitfield_device
+            ebits16 = ellipsoid_bitfield_device(device)[0]
+            keep_ms = args.max_steps
+            args.max_steps = 16
+            try:
+                jf = make_job("frame", args.tiles, 1, 8, head, mode="fused")
+                jl = make_job("frame", args.tiles, 1, 8, head, mode="loop")
+            finally:
+                args.max_steps = keep_ms
+            jf.r.bitfield = jl.r.bitfield = ebits16
+            k16 = args.steps
+            df, _, of_, _ = timed(jf, k16, 2, 1, device)
+            img_f, st_f = of_["image"].clone(), of_["state"].cpu().numpy()
+            dl, _, ol_, _ = timed(jl, k16, 2, 1, device)
+            st_l = ol_["state"].cpu().numpy()
+            cf = jf.r.render(*jf.sf.rays(jf.pose, jf.intr), *jf.cond, max_steps=16, count_samples=True)["ray_counts"].clone()
+            cl = jl.r.render(*jl.sf.rays(jl.pose, jl.intr), *jl.cond, max_steps=16, count_samples=True)["ray_counts"]
+            result["deployed_max_steps_16"] = dict(
+                workload=f"{H}x{W} frame, ellipsoid occupancy, max_steps 16 (the reference's deployed value), cap = {args.cap}",
+                ms_per_step=round(df / k16 * 1e3, 4), composited_samples_per_frame=int(st_f[5]), value=round(int(st_f[5]) * k16 / df, 1), unit="samples/s",
+                c_eff=int(st_f[10]), reference_loop_iterations=int(st_f[11]), rays_continued_past_max_steps=int(st_f[9]),
+                loop_mode_reference_schedule_ms_per_step=round(dl / k16 * 1e3, 4), loop_mode_iterations=int(st_l[6]),
+                image_equal_to_reference_schedule=bool(torch.equal(img_f, ol_["image"])),
+                ray_counts_equal_to_reference_schedule=bool(torch.equal(cf, cl)), max_ray_count=int(cf.max()))
+            del jf, jl
+        except Exception as exc:
+            err("deployed_max_steps_16", exc)
     if args.precision == "f32" and args.mode == "fused" and not args.no_fat_schedule:
         try:
             # the same frame with geo = Wg s2 folded into color_net.0 at pack time (head.py fold_geo, precision 2): 297 instead of 361
@@ -987,7 +1025,7 @@ def main():
 
     def make_job(shard, tiles, budget_factor=None, n_step_cap=None, h=None, shard_of=0, mode=None):
         r = TriplaneRenderer(h or head, bits_dev, bound=1.0, budget_factor=budget_factor or args.budget_factor,
-                             n_step_cap=n_step_cap or args.n_step_cap, mode=mode or args.mode)
+                             n_step_cap=n_step_cap or args.n_step_cap, mode=mode or args.mode, cap=args.cap)
         r.steps_per_pass = args.steps_per_pass
         k = rank if (world > 1 and shard == "clip") else 0     # clip mode: frame `rank` of the clip, with its own audio feature
         enc_a = enc_a0
@@ -1110,9 +1148,15 @@ def main():
                    "samples_per_step": samples_per_step, "iterations_per_frame": iters_per_frame,
                    "nominal_samples_per_frame": N * args.max_steps, "parallelism": par,
                    "mode": args.mode,
-                   "schedule": "one persistent kernel per frame (csrc/lz_frame.hip): the loop under n_step = 1 with finished ray slots refilled "
-                               "on the fly; same pixels and sample counts as the multi-launch loop ('loop_mode') and as the reference's "
-                               "schedule ('reference_schedule')" if args.mode == "fused" else
+                   "schedule": ("one persistent kernel per frame (csrc/lz_frame.hip), finished ray slots refilled on the fly; rays still alive at "
+                                "max_steps receive the reference loop's frame-wide count C_eff = sum of n_step (renderer.py:503-548: phase 1 to "
+                                "max_steps, device-side replay of n_alive / n_step from a histogram, phase 2 to C_eff): same pixels and per-ray "
+                                "counts as the multi-launch loop under the reference's schedule ('reference_schedule'; with the cap binding: "
+                                "'deployed_max_steps_16')" if args.cap == "reference" else
+                                "one persistent kernel per frame (csrc/lz_frame.hip): the loop under n_step = S with finished ray slots refilled "
+                                "on the fly; a ray still alive at max_steps stops at ceil(max_steps / S) * S samples (--cap per_ray: NOT the "
+                                "reference's count on such rays; none in this frame if 'reference_schedule.image_equal_to_headline_schedule')")
+                               if args.mode == "fused" else
                                f"n_step = max(min({args.budget_factor} * N // n_alive, {args.n_step_cap}), 1)"
                                + (" (the reference's, renderer.py:513)" if (args.budget_factor, args.n_step_cap) == (1, 8) else
                                   " -- sample rows per iteration sized for 288 GB of HBM; the reference's rule is 1 x N rows, <= 8 steps "

@@ -598,7 +598,7 @@ int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterations, lz_ti
  *   LZ_LOOP_STAT_ROWS; cap_mode 1 adds [9] rays phase 2 continued, [10] C_eff, [11] iterations of the reference's loop. */
 #define LZ_FRAME_CAP_PER_RAY 0
 #define LZ_FRAME_CAP_REFERENCE 1
-#define LZ_FRAME_CAP_WS_INTS(max_steps) (2 * (max_steps) + 16)
+#define LZ_FRAME_CAP_WS_INTS(max_steps) (2 * (max_steps) + 24)
 #define LZ_FRAME_STATE_INTS 1024
 typedef struct {
     lz_head_params head;           /* testing = 1; precision 0 (f32) or 1 (f16) */

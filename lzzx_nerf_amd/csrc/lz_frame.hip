@@ -109,6 +109,8 @@ __device__ __forceinline__ void lzf_write_pixel(const LzFrameK& F, int ray, floa
 __global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
     __shared__ int hist[LZF_BINS];
     __shared__ uint32_t mlut[LZF_LUT];                       // Morton bit-spread table for the march (as in lz_k_frame)
+    if (F.cap_mode && blockIdx.x == 0)                       // the cap's histogram and tables: first touched two launches later
+        for (uint32_t i = threadIdx.x; i < LZ_FRAME_CAP_WS_INTS(F.max_steps); i += blockDim.x) F.cap_ws[i] = 0;
     hist[threadIdx.x] = 0;
     mlut[threadIdx.x] = lz_expand_bits(threadIdx.x);
     __syncthreads();
@@ -648,67 +650,150 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
 // cap_ws: [0 .. max_steps] histogram of L (bin max_steps = rays alive at the cap); behind it the schedule tables, see lzf_ws_*
 __host__ __device__ __forceinline__ int lzf_ws_chunk_end(int max_steps) { return max_steps + 1; }     // [max_steps + 9]: index c = 1-based sample
 
-// one lane per ray: LDS histogram of ray_last per workgroup, flushed with one atomic per non-empty bin; the rays parked at the cap are
-// compacted into the queue (order[]; phase 1 has consumed it) with one global atomic per workgroup
-__global__ void __launch_bounds__(256) lz_k_frame_cap_hist(LzFrameK F) {
-    extern __shared__ int ch_lds[];                      // [max_steps + 1] bins, then 2 words
-    const int bins = (int)F.max_steps + 1;
-    int* cnt = ch_lds + bins;                            // [0] parked rays of this workgroup, [1] their base in the queue
-    for (int i = threadIdx.x; i < bins + 2; i += blockDim.x) ch_lds[i] = 0;
+// The reference's loop on the counts alone (renderer.py:503-548): n_alive -> n_step = max(min(N // n_alive, 8), 1) -> step += n_step while
+// step < max_steps, with n_alive at boundary B = rays with L >= B (suffix sums of the histogram).  n_alive never grows along B, so n_step
+// never shrinks: the boundaries the loop visits fall into at most 8 runs of constant stride k = 1 .. 8, each ending where n_step first
+// exceeds k (found data-parallel), and one lane walks the runs in closed form instead of chasing ~max_steps dependent LDS reads.
+// Writes C_eff (the boundary the loop stops at), the iteration count, chunk_end[c] = the boundary closing the chunk of sample c (1-based),
+// and empties phase 2's queue when C_eff <= max_steps (the parked rays are complete as they are).  lds: LZF_SCHED_LDS_INTS.
+#define LZF_SCHED_LDS_INTS(max_steps) ((max_steps) + 9 + 64)
+__device__ __forceinline__ int lzf_n_step(uint32_t N, int n_alive) {   // max(min(N // n_alive, 8), 1) without the division
+    const unsigned long long na = (unsigned long long)n_alive;
+    int k = 1;
+#pragma unroll
+    for (int j = 2; j <= 8; j++) k += (na * j <= (unsigned long long)N) ? 1 : 0;
+    return k;
+}
+__device__ void lzf_schedule(const LzFrameK& F, int* lds) {
+    const int ms = (int)F.max_steps, n = ms + 9, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = (nt + 63) >> 6;
+    const uint32_t N = F.N_total ? F.N_total : F.N;
+    int* alive = lds;                    // [n]
+    int* wtot = lds + n;                 // [16] wave totals of the scan
+    int* first = lds + n + 16;           // [10]: first[k] = first boundary whose n_step exceeds k (k = 1 .. 8; 0 unused); first[9] = first boundary nobody is alive at
+    int* run = lds + n + 32;             // [8][3] runs of the walk: start, stride, steps; run[24] = count, [25] = C_eff, [26] = iterations
+    for (int i = tid; i < n; i += nt) alive[i] = i <= ms ? __hip_atomic_load(F.cap_ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    if (tid < 10) first[tid] = n;
     __syncthreads();
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    int L = -1, rank = 0;
-    if (n < F.N) {
-        L = F.ray_last[n];
-        L = L < 0 ? 0 : (L > (int)F.max_steps ? (int)F.max_steps : L);
-        if (L == (int)F.max_steps) rank = atomicAdd(&cnt[0], 1);
-        else atomicAdd(&ch_lds[L], 1);
+    // suffix sums: a contiguous stretch per lane, lanes of a wave by shuffles, waves through LDS
+    const int E = (n + nt - 1) / nt, lo = min(tid * E, n), hi = min(lo + E, n);
+    int tot = 0;
+    for (int i = hi - 1; i >= lo; i--) { tot += alive[i]; alive[i] = tot; }
+    int incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_down(incl, off, 64);
+        if (lane + off < 64) incl += v;
+    }
+    if (lane == 0) wtot[wave] = incl;
+    __syncthreads();
+    int add = incl - tot;
+    for (int w = wave + 1; w < nw; w++) add += wtot[w];
+    for (int i = lo; i < hi; i++) alive[i] += add;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+        const int na = alive[i];
+        if (na <= 0) { atomicMin(&first[9], i); continue; }
+        const int k = lzf_n_step(N, na);
+        const int kp = i > 0 ? (alive[i - 1] > 0 ? lzf_n_step(N, alive[i - 1]) : 9) : 0;     // n_step just below: only the lanes where it changes write
+        for (int j = kp; j < k; j++) if (j >= 1) atomicMin(&first[j], i);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int stop = min(ms, first[9]);              // the loop ends at max_steps, or where n_alive == 0
+        int B = 0, K = 0, r = 0;
+        while (B < stop && r < 8) {
+            const int k = lzf_n_step(N, alive[B]);
+            const int lim = min(stop, first[k]);         // boundaries below `lim` step by k
+            const int m = (lim - B + k - 1) / k;         // >= 1: n_step(B) == k means B < first[k]
+            run[3 * r] = B; run[3 * r + 1] = k; run[3 * r + 2] = m;
+            B += m * k;
+            K += m;
+            r++;
+        }
+        run[24] = r; run[25] = B; run[26] = K;
+        F.state[LZF_CEFF] = B;
+        F.state[LZF_SCHED_K] = K;
+        if (B <= ms) atomicExch(F.state + LZF_P_SIZE, 0);
+    }
+    __syncthreads();
+    int* chunk_end = F.cap_ws + lzf_ws_chunk_end(ms);
+    const int nr = run[24], c_eff = run[25];
+    for (int c = 1 + tid; c < n; c += nt) {
+        int e = c;                                       // behind the loop's end: unused
+        if (c <= c_eff) {
+            for (int r = 0; r < nr; r++) {
+                const int b0 = run[3 * r], k = run[3 * r + 1], b1 = b0 + k * run[3 * r + 2];
+                if (c > b0 && c <= b1) e = b0 + (c - b0 + k - 1) / k * k;
+            }
+        }
+        chunk_end[c] = e;
+    }
+}
+__global__ void __launch_bounds__(256) lz_k_frame_schedule(LzFrameK F) {
+    extern __shared__ int sc_lds[];
+    lzf_schedule(F, sc_lds);
+}
+
+// one lane per ray: LDS histogram of ray_last per workgroup, flushed with one atomic per non-empty bin; the rays parked at the cap are
+// compacted into the queue (order[]; phase 1 has consumed it) with one global atomic per workgroup.  SCHED (a whole frame, nothing to
+// exchange): the last workgroup to flush replays the schedule right here (one launch less).
+template <bool SCHED>
+__global__ void __launch_bounds__(1024) lz_k_frame_cap_hist(LzFrameK F) {
+    extern __shared__ int ch_lds[];                      // [max_steps + 1] bins, then 4 words; SCHED: lzf_schedule's LZF_SCHED_LDS_INTS
+    const int ms = (int)F.max_steps, bins = ms + 1;
+    int* cnt = ch_lds + bins;                            // [0] parked rays of this workgroup, [1] their base in the queue, [2] cursor, [3] ticket
+    for (int i = threadIdx.x; i < bins + 4; i += blockDim.x) ch_lds[i] = 0;
+    __syncthreads();
+    // few, fat workgroups (grid-stride): every workgroup ends with one global atomic per non-empty bin, and same-address atomics serialise
+    // in the L2 (one workgroup per 256 rays: 1024 x ~100 bins took 80 us)
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t n0 = blockIdx.x * blockDim.x; n0 < F.N; n0 += 8 * stride) {      // (workgroup-uniform trip count)
+        int Lv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {                    // eight loads in flight (the words come from HBM: the kernel before wrote them on other XCDs)
+            const uint32_t n = n0 + u * stride + threadIdx.x;
+            Lv[u] = n < F.N ? F.ray_last[n] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t n = n0 + u * stride + threadIdx.x;
+            int L = Lv[u];
+            if (n < F.N) L = L < 0 ? 0 : (L > ms ? ms : L);
+            // neighbouring rays end at the same boundary more often than not: one LDS atomic per distinct value of the wave, not per lane
+            unsigned long long todo = __ballot(L >= 0);
+            while (todo) {
+                const int v = __shfl(L, __ffsll((long long)todo) - 1, 64);
+                const unsigned long long same = __ballot(L == v);
+                if ((threadIdx.x & 63) == __ffsll((long long)same) - 1) atomicAdd(v == ms ? &cnt[0] : &ch_lds[v], __popcll(same));
+                todo &= ~same;
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0 && cnt[0] > 0) {
         cnt[1] = atomicAdd(F.state + LZF_P_SIZE, cnt[0]);
-        atomicAdd(F.cap_ws + F.max_steps, cnt[0]);
+        atomicAdd(F.cap_ws + ms, cnt[0]);
     }
     __syncthreads();
-    if (L == (int)F.max_steps) F.order[cnt[1] + rank] = (int)n;
-    for (int i = threadIdx.x; i < bins - 1; i += blockDim.x) {
+    if (cnt[0] > 0) {                                    // second sweep (the words are cache-hot): queue positions for the parked rays
+        for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < F.N; n += stride)
+            if (F.ray_last[n] >= ms) F.order[cnt[1] + atomicAdd(&cnt[2], 1)] = (int)n;
+    }
+    for (int i = threadIdx.x; i < ms; i += blockDim.x) {
         const int h = ch_lds[i];
         if (h) atomicAdd(F.cap_ws + i, h);
     }
-}
-
-// one workgroup: suffix sums of the histogram (rays alive at boundary B = rays with L >= B), then the reference's loop on the counts alone
-// (renderer.py:503-548): n_alive -> n_step = max(min(N // n_alive, 8), 1) -> step += n_step while step < max_steps.  Writes C_eff, the
-// iteration count, chunk_end[c] = the boundary that closes the chunk of sample c (1-based), and empties phase 2's queue when C_eff ==
-// max_steps (the parked rays are complete as they are).
-__global__ void __launch_bounds__(1024) lz_k_frame_schedule(LzFrameK F) {
-    extern __shared__ int sc_lds[];                      // 2 x [max_steps + 2]: alive-at-boundary counts, ping-pong for the scan
-    const int ms = (int)F.max_steps;
-    int* alive = sc_lds;
-    int* other = sc_lds + ms + 2;
-    for (int i = threadIdx.x; i <= ms; i += blockDim.x) alive[i] = F.cap_ws[i];
-    __syncthreads();
-    for (int off = 1; off <= ms; off <<= 1) {            // suffix scan (Hillis-Steele)
-        for (int i = threadIdx.x; i <= ms; i += blockDim.x) other[i] = alive[i] + ((i + off <= ms) ? alive[i + off] : 0);
+    if constexpr (SCHED) {
+        // last workgroup out replays the schedule.  Everything it reads was written with agent-scope atomics (performed at the
+        // coherence point, past the per-XCD L2s) and is read back with agent-scope atomic loads, so ordering is all that is needed: every
+        // lane's atomics acknowledged (vmcnt 0) before the ticket is taken.  NOT __threadfence(): an agent-scope fence on this part writes
+        // back and invalidates the XCD's whole L2 -- with the frame's outputs dirty in it that cost ~30 us per workgroup that did it.
+        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        int* sw = alive; alive = other; other = sw;
-    }
-    if (threadIdx.x == 0) {
-        int* chunk_end = F.cap_ws + lzf_ws_chunk_end(ms);
-        const long long N = F.N_total ? (long long)F.N_total : (long long)F.N;
-        int B = 0, K = 0;
-        while (B < ms) {
-            const long long na = alive[B];
-            if (na <= 0) break;
-            long long q = N / na;
-            const int n_step = (int)(q > 8 ? 8 : (q < 1 ? 1 : q));
-            for (int c = B + 1; c <= B + n_step; c++) chunk_end[c] = B + n_step;
-            B += n_step;
-            K++;
-        }
-        F.state[LZF_CEFF] = B;
-        F.state[LZF_SCHED_K] = K;
-        if (B <= ms) F.state[LZF_P_SIZE] = 0;
+        if (threadIdx.x == 0) cnt[3] = atomicAdd(F.state + LZF_TICKET, 1);
+        __syncthreads();
+        if (cnt[3] != (int)gridDim.x - 1) return;        // workgroup-uniform
+        lzf_schedule(F, ch_lds);
     }
 }
 
@@ -954,7 +1039,7 @@ extern "C" int lz_frame_finish(const lz_frame_fused* f, lz_stream_t stream) {
     hipStream_t st = lz_st(stream);
     LzFrameK K;
     lzf_fill(f, K);
-    hipLaunchKernelGGL(lz_k_frame_schedule, dim3(1), dim3(1024), 2 * (f->max_steps + 2) * sizeof(int), st, K);
+    if (f->defer_finish) hipLaunchKernelGGL(lz_k_frame_schedule, dim3(1), dim3(256), LZF_SCHED_LDS_INTS(f->max_steps) * sizeof(int), st, K);
     K.phase2 = 1;
     rc = lzf_launch_persistent(f, K, st);
     if (rc != LZ_OK) return rc;
@@ -973,11 +1058,7 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     lzf_fill(f, K);
     hipError_t hrc = hipMemsetAsync(f->state, 0, LZ_FRAME_STATE_INTS * sizeof(int32_t), st);
     if (hrc != hipSuccess) { lz_set_error("frame_render: memset: %s", hipGetErrorString(hrc)); return (int)hrc; }
-    const bool ref_cap = f->cap_mode == LZ_FRAME_CAP_REFERENCE;
-    if (ref_cap) {
-        hrc = hipMemsetAsync(f->cap_ws, 0, LZ_FRAME_CAP_WS_INTS(f->max_steps) * sizeof(int32_t), st);
-        if (hrc != hipSuccess) { lz_set_error("frame_render: memset: %s", hipGetErrorString(hrc)); return (int)hrc; }
-    }
+    const bool ref_cap = f->cap_mode == LZ_FRAME_CAP_REFERENCE;      // (cap_ws is zeroed by lz_k_frame_prepare)
     const uint32_t nb = lz_div_up(f->N, 256);
     hipLaunchKernelGGL(lz_k_frame_prepare, dim3(nb), dim3(256), 0, st, K);
     hipLaunchKernelGGL(lz_k_frame_scatter, dim3(nb), dim3(256), 0, st, K);
@@ -985,7 +1066,13 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     rc = lzf_launch_persistent(f, K, st);
     if (rc != LZ_OK) return rc;
     if (timing) (void)lz_timing_mark(timing, 1, stream);
-    if (ref_cap) hipLaunchKernelGGL(lz_k_frame_cap_hist, dim3(nb), dim3(256), (f->max_steps + 3) * sizeof(int), st, K);
+    if (ref_cap) {
+        const size_t lds = LZF_SCHED_LDS_INTS((size_t)f->max_steps) * sizeof(int);      // >= the histogram's max_steps + 5
+        uint32_t hb = lz_div_up(f->N, 1024 * 8);            // 8 rays per lane, at most 32 workgroups
+        hb = hb < 1 ? 1 : (hb > 32 ? 32 : hb);
+        if (f->defer_finish) hipLaunchKernelGGL(lz_k_frame_cap_hist<false>, dim3(hb), dim3(1024), lds, st, K);
+        else hipLaunchKernelGGL(lz_k_frame_cap_hist<true>, dim3(hb), dim3(1024), lds, st, K);
+    }
     LZ_CHECK_LAUNCH("frame_render");
     if (ref_cap && !f->defer_finish) return lz_frame_finish(f, stream);
     return LZ_OK;

@@ -25,6 +25,9 @@ _N_SAMPLES_OFF = (74 + 2) * 4   # LZ_LOOP_NEXT + 2: n_samples of the iteration i
 
 from .utils import frame_rays   # noqa: E402,F401  (full-image rays of one pose; utils.get_rays has the reference's signature)
 
+import os as _os  # noqa: E402
+_SPLIT_CAP = bool(_os.environ.get("LZ_FRAME_SPLIT_CAP"))
+
 get_rays = frame_rays   # round-1 name, kept for callers of (pose, intrinsics, H, W) -> (rays_o, rays_d)
 
 
@@ -356,10 +359,13 @@ class TriplaneRenderer:
             f.occupied_aabb, f.t_end = p(self.occupied_bounds()), p(b["t_end"])
         deferred = False
         if self.cap == "reference":
-            need = 2 * int(max_steps) + 16            # LZ_FRAME_CAP_WS_INTS
+            need = 2 * int(max_steps) + 24            # LZ_FRAME_CAP_WS_INTS
             if b["cap_ws"] is None or b["cap_ws"].numel() < need:
                 b["cap_ws"] = torch.zeros(need, dtype=torch.int32, device=dev)
             f.cap_mode, f.ray_last, f.cap_ws = 1, p(b["ray_last"]), p(b["cap_ws"])
+            if self.frame_rays_total is None and _SPLIT_CAP:      # diagnostic: the two cap kernels as separate launches (tools/frame_trace.sh)
+                f.N_total, f.defer_finish = N, 1
+                deferred = True
             if self.frame_rays_total is not None:
                 if int(self.frame_rays_total) < N:
                     raise ValueError("frame_rays_total is the ray count of the whole frame (>= the rays of this call)")
