@@ -4,6 +4,9 @@ The reference has no CPU renderer (train.py:152 forces cuda_ray; renderer.py:952
 so this file arranges the checker's kernels exactly like the reference's loops:
   * inference: NeRFRenderer.run_cuda_for_inference   /root/reference/nerf_triplane/renderer.py:436-561
   * training forward: NeRFRenderer.run_cuda, training branch   renderer.py:279-304, 380-385
+PINNED (round 4): tests/golden/reference_loops.npz holds what the reference's OWN loops and raymarching wrappers produce when they are
+run unmodified on the checker's kernels (tests/golden/make_golden_loops.py); tests/test_golden_loops.py holds these two functions to
+it -- iteration schedule, buffer sizes, per-ray counts exactly; images bit for bit with the reference's MLP arrangement.
 """
 import numpy as np
 
@@ -20,10 +23,11 @@ def default_aabb(bound):
 
 def render_inference(spec, P, rays_o, rays_d, bitfield, enc_a, ind_code, eye, cascade=1, grid_size=128, aabb=None,
                      min_near=0.05, dt_gamma=1.0 / 256, max_steps=16, T_thresh=1e-4, bg_color=1.0, stats=None,
-                     budget_factor=1, n_step_cap=8, head=None, noises=None):
+                     budget_factor=1, n_step_cap=8, head=None, noises=None, testing=True):
     """head: the per-sample network, default the bit-pinned checker `head_forward`; bench.py's cpu_baseline passes
     `head_forward_torch` (the reference's torch-CPU MLP arrangement).  noises [N]: `perturb` -- handed to march_rays on the first
-    iteration only, like renderer.py:521 (`perturb if step == 0 else False`)"""
+    iteration only, like renderer.py:521 (`perturb if step == 0 else False`).  testing: NeRFNetwork.testing -- the test path sets it
+    around render (TrainerUtil.py:432-436: uncertainty = ln 2), the evaluation path does not (:390-394: unc_net runs)"""
     if head is None:
         head = head_forward
     rays_o = np.ascontiguousarray(rays_o, dtype=F32).reshape(-1, 3)
@@ -51,7 +55,7 @@ def render_inference(spec, P, rays_o, rays_d, bitfield, enc_a, ind_code, eye, ca
         n_step = max(min(budget_factor * N // n_alive, n_step_cap), 1)           # renderer.py:513 (factor 1, cap 8)
         xyzs, dirs, deltas = O.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, bitfield,
                                           cascade, grid_size, nears, fars, 128, noises if step == 0 else None, dt_gamma, max_steps)
-        sigmas, rgbs, amb_aud, amb_eye, unc = head(spec, P, xyzs, dirs, enc_a, ind_code, eye, testing=True)
+        sigmas, rgbs, amb_aud, amb_eye, unc = head(spec, P, xyzs, dirs, enc_a, ind_code, eye, testing=testing)
         if amb_eye is None:
             amb_eye = np.zeros_like(amb_aud)
         valid = (deltas[: n_alive * n_step, 0] != 0).reshape(n_alive, n_step).sum(1)
@@ -72,7 +76,8 @@ def render_inference(spec, P, rays_o, rays_d, bitfield, enc_a, ind_code, eye, ca
 
 def render_train_forward(spec, P, rays_o, rays_d, bitfield, enc_a, ind_code, eye, cascade=1, grid_size=128, aabb=None,
                          min_near=0.05, dt_gamma=1.0 / 256, max_steps=16, T_thresh=1e-4, bg_color=1.0, noises=None,
-                         mean_count=-1, force_all_rays=False, unc_loss=True):
+                         mean_count=-1, force_all_rays=False, unc_loss=True, head=None):
+    """head: None = the bit-pinned checker head_forward; head_forward_torch = the reference's torch-CPU MLP arrangement"""
     rays_o = np.ascontiguousarray(rays_o, dtype=F32).reshape(-1, 3)
     rays_d = np.ascontiguousarray(rays_d, dtype=F32).reshape(-1, 3)
     bound = spec.bound
@@ -82,8 +87,10 @@ def render_train_forward(spec, P, rays_o, rays_d, bitfield, enc_a, ind_code, eye
     counter = np.zeros(2, np.int32)
     xyzs, dirs, deltas, rays = O.march_rays_train(rays_o, rays_d, bound, bitfield, cascade, grid_size, nears, fars,
                                                   counter, mean_count, noises, 128, force_all_rays, dt_gamma, max_steps)
-    sigmas, rgbs, amb_aud, amb_eye, unc = head_forward(spec, P, xyzs, dirs, enc_a, ind_code, eye, testing=False,
-                                                       unc_loss=unc_loss)
+    if head is None:
+        sigmas, rgbs, amb_aud, amb_eye, unc = head_forward(spec, P, xyzs, dirs, enc_a, ind_code, eye, testing=False, unc_loss=unc_loss)
+    else:
+        sigmas, rgbs, amb_aud, amb_eye, unc = head(spec, P, xyzs, dirs, enc_a, ind_code, eye, testing=False)
     if amb_eye is None:
         amb_eye = np.zeros_like(amb_aud)
     comp = O.composite_rays_train_forward("triplane", sigmas, rgbs, deltas, rays, amb0=np.abs(amb_aud).sum(-1),

@@ -550,3 +550,34 @@ def test_fused_reference_cap_tiles_equal_the_unsharded_reference_frame(params, g
     assert torch.equal(D.assemble_frame(torch.cat(deps)[:, None], H, W, world, tiles)[:, 0], ref["depth"])
     assert torch.equal(D.assemble_frame(torch.cat(cnts)[:, None], H, W, world, tiles)[:, 0], ref["ray_counts"])
     assert int(ref["ray_counts"].max()) > max_steps
+
+
+@pytest.mark.parametrize("tag", ["ms16", "ms32", "ms16_T", "ms32_perturb", "ms24_dg0"])
+def test_hip_renderers_against_the_reference_loop_fixture(params, tag):
+    """tests/golden/reference_loops.npz = the reference's OWN run_cuda_for_inference (renderer.py:406-570) run unmodified on the checker's
+    kernels (make_golden_loops.py).  Loop mode under the reference schedule and the fused frame with the reference cap against it:
+    iteration count, C_eff and per-ray marched counts exactly, image / depth / sums within north_star's 1e-4 (the fixture's MLP is
+    torch's CPU GEMM, the kernels' the order-pinned MFMA chain)."""
+    import os
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    loops = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_loops.npz"), allow_pickle=False)
+    ms, dg, T, pert = loops[f"{tag}/kw"]
+    kw = dict(max_steps=int(ms), dt_gamma=float(dg), T_thresh=float(T))
+    pre = f"{tag}/inference/"
+    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in params.items()}, bound=1.0)
+    bits = dev(ellipsoid_bitfield()[0])
+    ro, rd = dev(loops["rays_o"]), dev(loops["rays_d"])
+    cond = (dev(loops["enc_a"]), dev(loops["ind_code"]), dev(loops["eye"]))
+    noises = dev(loops[pre + "noises"]) if pert else None
+    sched = loops[pre + "schedule"]
+    for mode in ("loop", "fused"):
+        r = TriplaneRenderer(head, bits, bound=1.0, mode=mode)
+        o = r.render(ro, rd, *cond, count_samples=True, noises=noises, **kw)
+        assert np.array_equal(o["ray_counts"].cpu().numpy().astype(np.int64), loops[pre + "counts"]), mode
+        if mode == "loop":
+            assert int(o["state"][6]) == len(sched)
+        else:
+            assert int(o["state"][11]) == len(sched) and int(o["state"][10]) == int(sched[:, 1].sum())
+        for k in ("image", "image_raw", "weights_sum", "depth", "amb_aud_sum", "amb_eye_sum", "uncertainty_sum"):
+            assert float((o[k].cpu() - torch.from_numpy(loops[pre + k])).abs().max()) <= 1e-4, (mode, k)
