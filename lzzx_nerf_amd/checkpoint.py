@@ -40,11 +40,40 @@ class Checkpoint(NamedTuple):
 _CONTAINER_KEYS = ("model", "mean_count", "mean_density", "mean_density_torso", "epoch", "global_step")
 
 
+def _load(f, map_location, weights_only):
+    """torch.load with the restricted unpickler; the trainer pickles `stats` into the container (TrainerUtil.py:1227-1231), and with
+    use_loss_as_metric off its results are numpy float64 scalars (PSNRMeter.measure: V / N from np.log10), which the restricted unpickler
+    rejects -- retried with exactly the numpy scalar / dtype reconstructors allow-listed, still without arbitrary code execution."""
+    import pickle
+    try:
+        return torch.load(f, map_location=map_location, weights_only=weights_only)
+    except pickle.UnpicklingError as exc:
+        if not weights_only:
+            raise
+        import numpy as np
+        allow = [np.dtype, np.float64, np.float32, np.int64, np.ndarray]
+        for mod, names in (("numpy.core.multiarray", ("scalar", "_reconstruct")), ("numpy._core.multiarray", ("scalar", "_reconstruct"))):
+            try:
+                m = __import__(mod, fromlist=list(names))
+                allow += [getattr(m, n) for n in names if hasattr(m, n)]
+            except ImportError:
+                pass
+        allow += [type(np.dtype(t)) for t in ("float64", "float32", "int64")]
+        if hasattr(f, "seek"):
+            f.seek(0)
+        try:
+            with torch.serialization.safe_globals(allow):
+                return torch.load(f, map_location=map_location, weights_only=True)
+        except pickle.UnpicklingError:
+            raise RuntimeError("checkpoint holds pickled objects beyond tensors and numpy scalars (%s); for a file you trust pass "
+                               "weights_only=False (read_checkpoint / TalkingHeadFrame.from_checkpoint(load_kwargs=dict(weights_only=False)))" % exc) from exc
+
+
 def read_checkpoint(path_or_dict, map_location="cpu", weights_only=True) -> Checkpoint:
     """Parse either layout (TrainerUtil.py:1295-1312).  `path_or_dict`: a file path / file object for `torch.load`, or the dict itself."""
     obj = path_or_dict
     if not isinstance(obj, dict):
-        obj = torch.load(obj, map_location=map_location, weights_only=weights_only)
+        obj = _load(obj, map_location, weights_only)
     if not isinstance(obj, dict):
         raise RuntimeError("checkpoint does not hold a dict (got %s)" % type(obj).__name__)
     if "model" not in obj:                       # TrainerUtil.py:1297-1300: a bare state dict

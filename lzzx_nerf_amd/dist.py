@@ -138,15 +138,20 @@ class PeerTileGatherer:
     `gather(tile)` returns this rank's own frame buffer of frame k, complete once `wait()` has run; valid until the second-next call.
     A buffer is reused two frames later: a peer may only overwrite it after this rank has finished reading frame k - 2, which the
     caller guarantees by calling `wait()` (and consuming the frame) before the second-next `gather` -- the flags of frame k - 1 that the
-    peer waited for were written by this rank after that.  `timed_out` (device int32) is 1 if a wait ever expired.
+    peer waited for were written by this rank after that.
+    An expired wait is FATAL, not silent: the device flag `timed_out` is copied to pinned host memory behind every wait kernel, and the
+    next `gather()` (or an explicit `check()`, which synchronises) raises RuntimeError once it is set -- a peer skewed by more than the
+    poll budget (first-frame warm-up, graph capture, a checkpoint load) would otherwise leave a torn frame in the returned buffer, and
+    the buffer-reuse argument above would stop holding.  `max_polls` (~1 us each) sizes that budget per instance.
 
     CPU tensors (the gloo tests) take the same OFFSET / double-buffer / flag bookkeeping with the peer writes carried by a gloo
     all_gather: the indexing is what those tests pin; the transport needs the GPUs."""
 
     MAX_POLLS = 2_000_000   # ~2 s of polling before a wait gives up
 
-    def __init__(self, n_local, channels, dtype, device, sizes=None, group=None):
+    def __init__(self, n_local, channels, dtype, device, sizes=None, group=None, max_polls=None):
         self.group = group
+        self.max_polls = int(max_polls) if max_polls is not None else self.MAX_POLLS
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.sizes = list(sizes) if sizes is not None else [n_local] * self.world
@@ -159,6 +164,8 @@ class PeerTileGatherer:
         self.frame = [torch.zeros(self.total, channels, dtype=dtype, device=device) for _ in range(2)]
         self.flags = [torch.zeros(max(self.world, 1), dtype=torch.int32, device=device) for _ in range(2)]
         self.timed_out = torch.zeros(1, dtype=torch.int32, device=device)
+        self._timed_out_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.cuda else torch.zeros(1, dtype=torch.int32)
+        self._checked = None       # event behind the newest host copy of `timed_out`
         self.comm = None
         self.peer_frame = self.peer_flags = None
         if self.world > 1 and self.cuda:
@@ -185,9 +192,19 @@ class PeerTileGatherer:
             self.peer_flags.append(ts[2:])
         dist.barrier(group=self.group)   # nobody proceeds (or frees) before every import has succeeded
 
+    def check(self, synchronize=True):
+        """raise if any wait so far has expired.  synchronize=False looks only at host copies that have already landed (what gather() does)"""
+        if self._checked is not None:
+            if synchronize:
+                self._checked.synchronize()
+            if (synchronize or self._checked.query()) and int(self._timed_out_host[0]) != 0:
+                raise RuntimeError("PeerTileGatherer: a wait for the peers' tiles expired after %d polls (rank %d, frame <= %d): the frame buffer is torn; "
+                                   "raise max_polls or find the stalled peer" % (self.max_polls, self.rank, self.k))
+
     def gather(self, tile):
         if self.world == 1:
             return tile
+        self.check(synchronize=False)      # the wait of an earlier frame expired: stop writing into peers' buffers
         i, want = self.k & 1, self.k + 1
         self.k += 1
         lo = self.offsets[self.rank]
@@ -217,7 +234,10 @@ class PeerTileGatherer:
                 self.peer_frame[p][i][lo: lo + self.n_local].copy_(tile, non_blocking=True)
                 self.peer_flags[p][i][self.rank: self.rank + 1].copy_(self._tick[i], non_blocking=True)
             from ._util import call, ptr
-            call("lz_wait_flags", ptr(self.flags[i]), self.world, want, self.MAX_POLLS, ptr(self.timed_out), self.comm.cuda_stream)
+            call("lz_wait_flags", ptr(self.flags[i]), self.world, want, self.max_polls, ptr(self.timed_out), self.comm.cuda_stream)
+            self._timed_out_host.copy_(self.timed_out, non_blocking=True)
+            self._checked = torch.cuda.Event()
+            self._checked.record(self.comm)
         tile.record_stream(self.comm)
         return self.frame[i]
 

@@ -48,7 +48,7 @@ class TalkingHeadFrame:
         self.renderer = TriplaneRenderer(self.head, density_bitfield, bound=bound, **renderer_kw)
 
     @classmethod
-    def from_checkpoint(cls, path_or_dict, density_thresh=10.0, density_thresh_torso=0.01, bitfield="auto", device="cuda", **kw):
+    def from_checkpoint(cls, path_or_dict, density_thresh=10.0, density_thresh_torso=0.01, bitfield="auto", device="cuda", load_kwargs=None, **kw):
         """Build the frame pipeline from a checkpoint the reference's trainer wrote (TrainerUtil.py:1222-1281) or from a bare state dict
         (:1297-1300) -- see lzzx_nerf_amd/checkpoint.py for the two layouts.  `bound` and `exp_eye` default to what the tensors say;
         the occupancy bitfield is the stored buffer, else packbits(density_grid, min(mean_density, density_thresh)) (renderer.py:765),
@@ -56,7 +56,7 @@ class TalkingHeadFrame:
         (march_rays_train's buffer size, renderer.py:287), `mean_density`, `mean_density_torso`; with a torso grid in the file `render`
         masks the torso with `min(density_thresh_torso, mean_density_torso)` like run_torso (renderer.py:603) unless told otherwise."""
         from .checkpoint import infer_hyper, read_checkpoint, resolve_bitfield
-        ck = read_checkpoint(path_or_dict)
+        ck = read_checkpoint(path_or_dict, **(load_kwargs or {}))          # load_kwargs: map_location / weights_only for torch.load
         hyper = infer_hyper(ck.model)
         kw.setdefault("bound", hyper.get("bound", 1.0))
         kw.setdefault("exp_eye", hyper.get("exp_eye", True))

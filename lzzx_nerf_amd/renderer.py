@@ -118,17 +118,22 @@ class TriplaneRenderer:
     def occupied_bounds(self):
         """device tensor [6]: world-space box of the occupied cells of `self.bitfield`, dilated by `occupancy_margin` cells of each level's own size and by
         at least four of the march's longest steps (dt_max = sqrt(3) cells of the outermost level), so that the march walks its last steps
-        in front of the first occupied cell with its ordinary cell tests.  Cached per (tensor, version): an in-place update of the bitfield through torch or through this package
+        in front of the first occupied cell with its ordinary cell tests.  Cached per (tensor object, version): an in-place update of the bitfield through torch or through this package
         (occupancy.update_density_grid, raymarching.packbits into a supplied bitfield: both bump the version) recomputes it; code that writes
         the bitfield through its raw pointer by other means calls invalidate_occupancy()."""
         bf = self.bitfield
-        key = (bf.data_ptr(), bf._version, self.occupancy_margin)
-        if self._occ is None or self._occ[0] != key:
+        # the entry holds the tensor itself: identity (not the address, which the caching allocator hands to the next bitfield of the same
+        # size) plus the version counter.  Inference tensors (created under torch.inference_mode, e.g. a checkpoint loaded inside a serving
+        # loop) track no version: they are rescanned every frame (two small launches)
+        version = None if bf.is_inference() else bf._version
+        hit = (self._occ is not None and version is not None and self._occ[0] is bf and self._occ[1] == (version, self.occupancy_margin, self.cascade,
+                                                                                                      self.grid_size, self.bound))
+        if not hit:
             box = torch.empty(6, dtype=torch.float32, device=bf.device)
             ws = torch.empty(48, dtype=torch.int32, device=bf.device)
             call("lz_occupied_bounds", ptr(bf), int(self.cascade), int(self.grid_size), self.bound, int(self.occupancy_margin), ptr(ws), ptr(box), stream())
-            self._occ = (key, box, ws)
-        return self._occ[1]
+            self._occ = (bf, (version, self.occupancy_margin, self.cascade, self.grid_size, self.bound), box, ws)
+        return self._occ[2]
 
     def invalidate_occupancy(self):
         """forget the cached bounds of the occupied cells (the next fused frame rescans the bitfield)"""
@@ -436,8 +441,9 @@ class NetworkRenderer(TriplaneRenderer):
         N, dev = rays_o.shape[0], rays_o.device
         if N > MAX_RAYS_PER_PASS:
             raise RuntimeError("NetworkRenderer renders at most %d rays per call" % MAX_RAYS_PER_PASS)
-        fresh = self._buf is None or self._buf.N != N
+        prev = self._buf
         b = self._buffers(N, dev)
+        fresh = b is not prev      # (also when the row budget changed: budget_factor)
         if fresh:   # rows no march has written yet are evaluated too: give the network finite positions there
             b.xyzs.zero_(); b.dirs.zero_(); b.deltas.zero_()
             b.amb_aud.zero_(); b.amb_eye.zero_(); b.unc.zero_()
@@ -452,7 +458,9 @@ class NetworkRenderer(TriplaneRenderer):
             b.ray_counts.zero_()
         call("lz_loop_begin", N, int(max_steps), N * self.budget_factor, self.n_step_cap, ptr(b.nears), ptr(b.rays_alive[0]), ptr(b.rays_t), ptr(b.weights_sum),
              ptr(b.depth), ptr(b.image), ptr(b.amb_aud_sum), ptr(b.amb_eye_sum), ptr(b.unc_sum), ptr(b.state), ptr(b.workspace), stream())
-        key = (N, float(dt_gamma), int(max_steps), float(T_thresh), bool(count_samples))
+        # everything the captured launches bake in: scalars, the addresses of the bitfield / aabb / buffers, the schedule
+        key = (N, float(dt_gamma), int(max_steps), float(T_thresh), bool(count_samples), self.bitfield.data_ptr(), self.aabb.data_ptr(), self.bound,
+               int(self.cascade), int(self.grid_size), self.n_step_cap, self.budget_factor, self.min_near, id(b))
         if self.use_graph and (self._graph is None or self._graph[0] != key):
             # capture two iterations.  The capture itself executes nothing, and torch wants the ops warmed up on a side stream first:
             # run one pair for real there (it is simply the frame's first pair), then capture

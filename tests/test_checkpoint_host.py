@@ -98,3 +98,21 @@ def test_hyper_parameters_from_tensors(params):
     del sd2["density_grid"]
     sd2["density_bitfield"] = torch.zeros(2 * 128 ** 3 // 8, dtype=torch.uint8)
     assert infer_hyper(sd2) == {"bound": 2.0, "exp_eye": False, "cascade": 2, "grid_size": 128}
+
+
+def test_container_with_numpy_scalars_in_stats_loads_under_the_restricted_unpickler(params, tmp_path):
+    """use_loss_as_metric off: stats['results'] holds np.float64 values (PSNRMeter.measure = V / N built from np.log10), which
+    torch.load(weights_only=True) rejects; read_checkpoint retries with the numpy scalar reconstructors allow-listed"""
+    sd = reference_state_dict(params)
+    state = container(sd)
+    state["stats"]["results"] = [np.float64(31.25), np.float64(32.5)]
+    state["stats"]["best_result"] = np.float64(32.5)
+    path = tmp_path / "np_stats.pth"
+    torch.save(state, path)
+    with pytest.raises(Exception):
+        torch.load(str(path), weights_only=True)                     # the premise: the plain restricted load fails on this file
+    c = read_checkpoint(str(path))
+    assert c.kind == "container" and c.mean_count == 4321 and float(c.extra["stats"]["best_result"]) == 32.5
+    assert read_checkpoint(str(path), weights_only=False).mean_count == 4321
+    with open(path, "rb") as fh:                                      # file objects are rewound for the retry
+        assert read_checkpoint(fh).epoch == 7

@@ -189,3 +189,28 @@ def test_network_renderer_small_batches_and_recapture():
     want = g.render(ro, rd, aabb, bits, max_steps=64)
     got = r1.render(ro, rd, max_steps=64, count_samples=True)
     assert torch.equal(got["image"], want[0]) and int(got["state"][72]) == want[3]      # the reference's schedule: the same rows, too
+
+
+def test_network_renderer_graph_follows_a_swapped_bitfield_and_schedule():
+    """the captured hipGraph bakes in the bitfield / aabb / buffer addresses and the schedule; replacing `renderer.bitfield` (an
+    occupancy update) or changing budget_factor / n_step_cap between frames must re-capture, not replay launches on stale pointers."""
+    from lzzx_nerf_amd.renderer import NetworkRenderer
+    from lzzx_nerf_amd.synthetic import GenericHashgridNeRF
+    from lzzx_nerf_amd.utils import frame_rays
+    g = GenericHashgridNeRF(torch.device("cuda"))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    bits_a = dev(ellipsoid_bitfield()[0])
+    bits_b = dev(ellipsoid_bitfield(semi=(0.2, 0.25, 0.5))[0])
+    aabb = dev(np.array([-1, -1, -1, 1, 1, 1], F32))
+    pose, intr = synthetic_camera(64, 64)
+    ro, rd = frame_rays(dev(pose), intr, 64, 64)
+    r = NetworkRenderer(lambda x, d: g.net(x, d, 1.0), bits_a, bound=1.0, aabb=aabb, graph=True)
+    a = r.render(ro, rd, max_steps=64)["image"].clone()
+    assert torch.equal(a, g.render(ro, rd, aabb, bits_a, max_steps=64)[0])
+    r.bitfield = bits_b                                  # a new tensor: the old graph points at bits_a
+    b = r.render(ro, rd, max_steps=64)["image"].clone()
+    assert torch.equal(b, g.render(ro, rd, aabb, bits_b, max_steps=64)[0]) and not torch.equal(a, b)
+    r.budget_factor, r.n_step_cap = 1, 8                 # another row budget: new buffers, new graph
+    c = r.render(ro, rd, max_steps=64, count_samples=True)
+    want = g.render(ro, rd, aabb, bits_b, max_steps=64)
+    assert torch.equal(c["image"], want[0]) and int(c["state"][72]) == want[3]

@@ -581,3 +581,32 @@ def test_hip_renderers_against_the_reference_loop_fixture(params, tag):
             assert int(o["state"][11]) == len(sched) and int(o["state"][10]) == int(sched[:, 1].sum())
         for k in ("image", "image_raw", "weights_sum", "depth", "amb_aud_sum", "amb_eye_sum", "uncertainty_sum"):
             assert float((o[k].cpu() - torch.from_numpy(loops[pre + k])).abs().max()) <= 1e-4, (mode, k)
+
+
+def test_occupied_bounds_cache_is_keyed_on_the_tensor_object(params, golden):
+    """(a) a NEW bitfield tensor assigned to the renderer -- which the caching allocator may well place at the freed address of
+    the old one, with the same version counter -- must be rescanned (a stale box silently drops geometry); (b) a bitfield created under
+    torch.inference_mode() tracks no version: it renders (rescanned per frame) instead of raising."""
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    head, bits0, ro, rd, cond = setup(params, golden, 64, 64, "ellipsoid")
+    other = _bitfield_from_cells(_blob(0, (30, 50, 20), 8))
+    r = TriplaneRenderer(head, dev(bits0).clone(), bound=1.0, mode="fused")
+    r.render(ro, rd, *cond, max_steps=64)
+    addr = r.bitfield.data_ptr()
+    r.bitfield = None
+    r._occ = (None,) + tuple(r._occ[1:])     # drop the cache's reference too, as a long-lived server eventually would
+    torch.cuda.synchronize()
+    nb = dev(other).clone()                   # same size: the allocator's favourite block is the one just freed
+    r.bitfield = nb
+    b = {k: v.clone() for k, v in r.render(ro, rd, *cond, max_steps=64, count_samples=True).items()}
+    fresh = TriplaneRenderer(head, dev(other), bound=1.0, mode="fused").render(ro, rd, *cond, max_steps=64, count_samples=True)
+    for k in KEYS + ("ray_counts",):
+        assert torch.equal(b[k], fresh[k]), (k, nb.data_ptr() == addr)
+    assert int(b["state"][5]) > 100
+    with torch.inference_mode():
+        inf_bits = dev(other).clone()
+    assert inf_bits.is_inference()
+    ri = TriplaneRenderer(head, inf_bits, bound=1.0, mode="fused")
+    c = ri.render(ro, rd, *cond, max_steps=64, count_samples=True)
+    for k in KEYS + ("ray_counts",):
+        assert torch.equal(c[k], fresh[k]), k
