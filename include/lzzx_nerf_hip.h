@@ -536,6 +536,10 @@ int lz_loop_composite(lz_loop_state* state, uint32_t N, float T_thresh, int32_t*
                       const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,
                       const float* unc, float* weights_sum, float* depth, float* image, float* amb0_sum, float* amb1_sum,
                       float* unc_sum, void* workspace, lz_stream_t stream);
+/* lz_loop_composite for a network without ambient / uncertainty channels (composite_rays, raymarching.h:17) */
+int lz_loop_composite_plain(lz_loop_state* state, uint32_t N, float T_thresh, int32_t* rays_alive, float* rays_t,
+                            const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
+                            float* image, void* workspace, lz_stream_t stream);
 /* diagnostic (synchronises the device): out2[0] = shader-clock cycles, out2[1] = 100 MHz wall-clock ticks that wave 0 of
  * workgroup 0 spent inside the most recent lz_triplane_head_forward launch; ratio x 100 MHz = sustained shader clock */
 int lz_debug_head_clocks(uint64_t* out2);
@@ -650,6 +654,52 @@ struct lz_timing;
 int lz_frame_render(const lz_frame_fused* f, struct lz_timing* timing, lz_stream_t stream);
 /* cap_mode 1 with defer_finish: schedule replay from cap_ws, phase 2, marched counts (see above); lz_frame_render calls it itself otherwise */
 int lz_frame_finish(const lz_frame_fused* f, lz_stream_t stream);
+
+/* ---- BASELINE cfg2: a generic hash-grid NeRF on the operators of encoding.get_encoder (encoding.py:6-37) ---------------------------
+ * hashgrid (input_dim 3, num_levels 16, level_dim 2; gridencoder.h:12) -> sigma MLP 32-64-16 -> SH(4) + 15 geometry features -> colour
+ * MLP 31-64-3, bias-free Linear + ReLU (network.py:73-94), sigma = exp(row 0), rgb = sigmoid.
+ *
+ * lz_grid_encode_forward_tiled: the level-major gather of lz_grid_encode_forward alone, leaving the TILED layout
+ *     outputs = [tile][level][sample in tile][C], tiles of LZ_GRID_TILE_ROWS samples, a last partial tile of n rows as [level][n][C]
+ * for consumers that read it in place (the head below), so the [B, L*C] matrix is never untiled.  bound > 0: inputs arrive in
+ * [-bound, bound] and are mapped (x + bound) / (2 bound) like GridEncoder.forward (grid.py:143).  count (device int32, may be NULL):
+ * rows in use this launch -- tiles behind it are skipped. */
+#define LZ_GRID_TILE_ROWS 256
+int lz_grid_encode_forward_tiled(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B,
+                                 const int32_t* count, float bound, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                 uint32_t gridtype, int align_corners, int emb_f16, lz_stream_t stream);
+/* The per-sample network behind the gather as ONE kernel on v_mfma_f32_16x16x4_f32 (96 MFMAs per 16 samples).  packed: LZ_NGP_FRAGS
+ * fragments of 64 floats (lzzx_nerf_amd/ngp.py: pack_weights; fragment (ks, ft), lane l = W[16 ft + (l & 15)][k(ks, l >> 4)], zero padded);
+ * feats: feat_layout 0 = f32 [rows, 32] row-major (lz_grid_encode_forward, out_layout 1), 1 = the tiled f32 layout above, 2 = tiled f16
+ * (half tables: features are widened to f32, as `.float()` does in front of the reference's Linear); dirs [rows, 3]; count as above;
+ * sigmas [rows], rgbs [rows, 3]. */
+#define LZ_NGP_FRAGS 96
+int lz_ngp_head_forward(const float* packed, const void* feats, int feat_layout, const float* dirs, uint32_t rows, const int32_t* count,
+                        float* sigmas, float* rgbs, lz_stream_t stream);
+/* Everything one frame of the hash-grid NeRF loop touches (device pointers; sample buffers hold max(sample_budget, N) rows). */
+typedef struct {
+    const float* packed;           /* LZ_NGP_FRAGS * 64 floats */
+    const void* embeddings;        /* hash table, f32 or f16 [offsets[L], 2] */
+    const int32_t* offsets;        /* [L + 1] */
+    uint32_t enc_L, enc_H;         /* num_levels, base_resolution */
+    float enc_S;                   /* log2(per_level_scale), as gridencoder.h:12 */
+    int32_t emb_f16;
+    void* feats;                   /* rows * 32 elements of the table's type (tiled features) */
+    lz_loop_state* state;          /* LZ_LOOP_STATE_INTS int32 */
+    void* workspace;               /* >= 4096 int32 */
+    int32_t* rays_alive[2];
+    float* rays_t;
+    const float* rays_o;  const float* rays_d;  const float* nears;  const float* fars;
+    const uint8_t* grid;           /* density bitfield */
+    float* xyzs;  float* dirs;  float* deltas;  float* sigmas;  float* rgbs;
+    float* weights_sum;  float* depth;  float* image;
+    int32_t* ray_counts;           /* [N] or NULL */
+    uint32_t N, max_steps, C, H;
+    float bound, dt_gamma, T_thresh;
+    uint32_t sample_budget, n_step_cap;   /* 0 = the reference's schedule (N, 8) */
+} lz_frame_ngp;
+/* enqueue `n_iterations` iterations (march -> gather -> head -> composite, 4 launches each) back to back; parity as lz_loop_run */
+int lz_ngp_loop_run(const lz_frame_ngp* f, uint32_t parity, uint32_t n_iterations, lz_stream_t stream);
 
 /* Multi-GPU tile hand-off without a collective (lzzx_nerf_amd/dist.py: PeerTileGatherer): every rank copies its rendered tile straight
  * into each peer's frame buffer (one xGMI hop), then raises its flag there; lz_wait_flags makes `stream` wait, ON THE DEVICE, until all `n`

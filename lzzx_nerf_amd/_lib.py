@@ -57,6 +57,15 @@ class FrameFused(C.Structure):
                 ("cap_mode", u32), ("N_total", u32), ("defer_finish", u32), ("ray_last", vp), ("cap_ws", vp)]
 
 
+class FrameNgp(C.Structure):
+    """mirror of lz_frame_ngp (include/lzzx_nerf_hip.h)"""
+    _fields_ = [("packed", vp), ("embeddings", vp), ("offsets", vp), ("enc_L", u32), ("enc_H", u32), ("enc_S", f32), ("emb_f16", i32), ("feats", vp),
+                ("state", vp), ("workspace", vp), ("rays_alive", vp * 2), ("rays_t", vp), ("rays_o", vp), ("rays_d", vp), ("nears", vp), ("fars", vp),
+                ("grid", vp), ("xyzs", vp), ("dirs", vp), ("deltas", vp), ("sigmas", vp), ("rgbs", vp), ("weights_sum", vp), ("depth", vp),
+                ("image", vp), ("ray_counts", vp), ("N", u32), ("max_steps", u32), ("C", u32), ("H", u32), ("bound", f32), ("dt_gamma", f32),
+                ("T_thresh", f32), ("sample_budget", u32), ("n_step_cap", u32)]
+
+
 # name -> argtypes, in the order of include/lzzx_nerf_hip.h
 SIGNATURES = {
     "lz_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, i32, i32, vp],
@@ -101,7 +110,11 @@ SIGNATURES = {
     "lz_loop_begin": [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_march": [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_composite": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_loop_composite_plain": [vp, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_loop_run": [C.POINTER(Frame), u32, u32, vp, vp],
+    "lz_grid_encode_forward_tiled": [vp, vp, vp, vp, u32, vp, f32, u32, u32, u32, f32, u32, u32, i32, i32, vp],
+    "lz_ngp_head_forward": [vp, vp, i32, vp, u32, vp, vp, vp, vp],
+    "lz_ngp_loop_run": [C.POINTER(FrameNgp), u32, u32, vp],
     "lz_timing_create": [u32, C.POINTER(vp)],
     "lz_timing_destroy": [vp],
     "lz_timing_reset": [vp],

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 SO = os.path.join(LIBDIR, "liblzzx_nerf_hip.so")
-SOURCES = ["lz_grid.hip", "lz_encoders.hip", "lz_raymarch.hip", "lz_head.hip", "lz_head_bwd.hip", "lz_head_rec.hip", "lz_head_rec16.hip", "lz_head_gradw.hip", "lz_head_f16.hip", "lz_frame.hip", "lz_render.hip", "lz_linear.hip", "lz_torso.hip", "lz_audio.hip"]
+SOURCES = ["lz_grid.hip", "lz_encoders.hip", "lz_raymarch.hip", "lz_head.hip", "lz_head_bwd.hip", "lz_head_rec.hip", "lz_head_rec16.hip", "lz_head_gradw.hip", "lz_head_f16.hip", "lz_frame.hip", "lz_ngp.hip", "lz_render.hip", "lz_linear.hip", "lz_torso.hip", "lz_audio.hip"]
 # -ffp-contract=off: every FMA in the kernels is explicit, so results are bit-identical to the CPU checker
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
          "-Rpass-analysis=kernel-resource-usage"]   # the remarks are parsed into lib/kernel_resources.json (registers, spills, LDS per kernel)

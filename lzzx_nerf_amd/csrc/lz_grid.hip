@@ -717,11 +717,15 @@ lz_k_grid_forward_lm(const float* __restrict__ inputs, const T* __restrict__ gri
 template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(512)
 lz_k_grid_forward_lmp(const float* __restrict__ inputs, const T* __restrict__ grid, const int* __restrict__ offsets,
-                      T* __restrict__ outputs, uint32_t B, uint32_t L, LzGridLevels lv, uint32_t gridtype, bool align_corners) {
+                      T* __restrict__ outputs, uint32_t B, uint32_t L, LzGridLevels lv, uint32_t gridtype, bool align_corners,
+                      const int* __restrict__ count = nullptr, float bound = 0.0f) {
+    // count (lz_grid_encode_forward_tiled): rows that hold samples this launch, read on the device (the render loop's n_alive * n_step); tiles
+    // behind it do nothing.  bound > 0: inputs arrive in [-bound, bound] and are mapped like GridEncoder.forward, (x + bound) / (2 bound) (grid.py:143)
     constexpr uint32_t NC = 1u << (D - 1), WORDS = sizeof(T) * C / 4;
     static_assert(sizeof(T) * C % 4 == 0, "pair kernel moves whole dwords");
     const uint32_t Tn = blockDim.x >> 1, tile = blockIdx.x, level = blockIdx.y, t = threadIdx.x >> 1, xb = threadIdx.x & 1u;
     const uint32_t b0 = tile * Tn;
+    if (count && b0 >= (uint32_t)*count) return;
     const uint32_t n = (B - b0 < Tn) ? B - b0 : Tn;
     if (t >= n) return;   // pair-uniform
     const uint32_t b = b0 + t;
@@ -735,6 +739,7 @@ lz_k_grid_forward_lmp(const float* __restrict__ inputs, const T* __restrict__ gr
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
         x[d] = inputs[(size_t)b * D + d];
+        if (bound > 0.0f) x[d] = (x[d] + bound) / (2.0f * bound);
         if (x[d] < 0 || x[d] > 1) oob = true;
     }
     float pos[D];
@@ -859,7 +864,8 @@ static void lz_grid_lm_launch(const float* inputs, const T* emb, const int* offs
     const uint32_t tiles = lz_div_up(B, Tn);
     if constexpr (sizeof(T) * C % 4 == 0 && D >= 3)   // two lanes per sample (x corner pairs share a line); measured: D3/C2 f32
                                                       // 3.62 -> 3.29 ms, f16 3.05 -> 2.36 ms per 2^23 samples; D2/C1 gets slower
-        hipLaunchKernelGGL((lz_k_grid_forward_lmp<T, D, C>), dim3(tiles, L), dim3(2 * Tn), 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac);
+        hipLaunchKernelGGL((lz_k_grid_forward_lmp<T, D, C>), dim3(tiles, L), dim3(2 * Tn), 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac,
+                           (const int*)nullptr, 0.0f);
     else
         hipLaunchKernelGGL((lz_k_grid_forward_lm<T, D, C>), dim3(tiles, L), dim3(Tn), 0, st, inputs, emb, offsets, out, B, L, lv, gridtype, ac);
     // LDS row pitch: level l starts at bank (l * 64/L) so the 64 lanes of a store (64/LW samples x L levels x W) hit 64 banks
@@ -1231,6 +1237,31 @@ extern "C" int lz_grid_encode_forward(const float* inputs, const void* embedding
                                   gridtype, align_corners != 0, sm, resident, lz_st(stream));
     if (rc != LZ_OK) return rc;
     LZ_CHECK_LAUNCH("grid_encode_forward");
+    return LZ_OK;
+}
+
+// The level-major pass alone, for consumers that read the TILED layout themselves (lz_ngp.hip: the hash-grid NeRF head gathers its MFMA
+// operands straight from it, so the [B, L*C] matrix is never untiled): outputs = [tile][level][sample in tile][C], tiles of
+// LZ_GRID_TILE_ROWS samples, a last partial tile of n rows packed as [level][n][C].  `count` (device int32, may be NULL): rows in use.
+extern "C" int lz_grid_encode_forward_tiled(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B,
+                                            const int32_t* count, float bound, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                            uint32_t gridtype, int align_corners, int emb_f16, lz_stream_t stream) {
+    if (B == 0) return LZ_OK;
+    LZ_REQUIRE(inputs && embeddings && offsets && outputs, LZ_ERR_BAD_ARGUMENT, "grid_encode_forward_tiled: null tensor");
+    LZ_REQUIRE(D == 3 && C == 2, LZ_ERR_UNSUPPORTED, "grid_encode_forward_tiled: input_dim 3, level_dim 2 (get_encoder('hashgrid') defaults, encoding.py:6-8)");
+    LZ_REQUIRE(bound >= 0.0f, LZ_ERR_BAD_ARGUMENT, "grid_encode_forward_tiled: bound must be >= 0 (0 = inputs already in [0, 1])");
+    LzGridLevels lv;
+    LZ_REQUIRE(lz_fill_levels(lv, L, S, H) == 0, LZ_ERR_UNSUPPORTED, "grid_encode_forward_tiled: at most %d levels", LZ_MAX_LEVELS);
+    const uint32_t Tn = LZ_GRID_TILE_ROWS, tiles = lz_div_up(B, Tn);
+    const bool ac = align_corners != 0;
+    hipStream_t st = lz_st(stream);
+    if (emb_f16)
+        hipLaunchKernelGGL((lz_k_grid_forward_lmp<__half, 3, 2>), dim3(tiles, L), dim3(2 * Tn), 0, st, inputs, (const __half*)embeddings, offsets,
+                           (__half*)outputs, B, L, lv, gridtype, ac, count, bound);
+    else
+        hipLaunchKernelGGL((lz_k_grid_forward_lmp<float, 3, 2>), dim3(tiles, L), dim3(2 * Tn), 0, st, inputs, (const float*)embeddings, offsets,
+                           (float*)outputs, B, L, lv, gridtype, ac, count, bound);
+    LZ_CHECK_LAUNCH("grid_encode_forward_tiled");
     return LZ_OK;
 }
 

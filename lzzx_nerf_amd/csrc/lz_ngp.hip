@@ -1,0 +1,176 @@
+// lz_ngp.hip -- BASELINE cfg2: a generic hash-grid NeRF ("256 x 256, 128 samples / ray, hash-grid L = 16 F = 2, forward render") on the
+// operators of encoding.get_encoder (encoding.py:6-37): hashgrid (D 3, L 16, C 2, T 2^19; gridencoder.cu:75-223) -> sigma MLP 32-64-16,
+// SH(4) of the view direction + 15 geometry features -> colour MLP 31-64-3, bias-free Linear + ReLU (network.py:73-94), sigma = exp,
+// rgb = sigmoid -- and the reference's inference loop around it (renderer.py:495-548).
+//
+// MI355X design.  The hash-grid gather wants to run LEVEL-major: with level the slow launch dimension the whole chip reads one or two
+// <= 4 MB levels at a time and they stay resident in the 4 MB L2 of every XCD (69 % of the HBM roofline in march order), whereas a kernel
+// in which every wave touches all 16 levels at once (a persistent frame kernel like lz_frame.hip) has the whole 49 MB table as its L2
+// working set and was measured at 16 %.  So the gather stays the level-major pass of lz_grid.hip and everything else is fused around it:
+//     lz_loop_march            state advance + compaction + march of the survivors                    (lz_raymarch.hip)
+//     lz_k_grid_forward_lmp    level-major gather, TILED output, rows bounded by the device-side sample count, no untile pass
+//     lz_k_ngp_head            per 16-sample slice: B operands straight from the tiles -> sigma MLP -> SH(4) -> colour MLP on
+//                              v_mfma_f32_16x16x4_f32 (96 MFMAs), sigma / rgb out -- replaces 4 Linear launches + cat + activations + copies
+//     lz_loop_composite_plain  accumulate, kill, count survivors
+// four launches per iteration of the reference's loop, enqueued back to back by lz_ngp_loop_run with the loop state in device memory.
+//
+// Arithmetic: every Linear is an fma chain in MFMA k order (oracle/ngp.py spells the order per layer); the first layer's k order follows
+// the tiled layout (lane q of a sample reads levels q, q + 4, q + 8, q + 12, both channels: one 8-byte load each), the hidden layers
+// consume the previous accumulator tile in place ("chained" order, as lz_head.hip).
+#include "lz_common.h"
+#include "lzzx_detmath.h"
+#include "lzzx_sh_eval.h"
+#include "lz_head_layers.h"
+#include <hip/hip_fp16.h>
+
+// fragment (ks, ft) of a layer: 64 floats, lane l = W[16 ft + (l & 15)][k(ks, l >> 4)]
+#define LZN_S1 0       // 32 -> 64: 8 k-steps x 4 tiles
+#define LZN_S2 32      // 64 -> 16: 16 x 1
+#define LZN_C1 48      // 32 slots (SH 16 | sigma_net output 16, slot of its row 0 weighted 0) -> 64: 8 x 4
+#define LZN_C2 80      // 64 -> 3 (one tile, rows 3..15 zero): 16 x 1
+static_assert(LZN_C2 + 16 == LZ_NGP_FRAGS, "fragment count mismatch with the header");
+
+struct LzNgpK {
+    const float* packed;
+    const void* feats;
+    const float* dirs;
+    const int* count;
+    float* sigmas;
+    float* rgbs;
+    uint32_t rows;        // rows of feats / dirs (the encoder's B: it fixes the packing of the last, partial tile)
+};
+
+// FEAT: 0 = row-major f32 [rows, 32]; 1 = tiled f32 (lz_grid_encode_forward_tiled); 2 = tiled f16
+template <int FEAT>
+__global__ void __launch_bounds__(256) lz_k_ngp_head(LzNgpK P) {
+    __shared__ __align__(16) float wl[LZ_NGP_FRAGS * 64];
+    {
+        const float4* src = reinterpret_cast<const float4*>(P.packed);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (uint32_t i = threadIdx.x; i < LZ_NGP_FRAGS * 16; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    uint32_t rows = P.rows;
+    if (P.count) {
+        const int c = *P.count;
+        rows = c < 0 ? 0u : ((uint32_t)c < rows ? (uint32_t)c : rows);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = lane & 15, q = lane >> 4;
+    const uint32_t n_slices = (rows + 15u) / 16u, Tn = LZ_GRID_TILE_ROWS;
+    for (uint32_t slice = blockIdx.x * 4u + (uint32_t)wave; slice < n_slices; slice += gridDim.x * 4u) {
+        const uint32_t row = slice * 16u + (uint32_t)s;
+        const bool valid = row < rows;
+        const uint32_t r = valid ? row : rows - 1u;
+        // ---------------- B operands of sigma_net.0: levels q, q + 4, q + 8, q + 12 of sample s, both channels ----------------
+        float b1[8];
+        if constexpr (FEAT == 0) {
+            const float2* f = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(P.feats) + (size_t)r * 32);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const float2 v = f[q + 4 * i]; b1[2 * i] = v.x; b1[2 * i + 1] = v.y; }
+        } else {
+            const uint32_t tile = r / Tn, t = r - tile * Tn, b0 = tile * Tn, n = (P.rows - b0 < Tn) ? P.rows - b0 : Tn;
+            if constexpr (FEAT == 1) {
+                const float2* f = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(P.feats) + (size_t)b0 * 32);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const float2 v = f[(size_t)(q + 4 * i) * n + t]; b1[2 * i] = v.x; b1[2 * i + 1] = v.y; }
+            } else {
+                const __half2* f = reinterpret_cast<const __half2*>(reinterpret_cast<const __half*>(P.feats) + (size_t)b0 * 32);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const float2 v = __half22float2(f[(size_t)(q + 4 * i) * n + t]); b1[2 * i] = v.x; b1[2 * i + 1] = v.y; }
+            }
+        }
+        const float dx = P.dirs[(size_t)r * 3], dy = P.dirs[(size_t)r * 3 + 1], dz = P.dirs[(size_t)r * 3 + 2];
+        // ---------------- sigma_net: 32 -> 64 (ReLU) -> 16 ----------------
+        float h1[16];
+        {
+            lz_f4 acc[4];
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++) acc[ft] = lz_f4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(LZN_S1 + ks * 4 + ft) * 64 + lane], b1[ks], acc[ft], 0, 0, 0);
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) h1[4 * ft + rr] = lz_relu(acc[ft][rr]);
+        }
+        lz_f4 h = lz_f4{0, 0, 0, 0};          // h[rr] = output 4 q + rr of sigma_net: row 0 -> sigma, rows 1..15 -> geometry features
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) h = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(LZN_S2 + ks) * 64 + lane], h1[ks], h, 0, 0, 0);
+        // ---------------- colour_net: [SH(4) of the direction | geometry] -> 64 (ReLU) -> 3 ----------------
+        float sh[16];
+        lz_sh_eval(dx, dy, dz, 4, sh, nullptr, nullptr, nullptr);
+        float c1[16];
+        {
+            lz_f4 acc[4];
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++) acc[ft] = lz_f4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+                float b;
+                if (ks < 4) b = q == 0 ? sh[4 * ks] : (q == 1 ? sh[4 * ks + 1] : (q == 2 ? sh[4 * ks + 2] : sh[4 * ks + 3]));     // SH component 4 ks + q
+                else b = h[ks - 4];                                                                                              // sigma_net output 4 q + (ks - 4)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(LZN_C1 + ks * 4 + ft) * 64 + lane], b, acc[ft], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) c1[4 * ft + rr] = lz_relu(acc[ft][rr]);
+        }
+        lz_f4 c = lz_f4{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(LZN_C2 + ks) * 64 + lane], c1[ks], c, 0, 0, 0);
+        if (q == 0 && valid) {
+            P.sigmas[row] = lz_expf(h[0]);
+            P.rgbs[(size_t)row * 3] = lz_sigmoidf(c[0]);
+            P.rgbs[(size_t)row * 3 + 1] = lz_sigmoidf(c[1]);
+            P.rgbs[(size_t)row * 3 + 2] = lz_sigmoidf(c[2]);
+        }
+    }
+}
+
+extern "C" int lz_ngp_head_forward(const float* packed, const void* feats, int feat_layout, const float* dirs, uint32_t rows, const int32_t* count,
+                                   float* sigmas, float* rgbs, lz_stream_t stream) {
+    if (rows == 0) return LZ_OK;
+    LZ_REQUIRE(packed && feats && dirs && sigmas && rgbs, LZ_ERR_BAD_ARGUMENT, "ngp_head_forward: null tensor");
+    LZ_REQUIRE(feat_layout >= 0 && feat_layout <= 2, LZ_ERR_BAD_ARGUMENT, "ngp_head_forward: feat_layout 0 (row-major f32), 1 (tiled f32) or 2 (tiled f16)");
+    LzNgpK K{packed, feats, dirs, count, sigmas, rgbs, rows};
+    uint32_t grid = lz_div_up(rows, 16 * 4 * 4);      // ~4 slices per wave
+    const uint32_t cap = (uint32_t)lz_cu_count() * 8u;
+    grid = grid < 1 ? 1 : (grid > cap ? cap : grid);
+    hipStream_t st = lz_st(stream);
+    if (feat_layout == 0) hipLaunchKernelGGL((lz_k_ngp_head<0>), dim3(grid), dim3(256), 0, st, K);
+    else if (feat_layout == 1) hipLaunchKernelGGL((lz_k_ngp_head<1>), dim3(grid), dim3(256), 0, st, K);
+    else hipLaunchKernelGGL((lz_k_ngp_head<2>), dim3(grid), dim3(256), 0, st, K);
+    LZ_CHECK_LAUNCH("ngp_head_forward");
+    return LZ_OK;
+}
+
+// enqueue `n_iterations` iterations of the reference's inference loop (renderer.py:503-548) around the hash-grid NeRF: march -> gather ->
+// head -> composite, four launches each, no host round trip; iterations past the end of the frame are no-ops on the device
+extern "C" int lz_ngp_loop_run(const lz_frame_ngp* f, uint32_t parity, uint32_t n_iterations, lz_stream_t stream) {
+    LZ_REQUIRE(f && f->state && f->workspace && f->rays_alive[0] && f->rays_alive[1] && f->packed && f->embeddings && f->offsets && f->feats,
+               LZ_ERR_BAD_ARGUMENT, "ngp_loop_run: incomplete lz_frame_ngp");
+    uint32_t cur = parity & 1u;
+    const int32_t* count = reinterpret_cast<const int32_t*>(f->state) + LZ_LOOP_NEXT + 2;  // n_samples of the iteration in flight
+    const uint32_t rows = f->sample_budget > f->N ? f->sample_budget : f->N;  // capacity of the sample buffers
+    for (uint32_t it = 0; it < n_iterations; it++) {
+        const uint32_t nxt = cur ^ 1u;
+        int rc = lz_loop_march(f->state, f->N, f->sample_budget, f->n_step_cap, f->rays_alive[cur], f->rays_alive[nxt], f->workspace, f->rays_t,
+                               f->rays_o, f->rays_d, f->bound, f->dt_gamma, f->max_steps, f->C, f->H, f->grid, f->nears, f->fars, f->xyzs,
+                               f->dirs, f->deltas, f->ray_counts, stream);
+        if (rc != LZ_OK) return rc;
+        rc = lz_grid_encode_forward_tiled(f->xyzs, f->embeddings, f->offsets, f->feats, rows, count, f->bound, 3, 2, f->enc_L, f->enc_S, f->enc_H, 0,
+                                          0, f->emb_f16, stream);
+        if (rc != LZ_OK) return rc;
+        rc = lz_ngp_head_forward(f->packed, f->feats, f->emb_f16 ? 2 : 1, f->dirs, rows, count, f->sigmas, f->rgbs, stream);
+        if (rc != LZ_OK) return rc;
+        rc = lz_loop_composite_plain(f->state, f->N, f->T_thresh, f->rays_alive[nxt], f->rays_t, f->sigmas, f->rgbs, f->deltas, f->weights_sum,
+                                     f->depth, f->image, f->workspace, stream);
+        if (rc != LZ_OK) return rc;
+        cur = nxt;
+    }
+    return LZ_OK;
+}

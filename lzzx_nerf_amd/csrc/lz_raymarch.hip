@@ -1351,6 +1351,18 @@ extern "C" int lz_loop_composite(lz_loop_state* state, uint32_t N, float T_thres
     return LZ_OK;
 }
 
+// the same for a network without ambient / uncertainty channels (composite_rays, raymarching.cu:942-1020): the hash-grid NeRF loop (lz_ngp.hip)
+extern "C" int lz_loop_composite_plain(lz_loop_state* state, uint32_t N, float T_thresh, int32_t* rays_alive, float* rays_t, const float* sigmas,
+                                       const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image, void* workspace,
+                                       lz_stream_t stream) {
+    LZ_REQUIRE(state && workspace, LZ_ERR_BAD_ARGUMENT, "loop_composite_plain: null state / workspace");
+    if (N == 0) return LZ_OK;
+    hipLaunchKernelGGL((lz_k_composite_rays<0, false, false, true>), dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), 0u, 0u, state, T_thresh,
+                       rays_alive, rays_t, sigmas, rgbs, deltas, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, weights_sum,
+                       depth, image, (float*)nullptr, (float*)nullptr, (float*)nullptr, reinterpret_cast<int*>(workspace));
+    LZ_CHECK_LAUNCH("loop_composite_plain");
+    return LZ_OK;
+}
 
 __global__ void __launch_bounds__(256)
 lz_k_final_blend(const float* __restrict__ image, const float* __restrict__ weights_sum, const float* __restrict__ bg, float bg_scalar,
