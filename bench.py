@@ -824,6 +824,31 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
                                      samples_per_s=round(int(st3[5]) / ms3 * 1e3, 1), iterations_per_frame=int(st3[6]), rows_evaluated_per_frame=int(st3[6]) * 4 * 65536,
                                      image_equal_to_reference_loop=bool(torch.equal(o3["image"], img_ref)))
                     del nr
+                # the fused path (lzzx_nerf_amd/ngp.py): tiled level-major gather + one MFMA head kernel + composite, 4 launches per iteration
+                from lzzx_nerf_amd.ngp import FusedHashgridNeRF, HashgridRenderer
+                fnet = FusedHashgridNeRF(g2.enc, g2.sigma_net, g2.color_net, half_tables=half)
+                best = None
+                for sched in ((8, 8), (4, 4), (8, 16), (1, 8)):
+                    hr = HashgridRenderer(fnet, bits2, bound=1.0, aabb=aabb2, budget_factor=sched[0], n_step_cap=sched[1])
+                    ms4, o4 = time2(lambda: hr.render(ro2, rd2, max_steps=128))
+                    st4 = o4["state"].cpu().numpy()
+                    d4 = dict(ms_per_frame=round(ms4, 3), rays_per_s=round(65536 / ms4 * 1e3, 1), samples_per_frame=int(st4[5]),
+                              samples_per_s=round(int(st4[5]) / ms4 * 1e3, 1), iterations_per_frame=int(st4[6]), sample_rows_per_frame=int(st4[72]),
+                              schedule=f"n_step = max(min({sched[0]} * N // n_alive, {sched[1]}), 1)" + (" (the reference's)" if sched == (1, 8) else ""),
+                              max_abs_diff_vs_reference_loop_image=float((o4["image"] - img_ref).abs().max()))
+                    leg.setdefault("fused_schedules", {})["%dx%d" % sched] = d4
+                    if best is None or ms4 < best[0]:
+                        best = (ms4, d4)
+                    del hr
+                leg["fused"] = dict(best[1], note="lz_ngp_loop_run: march -> level-major gather (tiled, never untiled) -> lz_k_ngp_head (both MLPs + SH + "
+                                    "activations on v_mfma_f32_16x16x4_f32) -> composite; the fastest of fused_schedules; pixels differ from the "
+                                    "operator-API network only by the Linear layers' summation order")
+                # roofline of the leg: the gather's algorithmic bytes (1 164 B per sample f32 tables, 588 B f16) over the whole frame time
+                per = 588 if half else 1164
+                leg["fused"]["roofline"] = dict(bound="hbm", unit="GB/s", peak=8000.0, achieved=round(per * best[1]["sample_rows_per_frame"] / best[0] / 1e6, 1),
+                                                frac=round(per * best[1]["sample_rows_per_frame"] / best[0] / 1e6 / 8000.0, 4),
+                                                note="algorithmic gather bytes of the rows evaluated / whole-frame time (march, head and composite included)")
+                del fnet
                 legs2[tag] = leg
                 del g2
             result["cfg2_hashgrid_render"] = dict(

@@ -42,6 +42,32 @@ def lib():
     return _lib
 
 
+def build_fast():
+    """the second checker library: every product fused into the addition behind it that the compiler can reach, across statements too
+    (oracle/Makefile `fast`) -- the other reading of nvcc's -fmad; tests/test_fma_contraction_bound.py"""
+    so = os.path.join(_HERE, "_build", "liblzzx_oracle_fast.so")
+    subprocess.check_call(["make", "-C", _HERE, "fast"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class variant:
+    """`with oracle.variant(path):` -- every checker call inside goes to another build of the library"""
+
+    def __init__(self, so_path):
+        self.so = so_path
+
+    def __enter__(self):
+        global _lib
+        lib()
+        self.prev = _lib
+        _lib = C.CDLL(self.so)
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+
+
 def host_cores():
     """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands each job a share of
     its host: 256 CPUs in the mask, a quota of 16)"""

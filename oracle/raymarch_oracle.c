@@ -29,6 +29,17 @@
 #include <string.h>
 #include "lzzx_detmath.h"
 
+/* `weight = alpha * T; weight_sum += weight;` (raymarching.cu:2203-2206 and siblings): two statements.  The checker reads nvcc's default
+ * -fmad=true as "a * b + c inside ONE expression becomes an fma" and keeps these two roundings; a compiler that fuses across statements
+ * (NVPTX-style) may emit fma(alpha, T, weight_sum) for the sum while still materialising `weight`.  That reading is undecidable without
+ * nvcc, so the SECOND checker library (oracle/_build/liblzzx_oracle_fast.so: -DLZO_CONTRACT_ACROSS_STATEMENTS -ffp-contract=fast -mfma)
+ * takes the other side of every such choice, and tests/test_fma_contraction_bound.py measures how far apart the two land. */
+#ifdef LZO_CONTRACT_ACROSS_STATEMENTS
+#define LZO_ACC_PRODUCT(a, b, product, acc) lz_fmaf((a), (b), (acc))
+#else
+#define LZO_ACC_PRODUCT(a, b, product, acc) ((acc) + (product))
+#endif
+
 #define SQRT3F 1.7320508075688772f
 #define RPIF 0.3183098861837907f
 
@@ -338,7 +349,7 @@ void lzo_composite_rays_train_forward(const float* sigmas, const float* rgbs, co
                 g = lz_fmaf(weight, rgbs[i * 3 + 1], g);
                 b = lz_fmaf(weight, rgbs[i * 3 + 2], b);
                 d = lz_fmaf(weight, deltas[i * 2 + 1], d);
-                ws += weight;
+                ws = LZO_ACC_PRODUCT(alpha, T, weight, ws);
                 if (n_amb > 0) a0 = amb_weighted ? lz_fmaf(weight, amb0[i], a0) : a0 + amb0[i];
                 if (n_amb > 1) a1 = amb_weighted ? lz_fmaf(weight, amb1[i], a1) : a1 + amb1[i];
                 if (has_unc) u = lz_fmaf(weight, unc[i], u);
@@ -384,7 +395,7 @@ void lzo_composite_rays_train_backward(const float* grad_weights_sum, const floa
             b = lz_fmaf(weight, rgbs[i * 3 + 2], b);
             if (n_amb > 0 && amb_weighted) amb = lz_fmaf(weight, amb0[i], amb);
             if (has_unc) u = lz_fmaf(weight, unc[i], u);
-            ws += weight;
+            ws = LZO_ACC_PRODUCT(alpha, T, weight, ws);
             T *= 1.0f - alpha;
             grad_rgbs[i * 3] = gi0 * weight;
             grad_rgbs[i * 3 + 1] = gi1 * weight;
@@ -424,7 +435,7 @@ void lzo_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32
             const float alpha = 1.0f - lz_expf(-sigmas[i] * deltas[i * 2]);
             const float T = 1 - weight_sum;
             const float weight = alpha * T;
-            weight_sum += weight;
+            weight_sum = LZO_ACC_PRODUCT(alpha, T, weight, weight_sum);
             t = deltas[i * 2 + 1];
             d = lz_fmaf(weight, t, d);
             r = lz_fmaf(weight, rgbs[i * 3], r);
