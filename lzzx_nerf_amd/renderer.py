@@ -98,6 +98,7 @@ class TriplaneRenderer:
         if aabb is None:  # renderer.py:110 -- y extent halved
             aabb = torch.tensor([-bound, -bound / 2, -bound, bound, bound / 2, bound], dtype=torch.float32, device=dev)
         self.aabb = aabb.to(dev, torch.float32).contiguous()
+        self._aabb_diag = None      # (tensor, version, diagonal): see _cap_can_bind
         self.min_near = float(min_near)
         if density_scale != 1:
             raise NotImplementedError("density_scale != 1 (the reference hard-codes 1, renderer.py:95)")
@@ -134,6 +135,22 @@ class TriplaneRenderer:
             call("lz_occupied_bounds", ptr(bf), int(self.cascade), int(self.grid_size), self.bound, int(self.occupancy_margin), ptr(ws), ptr(box), stream())
             self._occ = (bf, (version, self.occupancy_margin, self.cascade, self.grid_size, self.bound), box, ws)
         return self._occ[2]
+
+    def _cap_can_bind(self, dt_gamma, max_steps):
+        """False when no ray can collect max_steps samples, so the cap -- and with it the iteration schedule -- cannot touch any pixel: a
+        ray's samples lie inside the aabb, at most its diagonal D apart, and consecutive samples are at least dt_min = min(dt_max, 2 sqrt(3) /
+        max_steps) apart (raymarching.cu:866-867, 907), so a ray holds at most D / dt_min + 1 of them.  The reference's own aabb (y extent
+        halved, renderer.py:110: D = 3 bound < 2 sqrt(3) bound) never reaches the cap once dt_min = 2 sqrt(3) / max_steps, e.g. the 192-step
+        headline frame; its deployed max_steps = 16 (dt_min = dt_max) does.  The diagonal is read back once per aabb tensor."""
+        a = self.aabb
+        ver = None if a.is_inference() else a._version
+        if self._aabb_diag is None or self._aabb_diag[0] is not a or self._aabb_diag[1] != ver or ver is None:
+            lo_hi = a.detach().cpu().double()
+            self._aabb_diag = (a, ver, float(((lo_hi[3:] - lo_hi[:3]) ** 2).sum().sqrt()))
+        import math
+        dt_max = 2 * math.sqrt(3) * (1 << (int(self.cascade) - 1)) / int(self.grid_size)
+        dt_min = min(dt_max, 2 * math.sqrt(3) / max(int(max_steps), 1))
+        return self._aabb_diag[2] / dt_min + 2 >= int(max_steps)
 
     def invalidate_occupancy(self):
         """forget the cached bounds of the occupied cells (the next fused frame rescans the bitfield)"""
@@ -363,7 +380,10 @@ class TriplaneRenderer:
         if self.clip_to_occupancy:
             f.occupied_aabb, f.t_end = p(self.occupied_bounds()), p(b["t_end"])
         deferred = False
-        if self.cap == "reference":
+        # the reference's cap needs the schedule replay only if some ray can reach max_steps at all (or marched counts are asked for: a
+        # T_thresh-cut ray's count depends on the chunk it was cut in); otherwise the plain launch renders the same pixels
+        # (ranks rendering tiles of one frame share aabb and max_steps, so they take the same branch: no histogram exchange either)
+        if self.cap == "reference" and (count_samples or self._cap_can_bind(dt_gamma, max_steps)):
             need = 2 * int(max_steps) + 24            # LZ_FRAME_CAP_WS_INTS
             if b["cap_ws"] is None or b["cap_ws"].numel() < need:
                 b["cap_ws"] = torch.zeros(need, dtype=torch.int32, device=dev)
