@@ -394,31 +394,85 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                     }
                     if (base + take >= n_queue) dry = true;
                 }
-                if (leader && ray >= 0 && kk == 0) {
-                    m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, slot[SF_RD * 16 + s], slot[(SF_RD + 1) * 16 + s], slot[(SF_RD + 2) * 16 + s],
-                           F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
-                    if (use_lut) m.morton_lut = mlut;
-                    float t = slot[SF_T * 16 + s];
-                    const float far = slot[SF_FAR * 16 + s];
-                    const int want = min(S, cap - sloti[SF_CNT * 16 + s]);      // >= 1: a ray at the cap has left its slot
-                    while (t < far && kk < want) {
-                        float x, y, z, dt;
-                        if (m.probe(t, x, y, z, dt)) {
-                            const int sl = s + kk;
-                            slot[SF_X * 16 + sl] = x; slot[SF_Y * 16 + sl] = y; slot[SF_Z * 16 + sl] = z;
-                            slot[SF_DT * 16 + sl] = dt;
-                            t += dt;
-                            slot[SF_TS * 16 + sl] = t;
-                            kk++;
+                // ---- march, S candidates of a ray per round on the S lanes of its group (lanes q == 0: lane lead + j takes candidate j) ----
+                // Every step of the reference's march -- the sample step and the empty-space skip alike -- is t += clamp(t dt_gamma, dt_min,
+                // dt_max) (raymarching.cu:907, 919-926): a ray visits a subsequence of ONE fixed chain c_0 = t, c_{i+1} = c_i + step(c_i).  So
+                // the group's lanes locate and test the next S chain points TOGETHER (one cell test and one bitfield load deep instead of S),
+                // and then all of them replay the serial rule on the S results: an occupied cell is a sample; an empty one at c_i moves the
+                // ray to the first chain point at or behind its exit time, exactly what LzMarch::probe's do-while does.  Same cells, same
+                // arithmetic per cell (LzMarch::locate / exit_t), same samples.
+                {
+                    const int gray = __shfl(ray, lead, 64);                      // the group's ray and whether it still has to march this pass
+                    const int gkk0 = __shfl(kk, lead, 64);
+                    const bool grp = q == 0 && gray >= 0 && gkk0 == 0;
+                    if (__ballot(grp)) {
+                        float t0 = 0.0f, far = 0.0f;
+                        int want = 0, got = 0;
+                        if (grp) {
+                            m.init(F.rays_o + (size_t)gray * 3, F.rays_d + (size_t)gray * 3, slot[SF_RD * 16 + lead], slot[(SF_RD + 1) * 16 + lead],
+                                   slot[(SF_RD + 2) * 16 + lead], F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+                            if (use_lut) m.morton_lut = mlut;
+                            t0 = slot[SF_T * 16 + lead];
+                            far = slot[SF_FAR * 16 + lead];
+                            want = min(S, cap - sloti[SF_CNT * 16 + lead]);      // >= 1: a ray at the cap has left its slot
                         }
-                    }
-                    if (kk == 0) {     // the ray left the box without another sample
-                        const int c0 = sloti[SF_CNT * 16 + s];
-                        lzf_ray_end(F, ph2, ray, LZF_END_BOX, c0, c0, t, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s],
-                                    slot[SF_B * 16 + s], slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s]);
-                        my_samples += c0 - cnt_base;
-                        ray = -1;
-                        sloti[SF_RAY * 16 + s] = -1;
+                        bool more = grp && t0 < far;
+                        while (__ballot(more)) {
+                            float c = t0;
+#pragma unroll
+                            for (int i = 0; i < S - 1; i++) c = (i < j) ? c + m.step_at(c) : c;        // chain point j
+                            LzMarch::Cell cell;
+                            cell.x = cell.y = cell.z = cell.dt = 0.0f;
+                            float txo = 0.0f;                                     // < 0: the cell is occupied; else the exit time of the empty cell
+                            const bool valid = more && c < far;
+                            if (valid) {
+                                m.locate(c, cell);
+                                txo = m.occupied(cell) ? -1.0f : m.exit_t(c, cell);
+                            }
+                            const float cn = c + m.step_at(c);                    // chain point j + 1 (= c + cell.dt)
+                            // replay of the serial rule over the S candidates, identical on every lane of the group (the chain is recomputed
+                            // in step with it -- same operations, same bits -- so only the test results cross lanes: one shuffle per candidate)
+                            float skip = -FLT_MAX, t_new = t0, ci = t0;
+                            bool stop = false;
+                            int rank = -1;
+#pragma unroll
+                            for (int i = 0; i < S; i++) {
+                                const float cni = ci + m.step_at(ci);
+                                const float txi = __shfl(txo, lead + i, 64);
+                                const bool live = !stop && ci >= skip;            // not inside an empty cell already stepped over
+                                if (live && !(ci < far)) { stop = true; t_new = ci; }               // the ray has left the box
+                                else if (live && txi < 0.0f) {
+                                    if (i == j) rank = got;
+                                    got++;
+                                    t_new = cni;
+                                    if (got >= want) stop = true;
+                                } else if (live) skip = txi;
+                                if (!stop && i == S - 1) t_new = cni;
+                                ci = cni;
+                            }
+                            if (more && !stop) {                                  // first chain point at or behind the last empty cell's exit
+                                while (t_new < skip) t_new += m.step_at(t_new);
+                            }
+                            if (more && rank >= 0) {
+                                const int sl = lead + rank;
+                                slot[SF_X * 16 + sl] = cell.x; slot[SF_Y * 16 + sl] = cell.y; slot[SF_Z * 16 + sl] = cell.z;
+                                slot[SF_DT * 16 + sl] = cell.dt;
+                                slot[SF_TS * 16 + sl] = cn;
+                            }
+                            t0 = t_new;
+                            more = more && got < want && t0 < far;
+                        }
+                        if (leader && grp) {
+                            kk = got;
+                            if (kk == 0) {     // the ray left the box without another sample
+                                const int c0 = sloti[SF_CNT * 16 + s];
+                                lzf_ray_end(F, ph2, ray, LZF_END_BOX, c0, c0, t0, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s],
+                                            slot[SF_B * 16 + s], slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s]);
+                                my_samples += c0 - cnt_base;
+                                ray = -1;
+                                sloti[SF_RAY * 16 + s] = -1;
+                            }
+                        }
                     }
                 }
                 if (!__ballot(leader && ray < 0 && !dry)) break;
@@ -436,10 +490,13 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
             HD::slice(ctx, lane, px, py, pz, typename HD::ShSlot{slot, lead, 16}, o);
             my_slices++;
             if (q == 0) {
-                slot[SF_OSIG * 16 + s] = o.sigma;
+                // alpha = 1 - exp(-sigma delta) of this slot's sample (raymarching.cu:2197), computed here by the sample's own lane: the
+                // leader's serial walk below then costs a handful of instructions per sample instead of an exp each
+                slot[SF_OSIG * 16 + s] = 1.0f - lz_expf(-o.sigma * slot[SF_DT * 16 + s]);
                 slot[SF_OR * 16 + s] = o.rgb[0]; slot[SF_OG * 16 + s] = o.rgb[1]; slot[SF_OB * 16 + s] = o.rgb[2];
                 slot[SF_OA0 * 16 + s] = o.ambaud; slot[SF_OA1 * 16 + s] = o.eyeatt; slot[SF_OU * 16 + s] = o.unc;
             }
+            __builtin_amdgcn_wave_barrier();
             // ---------------- composite (lz_k_composite_rays, n_step = S): the leader walks its ray's staged samples ----------------
             if (leader && kk > 0) {
                 float ws = slot[SF_WS * 16 + s], d = slot[SF_D * 16 + s], r = slot[SF_R * 16 + s], g = slot[SF_G * 16 + s], b = slot[SF_B * 16 + s];
@@ -447,7 +504,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 int step = 0;
                 while (step < kk) {
                     const int sl = s + step;
-                    const float alpha = 1.0f - lz_expf(-slot[SF_OSIG * 16 + sl] * slot[SF_DT * 16 + sl]);
+                    const float alpha = slot[SF_OSIG * 16 + sl];
                     const float T = 1 - ws;
                     const float w = alpha * T;
                     ws += w;

@@ -102,23 +102,30 @@ struct LzMarch {
         dt_min = lz_fminf(dt_max, 2 * LZ_SQRT3F / (float)max_steps);
     }
 
-    // 1: cell occupied (x, y, z, dt describe the sample, caller advances t by dt); 0: t advanced past the empty cell
-    __device__ __forceinline__ int probe(float& t, float& x, float& y, float& z, float& dt) const {
-        const float tt0 = t;
-        x = lz_clampf(lz_fmaf(tt0, dx, ox), -bound, bound);
-        y = lz_clampf(lz_fmaf(tt0, dy, oy), -bound, bound);
-        z = lz_clampf(lz_fmaf(tt0, dz, oz), -bound, bound);
-        dt = lz_clampf(tt0 * dt_gamma, dt_min, dt_max);
+    // the step of the march at t -- sample step and empty-space skip alike (raymarching.cu:907, 919-926)
+    __device__ __forceinline__ float step_at(float t) const { return lz_clampf(t * dt_gamma, dt_min, dt_max); }
+
+    // where the march stands at t: clamped position, step, and the cell it tests (raymarching.cu:876-895)
+    struct Cell {
+        float x, y, z, dt, mip_bound;
+        int nx, ny, nz;
+        uint32_t index;      // bit index into the density bitfield
+    };
+    __device__ __forceinline__ void locate(float tt0, Cell& c) const {
+        c.x = lz_clampf(lz_fmaf(tt0, dx, ox), -bound, bound);
+        c.y = lz_clampf(lz_fmaf(tt0, dy, oy), -bound, bound);
+        c.z = lz_clampf(lz_fmaf(tt0, dz, oz), -bound, bound);
+        c.dt = lz_clampf(tt0 * dt_gamma, dt_min, dt_max);
         int level = 0;
-        float mip_bound, mip_rbound;
+        float mip_rbound;
         if (one_cascade) {          // wave-uniform; the same values the general branch yields for level = 0, without its ~20 instructions
-            mip_bound = lz_fminf(1.0f, bound);
+            c.mip_bound = lz_fminf(1.0f, bound);
             mip_rbound = (1.0f <= bound) ? 1.0f : rbound;
         } else {
-            const int lp = lz_mip_from_pos(x, y, z, fC), ld = lz_mip_from_dt(dt, fH, fC);
+            const int lp = lz_mip_from_pos(c.x, c.y, c.z, fC), ld = lz_mip_from_dt(c.dt, fH, fC);
             level = lp > ld ? lp : ld;
             const float lb = lz_scalbnf(1.0f, level);
-            mip_bound = lz_fminf(lb, bound);
+            c.mip_bound = lz_fminf(lb, bound);
             // 1 / mip_bound without a division per probe: the reciprocal of 2^level is exact, the one of `bound` is hoisted to init()
             mip_rbound = (lb <= bound) ? lz_scalbnf(1.0f, -level) : rbound;
         }
@@ -126,27 +133,38 @@ struct LzMarch {
         // raymarching.cu:415-417 evaluates 0.5 * (x * mip_rbound + 1) * H in double and narrows.  For a power-of-two H (the reference
         // hard-codes 128, renderer.py:94) the two multiplications are exact in float as well, so both evaluations give the same bits
         // and the f64 pipe (half rate, plus four conversions per axis) stays out of the march; any other H takes the double path.
-        int nx, ny, nz;
         if (pow2H) {
-            nx = (int)lz_clampf(lz_fmaf(x, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
-            ny = (int)lz_clampf(lz_fmaf(y, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
-            nz = (int)lz_clampf(lz_fmaf(z, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
+            c.nx = (int)lz_clampf(lz_fmaf(c.x, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
+            c.ny = (int)lz_clampf(lz_fmaf(c.y, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
+            c.nz = (int)lz_clampf(lz_fmaf(c.z, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
         } else {
-            nx = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
-            ny = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
-            nz = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+            c.nx = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(c.x, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+            c.ny = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(c.y, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+            c.nz = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(c.z, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
         }
-        const uint32_t mort = morton_lut ? (morton_lut[nx] | (morton_lut[ny] << 1) | (morton_lut[nz] << 2))      // three LDS reads for 24 vector instructions
-                                         : lz_morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-        const uint32_t index = (uint32_t)((float)level * H3 + (float)mort);
-        const int occ = grid[index / 8] & (1 << (index % 8));
-        if (occ) return 1;
-        const float tx = lz_fmaf(lz_fmaf(((float)nx + 0.5f + 0.5f * lz_signf(dx)) * rH, 2.0f, -1.0f), mip_bound, -x) * rdx;
-        const float ty = lz_fmaf(lz_fmaf(((float)ny + 0.5f + 0.5f * lz_signf(dy)) * rH, 2.0f, -1.0f), mip_bound, -y) * rdy;
-        const float tz = lz_fmaf(lz_fmaf(((float)nz + 0.5f + 0.5f * lz_signf(dz)) * rH, 2.0f, -1.0f), mip_bound, -z) * rdz;
-        const float tt = tt0 + lz_fmaxf(0.0f, lz_fminf(tx, lz_fminf(ty, tz)));
+        const uint32_t mort = morton_lut ? (morton_lut[c.nx] | (morton_lut[c.ny] << 1) | (morton_lut[c.nz] << 2))      // three LDS reads for 24 vector instructions
+                                         : lz_morton3((uint32_t)c.nx, (uint32_t)c.ny, (uint32_t)c.nz);
+        c.index = (uint32_t)((float)level * H3 + (float)mort);
+    }
+    __device__ __forceinline__ int occupied(const Cell& c) const { return grid[c.index / 8] & (1 << (c.index % 8)); }
+    // t at which the ray leaves the (empty) cell it is in at tt0 (raymarching.cu:919-924)
+    __device__ __forceinline__ float exit_t(float tt0, const Cell& c) const {
+        const float tx = lz_fmaf(lz_fmaf(((float)c.nx + 0.5f + 0.5f * lz_signf(dx)) * rH, 2.0f, -1.0f), c.mip_bound, -c.x) * rdx;
+        const float ty = lz_fmaf(lz_fmaf(((float)c.ny + 0.5f + 0.5f * lz_signf(dy)) * rH, 2.0f, -1.0f), c.mip_bound, -c.y) * rdy;
+        const float tz = lz_fmaf(lz_fmaf(((float)c.nz + 0.5f + 0.5f * lz_signf(dz)) * rH, 2.0f, -1.0f), c.mip_bound, -c.z) * rdz;
+        return tt0 + lz_fmaxf(0.0f, lz_fminf(tx, lz_fminf(ty, tz)));
+    }
+
+    // 1: cell occupied (x, y, z, dt describe the sample, caller advances t by dt); 0: t advanced past the empty cell
+    __device__ __forceinline__ int probe(float& t, float& x, float& y, float& z, float& dt) const {
+        const float tt0 = t;
+        Cell c;
+        locate(tt0, c);
+        x = c.x; y = c.y; z = c.z; dt = c.dt;
+        if (occupied(c)) return 1;
+        const float tt = exit_t(tt0, c);
         float tc = tt0;
-        do { tc += lz_clampf(tc * dt_gamma, dt_min, dt_max); } while (tc < tt);
+        do { tc += step_at(tc); } while (tc < tt);      // (raymarching.cu:925-926: at least one step)
         t = tc;
         return 0;
     }
