@@ -435,7 +435,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             float skip = -FLT_MAX, t_new = t0, ci = t0;
                             bool stop = false;
                             int rank = -1;
-#pragma unroll
+#pragma unroll      // (not unrolled it spills less -- the f16 variants nothing at all -- and runs 2 % slower on an 8-way tile)
                             for (int i = 0; i < S; i++) {
                                 const float cni = ci + m.step_at(ci);
                                 const float txi = __shfl(txo, lead + i, 64);
@@ -1037,8 +1037,9 @@ static int lzf_launch_persistent(const lz_frame_fused* f, const LzFrameK& K, hip
     // 16-sample rows in flight (N * S / 16) reach that number otherwise (f->steps_per_pass overrides: 1, 2, 4, 8 or 16)
     uint32_t S = f->steps_per_pass;
     if (S == 0) {
-        // (the f16 head's passes are a quarter as long: it wants the rows in flight once over, not twice -- 32 768 rays: 0.45 ms at S = 2, 0.47 at 4)
-        const uint64_t want = (uint64_t)n_cu * LZF_WAVES * 16 * (p->precision == 1 ? 1 : 2);
+        // (round 4, with the batched march: rank 0's tile of a 512^2 frame sharded 8 / 4 ways, f16 kernel ms at S = 1 / 2 / 4: 0.573 / 0.454 /
+        // 0.421 and 0.733 / 0.705 / 0.768; f32: 2.22 / 1.57 / 1.30 and 2.97 / 2.57 / 2.53 -- both heads want the rows in flight twice over)
+        const uint64_t want = (uint64_t)n_cu * LZF_WAVES * 16 * 2;
         S = 1;
         while (S < 16 && (uint64_t)f->N * S < want) S *= 2;
     }
