@@ -46,6 +46,7 @@ FLOP_PER_SAMPLE = 46368          # 23 184 MAC per sample, inference h
 ISSUED_FLOP_PER_ROW = 361 * 2048 // 16   # the head issues 361 v_mfma_f32_16x16x4_f32 (2048 FLOP each) per 16-row slice
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
+GRID_ORDERED_PMC_SUMMARY = "r4_grid_ordered_pmc_summary.json"   # tools/profile_grid_ordered.sh
 GRID_PMC_SUMMARY = "r3_grid_pmc_summary.json"   # tools/profile_grid.sh over the CURRENT kernels (a summary of an older round describes code that no longer exists)
 
 
@@ -60,6 +61,14 @@ def _grid_traffic(tag, B):
     """HBM-side bytes per launch at batch size B from the committed PMC summary (KiB per launch at the profiled batch size, scaled
     per sample; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 -- calibrated there for wide streaming reads, so an
     upper bound for the gather-dominated kernels).  None when the summary is absent."""
+    for suffix, order in (("_ray_ordered", "ray"), ("_march_order", "march")):
+        if tag.endswith(suffix):   # the ordered legs share kernel names with the random one: profiled one process per case (tools/profile_grid_ordered.sh)
+            try:
+                case = json.load(open(os.path.join(ROOT, "profiles", GRID_ORDERED_PMC_SUMMARY)))[order + ("_f16" if "f16" in tag else "_f32")]
+                kib = sum(2 * case["FETCH_SIZE"][k]["avg_per_launch"] + case["WRITE_SIZE"][k]["avg_per_launch"] for k in case["FETCH_SIZE"] if "lz_k_grid" in k)
+                return round(kib * 1024 / (1 << 23) * B)
+            except (OSError, KeyError, ValueError):
+                return None
     path = os.path.join(ROOT, "profiles", GRID_PMC_SUMMARY)
     if not os.path.exists(path) or tag not in _GRID_PMC:
         return None
