@@ -29,6 +29,9 @@
 #define LZN_C1 48      // 32 slots (SH 16 | sigma_net output 16, slot of its row 0 weighted 0) -> 64: 8 x 4
 #define LZN_C2 80      // 64 -> 3 (one tile, rows 3..15 zero): 16 x 1
 static_assert(LZN_C2 + 16 == LZ_NGP_FRAGS, "fragment count mismatch with the header");
+#ifndef LZN_T
+#define LZN_T 1     // 16-sample slices a wave takes through the head together (2: every fragment read feeds two MFMAs, but 179 registers = two waves per SIMD instead of three: the frame takes the same 2.15 ms)
+#endif
 
 struct LzNgpK {
     const float* packed;
@@ -57,77 +60,118 @@ __global__ void __launch_bounds__(256) lz_k_ngp_head(LzNgpK P) {
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = lane & 15, q = lane >> 4;
     const uint32_t n_slices = (rows + 15u) / 16u, Tn = LZ_GRID_TILE_ROWS;
-    for (uint32_t slice = blockIdx.x * 4u + (uint32_t)wave; slice < n_slices; slice += gridDim.x * 4u) {
-        const uint32_t row = slice * 16u + (uint32_t)s;
-        const bool valid = row < rows;
-        const uint32_t r = valid ? row : rows - 1u;
-        // ---------------- B operands of sigma_net.0: levels q, q + 4, q + 8, q + 12 of sample s, both channels ----------------
-        float b1[8];
-        if constexpr (FEAT == 0) {
-            const float2* f = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(P.feats) + (size_t)r * 32);
+    // T slices per pass: every A fragment is read from LDS once and feeds T MFMAs, and the T accumulation chains interleave (the 16-deep
+    // chains of the two 64 -> N layers are dependent MFMAs otherwise)
+    constexpr int T = LZN_T;
+    for (uint32_t slice0 = (blockIdx.x * 4u + (uint32_t)wave) * T; slice0 < n_slices; slice0 += gridDim.x * 4u * T) {
+        uint32_t row[T];
+        bool valid[T];
+        float b1[T][8], dx[T], dy[T], dz[T];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { const float2 v = f[q + 4 * i]; b1[2 * i] = v.x; b1[2 * i + 1] = v.y; }
-        } else {
-            const uint32_t tile = r / Tn, t = r - tile * Tn, b0 = tile * Tn, n = (P.rows - b0 < Tn) ? P.rows - b0 : Tn;
-            if constexpr (FEAT == 1) {
-                const float2* f = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(P.feats) + (size_t)b0 * 32);
+        for (int u = 0; u < T; u++) {
+            row[u] = (slice0 + u) * 16u + (uint32_t)s;
+            valid[u] = row[u] < rows;
+            const uint32_t r = valid[u] ? row[u] : rows - 1u;
+            // ---------------- B operands of sigma_net.0: levels q, q + 4, q + 8, q + 12 of sample s, both channels ----------------
+            if constexpr (FEAT == 0) {
+                const float2* f = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(P.feats) + (size_t)r * 32);
 #pragma unroll
-                for (int i = 0; i < 4; i++) { const float2 v = f[(size_t)(q + 4 * i) * n + t]; b1[2 * i] = v.x; b1[2 * i + 1] = v.y; }
+                for (int i = 0; i < 4; i++) { const float2 v = f[q + 4 * i]; b1[u][2 * i] = v.x; b1[u][2 * i + 1] = v.y; }
             } else {
-                const __half2* f = reinterpret_cast<const __half2*>(reinterpret_cast<const __half*>(P.feats) + (size_t)b0 * 32);
+                const uint32_t tile = r / Tn, t = r - tile * Tn, b0 = tile * Tn, n = (P.rows - b0 < Tn) ? P.rows - b0 : Tn;
+                if constexpr (FEAT == 1) {
+                    const float2* f = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(P.feats) + (size_t)b0 * 32);
 #pragma unroll
-                for (int i = 0; i < 4; i++) { const float2 v = __half22float2(f[(size_t)(q + 4 * i) * n + t]); b1[2 * i] = v.x; b1[2 * i + 1] = v.y; }
+                    for (int i = 0; i < 4; i++) { const float2 v = f[(size_t)(q + 4 * i) * n + t]; b1[u][2 * i] = v.x; b1[u][2 * i + 1] = v.y; }
+                } else {
+                    const __half2* f = reinterpret_cast<const __half2*>(reinterpret_cast<const __half*>(P.feats) + (size_t)b0 * 32);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const float2 v = __half22float2(f[(size_t)(q + 4 * i) * n + t]); b1[u][2 * i] = v.x; b1[u][2 * i + 1] = v.y; }
+                }
             }
+            dx[u] = P.dirs[(size_t)r * 3]; dy[u] = P.dirs[(size_t)r * 3 + 1]; dz[u] = P.dirs[(size_t)r * 3 + 2];
         }
-        const float dx = P.dirs[(size_t)r * 3], dy = P.dirs[(size_t)r * 3 + 1], dz = P.dirs[(size_t)r * 3 + 2];
         // ---------------- sigma_net: 32 -> 64 (ReLU) -> 16 ----------------
-        float h1[16];
+        float h1[T][16];
         {
-            lz_f4 acc[4];
+            lz_f4 acc[T][4];
 #pragma unroll
-            for (int ft = 0; ft < 4; ft++) acc[ft] = lz_f4{0, 0, 0, 0};
+            for (int u = 0; u < T; u++)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++) acc[u][ft] = lz_f4{0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < 8; ks++)
 #pragma unroll
-                for (int ft = 0; ft < 4; ft++) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(LZN_S1 + ks * 4 + ft) * 64 + lane], b1[ks], acc[ft], 0, 0, 0);
+                for (int ft = 0; ft < 4; ft++) {
+                    const float a = wl[(LZN_S1 + ks * 4 + ft) * 64 + lane];
 #pragma unroll
-            for (int ft = 0; ft < 4; ft++)
+                    for (int u = 0; u < T; u++) acc[u][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[u][ks], acc[u][ft], 0, 0, 0);
+                }
 #pragma unroll
-                for (int rr = 0; rr < 4; rr++) h1[4 * ft + rr] = lz_relu(acc[ft][rr]);
+            for (int u = 0; u < T; u++)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) h1[u][4 * ft + rr] = lz_relu(acc[u][ft][rr]);
         }
-        lz_f4 h = lz_f4{0, 0, 0, 0};          // h[rr] = output 4 q + rr of sigma_net: row 0 -> sigma, rows 1..15 -> geometry features
+        lz_f4 h[T];          // h[rr] = output 4 q + rr of sigma_net: row 0 -> sigma, rows 1..15 -> geometry features
 #pragma unroll
-        for (int ks = 0; ks < 16; ks++) h = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(LZN_S2 + ks) * 64 + lane], h1[ks], h, 0, 0, 0);
+        for (int u = 0; u < T; u++) h[u] = lz_f4{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) {
+            const float a = wl[(LZN_S2 + ks) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < T; u++) h[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, h1[u][ks], h[u], 0, 0, 0);
+        }
         // ---------------- colour_net: [SH(4) of the direction | geometry] -> 64 (ReLU) -> 3 ----------------
-        float sh[16];
-        lz_sh_eval(dx, dy, dz, 4, sh, nullptr, nullptr, nullptr);
-        float c1[16];
+        float c1[T][16];
         {
-            lz_f4 acc[4];
+            float shq[T][4];     // SH components 4 ks + q of this lane's sample
 #pragma unroll
-            for (int ft = 0; ft < 4; ft++) acc[ft] = lz_f4{0, 0, 0, 0};
+            for (int u = 0; u < T; u++) {
+                float sh[16];
+                lz_sh_eval(dx[u], dy[u], dz[u], 4, sh, nullptr, nullptr, nullptr);
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-                float b;
-                if (ks < 4) b = q == 0 ? sh[4 * ks] : (q == 1 ? sh[4 * ks + 1] : (q == 2 ? sh[4 * ks + 2] : sh[4 * ks + 3]));     // SH component 4 ks + q
-                else b = h[ks - 4];                                                                                              // sigma_net output 4 q + (ks - 4)
-#pragma unroll
-                for (int ft = 0; ft < 4; ft++) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(LZN_C1 + ks * 4 + ft) * 64 + lane], b, acc[ft], 0, 0, 0);
+                for (int ks = 0; ks < 4; ks++) shq[u][ks] = q == 0 ? sh[4 * ks] : (q == 1 ? sh[4 * ks + 1] : (q == 2 ? sh[4 * ks + 2] : sh[4 * ks + 3]));
             }
+            lz_f4 acc[T][4];
 #pragma unroll
-            for (int ft = 0; ft < 4; ft++)
+            for (int u = 0; u < T; u++)
 #pragma unroll
-                for (int rr = 0; rr < 4; rr++) c1[4 * ft + rr] = lz_relu(acc[ft][rr]);
+                for (int ft = 0; ft < 4; ft++) acc[u][ft] = lz_f4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++) {
+                    const float a = wl[(LZN_C1 + ks * 4 + ft) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < T; u++)      // SH component 4 ks + q, then sigma_net output 4 q + (ks - 4)
+                        acc[u][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ks < 4 ? shq[u][ks] : h[u][ks - 4], acc[u][ft], 0, 0, 0);
+                }
+#pragma unroll
+            for (int u = 0; u < T; u++)
+#pragma unroll
+                for (int ft = 0; ft < 4; ft++)
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) c1[u][4 * ft + rr] = lz_relu(acc[u][ft][rr]);
         }
-        lz_f4 c = lz_f4{0, 0, 0, 0};
+        lz_f4 c[T];
 #pragma unroll
-        for (int ks = 0; ks < 16; ks++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(LZN_C2 + ks) * 64 + lane], c1[ks], c, 0, 0, 0);
-        if (q == 0 && valid) {
-            P.sigmas[row] = lz_expf(h[0]);
-            P.rgbs[(size_t)row * 3] = lz_sigmoidf(c[0]);
-            P.rgbs[(size_t)row * 3 + 1] = lz_sigmoidf(c[1]);
-            P.rgbs[(size_t)row * 3 + 2] = lz_sigmoidf(c[2]);
+        for (int u = 0; u < T; u++) c[u] = lz_f4{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) {
+            const float a = wl[(LZN_C2 + ks) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < T; u++) c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, c1[u][ks], c[u], 0, 0, 0);
         }
+#pragma unroll
+        for (int u = 0; u < T; u++)
+            if (q == 0 && valid[u]) {
+                P.sigmas[row[u]] = lz_expf(h[u][0]);
+                P.rgbs[(size_t)row[u] * 3] = lz_sigmoidf(c[u][0]);
+                P.rgbs[(size_t)row[u] * 3 + 1] = lz_sigmoidf(c[u][1]);
+                P.rgbs[(size_t)row[u] * 3 + 2] = lz_sigmoidf(c[u][2]);
+            }
     }
 }
 
@@ -137,7 +181,7 @@ extern "C" int lz_ngp_head_forward(const float* packed, const void* feats, int f
     LZ_REQUIRE(packed && feats && dirs && sigmas && rgbs, LZ_ERR_BAD_ARGUMENT, "ngp_head_forward: null tensor");
     LZ_REQUIRE(feat_layout >= 0 && feat_layout <= 2, LZ_ERR_BAD_ARGUMENT, "ngp_head_forward: feat_layout 0 (row-major f32), 1 (tiled f32) or 2 (tiled f16)");
     LzNgpK K{packed, feats, dirs, count, sigmas, rgbs, rows};
-    uint32_t grid = lz_div_up(rows, 16 * 4 * 4);      // ~4 slices per wave
+    uint32_t grid = lz_div_up(rows, 16 * 4 * 4 * LZN_T);      // ~4 passes per wave
     const uint32_t cap = (uint32_t)lz_cu_count() * 8u;
     grid = grid < 1 ? 1 : (grid > cap ? cap : grid);
     hipStream_t st = lz_st(stream);
