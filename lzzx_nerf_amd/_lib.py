@@ -173,7 +173,10 @@ def load():
             "liblzzx_nerf_hip.so not found at %s -- build it with `python -m lzzx_nerf_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no fallback path." % SO_PATH)
     lib = C.CDLL(SO_PATH)
+    older = bool(os.environ.get("LZZX_NERF_HIP_SO_OLDER"))   # A/B runs against a library of an EARLIER round (tools/ab_rounds.sh): entry points it lacks stay unbound
     for name, argtypes in SIGNATURES.items():
+        if older and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = i32

@@ -253,7 +253,7 @@ __device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* 
 
 // a slot takes a ray: fresh accumulators (phase 1), or the ones phase 1 parked in the output arrays when the ray reached max_steps (phase 2)
 __device__ __forceinline__ void lzf_slot_take(const LzFrameK& F, bool ph2, int ray, float* slot, int* sloti, int sl, int ns) {
-    if (ph2) {
+    if (__builtin_expect(ph2, 0)) {
         slot[SF_WS * ns + sl] = F.weights_sum[ray];
         slot[SF_D * ns + sl] = F.depth[ray];
         slot[SF_R * ns + sl] = F.image[(size_t)ray * 3];
@@ -276,7 +276,7 @@ __device__ __forceinline__ void lzf_slot_take(const LzFrameK& F, bool ph2, int r
 enum { LZF_END_BOX = 0, LZF_END_T = 1, LZF_END_CAP = 2 };
 __device__ __forceinline__ void lzf_ray_end(const LzFrameK& F, bool ph2, int ray, int kind, int composited, int report, float t, float ws, float d,
                                             float r, float g, float b, float a0, float a1, float u) {
-    if (F.cap_mode) {
+    if (__builtin_expect(F.cap_mode != 0, 0)) {
         report = composited;
         if (kind == LZF_END_T) {
             if (F.ray_counts) { report = -composited; F.rays_t[ray] = t; }
@@ -342,7 +342,9 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     const int s = lane & 15, q = lane >> 4;
     // phase 2 of the reference's cap continues the rays phase 1 parked at max_steps; none parked (or C_eff == max_steps): nothing to stage
     const bool ph2 = F.phase2 != 0;
+#ifndef LZF_EXP_NO_EARLY
     if (ph2 && F.state[LZF_P_SIZE] <= 0) return;
+#endif
     typename HD::Ctx ctx;
     HD::stage(P, lds, q, ctx);
     float* slot = lds + HD::LDS_WORDS + wave * NF * NS;      // this wave's slots: slot[field * 16 + s]
@@ -356,11 +358,15 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     if (use_lut && threadIdx.x < LZF_LUT) mlut[threadIdx.x] = lz_expand_bits(threadIdx.x);
     __syncthreads();
     const int n_queue = F.state[ph2 ? LZF_P_SIZE : LZF_Q_SIZE];
-    int* const q_head = F.state + (ph2 ? LZF_P_HEAD : LZF_Q_HEAD);
+#define q_head (F.state + (ph2 ? LZF_P_HEAD : LZF_Q_HEAD))        /* (not a variable: it would sit in two scalar registers through every pass) */
     // samples at which a ray still alive is stopped: the per-ray cap ceil(max_steps / S) * S (cap_mode 0), or exactly max_steps in phase 1 and
     // the schedule's C_eff in phase 2 (cap_mode 1)
+#ifdef LZF_EXP_NO_CAPVAR
+#define cap ((((int)F.max_steps + S - 1) / S) * S)
+#else
     const int cap = ph2 ? F.state[LZF_CEFF] : (F.cap_mode ? (int)F.max_steps : (((int)F.max_steps + S - 1) / S) * S);
-    const int cnt_base = ph2 ? (int)F.max_steps : 0;      // samples a ray brings along when it takes a slot
+#endif
+#define cnt_base (ph2 ? (int)F.max_steps : 0)                     /* samples a ray brings along when it takes a slot */
     LzMarch m;   // the frame-constant part of LzMarch (init() below sets the per-ray part)
     bool dry = n_queue <= 0;
     int my_samples = 0, my_slices = 0;
@@ -702,6 +708,9 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
         }
     }
 }
+
+#undef q_head
+#undef cnt_base
 
 // ---- the reference's cap (cap_mode 1): histogram of L, schedule replay, marched counts ------------------------------------------------
 // cap_ws: [0 .. max_steps] histogram of L (bin max_steps = rays alive at the cap); behind it the schedule tables, see lzf_ws_*

@@ -155,16 +155,53 @@ struct LzMarch {
         return tt0 + lz_fmaxf(0.0f, lz_fminf(tx, lz_fminf(ty, tz)));
     }
 
+    // (kept as ONE function next to locate / occupied / exit_t, which restate it in pieces for the batched march of lz_frame.hip: split into
+    // calls the f32 frame kernel, 130 instructions of whose every pass this is, measured 1 % slower)
     // 1: cell occupied (x, y, z, dt describe the sample, caller advances t by dt); 0: t advanced past the empty cell
     __device__ __forceinline__ int probe(float& t, float& x, float& y, float& z, float& dt) const {
         const float tt0 = t;
-        Cell c;
-        locate(tt0, c);
-        x = c.x; y = c.y; z = c.z; dt = c.dt;
-        if (occupied(c)) return 1;
-        const float tt = exit_t(tt0, c);
+        x = lz_clampf(lz_fmaf(tt0, dx, ox), -bound, bound);
+        y = lz_clampf(lz_fmaf(tt0, dy, oy), -bound, bound);
+        z = lz_clampf(lz_fmaf(tt0, dz, oz), -bound, bound);
+        dt = lz_clampf(tt0 * dt_gamma, dt_min, dt_max);
+        int level = 0;
+        float mip_bound, mip_rbound;
+        if (one_cascade) {          // wave-uniform; the same values the general branch yields for level = 0, without its ~20 instructions
+            mip_bound = lz_fminf(1.0f, bound);
+            mip_rbound = (1.0f <= bound) ? 1.0f : rbound;
+        } else {
+            const int lp = lz_mip_from_pos(x, y, z, fC), ld = lz_mip_from_dt(dt, fH, fC);
+            level = lp > ld ? lp : ld;
+            const float lb = lz_scalbnf(1.0f, level);
+            mip_bound = lz_fminf(lb, bound);
+            // 1 / mip_bound without a division per probe: the reciprocal of 2^level is exact, the one of `bound` is hoisted to init()
+            mip_rbound = (lb <= bound) ? lz_scalbnf(1.0f, -level) : rbound;
+        }
+        const float hm1 = (float)(H - 1);
+        // raymarching.cu:415-417 evaluates 0.5 * (x * mip_rbound + 1) * H in double and narrows.  For a power-of-two H (the reference
+        // hard-codes 128, renderer.py:94) the two multiplications are exact in float as well, so both evaluations give the same bits
+        // and the f64 pipe (half rate, plus four conversions per axis) stays out of the march; any other H takes the double path.
+        int nx, ny, nz;
+        if (pow2H) {
+            nx = (int)lz_clampf(lz_fmaf(x, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
+            ny = (int)lz_clampf(lz_fmaf(y, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
+            nz = (int)lz_clampf(lz_fmaf(z, mip_rbound, 1.0f) * halfH, 0.0f, hm1);
+        } else {
+            nx = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+            ny = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+            nz = (int)lz_clampf((float)(0.5 * (double)lz_fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+        }
+        const uint32_t mort = morton_lut ? (morton_lut[nx] | (morton_lut[ny] << 1) | (morton_lut[nz] << 2))      // three LDS reads for 24 vector instructions
+                                         : lz_morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+        const uint32_t index = (uint32_t)((float)level * H3 + (float)mort);
+        const int occ = grid[index / 8] & (1 << (index % 8));
+        if (occ) return 1;
+        const float tx = lz_fmaf(lz_fmaf(((float)nx + 0.5f + 0.5f * lz_signf(dx)) * rH, 2.0f, -1.0f), mip_bound, -x) * rdx;
+        const float ty = lz_fmaf(lz_fmaf(((float)ny + 0.5f + 0.5f * lz_signf(dy)) * rH, 2.0f, -1.0f), mip_bound, -y) * rdy;
+        const float tz = lz_fmaf(lz_fmaf(((float)nz + 0.5f + 0.5f * lz_signf(dz)) * rH, 2.0f, -1.0f), mip_bound, -z) * rdz;
+        const float tt = tt0 + lz_fmaxf(0.0f, lz_fminf(tx, lz_fminf(ty, tz)));
         float tc = tt0;
-        do { tc += step_at(tc); } while (tc < tt);      // (raymarching.cu:925-926: at least one step)
+        do { tc += lz_clampf(tc * dt_gamma, dt_min, dt_max); } while (tc < tt);
         t = tc;
         return 0;
     }
