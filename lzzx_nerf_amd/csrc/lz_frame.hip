@@ -84,25 +84,49 @@ struct LzFrameK {
     uint32_t cap_mode, phase2, N_total;
 };
 
-__device__ __forceinline__ void lzf_write_pixel(const LzFrameK& F, int ray, float ws, float d, float r, float g, float b, float a0, float a1,
+// The per-ray OUTPUT side of LzFrameK (eleven pointers, the background, the cap's buffers) is touched once per ray, when it leaves its slot.
+// Read as ordinary kernel arguments these fields are loop-invariant scalars, the compiler keeps all of them in scalar registers through every
+// pass, and the f32 frame kernel -- short of scalar registers next to the head's -- spills them to vector lanes and restores them inside the
+// pass loop (round 4 measured that: ten more live scalars = +0.9 % on the headline frame).  LzfOut reads a field from the kernel-argument
+// segment AT THE POINT OF USE instead (a volatile scalar load: not hoisted), for the price of a few s_load per finished ray.
+typedef const char __attribute__((address_space(4))) lz_kernarg_t;
+struct LzfOut {
+    lz_kernarg_t* f;      // where the kernel's LzFrameK argument sits in its kernel-argument segment
+    template <typename T> __device__ __forceinline__ T get(size_t off) const {
+        return *reinterpret_cast<const volatile T __attribute__((address_space(4)))*>(f + off);
+    }
+};
+#define LZF_OUT(o, name) ((o).template get<decltype(LzFrameK::name)>(__builtin_offsetof(LzFrameK, name)))
+template <size_t ARGS_BEFORE>    // bytes of kernel arguments in front of the LzFrameK (0: it is the first)
+__device__ __forceinline__ LzfOut lzf_out() {
+    return LzfOut{(lz_kernarg_t*)__builtin_amdgcn_kernarg_segment_ptr() + ((ARGS_BEFORE + 7) & ~size_t(7))};
+}
+
+__device__ __forceinline__ void lzf_write_pixel(const LzfOut& O, int ray, float ws, float d, float r, float g, float b, float a0, float a1,
                                                 float u, int cnt) {
-    F.weights_sum[ray] = ws;
-    F.depth[ray] = d;
+    LZF_OUT(O, weights_sum)[ray] = ws;
+    LZF_OUT(O, depth)[ray] = d;
     const float rgb[3] = {r, g, b};
+    float* image = LZF_OUT(O, image);
+    float* out = LZF_OUT(O, out);
+    const float* bg = LZF_OUT(O, bg);
+    uint8_t* out_rgb24 = LZF_OUT(O, out_rgb24);
+    const float bg_scalar = LZF_OUT(O, bg_scalar);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const size_t t = (size_t)ray * 3 + c;
-        F.image[t] = rgb[c];
-        const float bgv = F.bg ? F.bg[t] : F.bg_scalar;
+        image[t] = rgb[c];
+        const float bgv = bg ? bg[t] : bg_scalar;
         const float v = rgb[c] + (1.0f - ws) * bgv;              // renderer.py:559, two roundings like lz_k_final_blend
         const float cl = lz_fminf(lz_fmaxf(v, 0.0f), 1.0f);
-        F.out[t] = cl;
-        if (F.out_rgb24) F.out_rgb24[t] = (uint8_t)(cl * 255.0f);
+        out[t] = cl;
+        if (out_rgb24) out_rgb24[t] = (uint8_t)(cl * 255.0f);
     }
-    F.amb0_sum[ray] = a0;
-    F.amb1_sum[ray] = a1;
-    F.unc_sum[ray] = u;
-    if (F.ray_counts) F.ray_counts[ray] = cnt;
+    LZF_OUT(O, amb0_sum)[ray] = a0;
+    LZF_OUT(O, amb1_sum)[ray] = a1;
+    LZF_OUT(O, unc_sum)[ray] = u;
+    int* ray_counts = LZF_OUT(O, ray_counts);
+    if (ray_counts) ray_counts[ray] = cnt;
 }
 
 // ---- pass 1: near / far, first occupied cell, sort key, histogram -------------------------------------------------------------
@@ -154,7 +178,7 @@ __global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
             key = key < 1 ? 1 : (key > 255 ? 255 : key);
             atomicAdd(&hist[key], 1);
         } else {
-            lzf_write_pixel(F, (int)n, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0);   // no sample on this ray: background
+            lzf_write_pixel(lzf_out<0>(), (int)n, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0);   // no sample on this ray: background
             if (F.cap_mode) F.ray_last[n] = 0;     // alive in the reference's first iteration only
         }
         F.keys[n] = (uint8_t)key;
@@ -252,17 +276,18 @@ __device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* 
 }
 
 // a slot takes a ray: fresh accumulators (phase 1), or the ones phase 1 parked in the output arrays when the ray reached max_steps (phase 2)
-__device__ __forceinline__ void lzf_slot_take(const LzFrameK& F, bool ph2, int ray, float* slot, int* sloti, int sl, int ns) {
+__device__ __forceinline__ void lzf_slot_take(const LzfOut& O, bool ph2, int ray, float* slot, int* sloti, int sl, int ns) {
     if (__builtin_expect(ph2, 0)) {
-        slot[SF_WS * ns + sl] = F.weights_sum[ray];
-        slot[SF_D * ns + sl] = F.depth[ray];
-        slot[SF_R * ns + sl] = F.image[(size_t)ray * 3];
-        slot[SF_G * ns + sl] = F.image[(size_t)ray * 3 + 1];
-        slot[SF_B * ns + sl] = F.image[(size_t)ray * 3 + 2];
-        slot[SF_A0 * ns + sl] = F.amb0_sum[ray];
-        slot[SF_A1 * ns + sl] = F.amb1_sum[ray];
-        slot[SF_U * ns + sl] = F.unc_sum[ray];
-        sloti[SF_CNT * ns + sl] = (int)F.max_steps;
+        slot[SF_WS * ns + sl] = LZF_OUT(O, weights_sum)[ray];
+        slot[SF_D * ns + sl] = LZF_OUT(O, depth)[ray];
+        const float* image = LZF_OUT(O, image);
+        slot[SF_R * ns + sl] = image[(size_t)ray * 3];
+        slot[SF_G * ns + sl] = image[(size_t)ray * 3 + 1];
+        slot[SF_B * ns + sl] = image[(size_t)ray * 3 + 2];
+        slot[SF_A0 * ns + sl] = LZF_OUT(O, amb0_sum)[ray];
+        slot[SF_A1 * ns + sl] = LZF_OUT(O, amb1_sum)[ray];
+        slot[SF_U * ns + sl] = LZF_OUT(O, unc_sum)[ray];
+        sloti[SF_CNT * ns + sl] = (int)LZF_OUT(O, max_steps);
     } else {
 #pragma unroll
         for (int f = SF_WS; f <= SF_U; f++) slot[f * ns + sl] = 0.0f;
@@ -274,19 +299,19 @@ __device__ __forceinline__ void lzf_slot_take(const LzFrameK& F, bool ph2, int r
 // records L for the schedule (phase 1), parks a capped ray's t for phase 2, and flags the count of a T-cut ray (negative, its t kept)
 // for lz_k_frame_counts; `report` is the count written otherwise.
 enum { LZF_END_BOX = 0, LZF_END_T = 1, LZF_END_CAP = 2 };
-__device__ __forceinline__ void lzf_ray_end(const LzFrameK& F, bool ph2, int ray, int kind, int composited, int report, float t, float ws, float d,
+__device__ __forceinline__ void lzf_ray_end(const LzfOut& O, bool ph2, int ray, int kind, int composited, int report, float t, float ws, float d,
                                             float r, float g, float b, float a0, float a1, float u) {
-    if (__builtin_expect(F.cap_mode != 0, 0)) {
+    if (__builtin_expect(LZF_OUT(O, cap_mode) != 0, 0)) {
         report = composited;
         if (kind == LZF_END_T) {
-            if (F.ray_counts) { report = -composited; F.rays_t[ray] = t; }
-            if (!ph2) F.ray_last[ray] = composited - 1;
+            if (LZF_OUT(O, ray_counts)) { report = -composited; LZF_OUT(O, rays_t)[ray] = t; }
+            if (!ph2) LZF_OUT(O, ray_last)[ray] = composited - 1;
         } else if (!ph2) {
-            F.ray_last[ray] = composited;          // LZF_END_CAP: composited == max_steps, the bin of the rays phase 2 continues
-            if (kind == LZF_END_CAP) F.rays_t[ray] = t;
+            LZF_OUT(O, ray_last)[ray] = composited;          // LZF_END_CAP: composited == max_steps, the bin of the rays phase 2 continues
+            if (kind == LZF_END_CAP) LZF_OUT(O, rays_t)[ray] = t;
         }
     }
-    lzf_write_pixel(F, ray, ws, d, r, g, b, a0, a1, u, report);
+    lzf_write_pixel(O, ray, ws, d, r, g, b, a0, a1, u, report);
 }
 
 template <int PREC> struct LzfHead;
@@ -340,6 +365,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     __shared__ __align__(16) float lds[HD::LDS_WORDS + SLOT_WORDS + 4 + LZF_LUT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
+    const LzfOut OUT = lzf_out<sizeof(typename HD::Args)>();
     // phase 2 of the reference's cap continues the rays phase 1 parked at max_steps; none parked (or C_eff == max_steps): nothing to stage
     const bool ph2 = F.phase2 != 0;
 #ifndef LZF_EXP_NO_EARLY
@@ -394,7 +420,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             sloti[SF_RAY * 16 + s] = ray;
                             slot[SF_T * 16 + s] = F.rays_t[ray];
                             slot[SF_FAR * 16 + s] = (F.occ ? F.t_end[ray] : F.fars[ray]);
-                            lzf_slot_take(F, ph2, ray, slot, sloti, s, 16);
+                            lzf_slot_take(OUT, ph2, ray, slot, sloti, s, 16);
                             lzf_store_sh<PREC>(F, ray, slot, s, 16, SF_RD);
                         }
                     }
@@ -472,7 +498,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             kk = got;
                             if (kk == 0) {     // the ray left the box without another sample
                                 const int c0 = sloti[SF_CNT * 16 + s];
-                                lzf_ray_end(F, ph2, ray, LZF_END_BOX, c0, c0, t0, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s],
+                                lzf_ray_end(OUT, ph2, ray, LZF_END_BOX, c0, c0, t0, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s],
                                             slot[SF_B * 16 + s], slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s]);
                                 my_samples += c0 - cnt_base;
                                 ray = -1;
@@ -532,7 +558,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 if (cut || short_chunk || cnt >= cap) {
                     const int kind = cut ? LZF_END_T : (short_chunk ? LZF_END_BOX : LZF_END_CAP);
                     const int composited = cut ? c0 + step + 1 : cnt;
-                    lzf_ray_end(F, ph2, ray, kind, composited, cnt, t, ws, d, r, g, b, a0, a1, u);
+                    lzf_ray_end(OUT, ph2, ray, kind, composited, cnt, t, ws, d, r, g, b, a0, a1, u);
                     my_samples += (F.cap_mode ? composited : cnt) - cnt_base;
                     sloti[SF_RAY * 16 + s] = -1;
                 } else {
@@ -573,7 +599,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             sloti[SF_RAY * NS + sl] = ray;
                             slot[SF_T * NS + sl] = F.rays_t[ray];
                             slot[SF_FAR * NS + sl] = (F.occ ? F.t_end[ray] : F.fars[ray]);
-                            lzf_slot_take(F, ph2, ray, slot, sloti, sl, NS);
+                            lzf_slot_take(OUT, ph2, ray, slot, sloti, sl, NS);
                             lzf_store_sh<PREC>(F, ray, slot, sl, NS, SF_RD);
                         }
                     }
@@ -600,7 +626,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                         x = y = z = 0.0f;
                     } else {        // the ray left the box (renderer.py: the march writes no row, compositing kills the ray on delta == 0)
                         const int c0 = sloti[SF_CNT * NS + sl];
-                        lzf_ray_end(F, ph2, ray, LZF_END_BOX, c0, c0, t, slot[SF_WS * NS + sl], slot[SF_D * NS + sl], slot[SF_R * NS + sl], slot[SF_G * NS + sl],
+                        lzf_ray_end(OUT, ph2, ray, LZF_END_BOX, c0, c0, t, slot[SF_WS * NS + sl], slot[SF_D * NS + sl], slot[SF_R * NS + sl], slot[SF_G * NS + sl],
                                     slot[SF_B * NS + sl], slot[SF_A0 * NS + sl], slot[SF_A1 * NS + sl], slot[SF_U * NS + sl]);
                         my_samples += c0 - cnt_base;
                         ray = -1;
@@ -681,7 +707,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 const float u = lz_fmaf(w, un, slot[SF_U * NS + sl]);
                 const int cnt = sloti[SF_CNT * NS + sl] + 1;
                 if (T < F.T_thresh || cnt >= cap) {
-                    lzf_ray_end(F, ph2, ray, T < F.T_thresh ? LZF_END_T : LZF_END_CAP, cnt, cnt, t, ws, d, r, g, b, a0, a1, u);
+                    lzf_ray_end(OUT, ph2, ray, T < F.T_thresh ? LZF_END_T : LZF_END_CAP, cnt, cnt, t, ws, d, r, g, b, a0, a1, u);
                     my_samples += cnt - cnt_base;
                     sloti[SF_RAY * NS + sl] = -1;
                 } else {
