@@ -313,6 +313,22 @@ class ShardedFrame:
         return assemble_frame(gathered, self.H, self.W, self.world, self.tiles)
 
 
+def cap_schedule_from_histogram(hist, n_total, max_steps):
+    """Host mirror of lz_k_frame_schedule (csrc/lz_frame.hip), for tests and for reading a histogram: hist[l] = rays whose last surviving
+    chunk boundary is l (bin max_steps: alive at the cap), summed over every tile of the frame.  Replays the reference's loop on the counts
+    alone (renderer.py:503-548): n_alive at boundary B = rays with L >= B; n_step = max(min(N // n_alive, 8), 1); step += n_step while
+    step < max_steps.  -> (C_eff, iterations, [chunk boundaries])."""
+    h = [int(v) for v in hist]
+    alive = [0] * (max_steps + 2)
+    for b in range(max_steps, -1, -1):
+        alive[b] = alive[b + 1] + (h[b] if b < len(h) else 0)
+    B, bounds = 0, [0]
+    while B < max_steps and alive[B] > 0:
+        B += max(min(int(n_total) // alive[B], 8), 1)
+        bounds.append(B)
+    return B, len(bounds) - 1, bounds
+
+
 def gather_tiles(tile, n_total=None, group=None, sizes=None):
     """all-gather per-rank tiles [n_local, C] into [sum n_local, C] on every rank, in rank order, with ONE collective.
     Equal tiles: a plain all_gather_into_tensor.  Ragged tiles: `sizes` = every rank's n_local (or `n_total`, meaning the

@@ -214,3 +214,57 @@ def test_tile_partitions():
                 if tiles == "contiguous":
                     assert torch.equal(perm, torch.arange(H * W))
     assert D.tile_rows(512, 3, 8, "interleaved")[:9] == [24, 25, 26, 27, 28, 29, 30, 31, 88]
+
+
+# ---- the reference's cap across ranks (round 4): tiles exchange ONE histogram and replay the same schedule ------------------------------
+def _cap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D.init_from_env(backend="gloo")
+    from conftest import ellipsoid_bitfield, make_params, synthetic_camera
+    from lzzx_nerf_amd.synthetic import load_golden
+    from oracle.head import TriplaneSpec, get_rays
+    from oracle.render import render_inference
+    H = W = 32
+    M = 16                                               # the reference's deployed max_steps: the cap binds
+    golden = load_golden()
+    P = make_params(golden)
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = get_rays(pose, intr, H, W)
+    bits = ellipsoid_bitfield()[0]
+    sf = D.ShardedFrame(H, W, rank, world, "interleaved", device="cpu")
+
+    class R:                                             # what configure() sets on a TriplaneRenderer
+        pass
+    r = sf.configure(R())
+    ok = r.cap == "reference" and r.frame_rays_total == H * W and r.cap_exchange == sf.sum_over_ranks
+    px = sf.pixels.numpy()
+    # Under the schedule n_step = 1 the alive count of iteration k IS the number of this tile's rays with L >= k: the histogram phase 1 builds
+    st = {}
+    render_inference(TriplaneSpec(1.0), P, ro[px], rd[px], bits, golden["net_enc_a"], golden["net_ind"], golden["net_eye"], max_steps=M, stats=st,
+                     budget_factor=1, n_step_cap=1)
+    alive = [n for n, _ in st["schedule"]] + [0] * (M + 1)
+    hist = torch.tensor([alive[k] - alive[k + 1] for k in range(M)] + [0], dtype=torch.int32)
+    hist[M] = len(px) - int(hist.sum())                  # everything else is still alive at the cap
+    r.cap_exchange(hist)                                 # ONE all-reduce of max_steps + 1 words
+    ok = ok and int(hist.sum()) == H * W
+    c_eff, iters, bounds = D.cap_schedule_from_histogram(hist.tolist(), H * W, M)
+    # the unsharded reference frame under the reference's own schedule
+    full = {}
+    render_inference(TriplaneSpec(1.0), P, ro, rd, bits, golden["net_enc_a"], golden["net_ind"], golden["net_eye"], max_steps=M, stats=full)
+    ok = ok and c_eff == sum(n for _, n in full["schedule"]) and iters == len(full["schedule"]) and c_eff > M
+    ok = ok and bounds[1:] == list(np.cumsum([n for _, n in full["schedule"]]))
+    np.save(os.path.join(out_dir, f"cap_ok_{rank}.npy"), np.array([int(ok), c_eff, iters]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tiles_replay_the_reference_cap_from_one_summed_histogram(tmp_path):
+    """world 2 over gloo: every rank histograms its tile's rays by their last surviving chunk boundary, ShardedFrame.sum_over_ranks (what
+    configure() hands the fused renderer as cap_exchange) all-reduces the max_steps + 1 words, and the replay of the reference's n_step rule
+    on the summed counts (dist.cap_schedule_from_histogram, the host mirror of lz_k_frame_schedule) gives every rank the C_eff, the
+    iteration count and the chunk boundaries of the UNSHARDED frame under the reference's schedule -- with the CPU checker as the renderer"""
+    port = _free_port()
+    mp.spawn(_cap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [np.load(tmp_path / f"cap_ok_{r}.npy") for r in range(2)]
+    assert all(int(g[0]) == 1 for g in got), got
+    assert int(got[0][1]) == int(got[1][1]) > 16
