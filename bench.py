@@ -1112,7 +1112,7 @@ def main():
     if world > 1 and args.train_dp:   # every rank takes part: one gradient all-reduce per step
         train_dp = train_bench(args, device, P, golden, bits, rank, world)
     # correctness of the gathered frame on every rank: the assembled tiles equal this rank's own tile where they overlap
-    gather_ok = None
+    gather_ok = gather_equals_unsharded = None
     if world > 1 and args.shard == "frame":
         job.sf.wait()
         frame = job.sf.assemble(tiles)
@@ -1121,6 +1121,15 @@ def main():
         ok = torch.tensor([float(torch.equal(mine, own)), float(frame.shape[0] == N)], device=device)
         torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
         gather_ok = bool(ok.min().item() == 1.0)
+        if rank == 0 and args.gather == "f32" and args.mode == "fused" and args.cap == "reference":
+            # ... and the assembled frame equals the UNSHARDED frame of the multi-launch loop under the reference's own schedule (rank 0
+            # renders it alone): the cap histogram the ranks summed makes their tiles the reference's, also where max_steps binds
+            from lzzx_nerf_amd.utils import frame_rays as _fr
+            whole = TriplaneRenderer(head, bits_dev, bound=1.0, mode="loop")
+            ro_w, rd_w = _fr(job.pose, job.intr, H, W)
+            ref_w = whole.render(ro_w, rd_w, *job.cond, dt_gamma=1 / 256, max_steps=args.max_steps, T_thresh=1e-4)["image"]
+            gather_equals_unsharded = bool(torch.equal(frame, ref_w))
+            del whole
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -1201,6 +1210,8 @@ def main():
     }
     if gather_ok is not None:
         result["gathered_frame_ok"] = gather_ok
+    if gather_equals_unsharded is not None:
+        result["gathered_frame_equals_unsharded_reference_loop"] = gather_equals_unsharded
     result.update(multi)
     if train_dp is not None:
         result["train_step"] = train_dp

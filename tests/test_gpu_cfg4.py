@@ -101,18 +101,21 @@ def test_device_built_ellipsoid_bitfield_equals_checker():
     assert np.array_equal(bits.cpu().numpy(), bits_o) and np.array_equal(grid.cpu().numpy(), grid_o)
 
 
-def test_bench_self_spawns_two_ranks_and_prints_the_contract_line(tmp_path):
+@pytest.mark.parametrize("extra", [["--max-steps", "64"], ["--max-steps", "16", "--scene", "ellipsoid"]])
+def test_bench_self_spawns_two_ranks_and_prints_the_contract_line(tmp_path, extra):
+    """(second case: the reference's deployed max_steps, where the cap binds -- the two ranks all-reduce the cap histogram between the two
+    phases of every frame, and rank 0's check of the gathered frame against its own tile still holds)"""
     env = dict(os.environ, LZ_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "128", "--max-steps", "64"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "128"] + extra
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["steps"] == 2 and r["unit"] == "samples/s" and r["value"] > 0
-    assert r["gathered_frame_ok"] is True
+    assert r["gathered_frame_ok"] is True and r["gathered_frame_equals_unsharded_reference_loop"] is True
     assert "one frame ray-sharded x2" in r["config"]["parallelism"] and r["config"]["rays_per_rank"] == 128 * 128 // 2
     assert r["clip_weak_scaling"]["scaling"] == "weak" and r["clip_weak_scaling"]["frames_per_step"] == 2
     assert "tiles_contiguous" in r and "roofline" in r
