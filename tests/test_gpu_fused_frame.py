@@ -610,3 +610,22 @@ def test_occupied_bounds_cache_is_keyed_on_the_tensor_object(params, golden):
     c = ri.render(ro, rd, *cond, max_steps=64, count_samples=True)
     for k in KEYS + ("ray_counts",):
         assert torch.equal(c[k], fresh[k]), k
+
+
+def test_cap_machinery_is_skipped_only_when_no_ray_can_reach_max_steps(params, golden):
+    """_cap_can_bind: a ray holds at most diag(aabb) / dt_min + 1 samples.  The reference's aabb (y halved, renderer.py:110: diagonal 3 < 2 sqrt 3)
+    never reaches a 192-step cap; the full cube can; the deployed max_steps = 16 (dt_min = dt_max) always does.  Where the renderer skips the
+    schedule replay the frame equals the one rendered with it forced (count_samples asks for the marched counts, which need the schedule)."""
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    head, bits, ro, rd, cond = setup(params, golden, 64, 64, "ones")
+    r = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
+    assert r._cap_can_bind(1 / 256, 192) is False and r._cap_can_bind(1 / 256, 16) is True and r._cap_can_bind(1 / 256, 150) is True
+    cube = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused", aabb=torch.tensor([-1.0, -1, -1, 1, 1, 1]))
+    assert cube._cap_can_bind(1 / 256, 192) is True
+    a = {k: v.clone() for k, v in r.render(ro, rd, *cond, max_steps=192).items()}                       # skipped (state word 10, C_eff, stays 0)
+    b = r.render(ro, rd, *cond, max_steps=192, count_samples=True)                                       # forced
+    assert int(a["state"][10]) == 0 and int(b["state"][10]) >= 192
+    for k in KEYS:
+        assert torch.equal(a[k], b[k]), k
+    r.aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1], device="cuda")                                        # a new aabb tensor is looked at again
+    assert r._cap_can_bind(1 / 256, 192) is True
