@@ -548,11 +548,11 @@ def log(msg):
 
 
 REF_SCHEDULE = (1, 8)   # renderer.py:513
-PMC_SUMMARY = "r3_final_pmc_summary.json"   # written by tools/profile_bench.sh from rocprofv3 --pmc passes of this same command
+PMC_SUMMARY = "r4_final_pmc_summary.json"   # written by tools/profile_bench.sh from rocprofv3 --pmc passes of this same command
 F16_SLICE_MFMAS = 59    # v_mfma_f32_16x16x32_f16 per 16-row slice of lz_k_triplane_head_f16
 
 
-F16_PMC_SUMMARY = "r3_f16_head_pmc_summary.json"   # tools/profile_bench.sh f16 over the current kernel
+F16_PMC_SUMMARY = "r4_f16_head_pmc_summary.json"   # tools/profile_bench.sh f16 over the current kernel
 F16_MFMA_PEAK_TFLOPS = 2500.0                      # dense f16 (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 
 

@@ -619,7 +619,8 @@ def test_cap_machinery_is_skipped_only_when_no_ray_can_reach_max_steps(params, g
     from lzzx_nerf_amd.renderer import TriplaneRenderer
     head, bits, ro, rd, cond = setup(params, golden, 64, 64, "ones")
     r = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused")
-    assert r._cap_can_bind(1 / 256, 192) is False and r._cap_can_bind(1 / 256, 16) is True and r._cap_can_bind(1 / 256, 150) is True
+    assert r._cap_can_bind(1 / 256, 192) is False and r._cap_can_bind(1 / 256, 16) is True
+    assert r._cap_can_bind(1 / 256, 100) is True and r._cap_can_bind(1 / 256, 150) is False     # 3 / dt_max + 2 = 112.9 samples at most
     cube = TriplaneRenderer(head, dev(bits), bound=1.0, mode="fused", aabb=torch.tensor([-1.0, -1, -1, 1, 1, 1]))
     assert cube._cap_can_bind(1 / 256, 192) is True
     a = {k: v.clone() for k, v in r.render(ro, rd, *cond, max_steps=192).items()}                       # skipped (state word 10, C_eff, stays 0)
