@@ -130,13 +130,18 @@ __device__ __forceinline__ void lzf_write_pixel(const LzfOut& O, int ray, float 
 }
 
 // ---- pass 1: near / far, first occupied cell, sort key, histogram -------------------------------------------------------------
-__global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
+// (1 024 rays per workgroup in both small passes: each workgroup ends with one global atomic per non-empty key, and same-address atomics
+// serialise in the L2 at ~80 ns each -- with 256-ray workgroups a 512^2 frame queued ~1 000 of them on every popular key)
+#define LZF_PREP_WG 1024
+__global__ void __launch_bounds__(LZF_PREP_WG) lz_k_frame_prepare(LzFrameK F) {
     __shared__ int hist[LZF_BINS];
     __shared__ uint32_t mlut[LZF_LUT];                       // Morton bit-spread table for the march (as in lz_k_frame)
     if (F.cap_mode && blockIdx.x == 0)                       // the cap's histogram and tables: first touched two launches later
         for (uint32_t i = threadIdx.x; i < LZ_FRAME_CAP_WS_INTS(F.max_steps); i += blockDim.x) F.cap_ws[i] = 0;
-    hist[threadIdx.x] = 0;
-    mlut[threadIdx.x] = lz_expand_bits(threadIdx.x);
+    if (threadIdx.x < LZF_BINS) {
+        hist[threadIdx.x] = 0;
+        mlut[threadIdx.x] = lz_expand_bits(threadIdx.x);
+    }
     __syncthreads();
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n < F.N) {
@@ -184,30 +189,32 @@ __global__ void __launch_bounds__(256) lz_k_frame_prepare(LzFrameK F) {
         F.keys[n] = (uint8_t)key;
     }
     __syncthreads();
-    const int h = hist[threadIdx.x];
-    if (h && threadIdx.x > 0) atomicAdd(F.state + LZF_HIST + threadIdx.x, h);
+    if (threadIdx.x > 0 && threadIdx.x < LZF_BINS) {
+        const int h = hist[threadIdx.x];
+        if (h) atomicAdd(F.state + LZF_HIST + threadIdx.x, h);
+    }
 }
 
 // ---- pass 2: ray ids in descending key order (counting sort; order inside a bin is free -- rays are independent) ---------------
 // Per workgroup: a local histogram in LDS gives every ray its rank among the workgroup's rays of the same key (one LDS atomic each),
 // ONE global atomic per non-empty key reserves the workgroup's range in that bin, all of them in flight together.
-__global__ void __launch_bounds__(256) lz_k_frame_scatter(LzFrameK F) {
+__global__ void __launch_bounds__(LZF_PREP_WG) lz_k_frame_scatter(LzFrameK F) {
     __shared__ int start[LZF_BINS], lcount[LZF_BINS], lbase[LZF_BINS];
+    const bool bin = threadIdx.x < LZF_BINS;                  // the first 256 lanes also own a key each
     {
         // start[k] = rays with a larger key (they come first): suffix scan of the 256 bins (key 0 = no sample, not queued)
-        const int h = threadIdx.x > 0 ? F.state[LZF_HIST + threadIdx.x] : 0;
-        start[threadIdx.x] = h;
-        lcount[threadIdx.x] = 0;
+        const int h = (bin && threadIdx.x > 0) ? F.state[LZF_HIST + threadIdx.x] : 0;
+        if (bin) { start[threadIdx.x] = h; lcount[threadIdx.x] = 0; }
         __syncthreads();
         for (int off = 1; off < LZF_BINS; off <<= 1) {
-            const int v = (threadIdx.x + off < LZF_BINS) ? start[threadIdx.x + off] : 0;
+            const int v = (bin && threadIdx.x + off < LZF_BINS) ? start[threadIdx.x + off] : 0;
             __syncthreads();
-            start[threadIdx.x] += v;
+            if (bin) start[threadIdx.x] += v;
             __syncthreads();
         }
-        const int incl = start[threadIdx.x];      // rays with key >= k
+        const int incl = bin ? start[threadIdx.x] : 0;      // rays with key >= k
         __syncthreads();
-        start[threadIdx.x] = incl - h;
+        if (bin) start[threadIdx.x] = incl - h;
         if (blockIdx.x == 0 && threadIdx.x == 1) { F.state[LZF_Q_SIZE] = incl; F.state[LZF_DONE] = 1; F.state[LZF_ITER] = 1; }   // keys 1..255
     }
     __syncthreads();
@@ -215,8 +222,10 @@ __global__ void __launch_bounds__(256) lz_k_frame_scatter(LzFrameK F) {
     const int key = n < F.N ? (int)F.keys[n] : 0;
     const int lrank = key > 0 ? atomicAdd(&lcount[key], 1) : 0;
     __syncthreads();
-    const int c = lcount[threadIdx.x];
-    if (c > 0 && threadIdx.x > 0) lbase[threadIdx.x] = atomicAdd(F.state + LZF_CURSOR + threadIdx.x, c);
+    if (bin && threadIdx.x > 0) {
+        const int c = lcount[threadIdx.x];
+        if (c > 0) lbase[threadIdx.x] = atomicAdd(F.state + LZF_CURSOR + threadIdx.x, c);
+    }
     __syncthreads();
     if (key > 0) F.order[start[key] + lbase[key] + lrank] = (int)n;
 }
@@ -1152,9 +1161,9 @@ extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_st
     hipError_t hrc = hipMemsetAsync(f->state, 0, LZ_FRAME_STATE_INTS * sizeof(int32_t), st);
     if (hrc != hipSuccess) { lz_set_error("frame_render: memset: %s", hipGetErrorString(hrc)); return (int)hrc; }
     const bool ref_cap = f->cap_mode == LZ_FRAME_CAP_REFERENCE;      // (cap_ws is zeroed by lz_k_frame_prepare)
-    const uint32_t nb = lz_div_up(f->N, 256);
-    hipLaunchKernelGGL(lz_k_frame_prepare, dim3(nb), dim3(256), 0, st, K);
-    hipLaunchKernelGGL(lz_k_frame_scatter, dim3(nb), dim3(256), 0, st, K);
+    const uint32_t nb = lz_div_up(f->N, LZF_PREP_WG);
+    hipLaunchKernelGGL(lz_k_frame_prepare, dim3(nb), dim3(LZF_PREP_WG), 0, st, K);
+    hipLaunchKernelGGL(lz_k_frame_scatter, dim3(nb), dim3(LZF_PREP_WG), 0, st, K);
     if (timing) (void)lz_timing_mark(timing, 0, stream);    // the event pair brackets the persistent kernel alone
     rc = lzf_launch_persistent(f, K, st);
     if (rc != LZ_OK) return rc;

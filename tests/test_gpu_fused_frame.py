@@ -625,7 +625,7 @@ def test_cap_machinery_is_skipped_only_when_no_ray_can_reach_max_steps(params, g
     assert cube._cap_can_bind(1 / 256, 192) is True
     a = {k: v.clone() for k, v in r.render(ro, rd, *cond, max_steps=192).items()}                       # skipped (state word 10, C_eff, stays 0)
     b = r.render(ro, rd, *cond, max_steps=192, count_samples=True)                                       # forced
-    assert int(a["state"][10]) == 0 and int(b["state"][10]) >= 192
+    assert int(a["state"][10]) == 0 and 0 < int(b["state"][10]) < 192     # forced: the replayed loop ends when nobody is alive (no ray holds 192 samples)
     for k in KEYS:
         assert torch.equal(a[k], b[k]), k
     r.aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1], device="cuda")                                        # a new aabb tensor is looked at again
