@@ -29,6 +29,9 @@
 #define LZN_C1 48      // 32 slots (SH 16 | sigma_net output 16, slot of its row 0 weighted 0) -> 64: 8 x 4
 #define LZN_C2 80      // 64 -> 3 (one tile, rows 3..15 zero): 16 x 1
 static_assert(LZN_C2 + 16 == LZ_NGP_FRAGS, "fragment count mismatch with the header");
+#ifndef LZN_WG_PER_CU
+#define LZN_WG_PER_CU 3u
+#endif
 #ifndef LZN_T
 #define LZN_T 1     // 16-sample slices a wave takes through the head together (2: every fragment read feeds two MFMAs, but 179 registers = two waves per SIMD instead of three: the frame takes the same 2.15 ms)
 #endif
@@ -182,7 +185,9 @@ extern "C" int lz_ngp_head_forward(const float* packed, const void* feats, int f
     LZ_REQUIRE(feat_layout >= 0 && feat_layout <= 2, LZ_ERR_BAD_ARGUMENT, "ngp_head_forward: feat_layout 0 (row-major f32), 1 (tiled f32) or 2 (tiled f16)");
     LzNgpK K{packed, feats, dirs, count, sigmas, rgbs, rows};
     uint32_t grid = lz_div_up(rows, 16 * 4 * 4 * LZN_T);      // ~4 passes per wave
-    const uint32_t cap = (uint32_t)lz_cu_count() * 8u;
+    // every workgroup stages the 24 KB of weights once: as many workgroups as the chip holds at a time (3 waves per SIMD = 3 of these 4-wave
+    // workgroups per CU), each looping over its share of the slices, not one per 16 slices
+    const uint32_t cap = (uint32_t)lz_cu_count() * LZN_WG_PER_CU;
     grid = grid < 1 ? 1 : (grid > cap ? cap : grid);
     hipStream_t st = lz_st(stream);
     if (feat_layout == 0) hipLaunchKernelGGL((lz_k_ngp_head<0>), dim3(grid), dim3(256), 0, st, K);
