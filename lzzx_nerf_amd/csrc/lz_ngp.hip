@@ -66,34 +66,46 @@ __global__ void __launch_bounds__(256) lz_k_ngp_head(LzNgpK P) {
     // T slices per pass: every A fragment is read from LDS once and feeds T MFMAs, and the T accumulation chains interleave (the 16-deep
     // chains of the two 64 -> N layers are dependent MFMAs otherwise)
     constexpr int T = LZN_T;
-    for (uint32_t slice0 = (blockIdx.x * 4u + (uint32_t)wave) * T; slice0 < n_slices; slice0 += gridDim.x * 4u * T) {
-        uint32_t row[T];
-        bool valid[T];
-        float b1[T][8], dx[T], dy[T], dz[T];
+    // the inputs of a pass (features as the B operands of sigma_net.0: levels q, q + 4, q + 8, q + 12 of sample s, both channels; direction)
+    struct In { uint32_t row[T]; bool valid[T]; float b1[T][8], dx[T], dy[T], dz[T]; };
+    auto load = [&](uint32_t slice0, In& I) {
 #pragma unroll
         for (int u = 0; u < T; u++) {
-            row[u] = (slice0 + u) * 16u + (uint32_t)s;
-            valid[u] = row[u] < rows;
-            const uint32_t r = valid[u] ? row[u] : rows - 1u;
-            // ---------------- B operands of sigma_net.0: levels q, q + 4, q + 8, q + 12 of sample s, both channels ----------------
+            I.row[u] = (slice0 + u) * 16u + (uint32_t)s;
+            I.valid[u] = I.row[u] < rows;
+            const uint32_t r = I.valid[u] ? I.row[u] : rows - 1u;
             if constexpr (FEAT == 0) {
                 const float2* f = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(P.feats) + (size_t)r * 32);
 #pragma unroll
-                for (int i = 0; i < 4; i++) { const float2 v = f[q + 4 * i]; b1[u][2 * i] = v.x; b1[u][2 * i + 1] = v.y; }
+                for (int i = 0; i < 4; i++) { const float2 v = f[q + 4 * i]; I.b1[u][2 * i] = v.x; I.b1[u][2 * i + 1] = v.y; }
             } else {
                 const uint32_t tile = r / Tn, t = r - tile * Tn, b0 = tile * Tn, n = (P.rows - b0 < Tn) ? P.rows - b0 : Tn;
                 if constexpr (FEAT == 1) {
                     const float2* f = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(P.feats) + (size_t)b0 * 32);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { const float2 v = f[(size_t)(q + 4 * i) * n + t]; b1[u][2 * i] = v.x; b1[u][2 * i + 1] = v.y; }
+                    for (int i = 0; i < 4; i++) { const float2 v = f[(size_t)(q + 4 * i) * n + t]; I.b1[u][2 * i] = v.x; I.b1[u][2 * i + 1] = v.y; }
                 } else {
                     const __half2* f = reinterpret_cast<const __half2*>(reinterpret_cast<const __half*>(P.feats) + (size_t)b0 * 32);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { const float2 v = __half22float2(f[(size_t)(q + 4 * i) * n + t]); b1[u][2 * i] = v.x; b1[u][2 * i + 1] = v.y; }
+                    for (int i = 0; i < 4; i++) { const float2 v = __half22float2(f[(size_t)(q + 4 * i) * n + t]); I.b1[u][2 * i] = v.x; I.b1[u][2 * i + 1] = v.y; }
                 }
             }
-            dx[u] = P.dirs[(size_t)r * 3]; dy[u] = P.dirs[(size_t)r * 3 + 1]; dz[u] = P.dirs[(size_t)r * 3 + 2];
+            I.dx[u] = P.dirs[(size_t)r * 3]; I.dy[u] = P.dirs[(size_t)r * 3 + 1]; I.dz[u] = P.dirs[(size_t)r * 3 + 2];
         }
+    };
+    const uint32_t stride = gridDim.x * 4u * T;
+    uint32_t slice0 = (blockIdx.x * 4u + (uint32_t)wave) * T;
+    if (rows == 0 || slice0 >= n_slices) return;
+    In nxt;
+    load(slice0, nxt);
+    for (; slice0 < n_slices; slice0 += stride) {
+        // the next pass's inputs are requested before this pass's 96 MFMAs (a wave's pass otherwise starts with a round trip to the tiles)
+        const In cur = nxt;
+        if (slice0 + stride < n_slices) load(slice0 + stride, nxt);
+        const uint32_t (&row)[T] = cur.row;
+        const bool (&valid)[T] = cur.valid;
+        const float (&b1)[T][8] = cur.b1;
+        const float (&dx)[T] = cur.dx, (&dy)[T] = cur.dy, (&dz)[T] = cur.dz;
         // ---------------- sigma_net: 32 -> 64 (ReLU) -> 16 ----------------
         float h1[T][16];
         {
