@@ -82,6 +82,7 @@ struct LzFrameK {
     int* ray_last;        // [N]: L of every ray = the last chunk boundary it can survive, min(box samples, tau - 1), max_steps = parked at the cap
     int* cap_ws;          // [0 .. max_steps] histogram of L (what ranks all-reduce), then the schedule tables (lz_k_frame_schedule)
     uint32_t cap_mode, phase2, N_total;
+    LzMarchFrame mf;      // the march's frame-wide quotients (lz_march_frame on the host)
 };
 
 // The per-ray OUTPUT side of LzFrameK (eleven pointers, the background, the cap's buffers) is touched once per ray, when it leaves its slot.
@@ -451,7 +452,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                         int want = 0, got = 0;
                         if (grp) {
                             m.init(F.rays_o + (size_t)gray * 3, F.rays_d + (size_t)gray * 3, slot[SF_RD * 16 + lead], slot[(SF_RD + 1) * 16 + lead],
-                                   slot[(SF_RD + 2) * 16 + lead], F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+                                   slot[(SF_RD + 2) * 16 + lead], F.bound, F.dt_gamma, F.mf, F.C, F.H, F.grid);
                             if (use_lut) m.morton_lut = mlut;
                             t0 = slot[SF_T * 16 + lead];
                             far = slot[SF_FAR * 16 + lead];
@@ -616,7 +617,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 }
                 if (slot_lane && ray >= 0 && !have) {
                     m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, slot[SF_RD * NS + sl], slot[(SF_RD + 1) * NS + sl], slot[(SF_RD + 2) * NS + sl],
-                           F.bound, F.dt_gamma, F.max_steps, F.C, F.H, F.grid);
+                           F.bound, F.dt_gamma, F.mf, F.C, F.H, F.grid);
                     if (use_lut) m.morton_lut = mlut;
                     float t = slot[SF_T * NS + sl], dt = 0.0f;
                     const float far = slot[SF_FAR * NS + sl];
@@ -1045,6 +1046,7 @@ static int lzf_fill(const lz_frame_fused* f, LzFrameK& K) {
     K.noises = f->noises;
     K.occ = f->occupied_aabb; K.t_end = f->t_end;
     K.ray_last = f->ray_last; K.cap_ws = f->cap_ws; K.cap_mode = f->cap_mode; K.phase2 = 0; K.N_total = f->N_total;
+    K.mf = lz_march_frame(f->bound, f->max_steps, f->C, f->H);
     return LZ_OK;
 }
 

@@ -71,6 +71,21 @@ __device__ __forceinline__ void lz_near_far_ray(float ox, float oy, float oz, fl
 // ------------------------------------------------------------------------------------------------
 // marching
 // ------------------------------------------------------------------------------------------------
+// the divisions of LzMarch::init, which depend on the frame only (raymarching.cu:380-381, 866-867): a persistent kernel that re-initialises its
+// per-ray march every pass takes them from the host instead of running four IEEE division sequences (~11 vector instructions each) per pass
+struct LzMarchFrame {
+    float rbound, rH, dt_max, dt_min;
+};
+__host__ __device__ __forceinline__ LzMarchFrame lz_march_frame(float bound, uint32_t max_steps, uint32_t C, uint32_t H) {
+    LzMarchFrame f;
+    f.rbound = 1 / bound;
+    f.rH = 1 / (float)H;
+    f.dt_max = 2 * LZ_SQRT3F * (float)(1 << (C - 1)) / (float)H;
+    const float dmin = 2 * LZ_SQRT3F / (float)max_steps;
+    f.dt_min = f.dt_max < dmin ? f.dt_max : dmin;       // fminf(dt_max, 2 sqrt(3) / max_steps); max_steps = 0 gives +inf: dt_max
+    return f;
+}
+
 struct LzMarch {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
     float bound, rbound, dt_gamma, dt_min, dt_max, rH, H3, fC, fH, halfH;
@@ -87,19 +102,24 @@ struct LzMarch {
     // the ray, not once per pass: an IEEE division is ~11 vector instructions)
     __device__ __forceinline__ void init(const float* o, const float* d, float rdx_, float rdy_, float rdz_, float bound_, float dt_gamma_,
                                          uint32_t max_steps, uint32_t C, uint32_t H_, const uint8_t* grid_) {
+        init(o, d, rdx_, rdy_, rdz_, bound_, dt_gamma_, lz_march_frame(bound_, max_steps, C, H_), C, H_, grid_);
+    }
+    // ... and with the frame's quotients supplied as well (lz_march_frame on the host: the same IEEE divisions, the same bits)
+    __device__ __forceinline__ void init(const float* o, const float* d, float rdx_, float rdy_, float rdz_, float bound_, float dt_gamma_,
+                                         const LzMarchFrame& fr, uint32_t C, uint32_t H_, const uint8_t* grid_) {
         ox = o[0]; oy = o[1]; oz = o[2];
         dx = d[0]; dy = d[1]; dz = d[2];
         rdx = rdx_; rdy = rdy_; rdz = rdz_;
         morton_lut = nullptr;
-        bound = bound_; rbound = 1 / bound_; dt_gamma = dt_gamma_;
-        rH = 1 / (float)H_;
+        bound = bound_; rbound = fr.rbound; dt_gamma = dt_gamma_;
+        rH = fr.rH;
         H3 = (float)(H_ * H_ * H_);
         H = H_; fC = (float)C; fH = (float)H_; grid = grid_;
         one_cascade = C == 1;      // then both mip rules clamp to level 0 (raymarching.cu:42-54: min(max_cascade - 1, .)): nothing to evaluate
         pow2H = (H_ & (H_ - 1u)) == 0u && H_ >= 2u;
         halfH = 0.5f * (float)H_;
-        dt_max = 2 * LZ_SQRT3F * (float)(1 << (C - 1)) / (float)H_;
-        dt_min = lz_fminf(dt_max, 2 * LZ_SQRT3F / (float)max_steps);
+        dt_max = fr.dt_max;
+        dt_min = fr.dt_min;
     }
 
     // the step of the march at t -- sample step and empty-space skip alike (raymarching.cu:907, 919-926)
