@@ -91,7 +91,9 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
     }
     // (x + bound) / (2 bound), grid.py:143.  When 2 bound is a power of two (bound 1, 2, 4 ...: every scene of the reference) the
     // division equals the multiplication by its exact reciprocal bit for bit, and an IEEE division is ~11 VALU instructions
-    const uint32_t tb_bits = __float_as_uint(two_bound);
+    // (readfirstlane: `two_bound` reaches this point in a vector register, and a condition computed from it counts as divergent -- the compiler
+    // then evaluates BOTH sides below, three IEEE division sequences of ~10 instructions each per slice, and selects; as a scalar it is a branch)
+    const uint32_t tb_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(two_bound));
     const bool pow2 = (tb_bits & 0x007fffffu) == 0u && tb_bits > 0x00800000u && tb_bits < 0x7f000000u;   // wave-uniform
     float c01[3];
     if (pow2) {
