@@ -378,9 +378,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     const LzfOut OUT = lzf_out<sizeof(typename HD::Args)>();
     // phase 2 of the reference's cap continues the rays phase 1 parked at max_steps; none parked (or C_eff == max_steps): nothing to stage
     const bool ph2 = F.phase2 != 0;
-#ifndef LZF_EXP_NO_EARLY
     if (ph2 && F.state[LZF_P_SIZE] <= 0) return;
-#endif
     typename HD::Ctx ctx;
     HD::stage(P, lds, q, ctx);
     float* slot = lds + HD::LDS_WORDS + wave * NF * NS;      // this wave's slots: slot[field * 16 + s]
@@ -397,11 +395,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
 #define q_head (F.state + (ph2 ? LZF_P_HEAD : LZF_Q_HEAD))        /* (not a variable: it would sit in two scalar registers through every pass) */
     // samples at which a ray still alive is stopped: the per-ray cap ceil(max_steps / S) * S (cap_mode 0), or exactly max_steps in phase 1 and
     // the schedule's C_eff in phase 2 (cap_mode 1)
-#ifdef LZF_EXP_NO_CAPVAR
-#define cap ((((int)F.max_steps + S - 1) / S) * S)
-#else
     const int cap = ph2 ? F.state[LZF_CEFF] : (F.cap_mode ? (int)F.max_steps : (((int)F.max_steps + S - 1) / S) * S);
-#endif
 #define cnt_base (ph2 ? (int)F.max_steps : 0)                     /* samples a ray brings along when it takes a slot */
     LzMarch m;   // the frame-constant part of LzMarch (init() below sets the per-ray part)
     bool dry = n_queue <= 0;
