@@ -253,7 +253,7 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
             mean_count[0] = int(xyzs.shape[0]) + n_rays // 64   # margin: a perturbed ray gains or loses at most one sample
         sigma, rgb, a0, a1, unc = net(xyzs, dirs, enc_a, ind, eye)
         if args.train_mlp == "fused":
-            a0, a1, unc = a0[:, 0], a1[:, 0], unc[:, 0]
+            a0, a1, unc = a0.squeeze(-1), a1.squeeze(-1), unc.squeeze(-1)      # views: their backward is a view too (a select's is zeros + copy)
         ws, a0s, a1s, us, dep, img = R.composite_rays_train_triplane(sigma, rgb, a0, a1, unc, deltas, rays)
         loss = ((img + (1 - ws).unsqueeze(-1) - target) ** 2).mean() + 1e-4 * a0s.mean() + 1e-4 * a1s.mean() + 1e-3 * us.mean()
         if scaler is not None:   # half operands: loss scaling exactly as the reference's trainer does it (TrainerUtil.py:103, 865-870)

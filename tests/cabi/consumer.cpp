@@ -24,7 +24,7 @@ static uint32_t spread3(uint32_t v) {   // raymarching.cu:56-63
 }
 
 int main() {
-    CHECK(lz_abi_version() >= 6);
+    CHECK(lz_abi_version() >= 9);
     CHECK(lz_device_ok() == 1);
     hipStream_t st;
     HIP_OK(hipStreamCreate(&st));
@@ -103,6 +103,20 @@ int main() {
     CHECK(lz_occupied_bounds(d_bits, 9, 128, 1.0f, 8, d_idx, d_near, st) != 0);          // cascade out of range
     CHECK(lz_torso_anchor_encode(nullptr, nullptr, nullptr, st) != 0);
     CHECK(lz_frame_render(nullptr, nullptr, st) != 0);
+    // ... and the entry points of ABI 9: the deferred half of the reference's cap, the plain compositing of the loop, the hash-grid NeRF path
+    CHECK(lz_frame_finish(nullptr, st) != 0);
+    lz_frame_fused ff{};                                  // zeroed frame: no rays, no buffers
+    ff.cap_mode = LZ_FRAME_CAP_REFERENCE;
+    CHECK(lz_frame_render(&ff, nullptr, st) != 0);
+    CHECK(lz_frame_finish(&ff, st) != 0);
+    CHECK(lz_loop_composite_plain(nullptr, 4, 1e-4f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st) != 0);
+    CHECK(lz_grid_encode_forward_tiled(nullptr, nullptr, nullptr, nullptr, 256, nullptr, 1.0f, 3, 2, 16, 1.0f, 16, 0, 0, 0, st) != 0);
+    CHECK(lz_grid_encode_forward_tiled(d_near, d_near, d_idx, d_near, 256, nullptr, 1.0f, 2, 2, 16, 1.0f, 16, 0, 0, 0, st) != 0);   // D = 3, C = 2 only
+    CHECK(lz_ngp_head_forward(nullptr, nullptr, 0, nullptr, 16, nullptr, nullptr, nullptr, st) != 0);
+    CHECK(lz_ngp_head_forward(d_near, d_near, 7, d_near, 16, nullptr, d_near, d_near, st) != 0);                                       // unknown layout
+    CHECK(lz_ngp_loop_run(nullptr, 0, 1, st) != 0);
+    lz_frame_ngp fn{};
+    CHECK(lz_ngp_loop_run(&fn, 0, 1, st) != 0);
     CHECK(lz_last_error()[0] != 0);
     HIP_OK(hipStreamSynchronize(st));                     // nothing was launched: the stream is still healthy
     LZ_OK_(lz_packbits(d_grid, G, 0.5f, d_bits, st));

@@ -1,0 +1,74 @@
+"""Randomised differential test of the headline path: TriplaneRenderer(mode="fused", cap="reference") -- one persistent kernel, the
+frame-wide cap C_eff, any steps_per_pass -- against the multi-launch loop under the reference's schedule (budget_factor, n_step_cap) =
+(1, 8) (renderer.py:503-548), which the parity tests hold to the CPU checker and to the reference-run fixtures.  Seeded draws over frame
+size, occupancy, max_steps (1 .. 48: the cap binds in most cases), T_thresh, dt_gamma, launch shape, precision, perturbed starts, a
+background image, the march confined to the occupied bounds; every output and the per-ray marched counts must be identical."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ellipsoid_bitfield, synthetic_camera
+
+pytestmark = pytest.mark.gpu
+KEYS = ("image", "image_raw", "weights_sum", "depth", "amb_aud_sum", "amb_eye_sum", "uncertainty_sum", "nears", "fars", "ray_counts")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _bits(rng, kind):
+    n = 128 ** 3
+    if kind == "ones":
+        return np.full(n // 8, 255, np.uint8)
+    if kind == "empty":
+        return np.zeros(n // 8, np.uint8)
+    if kind == "ellipsoid":
+        return ellipsoid_bitfield()[0]
+    if kind == "dust":          # every cell occupied with probability p: rays alternate between samples and one-cell skips
+        p = rng.choice([0.02, 0.3, 0.7])
+        return np.packbits(rng.random(n) < p, bitorder="little")
+    # slabs: a few occupied byte runs in Morton order = spatially compact blocks with empty space between them
+    bits = np.zeros(n // 8, np.uint8)
+    for _ in range(int(rng.integers(2, 9))):
+        a = int(rng.integers(0, n // 8 - 4096))
+        bits[a:a + int(rng.integers(64, 4096))] = 255
+    return bits
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    c = dict(H=int(rng.integers(9, 90)), W=int(rng.integers(9, 90)), scene=str(rng.choice(["ones", "ellipsoid", "dust", "slabs", "slabs", "empty"], p=[.2, .25, .2, .15, .15, .05])),
+             max_steps=int(rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 24, 31, 32, 48])), T_thresh=float(rng.choice([1e-4, 1e-4, 0.3, 0.8])),
+             dt_gamma=float(rng.choice([0.0, 1 / 256, 1 / 256, 1 / 64])), S=int(rng.choice([0, 1, 2, 4, 8, 16])),
+             precision=str(rng.choice(["f32", "f32", "f16"])), noise=bool(rng.random() < 0.3), bg=bool(rng.random() < 0.3), occ=bool(rng.random() < 0.5))
+    return rng, c
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LZ_RANDOM_FRAMES", "48"))))     # LZ_RANDOM_FRAMES=600: the soak run of round 4
+def test_fused_reference_cap_equals_the_loop_on_random_frames(params, golden, seed):
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    from lzzx_nerf_amd.utils import frame_rays
+    rng, c = _case(seed)
+    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in params.items()}, bound=1.0, precision=c["precision"])
+    bits = dev(_bits(rng, c["scene"]))
+    pose, intr = synthetic_camera(c["H"], c["W"])
+    ro, rd = frame_rays(dev(pose), intr, c["H"], c["W"])
+    N = ro.shape[0]
+    cond = (dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]))
+    kw = dict(max_steps=c["max_steps"], T_thresh=c["T_thresh"], dt_gamma=c["dt_gamma"], count_samples=True)
+    if c["noise"]:
+        kw["noises"] = dev(rng.uniform(0, 1, N).astype(np.float32))
+    if c["bg"]:
+        kw["bg_color"] = dev(rng.uniform(0, 1, (N, 3)).astype(np.float32))
+    fr = TriplaneRenderer(head, bits, bound=1.0, mode="fused", cap="reference")
+    fr.steps_per_pass = c["S"]
+    fr.clip_to_occupancy = c["occ"]
+    fused = {k: v.clone() for k, v in fr.render(ro, rd, *cond, **kw).items()}
+    loop = TriplaneRenderer(head, bits, bound=1.0, budget_factor=1, n_step_cap=8).render(ro, rd, *cond, **kw)
+    for k in KEYS:
+        assert torch.equal(fused[k], loop[k]), (c, k, int((fused[k] != loop[k]).sum()))
+    assert int(fused["state"][5]) == int(loop["state"][5]) == int(fused["ray_counts"].sum()), c
