@@ -1130,10 +1130,10 @@ static int lzf_launch_persistent(const lz_frame_fused* f, const LzFrameK& K, hip
 
 extern "C" int lz_frame_finish(const lz_frame_fused* f, lz_stream_t stream) {
     LZ_REQUIRE(f, LZ_ERR_BAD_ARGUMENT, "frame_finish: null");
+    LZ_REQUIRE(f->cap_mode == LZ_FRAME_CAP_REFERENCE, LZ_ERR_BAD_ARGUMENT, "frame_finish: only after lz_frame_render with cap_mode 1");
+    if (f->N == 0 && f->state) return LZ_OK;       // an empty tile (see lz_frame_render)
     int rc = lzf_check(f, "frame_finish");
     if (rc != LZ_OK) return rc;
-    LZ_REQUIRE(f->cap_mode == LZ_FRAME_CAP_REFERENCE, LZ_ERR_BAD_ARGUMENT, "frame_finish: only after lz_frame_render with cap_mode 1");
-    if (f->N == 0) return LZ_OK;
     hipStream_t st = lz_st(stream);
     LzFrameK K;
     lzf_fill(f, K);
@@ -1148,10 +1148,20 @@ extern "C" int lz_frame_finish(const lz_frame_fused* f, lz_stream_t stream) {
 
 extern "C" int lz_frame_render(const lz_frame_fused* f, lz_timing* timing, lz_stream_t stream) {
     LZ_REQUIRE(f, LZ_ERR_BAD_ARGUMENT, "frame_render: null");
+    hipStream_t st = lz_st(stream);
+    if (f->N == 0 && f->state) {
+        // A rank whose tile of the frame holds no ray (a frame with fewer row blocks than ranks): nothing to render -- the per-ray
+        // buffers may be null -- but its words of the histogram exchange must read zero, and the state must say "done, no samples".
+        hipError_t e = hipMemsetAsync(f->state, 0, LZ_FRAME_STATE_INTS * sizeof(int32_t), st);
+        if (e == hipSuccess && f->cap_mode == LZ_FRAME_CAP_REFERENCE && f->cap_ws) {
+            LZ_REQUIRE(f->max_steps <= LZF_CAP_MAX_STEPS, LZ_ERR_UNSUPPORTED, "frame_render: cap_mode 1 supports max_steps <= %d", LZF_CAP_MAX_STEPS);
+            e = hipMemsetAsync(f->cap_ws, 0, LZ_FRAME_CAP_WS_INTS((size_t)f->max_steps) * sizeof(int32_t), st);
+        }
+        if (e != hipSuccess) { lz_set_error("frame_render: memset: %s", hipGetErrorString(e)); return (int)e; }
+        return LZ_OK;
+    }
     int rc = lzf_check(f, "frame_render");
     if (rc != LZ_OK) return rc;
-    if (f->N == 0) return LZ_OK;
-    hipStream_t st = lz_st(stream);
     LzFrameK K;
     lzf_fill(f, K);
     hipError_t hrc = hipMemsetAsync(f->state, 0, LZ_FRAME_STATE_INTS * sizeof(int32_t), st);

@@ -212,8 +212,10 @@ extern "C" int lz_ngp_head_forward(const float* packed, const void* feats, int f
 // enqueue `n_iterations` iterations of the reference's inference loop (renderer.py:503-548) around the hash-grid NeRF: march -> gather ->
 // head -> composite, four launches each, no host round trip; iterations past the end of the frame are no-ops on the device
 extern "C" int lz_ngp_loop_run(const lz_frame_ngp* f, uint32_t parity, uint32_t n_iterations, lz_stream_t stream) {
-    LZ_REQUIRE(f && f->state && f->workspace && f->rays_alive[0] && f->rays_alive[1] && f->packed && f->embeddings && f->offsets && f->feats,
-               LZ_ERR_BAD_ARGUMENT, "ngp_loop_run: incomplete lz_frame_ngp");
+    LZ_REQUIRE(f, LZ_ERR_BAD_ARGUMENT, "ngp_loop_run: null");
+    LZ_REQUIRE(f->state && f->workspace && f->packed && f->embeddings && f->offsets, LZ_ERR_BAD_ARGUMENT, "ngp_loop_run: incomplete lz_frame_ngp");
+    if (f->N == 0) return LZ_OK;                 // no ray: nothing to enqueue
+    LZ_REQUIRE(f->rays_alive[0] && f->rays_alive[1] && f->feats, LZ_ERR_BAD_ARGUMENT, "ngp_loop_run: incomplete lz_frame_ngp");
     uint32_t cur = parity & 1u;
     const int32_t* count = reinterpret_cast<const int32_t*>(f->state) + LZ_LOOP_NEXT + 2;  // n_samples of the iteration in flight
     const uint32_t rows = f->sample_budget > f->N ? f->sample_budget : f->N;  // capacity of the sample buffers

@@ -46,9 +46,9 @@ lz_k_get_rays(const float* __restrict__ poses, float fx, float fy, float cx, flo
 
 extern "C" int lz_get_rays(const float* poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, uint32_t B, uint32_t N,
                            const int64_t* inds, float* rays_o, float* rays_d, float* out_i, float* out_j, lz_stream_t stream) {
+    if ((uint64_t)B * N == 0) return LZ_OK;      // no ray (a rank's empty tile): the ray tensors of an empty batch have no storage
     LZ_REQUIRE(poses && rays_o && rays_d, LZ_ERR_BAD_ARGUMENT, "get_rays: null tensor");
     LZ_REQUIRE(inds || (uint64_t)N == (uint64_t)H * W, LZ_ERR_BAD_ARGUMENT, "get_rays: without inds N must be H * W");
-    if ((uint64_t)B * N == 0) return LZ_OK;
     LZ_REQUIRE((uint64_t)B * N < (1ull << 32) * 256, LZ_ERR_BAD_ARGUMENT, "get_rays: too many rays for one launch");
     hipLaunchKernelGGL(lz_k_get_rays, dim3((uint32_t)lz_div_up((uint64_t)B * N, 256)), dim3(256), 0, lz_st(stream), poses, fx, fy, cx, cy, W,
                        B, N, reinterpret_cast<const long long*>(inds), rays_o, rays_d, out_i, out_j);
@@ -1328,8 +1328,8 @@ extern "C" int lz_loop_march(lz_loop_state* state, uint32_t N, uint32_t sample_b
                              lz_stream_t stream) {
     (void)nears;
     LZ_REQUIRE(C >= 1 && C <= 8 && H > 0, LZ_ERR_BAD_ARGUMENT, "loop_march: cascade must be in [1, 8]");
+    if (N == 0) return LZ_OK;                    // no ray: the per-ray arrays of an empty batch have no storage
     LZ_REQUIRE(state && workspace && rays_alive_in && rays_alive_out, LZ_ERR_BAD_ARGUMENT, "loop_march: null argument");
-    if (N == 0) return LZ_OK;
     LZ_REQUIRE(lz_div_up(N, 256) <= 4096, LZ_ERR_UNSUPPORTED, "loop_march: at most %u rays per call", 4096u * 256u);
     hipLaunchKernelGGL((lz_k_march_rays<true>), dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), 0u, 0u, state, rays_alive_in,
                        reinterpret_cast<const int*>(workspace), rays_alive_out, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid,

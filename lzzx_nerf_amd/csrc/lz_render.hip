@@ -99,7 +99,9 @@ extern "C" int lz_timing_elapsed_ms(lz_timing* t, float* out_ms, uint32_t capaci
 }
 
 extern "C" int lz_loop_run(const lz_frame* f, uint32_t parity, uint32_t n_iterations, lz_timing* timing, lz_stream_t stream) {
-    LZ_REQUIRE(f && f->state && f->workspace && f->rays_alive[0] && f->rays_alive[1], LZ_ERR_BAD_ARGUMENT, "loop_run: incomplete lz_frame");
+    LZ_REQUIRE(f, LZ_ERR_BAD_ARGUMENT, "loop_run: null");
+    if (f->N == 0) return LZ_OK;                 // no ray: nothing to enqueue (the per-ray arrays of an empty batch have no storage)
+    LZ_REQUIRE(f->state && f->workspace && f->rays_alive[0] && f->rays_alive[1], LZ_ERR_BAD_ARGUMENT, "loop_run: incomplete lz_frame");
     uint32_t cur = parity & 1u;
     const int32_t* count = reinterpret_cast<const int32_t*>(f->state) + LZ_LOOP_NEXT + 2;  // n_samples of the iteration in flight
     const uint32_t rows = f->sample_budget > f->N ? f->sample_budget : f->N;  // capacity of the sample buffers

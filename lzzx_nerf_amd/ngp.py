@@ -152,6 +152,9 @@ class HashgridRenderer:
         N, dev = rays_o.shape[0], rays_o.device
         if N > MAX_RAYS_PER_PASS:
             raise RuntimeError("HashgridRenderer renders at most %d rays per call" % MAX_RAYS_PER_PASS)
+        if N == 0:
+            from .renderer import _empty_result
+            return _empty_result(dev, count_samples, ambient=False)
         b = self._buffers(N, dev)
         call("lz_near_far_from_aabb", ptr(rays_o), ptr(rays_d), ptr(self.aabb), N, self.min_near, ptr(b["nears"]), ptr(b["fars"]), stream())
         if count_samples:

@@ -53,6 +53,21 @@ class _Buffers:
         self.state_ring = [torch.zeros(8, dtype=torch.int32).pin_memory() for _ in range(4)]
 
 
+def _empty_result(device, count_samples=False, rgb24=False, ambient=True):
+    """what the loops return for a batch of no rays (a rank whose tile of a small frame is empty): empty outputs, a finished state"""
+    z = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
+    state = torch.zeros(1024, dtype=torch.int32, device=device)
+    state[3] = 1
+    res = dict(image=z(0, 3), image_raw=z(0, 3), weights_sum=z(0), depth=z(0), state=state, nears=z(0), fars=z(0))
+    if ambient:
+        res.update(amb_aud_sum=z(0), amb_eye_sum=z(0), uncertainty_sum=z(0))
+    if count_samples:
+        res["ray_counts"] = torch.empty(0, dtype=torch.int32, device=device)
+    if rgb24:
+        res["image_rgb24"] = torch.empty(0, 3, dtype=torch.uint8, device=device)
+    return res
+
+
 class TriplaneRenderer:
     """Inference renderer for one head / one occupancy grid.
 
@@ -261,6 +276,8 @@ class TriplaneRenderer:
             return res
         if self.mode == "fused":
             return self._render_fused(rays_o, rays_d, enc_a, ind_code, eye, dt_gamma, max_steps, T_thresh, bg_color, count_samples, rgb24, noises)
+        if N == 0:
+            return _empty_result(rays_o.device, count_samples, rgb24)
         b = self._buffers(N, rays_o.device)
         self._rays_o, self._rays_d = rays_o, rays_d
         call("lz_near_far_from_aabb", ptr(rays_o), ptr(rays_d), ptr(self.aabb), N, self.min_near, ptr(b.nears), ptr(b.fars), stream())
@@ -461,6 +478,8 @@ class NetworkRenderer(TriplaneRenderer):
         N, dev = rays_o.shape[0], rays_o.device
         if N > MAX_RAYS_PER_PASS:
             raise RuntimeError("NetworkRenderer renders at most %d rays per call" % MAX_RAYS_PER_PASS)
+        if N == 0:
+            return _empty_result(dev, count_samples, ambient=False)
         prev = self._buf
         b = self._buffers(N, dev)
         fresh = b is not prev      # (also when the row budget changed: budget_factor)

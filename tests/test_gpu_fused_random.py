@@ -72,3 +72,50 @@ def test_fused_reference_cap_equals_the_loop_on_random_frames(params, golden, se
     for k in KEYS:
         assert torch.equal(fused[k], loop[k]), (c, k, int((fused[k] != loop[k]).sum()))
     assert int(fused["state"][5]) == int(loop["state"][5]) == int(fused["ray_counts"].sum()), c
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LZ_RANDOM_TILED_FRAMES", "16"))))
+def test_tiles_of_random_frames_equal_the_unsharded_reference_loop(params, golden, seed):
+    """The same draws rendered as 2 .. 8 tiles of ONE frame (dist.ShardedFrame; every tile by its own fused renderer with its own launch
+    shape, the max_steps + 1 histogram words of the first phases summed as the all-reduce does): the assembled image, depth and marched
+    counts equal the unsharded loop under the reference schedule -- n_alive / N of renderer.py:513 are frame-wide quantities."""
+    from lzzx_nerf_amd import dist as D
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    from lzzx_nerf_amd.utils import frame_rays
+    rng, c = _case(5000 + seed)
+    world = int(rng.integers(2, 9))
+    tiles = str(rng.choice(["interleaved", "contiguous"]))
+    H, W = max(c["H"], 2 * world), c["W"]
+    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in params.items()}, bound=1.0, precision=c["precision"])
+    bits = dev(_bits(rng, c["scene"]))
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = frame_rays(dev(pose), intr, H, W)
+    cond = (dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]))
+    kw = dict(max_steps=c["max_steps"], T_thresh=c["T_thresh"], dt_gamma=c["dt_gamma"], count_samples=True)
+    noise = dev(rng.uniform(0, 1, H * W).astype(np.float32)) if c["noise"] else None
+    ref = TriplaneRenderer(head, bits, bound=1.0).render(ro, rd, *cond, noises=noise, **kw)
+    ref = {k: v.clone() for k, v in ref.items()}
+    rs, ctxs = [], []
+    for g in range(world):
+        sf = D.ShardedFrame(H, W, g, world, tiles, device="cuda")
+        sf.gatherer = None
+        r = sf.configure(TriplaneRenderer(head, bits, bound=1.0, mode="fused"))
+        r.steps_per_pass = int(rng.choice([0, 0, 1, 2, 4, 8, 16]))
+        r.clip_to_occupancy = c["occ"]
+        px = sf.pixels
+        tro, trd = sf.rays(dev(pose), intr)          # ray generation for the tile's pixels (an EMPTY tile when the frame has fewer row blocks than ranks)
+        assert torch.equal(tro, ro[px]) and torch.equal(trd, rd[px])
+        ctxs.append(r.fused_begin(tro, trd, *cond, noises=None if noise is None else noise[px].contiguous(), **kw))
+        rs.append(r)
+    total = torch.stack([x["hist"] for x in ctxs]).sum(0)
+    assert int(total.sum()) == H * W, (c, world, tiles)
+    outs = []
+    for r, x in zip(rs, ctxs):
+        x["hist"].copy_(total)
+        outs.append({k: v.clone() for k, v in r.fused_finish(x).items()})
+    for k in ("image", "depth", "weights_sum", "ray_counts"):
+        cat = torch.cat([o[k] for o in outs])
+        got = D.assemble_frame(cat if cat.dim() > 1 else cat[:, None], H, W, world, tiles)
+        got = got if cat.dim() > 1 else got[:, 0]
+        assert torch.equal(got, ref[k]), (c, world, tiles, k, int((got != ref[k]).sum()))
