@@ -246,7 +246,11 @@ template <int PREC, int S, int ROWS> struct LzfFields {
     static constexpr int OSIG = S > 1 ? ST + 4 : ST, OR = OSIG + 1, OG = OSIG + 2, OB = OSIG + 3, OA0 = OSIG + 4, OA1 = OSIG + 5, OU = OSIG + 6;
     static constexpr int IT = OSIG + 7;                                                       // S > 1 only
     static constexpr int RD = S > 1 ? ST + 12 : (ROWS > 1 ? ST + 7 : ST);                    // 1 / direction (3 words), set when the slot takes the ray
-    static constexpr int COUNT = RD + 3;
+    // origin and direction of the slot's ray (6 words) behind the reciprocals: LzMarch::init reads LDS instead of two dwordx3 global loads at the
+    // head of every pass's dependent chain (same-box A/B, round 4: f32 frame 8.95 -> 8.90 ms, f16 1.990 -> 1.985, f16 8-way tile 0.433 ->
+    // 0.426).  Not with three slot rows: the f16 kernel's LDS is full there (157 KB).
+    static constexpr bool GEO = ROWS < 3;
+    static constexpr int COUNT = RD + 3 + (GEO ? 6 : 0);
 };
 
 // SH(4) of the slot's ray from LDS: component k of the ray whose state sits at slot `ls` (fields are `ns` slots wide)
@@ -268,7 +272,7 @@ __device__ __forceinline__ void h_sh_pk(const LzShFromSlot16& f, int q, uint32_t
     w[1] = __float_as_uint(f.slot[(SF_SH + 2 * q + 1) * f.ns + f.ls]);
 }
 // evaluated by the lane that takes the ray (the same lz_sh_eval call on the same direction as the stand-alone head makes per sample)
-template <int PREC>
+template <int PREC, bool GEO = false>
 __device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* slot, int s, int ns, int rd_field) {
     const float* d = F.rays_d + (size_t)ray * 3;
     float o[16];
@@ -276,6 +280,14 @@ __device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* 
     slot[rd_field * ns + s] = 1 / d[0];              // LzMarch's reciprocals: per ray here, not per pass
     slot[(rd_field + 1) * ns + s] = 1 / d[1];
     slot[(rd_field + 2) * ns + s] = 1 / d[2];
+    if constexpr (GEO) {
+        const float* ro = F.rays_o + (size_t)ray * 3;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            slot[(rd_field + 3 + k) * ns + s] = ro[k];
+            slot[(rd_field + 6 + k) * ns + s] = d[k];
+        }
+    }
     if constexpr (PREC == 1) {
 #pragma unroll
         for (int k = 0; k < 8; k++) slot[(SF_SH + k) * ns + s] = __uint_as_float(h_cvt2(o[2 * k], o[2 * k + 1], false));
@@ -425,7 +437,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             slot[SF_T * 16 + s] = F.rays_t[ray];
                             slot[SF_FAR * 16 + s] = (F.occ ? F.t_end[ray] : F.fars[ray]);
                             lzf_slot_take(OUT, ph2, ray, slot, sloti, s, 16);
-                            lzf_store_sh<PREC>(F, ray, slot, s, 16, SF_RD);
+                            lzf_store_sh<PREC, FL::GEO>(F, ray, slot, s, 16, SF_RD);
                         }
                     }
                     if (base + take >= n_queue) dry = true;
@@ -445,6 +457,11 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                         float t0 = 0.0f, far = 0.0f;
                         int want = 0, got = 0;
                         if (grp) {
+                            if constexpr (FL::GEO) {
+                                const float go[3] = {slot[(SF_RD + 3) * 16 + lead], slot[(SF_RD + 4) * 16 + lead], slot[(SF_RD + 5) * 16 + lead]};
+                                const float gd[3] = {slot[(SF_RD + 6) * 16 + lead], slot[(SF_RD + 7) * 16 + lead], slot[(SF_RD + 8) * 16 + lead]};
+                                m.init(go, gd, slot[SF_RD * 16 + lead], slot[(SF_RD + 1) * 16 + lead], slot[(SF_RD + 2) * 16 + lead], F.bound, F.dt_gamma, F.mf, F.C, F.H, F.grid);
+                            } else
                             m.init(F.rays_o + (size_t)gray * 3, F.rays_d + (size_t)gray * 3, slot[SF_RD * 16 + lead], slot[(SF_RD + 1) * 16 + lead],
                                    slot[(SF_RD + 2) * 16 + lead], F.bound, F.dt_gamma, F.mf, F.C, F.H, F.grid);
                             if (use_lut) m.morton_lut = mlut;
@@ -604,12 +621,17 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             slot[SF_T * NS + sl] = F.rays_t[ray];
                             slot[SF_FAR * NS + sl] = (F.occ ? F.t_end[ray] : F.fars[ray]);
                             lzf_slot_take(OUT, ph2, ray, slot, sloti, sl, NS);
-                            lzf_store_sh<PREC>(F, ray, slot, sl, NS, SF_RD);
+                            lzf_store_sh<PREC, FL::GEO>(F, ray, slot, sl, NS, SF_RD);
                         }
                     }
                     if (base + take >= n_queue) dry = true;    // wave-uniform
                 }
                 if (slot_lane && ray >= 0 && !have) {
+                    if constexpr (FL::GEO) {
+                        const float go[3] = {slot[(SF_RD + 3) * NS + sl], slot[(SF_RD + 4) * NS + sl], slot[(SF_RD + 5) * NS + sl]};
+                        const float gd[3] = {slot[(SF_RD + 6) * NS + sl], slot[(SF_RD + 7) * NS + sl], slot[(SF_RD + 8) * NS + sl]};
+                        m.init(go, gd, slot[SF_RD * NS + sl], slot[(SF_RD + 1) * NS + sl], slot[(SF_RD + 2) * NS + sl], F.bound, F.dt_gamma, F.mf, F.C, F.H, F.grid);
+                    } else
                     m.init(F.rays_o + (size_t)ray * 3, F.rays_d + (size_t)ray * 3, slot[SF_RD * NS + sl], slot[(SF_RD + 1) * NS + sl], slot[(SF_RD + 2) * NS + sl],
                            F.bound, F.dt_gamma, F.mf, F.C, F.H, F.grid);
                     if (use_lut) m.morton_lut = mlut;
