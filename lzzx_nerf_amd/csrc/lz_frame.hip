@@ -273,15 +273,13 @@ __device__ __forceinline__ void h_sh_pk(const LzShFromSlot16& f, int q, uint32_t
 }
 // evaluated by the lane that takes the ray (the same lz_sh_eval call on the same direction as the stand-alone head makes per sample)
 template <int PREC, bool GEO = false>
-__device__ __forceinline__ void lzf_store_sh(const LzFrameK& F, int ray, float* slot, int s, int ns, int rd_field) {
-    const float* d = F.rays_d + (size_t)ray * 3;
+__device__ __forceinline__ void lzf_store_sh(const float* __restrict__ ro, const float* __restrict__ d, float* slot, int s, int ns, int rd_field) {
     float o[16];
     lz_sh_eval(d[0], d[1], d[2], 4, o, nullptr, nullptr, nullptr);
     slot[rd_field * ns + s] = 1 / d[0];              // LzMarch's reciprocals: per ray here, not per pass
     slot[(rd_field + 1) * ns + s] = 1 / d[1];
     slot[(rd_field + 2) * ns + s] = 1 / d[2];
     if constexpr (GEO) {
-        const float* ro = F.rays_o + (size_t)ray * 3;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             slot[(rd_field + 3 + k) * ns + s] = ro[k];
@@ -409,6 +407,12 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     // the schedule's C_eff in phase 2 (cap_mode 1)
     const int cap = ph2 ? F.state[LZF_CEFF] : (F.cap_mode ? (int)F.max_steps : (((int)F.max_steps + S - 1) / S) * S);
 #define cnt_base (ph2 ? (int)F.max_steps : 0)                     /* samples a ray brings along when it takes a slot */
+    // the pointers only the REFILL touches (queue, start / end times, the ray itself): read from the kernel-argument segment at that point like
+    // the outputs (LzfOut) -- six more loop-invariant scalar pairs out of the pass loop: the S > 1 kernels drop most of their scalar spills
+    // (S = 4: 12 -> 2, S = 16: 73 -> 42), the two-row f16 kernel its one vector spill.  Not with three slot rows, where the same change costs
+    // three vector spills instead (kernel_resources.json).  Same-box A/B: f16 8-way tile 0.423 -> 0.418 ms, the full frames within noise.
+    constexpr bool KREFILL = ROWS < 3;
+#define LZF_RF(name) (KREFILL ? LZF_OUT(OUT, name) : F.name)
     LzMarch m;   // the frame-constant part of LzMarch (init() below sets the per-ray part)
     bool dry = n_queue <= 0;
     int my_samples = 0, my_slices = 0;
@@ -432,12 +436,12 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                     if (need) {
                         const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
                         if (idx < n_queue) {
-                            ray = F.order[idx];
+                            ray = LZF_RF(order)[idx];
                             sloti[SF_RAY * 16 + s] = ray;
-                            slot[SF_T * 16 + s] = F.rays_t[ray];
-                            slot[SF_FAR * 16 + s] = (F.occ ? F.t_end[ray] : F.fars[ray]);
+                            slot[SF_T * 16 + s] = LZF_RF(rays_t)[ray];
+                            slot[SF_FAR * 16 + s] = (LZF_RF(occ) ? LZF_RF(t_end)[ray] : LZF_RF(fars)[ray]);
                             lzf_slot_take(OUT, ph2, ray, slot, sloti, s, 16);
-                            lzf_store_sh<PREC, FL::GEO>(F, ray, slot, s, 16, SF_RD);
+                            lzf_store_sh<PREC, FL::GEO>(LZF_RF(rays_o) + (size_t)ray * 3, LZF_RF(rays_d) + (size_t)ray * 3, slot, s, 16, SF_RD);
                         }
                     }
                     if (base + take >= n_queue) dry = true;
@@ -616,12 +620,12 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                     if (need) {
                         const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
                         if (idx < n_queue) {
-                            ray = F.order[idx];
+                            ray = LZF_RF(order)[idx];
                             sloti[SF_RAY * NS + sl] = ray;
-                            slot[SF_T * NS + sl] = F.rays_t[ray];
-                            slot[SF_FAR * NS + sl] = (F.occ ? F.t_end[ray] : F.fars[ray]);
+                            slot[SF_T * NS + sl] = LZF_RF(rays_t)[ray];
+                            slot[SF_FAR * NS + sl] = (LZF_RF(occ) ? LZF_RF(t_end)[ray] : LZF_RF(fars)[ray]);
                             lzf_slot_take(OUT, ph2, ray, slot, sloti, sl, NS);
-                            lzf_store_sh<PREC, FL::GEO>(F, ray, slot, sl, NS, SF_RD);
+                            lzf_store_sh<PREC, FL::GEO>(LZF_RF(rays_o) + (size_t)ray * 3, LZF_RF(rays_d) + (size_t)ray * 3, slot, sl, NS, SF_RD);
                         }
                     }
                     if (base + take >= n_queue) dry = true;    // wave-uniform
@@ -763,6 +767,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
 
 #undef q_head
 #undef cnt_base
+#undef LZF_RF
 
 // ---- the reference's cap (cap_mode 1): histogram of L, schedule replay, marched counts ------------------------------------------------
 // cap_ws: [0 .. max_steps] histogram of L (bin max_steps = rays alive at the cap); behind it the schedule tables, see lzf_ws_*
