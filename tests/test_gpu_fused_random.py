@@ -119,3 +119,45 @@ def test_tiles_of_random_frames_equal_the_unsharded_reference_loop(params, golde
         got = D.assemble_frame(cat if cat.dim() > 1 else cat[:, None], H, W, world, tiles)
         got = got if cat.dim() > 1 else got[:, 0]
         assert torch.equal(got, ref[k]), (c, world, tiles, k, int((got != ref[k]).sum()))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LZ_RANDOM_LOOP_FRAMES", "12"))))
+def test_loop_mode_on_random_schedules_equals_the_checker(params, golden, seed):
+    """mode="loop" (the device-resident form of renderer.py:503-548) under a random (budget_factor, n_step_cap) against the CPU checker's
+    loop under the same schedule: pixels, depth, sums, iteration count and per-ray marched counts bit for bit -- and the fused frame with
+    cap = "per_ray" and steps_per_pass = S against the checker under (S, S)"""
+    from lzzx_nerf_amd.head import FusedTriplaneHead
+    from lzzx_nerf_amd.renderer import TriplaneRenderer
+    from lzzx_nerf_amd.utils import frame_rays
+    from oracle.head import TriplaneSpec
+    from oracle.render import render_inference
+    rng, c = _case(9000 + seed)
+    H, W = min(c["H"], 40), min(c["W"], 40)                  # the checker's head is a CPU loop: keep the frames small
+    bf, cap_n = int(rng.choice([1, 2, 4])), int(rng.choice([1, 2, 4, 8]))
+    head = FusedTriplaneHead({k: torch.from_numpy(v) for k, v in params.items()}, bound=1.0)
+    bits_np = _bits(rng, c["scene"])
+    bits = dev(bits_np)
+    pose, intr = synthetic_camera(H, W)
+    ro, rd = frame_rays(dev(pose), intr, H, W)
+    cond = (dev(golden["net_enc_a"]), dev(golden["net_ind"]), dev(golden["net_eye"]))
+    kw = dict(max_steps=c["max_steps"], T_thresh=c["T_thresh"], dt_gamma=c["dt_gamma"])
+    noise = rng.uniform(0, 1, H * W).astype(np.float32) if c["noise"] else None
+    st = {}
+    ref = render_inference(TriplaneSpec(1.0), params, ro.cpu().numpy(), rd.cpu().numpy(), bits_np, golden["net_enc_a"], golden["net_ind"],
+                           golden["net_eye"], stats=st, budget_factor=bf, n_step_cap=cap_n, noises=noise, **kw)
+    loop = TriplaneRenderer(head, bits, bound=1.0, budget_factor=bf, n_step_cap=cap_n).render(
+        ro, rd, *cond, count_samples=True, noises=None if noise is None else dev(noise), **kw)
+    for k in ("image", "depth", "weights_sum", "amb_aud_sum", "amb_eye_sum", "uncertainty_sum"):
+        assert np.array_equal(loop[k].cpu().numpy(), ref[k]), (c, bf, cap_n, k)
+    assert np.array_equal(loop["ray_counts"].cpu().numpy().astype(np.int64), st["samples_per_ray"]), (c, bf, cap_n)
+    assert int(loop["state"][6]) == len(st["schedule"]), (c, bf, cap_n)
+    S = int(rng.choice([1, 2, 4, 8, 16]))
+    st2 = {}
+    ref2 = render_inference(TriplaneSpec(1.0), params, ro.cpu().numpy(), rd.cpu().numpy(), bits_np, golden["net_enc_a"], golden["net_ind"],
+                            golden["net_eye"], stats=st2, budget_factor=S, n_step_cap=S, noises=noise, **kw)
+    fr = TriplaneRenderer(head, bits, bound=1.0, mode="fused", cap="per_ray")
+    fr.steps_per_pass = S
+    fused = fr.render(ro, rd, *cond, count_samples=True, noises=None if noise is None else dev(noise), **kw)
+    for k in ("image", "depth", "weights_sum"):
+        assert np.array_equal(fused[k].cpu().numpy(), ref2[k]), (c, S, k)
+    assert np.array_equal(fused["ray_counts"].cpu().numpy().astype(np.int64), st2["samples_per_ray"]), (c, S)
