@@ -32,9 +32,11 @@ typedef void* lz_stream_t; /* hipStream_t */
 #define LZ_ERR_BAD_ARGUMENT (-2)
 /* Conventions.  Every pointer is device memory unless said otherwise; every entry enqueues on `stream` and returns without waiting.  A
  * null pointer where an array is required is LZ_ERR_BAD_ARGUMENT with a message (lz_last_error), never a launch.  A count of ZERO work
- * items (B, N, M, n_alive = 0; an empty batch of rays, e.g. a rank's empty tile of a small frame) is LZ_OK and launches nothing, whatever
- * the arrays' pointers are -- an empty torch tensor has no storage; lz_frame_render with N = 0 still zeroes `state` and, under cap_mode 1,
- * its words of the histogram exchange. */
+ * items (B, N, M, n_alive = 0 with otherwise valid shape parameters; an empty batch of rays, e.g. a rank's empty tile of a small frame)
+ * is LZ_OK and launches nothing for every entry whose outputs are per-item arrays, whatever those arrays' pointers are -- an empty
+ * torch tensor has no storage (tests/test_cabi.py).  Not per-item, and therefore still required: the loop's `state` / `workspace`
+ * words, the parameter blocks, the sums over items of lz_triplane_head_grad_w*.  lz_frame_render with N = 0 still zeroes `state` and,
+ * under cap_mode 1, its words of the histogram exchange. */
 
 const char* lz_last_error(void);
 /* ABI version of this header; bumped on any signature change */

@@ -66,8 +66,8 @@ lz_k_bg_coords(uint32_t H, uint32_t W, float* __restrict__ out) {
 }
 
 extern "C" int lz_bg_coords(uint32_t H, uint32_t W, float* out, lz_stream_t stream) {
-    LZ_REQUIRE(out, LZ_ERR_BAD_ARGUMENT, "bg_coords: null tensor");
     if (H * W == 0) return LZ_OK;
+    LZ_REQUIRE(out, LZ_ERR_BAD_ARGUMENT, "bg_coords: null tensor");
     hipLaunchKernelGGL(lz_k_bg_coords, dim3(lz_div_up((uint64_t)H * W, 256)), dim3(256), 0, lz_st(stream), H, W, out);
     LZ_CHECK_LAUNCH("bg_coords");
     return LZ_OK;
@@ -189,8 +189,8 @@ extern "C" int lz_packbits(const float* grid, uint32_t N, float density_thresh, 
     return LZ_OK;
 }
 extern "C" int lz_morton3D_dilation(const float* grid, uint32_t C, uint32_t H, float* grid_dilation, lz_stream_t stream) {
-    LZ_REQUIRE(grid && grid_dilation, LZ_ERR_BAD_ARGUMENT, "morton3D_dilation: null tensor");
     if (C * H == 0) return LZ_OK;
+    LZ_REQUIRE(grid && grid_dilation, LZ_ERR_BAD_ARGUMENT, "morton3D_dilation: null tensor");
     hipLaunchKernelGGL(lz_k_dilation, dim3(lz_div_up((uint64_t)C * H * H * H, 256)), dim3(256), 0, lz_st(stream), grid, C, H, grid_dilation);
     LZ_CHECK_LAUNCH("morton3D_dilation");
     return LZ_OK;
@@ -614,9 +614,9 @@ extern "C" int lz_march_rays_train(const float* rays_o, const float* rays_d, con
                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                                    const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
                                    const float* noises, void* workspace, lz_stream_t stream) {
-    LZ_REQUIRE(workspace, LZ_ERR_BAD_ARGUMENT, "march_rays_train: workspace of (N + 2) * 4 bytes required");
     LZ_REQUIRE(C >= 1 && C <= 8 && H > 0, LZ_ERR_BAD_ARGUMENT, "march_rays_train: cascade must be in [1, 8]");
     if (N == 0) return LZ_OK;
+    LZ_REQUIRE(workspace, LZ_ERR_BAD_ARGUMENT, "march_rays_train: workspace of (N + 2) * 4 bytes required");
     // noises is always a tensor (zeros without perturb, raymarching.py:226-229); with M == 0 the sample buffers are not written
     LZ_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises, LZ_ERR_BAD_ARGUMENT, "march_rays_train: null tensor");
     LZ_REQUIRE(M == 0 || (xyzs && dirs && deltas), LZ_ERR_BAD_ARGUMENT, "march_rays_train: null sample buffers with M > 0");

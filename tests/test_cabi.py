@@ -151,3 +151,38 @@ def test_no_kernel_spills_registers():
     frame = res["lz_frame.hip"]
     f16 = [r for k, r in frame.items() if k.startswith("_Z10lz_k_frameILi1E")]
     assert f16 and all(r["vgprs"] <= 128 and r["occupancy"] >= 4 for r in f16), f16     # four waves per SIMD is what the f16 frame is tuned for
+
+
+def test_zero_work_items_are_no_ops_without_touching_the_arrays():
+    """include/lzzx_nerf_hip.h, "Conventions": a count of zero work items returns LZ_OK before any pointer is looked at (an empty torch
+    tensor has no storage: round 4's empty-tile bug).  Runs without a GPU -- nothing is launched."""
+    import ctypes as C
+    from lzzx_nerf_amd import _lib
+    lib = _lib.load()
+    vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_float
+    # entries whose zero-count call needs valid shape parameters next to the count: (name, {argument index: value})
+    shaped = {
+        "lz_sh_encode_forward": {3: 3, 4: 4}, "lz_sh_encode_backward": {3: 3, 4: 4},
+        "lz_march_rays_train": {7: 1, 8: 128}, "lz_march_rays": {9: 1, 10: 128}, "lz_loop_march": {13: 1, 14: 128},
+        "lz_grid_encode_forward": {5: 3, 6: 2, 7: 16, 9: 16}, "lz_grid_encode_backward": {6: 3, 7: 2, 8: 16, 10: 16},
+        "lz_grid_corner_indices": {4: 3, 5: 2, 6: 16, 8: 16}, "lz_grid_encode_forward_tiled": {7: 3, 8: 2, 9: 16, 11: 16},
+        "lz_freq_encode_forward": {2: 3, 3: 4, 4: 27}, "lz_freq_encode_backward": {3: 3, 4: 4, 5: 27},
+        "lz_perturb_starts": {4: 1, 5: 128},
+    }
+    # not per-item (see the header): state / workspace words, parameter blocks, reductions, handles
+    other = {"lz_frame_render", "lz_frame_finish", "lz_loop_run", "lz_ngp_loop_run", "lz_audio_encode", "lz_torso_forward", "lz_timing_create",
+             "lz_timing_destroy", "lz_timing_reset", "lz_timing_mark", "lz_timing_elapsed_ms", "lz_debug_head_clocks", "lz_wait_flags",
+             "lz_occupied_bounds", "lz_torso_anchor_encode", "lz_loop_begin", "lz_loop_composite", "lz_loop_composite_plain",
+             "lz_triplane_head_grad_w", "lz_triplane_head_grad_w_f16"}
+    n = 0
+    for name, at in _lib.SIGNATURES.items():
+        if name in other or name.startswith("lz_head_pack") or any(a not in (vp, u32, i32, f32) for a in at):
+            continue
+        args = [None if a is vp else (a(0) if a in (u32, i32) else a(1.0)) for a in at]
+        for i, v in shaped.get(name, {}).items():
+            assert at[i] in (u32, i32), (name, i)
+            args[i] = at[i](v)
+        rc = getattr(lib, name)(*args)
+        assert rc == 0, (name, rc, lib.lz_last_error().decode())
+        n += 1
+    assert n >= 45
