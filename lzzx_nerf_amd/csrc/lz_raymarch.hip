@@ -792,6 +792,8 @@ extern "C" int lz_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* r
     (void)nears;
     LZ_REQUIRE(C >= 1 && C <= 8 && H > 0, LZ_ERR_BAD_ARGUMENT, "march_rays: cascade must be in [1, 8]");
     if (n_alive == 0) return LZ_OK;
+    // noises may be null (no perturbation, raymarching.py:371-374); everything else the kernel dereferences
+    LZ_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas, LZ_ERR_BAD_ARGUMENT, "march_rays: null tensor");
     hipLaunchKernelGGL((lz_k_march_rays<false>), dim3(lz_div_up(n_alive, 256)), dim3(256), 0, lz_st(stream), n_alive, n_step, (lz_loop_state*)nullptr,
                        rays_alive, (const int*)nullptr, (int*)nullptr, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, (int*)nullptr,
                        0u, 0u, 0u);

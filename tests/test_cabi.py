@@ -186,3 +186,35 @@ def test_zero_work_items_are_no_ops_without_touching_the_arrays():
         assert rc == 0, (name, rc, lib.lz_last_error().decode())
         n += 1
     assert n >= 45
+
+
+def test_null_arrays_are_rejected_before_any_launch():
+    """The other half of the convention (round 2's incident: a null pointer launched instead of rejected faulted the GPU; round 4 found
+    lz_march_rays still doing it): with a NON-zero count and every array null, each entry returns an argument error -- never a launch
+    error, which is what this box without a device would report if a kernel had been enqueued."""
+    import ctypes as C
+    from lzzx_nerf_amd import _lib
+    lib = _lib.load()
+    vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_float
+    shaped = {
+        "lz_sh_encode_forward": {3: 3, 4: 4}, "lz_sh_encode_backward": {3: 3, 4: 4},
+        "lz_march_rays_train": {7: 1, 8: 128}, "lz_march_rays": {9: 1, 10: 128}, "lz_loop_march": {13: 1, 14: 128},
+        "lz_grid_encode_forward": {5: 3, 6: 2, 7: 16, 9: 16}, "lz_grid_encode_backward": {6: 3, 7: 2, 8: 16, 10: 16},
+        "lz_grid_corner_indices": {4: 3, 5: 2, 6: 16, 8: 16}, "lz_grid_encode_forward_tiled": {7: 3, 8: 2, 9: 16, 11: 16},
+        "lz_freq_encode_forward": {2: 3, 3: 4, 4: 27}, "lz_freq_encode_backward": {3: 3, 4: 4, 5: 27},
+        "lz_perturb_starts": {4: 1, 5: 128},
+    }
+    handles = {"lz_timing_create", "lz_timing_destroy", "lz_timing_reset", "lz_timing_mark", "lz_timing_elapsed_ms", "lz_debug_head_clocks"}
+    n = 0
+    for name, at in _lib.SIGNATURES.items():
+        if name in handles or any(a not in (vp, u32, i32, f32) for a in at):
+            continue
+        args = [None if a is vp else (a(4) if a in (u32, i32) else a(1.0)) for a in at]
+        for i, v in shaped.get(name, {}).items():
+            args[i] = at[i](v)
+        rc = getattr(lib, name)(*args)
+        msg = lib.lz_last_error().decode()
+        assert rc in (-1, -2), (name, rc, msg)                     # LZ_ERR_UNSUPPORTED / LZ_ERR_BAD_ARGUMENT, not a hipError_t
+        assert not any(w in msg.lower() for w in ("launch failed", "rocm-capable", "hip error")), (name, msg)
+        n += 1
+    assert n >= 55
