@@ -1224,6 +1224,8 @@ extern "C" int lz_grid_encode_forward(const float* inputs, const void* embedding
                                       uint32_t gridtype, int align_corners, int emb_f16, int out_layout, lz_stream_t stream) {
     if (B == 0) return LZ_OK;
     LZ_REQUIRE(inputs && embeddings && offsets && outputs, LZ_ERR_BAD_ARGUMENT, "grid_encode_forward: null tensor");
+    LZ_REQUIRE(L >= 1 && H >= 1 && gridtype <= 1u, LZ_ERR_BAD_ARGUMENT, "grid_encode_forward: num_levels and base_resolution must be >= 1, gridtype 0 (hash) or 1 (tiled)");
+    LZ_REQUIRE(out_layout >= 0 && out_layout <= 2, LZ_ERR_BAD_ARGUMENT, "grid_encode_forward: out_layout must be 0 (level-major [L, B, C]), 1 or 2 (sample-major [B, L*C])");
     LzGridLevels lv;
     LZ_REQUIRE(lz_fill_levels(lv, L, S, H) == 0, LZ_ERR_UNSUPPORTED, "grid_encode_forward: at most %d levels", LZ_MAX_LEVELS);
     if (B == 0) return LZ_OK;
@@ -1249,6 +1251,7 @@ extern "C" int lz_grid_encode_forward_tiled(const float* inputs, const void* emb
     if (B == 0) return LZ_OK;
     LZ_REQUIRE(inputs && embeddings && offsets && outputs, LZ_ERR_BAD_ARGUMENT, "grid_encode_forward_tiled: null tensor");
     LZ_REQUIRE(D == 3 && C == 2, LZ_ERR_UNSUPPORTED, "grid_encode_forward_tiled: input_dim 3, level_dim 2 (get_encoder('hashgrid') defaults, encoding.py:6-8)");
+    LZ_REQUIRE(L >= 1 && H >= 1 && gridtype <= 1u, LZ_ERR_BAD_ARGUMENT, "grid_encode_forward_tiled: num_levels and base_resolution must be >= 1, gridtype 0 (hash) or 1 (tiled)");
     LZ_REQUIRE(bound >= 0.0f, LZ_ERR_BAD_ARGUMENT, "grid_encode_forward_tiled: bound must be >= 0 (0 = inputs already in [0, 1])");
     LzGridLevels lv;
     LZ_REQUIRE(lz_fill_levels(lv, L, S, H) == 0, LZ_ERR_UNSUPPORTED, "grid_encode_forward_tiled: at most %d levels", LZ_MAX_LEVELS);
@@ -1272,6 +1275,7 @@ extern "C" int lz_grid_corner_indices(const float* inputs, const int32_t* offset
     LZ_REQUIRE(lz_fill_levels(lv, L, S, H) == 0, LZ_ERR_UNSUPPORTED, "grid_corner_indices: at most %d levels", LZ_MAX_LEVELS);
     if (B == 0) return LZ_OK;
     LZ_REQUIRE(inputs && offsets && corner_idx, LZ_ERR_BAD_ARGUMENT, "grid_corner_indices: null tensor");
+    LZ_REQUIRE(L >= 1 && H >= 1 && gridtype <= 1u, LZ_ERR_BAD_ARGUMENT, "grid_corner_indices: num_levels and base_resolution must be >= 1, gridtype 0 (hash) or 1 (tiled)");
     dim3 grid(lz_div_up(B, 256), L, 1), block(256);
     const bool ac = align_corners != 0;
     hipStream_t st = lz_st(stream);
@@ -1350,6 +1354,9 @@ extern "C" int lz_grid_encode_backward(const void* grad, const float* inputs, co
     (void)embeddings;
     if (B == 0) return LZ_OK;
     LZ_REQUIRE(grad && inputs && offsets && grad_embeddings, LZ_ERR_BAD_ARGUMENT, "grid_encode_backward: null tensor");
+    LZ_REQUIRE(L >= 1 && H >= 1 && gridtype <= 1u, LZ_ERR_BAD_ARGUMENT, "grid_encode_backward: num_levels and base_resolution must be >= 1, gridtype 0 (hash) or 1 (tiled)");
+    LZ_REQUIRE(grad_layout >= 0 && grad_layout <= 3, LZ_ERR_BAD_ARGUMENT, "grid_encode_backward: grad_layout must be 0 .. 3 (see the header)");
+    LZ_REQUIRE(!grad_inputs || dy_dx, LZ_ERR_BAD_ARGUMENT, "grid_encode_backward: grad_inputs needs dy_dx");
     LzGridLevels lv;
     LZ_REQUIRE(lz_fill_levels(lv, L, S, H) == 0, LZ_ERR_UNSUPPORTED, "grid_encode_backward: at most %d levels", LZ_MAX_LEVELS);
     if (B == 0) return LZ_OK;

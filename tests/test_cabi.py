@@ -218,3 +218,32 @@ def test_null_arrays_are_rejected_before_any_launch():
         assert not any(w in msg.lower() for w in ("launch failed", "rocm-capable", "hip error")), (name, msg)
         n += 1
     assert n >= 55
+
+
+def test_out_of_range_parameters_are_rejected_before_any_launch():
+    """shape / mode parameters outside what the kernels are built for come back as argument errors (fake non-null pointers, no device:
+    a call that got as far as a launch would report a HIP error instead)"""
+    import ctypes as C
+    from lzzx_nerf_amd import _lib
+    lib = _lib.load()
+    vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_float
+
+    def run(name, over):
+        at = _lib.SIGNATURES[name]
+        args = [C.c_void_p(0x10000) if a is vp else (a(4) if a in (u32, i32) else a(1.0)) for a in at]
+        for i, v in over.items():
+            args[i] = at[i](v)
+        return getattr(lib, name)(*args), lib.lz_last_error().decode()
+
+    fwd, bwd, idx = {5: 3, 6: 2, 7: 16, 9: 16}, {6: 3, 7: 2, 8: 16, 10: 16}, {4: 3, 5: 2, 6: 16, 8: 16}
+    bad = [("lz_grid_encode_forward", fwd, k, v) for k, vals in {5: [0, 6], 6: [0, 3, 16], 7: [0, 33], 9: [0], 11: [2], 14: [3, -1]}.items() for v in vals]
+    bad += [("lz_grid_encode_backward", bwd, k, v) for k, vals in {6: [0, 6], 7: [0, 3], 8: [0, 33], 10: [0], 13: [2], 16: [4, -1]}.items() for v in vals]
+    bad += [("lz_grid_corner_indices", idx, k, v) for k, vals in {6: [0, 33], 8: [0], 9: [2]}.items() for v in vals]
+    bad += [("lz_sh_encode_forward", {3: 3, 4: 4}, 4, 0), ("lz_sh_encode_forward", {3: 3, 4: 4}, 4, 9), ("lz_sh_encode_forward", {3: 3, 4: 4}, 3, 2),
+            ("lz_freq_encode_forward", {2: 3, 3: 4, 4: 27}, 4, 20), ("lz_march_rays", {9: 1, 10: 128}, 9, 0), ("lz_march_rays", {9: 1, 10: 128}, 9, 9),
+            ("lz_march_rays", {9: 1, 10: 128}, 10, 0), ("lz_march_rays_train", {7: 1, 8: 128}, 7, 9), ("lz_loop_march", {13: 1, 14: 128}, 13, 0)]
+    for name, base, k, v in bad:
+        o = dict(base)
+        o[k] = v
+        rc, msg = run(name, o)
+        assert rc in (-1, -2), (name, k, v, rc, msg)
