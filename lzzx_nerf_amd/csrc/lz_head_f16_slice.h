@@ -201,7 +201,7 @@ __device__ __forceinline__ void lz_head16_slice_rows(const LzHead16Ctx& hc, int 
 #pragma unroll
     for (int r = 0; r < R; r++) {
         float encx[9];
-        lz_head_gather<IN_RANGE, true>(hc.emb, hc.tab, px[r], py[r], pz[r], q, hc.bound, hc.two_bound, encx);
+        lz_head_gather<IN_RANGE, LZ_GATHER_PACK16>(hc.emb, hc.tab, px[r], py[r], pz[r], q, hc.bound, hc.two_bound, encx);
         // h_round2: every f32 feature exists first, then its half (no v_fma_mixlo_f16 with the interpolation's last fma)
         const lz_u4v w0 = {h_round2(encx[0], encx[1]), h_round2(encx[2], encx[3]), h_round2(encx[4], encx[5]), h_round2(encx[6], encx[7])};
         const lz_u4v w1 = {h_round2(encx[8], 0.0f), 0u, 0u, 0u};

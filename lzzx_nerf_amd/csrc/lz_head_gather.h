@@ -14,9 +14,19 @@
 //     two <= 2^24), so it is a full-rate 24-bit multiply by P mod 2^24 instead of a quarter-rate 32-bit one;
 //   * what two planes share is computed once: positions / fractions / 1 - fraction per (coordinate, level) -- 9 sets, not 18 -- and the
 //     row terms of the yz and xz planes (both rows are z);
-//   * PACK: the interpolation runs two features per instruction on v_pk_mul_f32 / v_pk_fma_f32 (IEEE per half, same bits).
+//   * PACK: the interpolation can run two features per instruction on v_pk_mul_f32 / v_pk_fma_f32 (IEEE per half, same bits) -- see below.
 #ifndef LZ_HEAD_GATHER_H
 #define LZ_HEAD_GATHER_H
+// PACK (the interpolation on v_pk_mul_f32 / v_pk_fma_f32, two features per instruction) is OFF in every head since round 4: fewer instructions
+// but slower ones -- packed f32 vector ops cost more issue time than the two scalar ones they replace next to MFMA work
+// (MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever beside MFMAs").  Same-box A/B on the fused frame: f16 1.916 -> 1.894 ms, f32
+// 8.92 -> 8.88.  (-fno-slp-vectorize, which removes the compiler's own two dozen packed ops as well: no further gain.)
+#ifndef LZ_GATHER_PACK16
+#define LZ_GATHER_PACK16 false
+#endif
+#ifndef LZ_GATHER_PACK32
+#define LZ_GATHER_PACK32 false
+#endif
 #include "lz_common.h"
 #include "lzzx_detmath.h"
 

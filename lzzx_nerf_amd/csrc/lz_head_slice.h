@@ -90,7 +90,7 @@ __device__ __forceinline__ void lz_head_slice(const LzHeadCtx& hc, int lane, flo
     const int q = lane >> 4;
     // ---------------- gather: enc_x features f = 4i + q of sample s -> B operands (lz_head_gather.h) ----------------
     float encx[LZ_T][9];
-    lz_head_gather<IN_RANGE, true, YIELD, true>(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx[0]);
+    lz_head_gather<IN_RANGE, LZ_GATHER_PACK32, YIELD, true>(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx[0]);
     __builtin_amdgcn_sched_barrier(0);  // the tile's 36 reads in flight at a time: bounds the register footprint
 
     // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
