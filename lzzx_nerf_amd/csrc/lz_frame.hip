@@ -563,11 +563,19 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
             typename HD::Out o;
             HD::slice(ctx, lane, px, py, pz, typename HD::ShSlot{slot, lead, 16}, o);
             my_slices++;
+            if constexpr (PREC == 1) {
+                // the f16 head leaves a sample's four transcendentals one per lane group (LzHead16Out::own: colour q on q < 3, sigma on q == 3):
+                // every group parks its own -- the fields OSIG, OR, OG, OB are consecutive -- and nothing crosses lanes
+                const float a = 1.0f - lz_expf(-o.own * slot[SF_DT * 16 + s]);
+                slot[(SF_OSIG + ((q + 1) & 3)) * 16 + s] = q == 3 ? a : o.own;
+            }
             if (q == 0) {
                 // alpha = 1 - exp(-sigma delta) of this slot's sample (raymarching.cu:2197), computed here by the sample's own lane: the
                 // leader's serial walk below then costs a handful of instructions per sample instead of an exp each
-                slot[SF_OSIG * 16 + s] = 1.0f - lz_expf(-o.sigma * slot[SF_DT * 16 + s]);
-                slot[SF_OR * 16 + s] = o.rgb[0]; slot[SF_OG * 16 + s] = o.rgb[1]; slot[SF_OB * 16 + s] = o.rgb[2];
+                if constexpr (PREC != 1) {
+                    slot[SF_OSIG * 16 + s] = 1.0f - lz_expf(-o.sigma * slot[SF_DT * 16 + s]);
+                    slot[SF_OR * 16 + s] = o.rgb[0]; slot[SF_OG * 16 + s] = o.rgb[1]; slot[SF_OB * 16 + s] = o.rgb[2];
+                }
                 slot[SF_OA0 * 16 + s] = o.ambaud; slot[SF_OA1 * 16 + s] = o.eyeatt; slot[SF_OU * 16 + s] = o.unc;
             }
             __builtin_amdgcn_wave_barrier();
@@ -703,14 +711,11 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                     }
                     HD::slice2(ctx, lane, px2, py2, pz2, f2, o2);
                     my_slices += 2;
-                    if (q == 0) {
 #pragma unroll
-                        for (int r = 0; r < 2; r++) {
-                            const int rs = 16 * r + s;
-                            slot[SF_OSIG * NS + rs] = o2[r].sigma;
-                            slot[SF_OR * NS + rs] = o2[r].rgb[0]; slot[SF_OG * NS + rs] = o2[r].rgb[1]; slot[SF_OB * NS + rs] = o2[r].rgb[2];
-                            slot[SF_OA0 * NS + rs] = o2[r].ambaud; slot[SF_OA1 * NS + rs] = o2[r].eyeatt; slot[SF_OU * NS + rs] = o2[r].unc;
-                        }
+                    for (int r = 0; r < 2; r++) {   // every lane group parks its own transcendental (LzHead16Out::own; OSIG, OR, OG, OB are consecutive fields)
+                        const int rs = 16 * r + s;
+                        slot[(SF_OSIG + ((q + 1) & 3)) * NS + rs] = o2[r].own;
+                        if (q == 0) { slot[SF_OA0 * NS + rs] = o2[r].ambaud; slot[SF_OA1 * NS + rs] = o2[r].eyeatt; slot[SF_OU * NS + rs] = o2[r].unc; }
                     }
                     row0 = 2;
                 }
@@ -723,9 +728,12 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 const float px = __shfl(x, rs, 64), py = __shfl(y, rs, 64), pz = __shfl(z, rs, 64);
                 HD::slice(ctx, lane, px, py, pz, typename HD::ShSlot{slot, rs, NS}, o);
                 my_slices++;
+                if constexpr (ROWS > 1 && PREC == 1) slot[(SF_OSIG + ((q + 1) & 3)) * NS + rs] = o.own;   // (as in the pair above)
                 if (ROWS > 1 && q == 0) {   // park the row's outputs for the compositing below (lanes q == 0 hold valid bits in both heads)
-                    slot[SF_OSIG * NS + rs] = o.sigma;
-                    slot[SF_OR * NS + rs] = o.rgb[0]; slot[SF_OG * NS + rs] = o.rgb[1]; slot[SF_OB * NS + rs] = o.rgb[2];
+                    if constexpr (PREC != 1) {
+                        slot[SF_OSIG * NS + rs] = o.sigma;
+                        slot[SF_OR * NS + rs] = o.rgb[0]; slot[SF_OG * NS + rs] = o.rgb[1]; slot[SF_OB * NS + rs] = o.rgb[2];
+                    }
                     slot[SF_OA0 * NS + rs] = o.ambaud; slot[SF_OA1 * NS + rs] = o.eyeatt; slot[SF_OU * NS + rs] = o.unc;
                 }
             }

@@ -44,8 +44,12 @@ __global__ void __launch_bounds__(256) lz_k_head_pack_f16(LzPack16Args a, _Float
     const int local = frag - fb;
     const int ks = local / H_NT[layer], ft = local - ks * H_NT[layer];
     const int row = 16 * ft + (lane & 15), kg = lane >> 4;
+    // output rows.  sigma_net.2: geo rows first, the sigma row ALONE in tile 4 -- at row 12, i.e. register 0 of lane group q = 3; colour_net.1: channel
+    // c at row 4 c, i.e. register 0 of lane group q = c.  The four transcendentals of a sample (sigma = exp, three colour sigmoids) then sit one
+    // per lane group and are evaluated by ONE instruction sequence (lz_head16_slice_rows), not four.
     int srow;
-    if (layer == H_S3) srow = row < 64 ? row + 1 : (row == 64 ? 0 : -1);  // geo rows first, sigma row in tile 4
+    if (layer == H_S3) srow = row < 64 ? row + 1 : (row == 76 ? 0 : -1);
+    else if (layer == H_C2) srow = ((row & 3) == 0 && row < 12) ? (row >> 2) : -1;
     else srow = row < a.nout[layer] ? row : -1;
     for (int j = 0; j < 8; j++) {
         int kf;

@@ -146,7 +146,8 @@ struct LzHead16Ctx {
 };
 
 struct LzHead16Out {
-    float sigma, rgb[3], ambaud, eyeatt, unc;   // sigma / eyeatt are valid on lanes q == 0 only
+    float sigma, rgb[3], ambaud, eyeatt, unc;   // eyeatt is valid on lanes q == 0 only; sigma and rgb on every lane of the sample
+    float own;                                  // this lane group's own transcendental: rgb[q] on q < 3, sigma on q == 3
 };
 
 constexpr int LZ_HEAD16_LDS_H8 = H_FRAGS * 64 + LZ_LVTAB_WORDS / 4;   // lz_h8 elements: fragments, then the level table (enc_a inside)
@@ -262,6 +263,7 @@ __device__ __forceinline__ void lz_head16_slice_rows(const LzHead16Ctx& hc, int 
     }
     // ---------------- sigma net: [enc_x 36 | enc_a * att 32 | eye * eye_att 1] -> 64 -> 64 -> 65 ----------------
     lz_h8 geo16[R][2];
+    float spre[R];
     {
         lz_h8 b1[R][3];
         lz_f4 s1[R][4];
@@ -299,7 +301,7 @@ __device__ __forceinline__ void lz_head16_slice_rows(const LzHead16Ctx& hc, int 
         for (int r = 0; r < R; r++) {
             geo16[r][0] = h_pair(s3[r][0], s3[r][1], false);   // geo_feat, no activation (network.py:304)
             geo16[r][1] = h_pair(s3[r][2], s3[r][3], false);
-            out[r].sigma = h_exp32((float)(_Float16)s3[r][4][0]);   // exp is an autocast-to-f32 op: half -> f32 in, f32 out; lanes q == 0
+            spre[r] = (float)(_Float16)s3[r][4][0];               // the sigma row (half): lanes q == 3 (row 12 of tile 4, lz_k_head_pack_f16)
         }
     }
     // ---------------- colour net: [SH 16 | geo 64 | ind 4] -> 64 -> 3 ----------------
@@ -329,14 +331,25 @@ __device__ __forceinline__ void lz_head16_slice_rows(const LzHead16Ctx& hc, int 
             c2[r][0] = z4;
         }
         h_layer_rows<H_C2, R>(hc.wl, lane, b2, c2);
+        // The four transcendentals of a sample, one per lane group and ONE instruction sequence for all of them: lanes q < 3 hold colour channel
+        // q's pre-activation (register 0 of the colour_net.1 tile), lanes q == 3 the sigma row.  sigma = exp(x) (an autocast-to-f32 op: half in,
+        // f32 out) and sigmoid(x) = 1 / (1 + exp(-x)) both start with exp2 of x times +-log2(e) -- the same multiply and the same exp2 as
+        // h_exp32 / h_sigmoid, so the same bits -- and the colour lanes go on through network.py:275 in half (* 1.002, - 0.001, each rounded).
+        // Then the sample's lanes fetch each other's result.  (Round 4; before: three sigmoid chains + one exp on every lane.)
 #pragma unroll
-        for (int r = 0; r < R; r++)
+        for (int r = 0; r < R; r++) {
+            const float pre = q == 3 ? spre[r] : (float)(_Float16)c2[r][0][0];
+            const float e = __builtin_amdgcn_exp2f(pre * (q == 3 ? 1.44269504088896340736f : -1.44269504088896340736f));
+            const _Float16 sg = (_Float16)__builtin_amdgcn_rcpf(1.0f + e);
+            const _Float16 t1 = h_round((float)sg * 1.002f);
+            const float col = (float)h_round((float)t1 - 0.001f);
+            const float own = q == 3 ? e : col;
+            const int s0 = lane & 15;
+            out[r].own = own;
+            out[r].sigma = __shfl(own, s0 + 48, 64);
 #pragma unroll
-            for (int c = 0; c < 3; c++) {   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
-                const _Float16 sg = (_Float16)h_sigmoid((float)(_Float16)c2[r][0][c]);
-                const _Float16 t1 = h_round((float)sg * 1.002f);
-                out[r].rgb[c] = (float)h_round((float)t1 - 0.001f);
-            }
+            for (int c = 0; c < 3; c++) out[r].rgb[c] = __shfl(own, s0 + 16 * c, 64);
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {

@@ -223,7 +223,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             h_layer<H_S3>(hc.wl, lane, b3, s3);
             geo16[0] = h_pair(s3[0], s3[1], false);
             geo16[1] = h_pair(s3[2], s3[3], false);
-            spre = __shfl((float)(_Float16)s3[4][0], s, 64);
+            spre = __shfl((float)(_Float16)s3[4][0], s + 48, 64);      // the sigma row sits at row 12 of tile 4: lanes q == 3 (lz_k_head_pack_f16)
         }
         const float sigma = h_exp32(spre);
         // ---------------- colour net ----------------
@@ -253,7 +253,7 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             lz_f4 c2[1] = {lz_f4{0, 0, 0, 0}};
             h_layer<H_C2>(hc.wl, lane, b2, c2);
 #pragma unroll
-            for (int c = 0; c < 3; c++) cpre[c] = __shfl((float)(_Float16)c2[0][c], s, 64);   // rows 0..2 live on lanes q == 0
+            for (int c = 0; c < 3; c++) cpre[c] = __shfl((float)(_Float16)c2[0][0], s + 16 * c, 64);   // channel c sits at row 4 c: register 0 of lanes q == c
         }
         // ---------------- state words, outputs (the four lanes of a sample store the same values) ----------------
         {
