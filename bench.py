@@ -567,7 +567,7 @@ def f16_head_roofline(samples, rows, steps, head_total_ms, n_launch, launches_wi
     """roofline object of the f16 head / fused f16 frame kernel: ALGORITHMIC FLOP/s (46 368 FLOP per marched sample, the network's own
     count) against the dense f16 MFMA peak -- `frac` is that quotient, nothing else.  The kernel's matrix work is small (59
     v_mfma_f32_16x16x32_f16 per 16-row slice); what holds it is vector-instruction ISSUE (gathers' index arithmetic, conversions, the
-    march): the PMC passes (profiles/r3_f16_head_pmc_summary.json, rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_MFMA_MOPS_F16 over this
+    march): the PMC passes (profiles/r4_f16_head_pmc_summary.json, rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_MFMA_MOPS_F16 over this
     same command) give the instructions per slice, and with 4 issue cycles per wave64 VALU instruction and 8 per MFMA
     (MI355X_MICROARCH.md, cycle constants) the `valu_issue` block prices that stream -- a labelled DIAGNOSTIC of where the time goes,
     not a roofline: fewer instructions raise it."""
