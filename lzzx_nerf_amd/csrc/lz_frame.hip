@@ -98,6 +98,9 @@ struct LzfOut {
     }
 };
 #define LZF_OUT(o, name) ((o).template get<decltype(LzFrameK::name)>(__builtin_offsetof(LzFrameK, name)))
+// the hand-computed offset assumes that LzFrameK is laid out in the kernel-argument segment like any 8-byte-aligned trivially copyable struct
+// argument, directly behind ARGS_BEFORE bytes of arguments rounded up to 8 (lz_k_frame_prep: first argument; lz_k_frame: behind HD::Args)
+static_assert(alignof(LzFrameK) == 8 && __is_trivially_copyable(LzFrameK), "LZF_OUT reads LzFrameK from the kernel-argument segment at round8(ARGS_BEFORE)");
 template <size_t ARGS_BEFORE>    // bytes of kernel arguments in front of the LzFrameK (0: it is the first)
 __device__ __forceinline__ LzfOut lzf_out() {
     return LzfOut{(lz_kernarg_t*)__builtin_amdgcn_kernarg_segment_ptr() + ((ARGS_BEFORE + 7) & ~size_t(7))};
@@ -385,6 +388,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     __shared__ __align__(16) float lds[HD::LDS_WORDS + SLOT_WORDS + 4 + LZF_LUT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
+    static_assert(alignof(typename HD::Args) <= 8, "lz_k_frame(Args P, LzFrameK F): F sits at round8(sizeof(Args)) of the kernel-argument segment");
     const LzfOut OUT = lzf_out<sizeof(typename HD::Args)>();
     // phase 2 of the reference's cap continues the rays phase 1 parked at max_steps; none parked (or C_eff == max_steps): nothing to stage
     const bool ph2 = F.phase2 != 0;
@@ -821,6 +825,7 @@ __device__ void lzf_schedule(const LzFrameK& F, int* lds) {
     int* run = lds + n + 32;             // [8][3] runs of the walk: start, stride, steps; run[24] = count, [25] = C_eff, [26] = iterations
     for (int i = tid; i < n; i += nt) alive[i] = i <= ms ? __hip_atomic_load(F.cap_ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     if (tid < 10) first[tid] = n;
+    if (tid < 16) wtot[tid] = 0;
     __syncthreads();
     // suffix sums: a contiguous stretch per lane, lanes of a wave by shuffles, waves through LDS
     const int E = (n + nt - 1) / nt, lo = min(tid * E, n), hi = min(lo + E, n);
@@ -888,8 +893,11 @@ __global__ void __launch_bounds__(256) lz_k_frame_schedule(LzFrameK F) {
 template <bool SCHED>
 __global__ void __launch_bounds__(1024) lz_k_frame_cap_hist(LzFrameK F) {
     extern __shared__ int ch_lds[];                      // [max_steps + 1] bins, then 4 words; SCHED: lzf_schedule's LZF_SCHED_LDS_INTS
+    // the ticket lives OUTSIDE the dynamic array: lzf_schedule's first statement rewrites ch_lds[0 .. max_steps + 8], and a wave late to
+    // read a ticket kept in there would see the 0 a faster wave had already stored and leave (its stretch of the scan skipped)
+    __shared__ int ticket;
     const int ms = (int)F.max_steps, bins = ms + 1;
-    int* cnt = ch_lds + bins;                            // [0] parked rays of this workgroup, [1] their base in the queue, [2] cursor, [3] ticket
+    int* cnt = ch_lds + bins;                            // [0] parked rays of this workgroup, [1] their base in the queue, [2] cursor
     for (int i = threadIdx.x; i < bins + 4; i += blockDim.x) ch_lds[i] = 0;
     __syncthreads();
     // few, fat workgroups (grid-stride): every workgroup ends with one global atomic per non-empty bin, and same-address atomics serialise
@@ -938,9 +946,9 @@ __global__ void __launch_bounds__(1024) lz_k_frame_cap_hist(LzFrameK F) {
         // back and invalidates the XCD's whole L2 -- with the frame's outputs dirty in it that cost ~30 us per workgroup that did it.
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (threadIdx.x == 0) cnt[3] = atomicAdd(F.state + LZF_TICKET, 1);
+        if (threadIdx.x == 0) ticket = atomicAdd(F.state + LZF_TICKET, 1);
         __syncthreads();
-        if (cnt[3] != (int)gridDim.x - 1) return;        // workgroup-uniform
+        if (ticket != (int)gridDim.x - 1) return;        // workgroup-uniform
         lzf_schedule(F, ch_lds);
     }
 }

@@ -201,6 +201,8 @@ class _FusedHeadTrain(Function):
             call("lz_grid_encode_backward", ptr(g), ptr(c), ptr(e), ptr(mod.offsets), ptr(ge), M, 2, 1, 12, mod.S, mod.H, ptr(jac), ptr(gin), 0, 0,
                  0, 3 if M >= 16384 else 0, stream())
             demb.append(ge)
+        if mod.keep_denc:
+            mod.last_denc = denc
         g_xyzs = None
         if need_x:
             # planes xy = (x, y), yz = (y, z), xz = (x, z) (network.py:211) behind x01 = (x + bound) / (2 bound) (grid.py:143)
@@ -252,6 +254,9 @@ class FusedTriplaneTrainHead(nn.Module):
         self.S = float(np.float32(np.log2(self.encoder_xy.per_level_scale)))
         self.register_buffer("packed", torch.empty(_lib.load().lz_head_packed_size(), dtype=torch.float32), persistent=False)
         self._gw_ws = None   # partial-tile workspace of lz_triplane_head_grad_w, allocated on first backward
+        # diagnostics: with keep_denc set, the last backward leaves d loss / d enc_x (level-major [3, 12, M], what the table scatter consumed)
+        # in last_denc -- tests/test_gpu_train_fullsize.py checks the scatter against it (per-level sums, the checker's scatter)
+        self.keep_denc, self.last_denc = False, None
         if self.backward_f16:
             self.register_buffer("packed_bwd16", torch.empty(_lib.load().lz_head_packed_bwd_size_f16(), dtype=torch.uint8), persistent=False)
         if self.forward_f16:

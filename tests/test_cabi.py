@@ -57,19 +57,20 @@ def test_product_never_imports_the_oracle():
 
 
 def test_bench_uses_the_checker_only_for_the_cpu_baseline():
-    """bench.py imports neither pytest / the test tree nor -- outside its cpu_baseline leg -- the checker"""
+    """bench.py and its leg / contract modules import neither pytest / the test tree nor -- outside the cpu_baseline leg -- the checker"""
     import ast
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "conftest" not in src and "pytest" not in src
-    tree = ast.parse(src)
-    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
-        for node in ast.walk(fn):
+    for name in ("bench.py", "tools/bench_legs.py", "tools/bench_contract.py"):
+        src = open(os.path.join(ROOT, name)).read()
+        assert "conftest" not in src and "pytest" not in src, name
+        tree = ast.parse(src)
+        for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+            for node in ast.walk(fn):
+                mod = node.module if isinstance(node, ast.ImportFrom) else (node.names[0].name if isinstance(node, ast.Import) else None)
+                if mod and mod.split(".")[0] == "oracle":
+                    assert fn.name == "cpu_baseline", (name, fn.name, mod)
+        for node in tree.body:     # and nothing at module level
             mod = node.module if isinstance(node, ast.ImportFrom) else (node.names[0].name if isinstance(node, ast.Import) else None)
-            if mod and mod.split(".")[0] == "oracle":
-                assert fn.name == "cpu_baseline", (fn.name, mod)
-    for node in tree.body:     # and nothing at module level
-        mod = node.module if isinstance(node, ast.ImportFrom) else (node.names[0].name if isinstance(node, ast.Import) else None)
-        assert not (mod and mod.split(".")[0] in ("oracle", "tests")), mod
+            assert not (mod and mod.split(".")[0] in ("oracle", "tests")), (name, mod)
 
 
 def test_operator_api_surface():

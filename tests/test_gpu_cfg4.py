@@ -119,6 +119,13 @@ def test_bench_self_spawns_two_ranks_and_prints_the_contract_line(tmp_path, extr
     assert "one frame ray-sharded x2" in r["config"]["parallelism"] and r["config"]["rays_per_rank"] == 128 * 128 // 2
     assert r["clip_weak_scaling"]["scaling"] == "weak" and r["clip_weak_scaling"]["frames_per_step"] == 2
     assert "tiles_contiguous" in r and "roofline" in r
+    # the line the driver parses stays compact (21.9 KB was unparseable) and carries the contract's key set
+    from tools.bench_contract import CONFIG_KEYS, CONTRACT_KEYS, MAX_LINE_BYTES, ROOFLINE_KEYS
+    assert len(lines[0]) < MAX_LINE_BYTES // 2, len(lines[0])
+    assert set(CONTRACT_KEYS) <= set(r) and set(CONFIG_KEYS) <= set(r["config"]) and set(ROOFLINE_KEYS) <= set(r["roofline"])
+    assert p.stdout.strip().splitlines()[-1] == lines[0]
+    detail = json.load(open(os.path.join(ROOT, r["detail"])))
+    assert detail["value"] == r["value"] and "schedule" in detail["config"]
 
 
 def test_peer_tile_hand_off_two_ranks_on_one_card(tmp_path):
