@@ -221,13 +221,16 @@ int lz_bg_coords(uint32_t H, uint32_t W, float* out, lz_stream_t stream);
  * Weights are consumed in the packed "A-fragment" layout produced by lz_head_pack_weights; all arithmetic is f32
  * (v_mfma_f32_16x16x4_f32), summation order documented in DESIGN.md.  See network.py:252-311. */
 #define LZ_HEAD_PACKED_FLOATS 24576 /* 379 A-fragments x 64 lanes + 320 floats of VALU-layer rows */
-#define LZ_HEAD_PACKED_F16_BYTES 60416 /* f16 head: 59 A-fragments x 64 lanes x 8 halfs */
+#define LZ_HEAD_PACKED_F16_BYTES 60416 /* f16 recording forward (training): 59 A-fragments of v_mfma_f32_16x16x32_f16 x 64 lanes x 8 halfs */
+#define LZ_HEAD_PACKED_F16W_BYTES 61440 /* f16 inference head: 60 A-fragments of v_mfma_f32_32x32x16_f16 x 64 lanes x 8 halfs */
 typedef struct {
     const float* emb_xy;      /* [163584] tables of the three planes (device) */
     const float* emb_yz;
     const float* emb_xz;
     const int32_t* offsets;   /* [13] device */
-    const void* packed;       /* packed MLP weights (device), from lz_head_pack_weights (precision 0) or _f16 (precision 1) */
+    const void* packed;       /* packed MLP weights (device), from lz_head_pack_weights (precision 0, 2), lz_head_pack_weights_f16w (precision 1,
+                               * inference: lz_triplane_head_forward, lz_frame_*, lz_loop_*) or lz_head_pack_weights_f16 (precision 1, the
+                               * recording training forward lz_triplane_head_forward_record_f16) */
     const float* enc_a;       /* [32] device */
     const float* ind_code;    /* [4] device or NULL */
     const float* eye;         /* [1] device or NULL (exp_eye off) */
@@ -248,7 +251,14 @@ uint32_t lz_head_packed_size(void);
 int lz_head_pack_weights(const float* aud0, const float* aud1, const float* eye0, const float* eye1, const float* sig0,
                          const float* sig1, const float* sig2, const float* col0, const float* col1, const float* unc0,
                          const float* unc1, int has_eye, int has_ind, float* packed, lz_stream_t stream);
-/* the same for the f16 head (no uncertainty net: inference only); `packed`: LZ_HEAD_PACKED_F16_BYTES bytes (device) */
+/* the same for the f16 INFERENCE head (no uncertainty net), 32-sample slices on v_mfma_f32_32x32x16_f16 (ABI 10; csrc/lz_head_f16w_slice.h);
+ * `packed`: LZ_HEAD_PACKED_F16W_BYTES bytes (device) */
+uint32_t lz_head_packed_size_f16w(void);
+int lz_head_pack_weights_f16w(const float* aud0, const float* aud1, const float* eye0, const float* eye1, const float* sig0,
+                              const float* sig1, const float* sig2, const float* col0, const float* col1, int has_eye,
+                              int has_ind, void* packed, lz_stream_t stream);
+/* ... and for the f16 recording TRAINING forward (lz_triplane_head_forward_record_f16), 16-sample slices on v_mfma_f32_16x16x32_f16;
+ * `packed`: LZ_HEAD_PACKED_F16_BYTES bytes (device) */
 uint32_t lz_head_packed_size_f16(void);
 int lz_head_pack_weights_f16(const float* aud0, const float* aud1, const float* eye0, const float* eye1, const float* sig0,
                              const float* sig1, const float* sig2, const float* col0, const float* col1, int has_eye,

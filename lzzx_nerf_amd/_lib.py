@@ -128,6 +128,7 @@ SIGNATURES = {
     "lz_debug_head_clocks": [C.POINTER(C.c_uint64)],
     "lz_triplane_head_backward": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, C.POINTER(HeadBwdOut), vp],
     "lz_head_pack_weights_f16": [vp] * 9 + [i32, i32, vp, vp],
+    "lz_head_pack_weights_f16w": [vp] * 9 + [i32, i32, vp, vp],
     "lz_torso_forward": [C.POINTER(TorsoParams), vp, u32, vp, vp, vp, vp],
     "lz_torso_anchor_encode": [vp, vp, vp, vp],
     "lz_audio_encode": [C.POINTER(AudioParams), vp, vp, vp, vp],
@@ -150,11 +151,11 @@ SIGNATURES = {
     "lz_triplane_head_grad_w": [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp],
 }
 PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),
-         "lz_head_packed_size": ([], u32), "lz_head_packed_size_f16": ([], u32), "lz_head_packed_unc_size_f16": ([], u32), "lz_head_packed_bwd_size_f16": ([], u32),
+         "lz_head_packed_size": ([], u32), "lz_head_packed_size_f16": ([], u32), "lz_head_packed_size_f16w": ([], u32), "lz_head_packed_unc_size_f16": ([], u32), "lz_head_packed_bwd_size_f16": ([], u32),
          "lz_triplane_head_grad_w_workspace": ([], C.c_size_t)}
 
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
-ABI_VERSION = 9   # lz_abi_version() of the library this binding table describes (include/lzzx_nerf_hip.h)
+ABI_VERSION = 10  # lz_abi_version() of the library this binding table describes (include/lzzx_nerf_hip.h)
 
 _lib = None
 

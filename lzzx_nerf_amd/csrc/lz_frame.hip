@@ -43,6 +43,7 @@
 #include "lz_march.h"
 #include "lz_head_slice.h"
 #include "lz_head_f16_slice.h"
+#include "lz_head_f16w_slice.h"
 
 #define LZF_WG 1024
 #define LZF_WAVES (LZF_WG / 64)
@@ -270,9 +271,9 @@ struct LzShFromSlot16 {
     int ls, ns;
     __device__ __forceinline__ void prepare() const {}
 };
-__device__ __forceinline__ void h_sh_pk(const LzShFromSlot16& f, int q, uint32_t (&w)[2]) {
-    w[0] = __float_as_uint(f.slot[(SF_SH + 2 * q) * f.ns + f.ls]);
-    w[1] = __float_as_uint(f.slot[(SF_SH + 2 * q + 1) * f.ns + f.ls]);
+__device__ __forceinline__ void w_sh_pk(const LzShFromSlot16& f, int h, uint32_t (&w)[4]) {    // components 8 h .. 8 h + 7: words 4 h .. 4 h + 3
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = __float_as_uint(f.slot[(SF_SH + 4 * h + k) * f.ns + f.ls]);
 }
 // evaluated by the lane that takes the ray (the same lz_sh_eval call on the same direction as the stand-alone head makes per sample)
 template <int PREC, bool GEO = false>
@@ -353,18 +354,13 @@ template <> struct LzfHead<2> : LzfHead<0> {   // f32 with the geo projection fo
         lz_head_slice<false, true, true, true>(c, lane, x, y, z, f, o);
     }
 };
-template <> struct LzfHead<1> {
-    using Args = LzHead16Args; using Ctx = LzHead16Ctx; using Out = LzHead16Out; using ShSlot = LzShFromSlot16;
-    static constexpr int LDS_WORDS = LZ_HEAD16_LDS_H8 * 4;
-    __device__ static __forceinline__ void stage(const Args& P, float* lds, int, Ctx& c) { lz_head16_stage(P, reinterpret_cast<lz_h8*>(lds), LZF_WG, c); }
+template <> struct LzfHead<1> {   // f16: 32-sample slices on v_mfma_f32_32x32x16_f16 (lz_head_f16w_slice.h)
+    using Args = LzHead16Args; using Ctx = LzHead16Ctx; using Out = LzHead16wOut; using ShSlot = LzShFromSlot16;
+    static constexpr int LDS_WORDS = LZ_HEAD16W_LDS_H8 * 4;
+    __device__ static __forceinline__ void stage(const Args& P, float* lds, int, Ctx& c) { lz_head16w_stage(P, reinterpret_cast<lz_h8*>(lds), LZF_WG, c); }
     template <typename ShFn>
     __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
-        lz_head16_slice<true>(c, lane, x, y, z, f, o);
-    }
-    // two slot rows through the head together (lz_head16_slice_rows: every weight fragment read from LDS once for both)
-    template <typename ShFn>
-    __device__ static __forceinline__ void slice2(const Ctx& c, int lane, const float (&x)[2], const float (&y)[2], const float (&z)[2], ShFn (&f)[2], Out (&o)[2]) {
-        lz_head16_slice_rows<true, 2>(c, lane, x, y, z, f, o);
+        lz_head16w_slice<true>(c, lane, x, y, z, f, o);
     }
 };
 
@@ -377,7 +373,8 @@ template <int PREC, int S, int ROWS>
 __global__ void __launch_bounds__(LZF_WG, LZF_WG / 256)
 lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     using HD = LzfHead<PREC>;
-    static_assert(ROWS == 1 || S == 1, "several slot rows per wave only with one sample per ray and pass");
+    // f16: always two slot rows (32 slots) per wave -- the 32-sample slice of lz_head16w_slice; f32: one row of 16, several only with S == 1
+    static_assert(PREC == 1 ? ROWS == 2 : (ROWS == 1 || S == 1), "slot rows per wave: f16 two; f32 one, or several with one sample per ray and pass");
     constexpr int NS = 16 * ROWS;                                   // ray slots per wave
     using FL = LzfFields<PREC, S, ROWS>;
     constexpr int NF = FL::COUNT;
@@ -387,7 +384,9 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     constexpr int SLOT_WORDS = LZF_WAVES * NF * NS;
     __shared__ __align__(16) float lds[HD::LDS_WORDS + SLOT_WORDS + 4 + LZF_LUT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s = lane & 15, q = lane >> 4;
+    // S > 1: s = the lane's slot (f32: the four lanes l & 15 of a slot; f16: its two lanes l & 31); S == 1, f32: the slot of its row
+    const int s = (S > 1) ? (lane & (NS - 1)) : (lane & 15), q = lane >> 4;
+    const bool slot_lane = lane < NS;                               // the lane that marches / composites slot `lane`
     static_assert(alignof(typename HD::Args) <= 8, "lz_k_frame(Args P, LzFrameK F): F sits at round8(sizeof(Args)) of the kernel-argument segment");
     const LzfOut OUT = lzf_out<sizeof(typename HD::Args)>();
     // phase 2 of the reference's cap continues the rays phase 1 parked at max_steps; none parked (or C_eff == max_steps): nothing to stage
@@ -426,8 +425,8 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
         for (;;) {
             if constexpr (PREC != 1) __builtin_amdgcn_s_setprio(2);   // see the S = 1 loop
             // ---------------- refill + march (group leaders): up to S samples per ray into the staging fields ----------------
-            const bool leader = (q == 0) && j == 0;
-            int ray = leader ? sloti[SF_RAY * 16 + s] : -1;
+            const bool leader = slot_lane && j == 0;
+            int ray = leader ? sloti[SF_RAY * NS + s] : -1;
             int kk = 0;                                  // samples marched this pass (leaders)
             for (int attempt = 0; attempt < 4; attempt++) {
                 const bool need = leader && ray < 0 && !dry;
@@ -441,16 +440,16 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                         const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
                         if (idx < n_queue) {
                             ray = LZF_RF(order)[idx];
-                            sloti[SF_RAY * 16 + s] = ray;
-                            slot[SF_T * 16 + s] = LZF_RF(rays_t)[ray];
-                            slot[SF_FAR * 16 + s] = (LZF_RF(occ) ? LZF_RF(t_end)[ray] : LZF_RF(fars)[ray]);
-                            lzf_slot_take(OUT, ph2, ray, slot, sloti, s, 16);
-                            lzf_store_sh<PREC, FL::GEO>(LZF_RF(rays_o) + (size_t)ray * 3, LZF_RF(rays_d) + (size_t)ray * 3, slot, s, 16, SF_RD);
+                            sloti[SF_RAY * NS + s] = ray;
+                            slot[SF_T * NS + s] = LZF_RF(rays_t)[ray];
+                            slot[SF_FAR * NS + s] = (LZF_RF(occ) ? LZF_RF(t_end)[ray] : LZF_RF(fars)[ray]);
+                            lzf_slot_take(OUT, ph2, ray, slot, sloti, s, NS);
+                            lzf_store_sh<PREC, FL::GEO>(LZF_RF(rays_o) + (size_t)ray * 3, LZF_RF(rays_d) + (size_t)ray * 3, slot, s, NS, SF_RD);
                         }
                     }
                     if (base + take >= n_queue) dry = true;
                 }
-                // ---- march, S candidates of a ray per round on the S lanes of its group (lanes q == 0: lane lead + j takes candidate j) ----
+                // ---- march, S candidates of a ray per round on the S lanes of its group (the slot lanes: lane lead + j takes candidate j) ----
                 // Every step of the reference's march -- the sample step and the empty-space skip alike -- is t += clamp(t dt_gamma, dt_min,
                 // dt_max) (raymarching.cu:907, 919-926): a ray visits a subsequence of ONE fixed chain c_0 = t, c_{i+1} = c_i + step(c_i).  So
                 // the group's lanes locate and test the next S chain points TOGETHER (one cell test and one bitfield load deep instead of S),
@@ -460,22 +459,22 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 {
                     const int gray = __shfl(ray, lead, 64);                      // the group's ray and whether it still has to march this pass
                     const int gkk0 = __shfl(kk, lead, 64);
-                    const bool grp = q == 0 && gray >= 0 && gkk0 == 0;
+                    const bool grp = slot_lane && gray >= 0 && gkk0 == 0;
                     if (__ballot(grp)) {
                         float t0 = 0.0f, far = 0.0f;
                         int want = 0, got = 0;
                         if (grp) {
                             if constexpr (FL::GEO) {
-                                const float go[3] = {slot[(SF_RD + 3) * 16 + lead], slot[(SF_RD + 4) * 16 + lead], slot[(SF_RD + 5) * 16 + lead]};
-                                const float gd[3] = {slot[(SF_RD + 6) * 16 + lead], slot[(SF_RD + 7) * 16 + lead], slot[(SF_RD + 8) * 16 + lead]};
-                                m.init(go, gd, slot[SF_RD * 16 + lead], slot[(SF_RD + 1) * 16 + lead], slot[(SF_RD + 2) * 16 + lead], F.bound, F.dt_gamma, F.mf, F.C, F.H, F.grid);
+                                const float go[3] = {slot[(SF_RD + 3) * NS + lead], slot[(SF_RD + 4) * NS + lead], slot[(SF_RD + 5) * NS + lead]};
+                                const float gd[3] = {slot[(SF_RD + 6) * NS + lead], slot[(SF_RD + 7) * NS + lead], slot[(SF_RD + 8) * NS + lead]};
+                                m.init(go, gd, slot[SF_RD * NS + lead], slot[(SF_RD + 1) * NS + lead], slot[(SF_RD + 2) * NS + lead], F.bound, F.dt_gamma, F.mf, F.C, F.H, F.grid);
                             } else
-                            m.init(F.rays_o + (size_t)gray * 3, F.rays_d + (size_t)gray * 3, slot[SF_RD * 16 + lead], slot[(SF_RD + 1) * 16 + lead],
-                                   slot[(SF_RD + 2) * 16 + lead], F.bound, F.dt_gamma, F.mf, F.C, F.H, F.grid);
+                            m.init(F.rays_o + (size_t)gray * 3, F.rays_d + (size_t)gray * 3, slot[SF_RD * NS + lead], slot[(SF_RD + 1) * NS + lead],
+                                   slot[(SF_RD + 2) * NS + lead], F.bound, F.dt_gamma, F.mf, F.C, F.H, F.grid);
                             if (use_lut) m.morton_lut = mlut;
-                            t0 = slot[SF_T * 16 + lead];
-                            far = slot[SF_FAR * 16 + lead];
-                            want = min(S, cap - sloti[SF_CNT * 16 + lead]);      // >= 1: a ray at the cap has left its slot
+                            t0 = slot[SF_T * NS + lead];
+                            far = slot[SF_FAR * NS + lead];
+                            want = min(S, cap - sloti[SF_CNT * NS + lead]);      // >= 1: a ray at the cap has left its slot
                         }
                         bool more = grp && t0 < far;
                         while (__ballot(more)) {
@@ -502,7 +501,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                                 // behind `far`, which is the `cn` of the last one taken either way.  One ballot and one shuffle instead of S rounds
                                 // (same-box A/B on an 8-way tile: f16 0.420 -> 0.407 ms, f32 1.32 -> 1.30).
                                 const unsigned long long vm = __ballot(valid);
-                                const int nvalid = __popcll((vm >> lead) & ((1ull << S) - 1ull));     // (lanes q == 0: lane = slot)
+                                const int nvalid = __popcll((vm >> lead) & ((1ull << S) - 1ull));     // (slot lanes: lane = slot)
                                 const int take = min(want - got, nvalid);
                                 const float t_last = __shfl(cn, lead + max(take, 1) - 1, 64);
                                 if (more) {
@@ -533,9 +532,9 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                             }
                             if (more && rank >= 0) {
                                 const int sl = lead + rank;
-                                slot[SF_X * 16 + sl] = cell.x; slot[SF_Y * 16 + sl] = cell.y; slot[SF_Z * 16 + sl] = cell.z;
-                                slot[SF_DT * 16 + sl] = cell.dt;
-                                slot[SF_TS * 16 + sl] = cn;
+                                slot[SF_X * NS + sl] = cell.x; slot[SF_Y * NS + sl] = cell.y; slot[SF_Z * NS + sl] = cell.z;
+                                slot[SF_DT * NS + sl] = cell.dt;
+                                slot[SF_TS * NS + sl] = cn;
                             }
                             t0 = t_new;
                             more = more && got < want && t0 < far;
@@ -543,69 +542,67 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                         if (leader && grp) {
                             kk = got;
                             if (kk == 0) {     // the ray left the box without another sample
-                                const int c0 = sloti[SF_CNT * 16 + s];
-                                lzf_ray_end(OUT, ph2, ray, LZF_END_BOX, c0, c0, t0, slot[SF_WS * 16 + s], slot[SF_D * 16 + s], slot[SF_R * 16 + s], slot[SF_G * 16 + s],
-                                            slot[SF_B * 16 + s], slot[SF_A0 * 16 + s], slot[SF_A1 * 16 + s], slot[SF_U * 16 + s]);
+                                const int c0 = sloti[SF_CNT * NS + s];
+                                lzf_ray_end(OUT, ph2, ray, LZF_END_BOX, c0, c0, t0, slot[SF_WS * NS + s], slot[SF_D * NS + s], slot[SF_R * NS + s], slot[SF_G * NS + s],
+                                            slot[SF_B * NS + s], slot[SF_A0 * NS + s], slot[SF_A1 * NS + s], slot[SF_U * NS + s]);
                                 my_samples += c0 - cnt_base;
                                 ray = -1;
-                                sloti[SF_RAY * 16 + s] = -1;
+                                sloti[SF_RAY * NS + s] = -1;
                             }
                         }
                     }
                 }
                 if (!__ballot(leader && ray < 0 && !dry)) break;
             }
-            if (leader) sloti[SF_IT * 16 + s] = kk;      // samples of this pass
+            if (leader) sloti[SF_IT * NS + s] = kk;      // samples of this pass
             if (!__ballot(kk > 0)) {
                 if (dry) break;
                 continue;
             }
             // ---------------- head: slot s evaluates sample j of its ray when the leader staged one ----------------
-            const int lkk = sloti[SF_IT * 16 + lead];
-            const bool live = sloti[SF_RAY * 16 + lead] >= 0 && j < lkk;
-            const float px = live ? slot[SF_X * 16 + s] : 0.0f, py = live ? slot[SF_Y * 16 + s] : 0.0f, pz = live ? slot[SF_Z * 16 + s] : 0.0f;
+            const int lkk = sloti[SF_IT * NS + lead];
+            const bool live = sloti[SF_RAY * NS + lead] >= 0 && j < lkk;
+            const float px = live ? slot[SF_X * NS + s] : 0.0f, py = live ? slot[SF_Y * NS + s] : 0.0f, pz = live ? slot[SF_Z * NS + s] : 0.0f;
             typename HD::Out o;
-            HD::slice(ctx, lane, px, py, pz, typename HD::ShSlot{slot, lead, 16}, o);
-            my_slices++;
+            HD::slice(ctx, lane, px, py, pz, typename HD::ShSlot{slot, lead, NS}, o);
+            my_slices += ROWS;
             if constexpr (PREC == 1) {
-                // the f16 head leaves a sample's four transcendentals one per lane group (LzHead16Out::own: colour q on q < 3, sigma on q == 3):
-                // every group parks its own -- the fields OSIG, OR, OG, OB are consecutive -- and nothing crosses lanes
-                const float a = 1.0f - lz_expf(-o.own * slot[SF_DT * 16 + s]);
-                slot[(SF_OSIG + ((q + 1) & 3)) * 16 + s] = q == 3 ? a : o.own;
-            }
-            if (q == 0) {
-                // alpha = 1 - exp(-sigma delta) of this slot's sample (raymarching.cu:2197), computed here by the sample's own lane: the
-                // leader's serial walk below then costs a handful of instructions per sample instead of an exp each
-                if constexpr (PREC != 1) {
-                    slot[SF_OSIG * 16 + s] = 1.0f - lz_expf(-o.sigma * slot[SF_DT * 16 + s]);
-                    slot[SF_OR * 16 + s] = o.rgb[0]; slot[SF_OG * 16 + s] = o.rgb[1]; slot[SF_OB * 16 + s] = o.rgb[2];
-                }
-                slot[SF_OA0 * 16 + s] = o.ambaud; slot[SF_OA1 * 16 + s] = o.eyeatt; slot[SF_OU * 16 + s] = o.unc;
+                // the f16 head leaves a sample's four transcendentals two per lane (LzHead16wOut: rgb[0], rgb[2] on lane half 0; rgb[1], sigma on
+                // half 1): every lane parks its own, nothing crosses lanes.  alpha = 1 - exp(-sigma delta) of the sample (raymarching.cu:2197) is
+                // computed here by the sigma lane: the leader's serial walk below then costs a handful of instructions per sample
+                const int hh = lane >> 5;
+                slot[(SF_OR + hh) * NS + s] = o.a;                                  // SF_OR, SF_OG are consecutive
+                slot[(hh ? SF_OSIG : SF_OB) * NS + s] = hh ? 1.0f - lz_expf(-o.b * slot[SF_DT * NS + s]) : o.b;
+                if (hh == 0) { slot[SF_OA0 * NS + s] = o.ambaud; slot[SF_OA1 * NS + s] = o.eyeatt; slot[SF_OU * NS + s] = o.unc; }
+            } else if (q == 0) {
+                slot[SF_OSIG * NS + s] = 1.0f - lz_expf(-o.sigma * slot[SF_DT * NS + s]);
+                slot[SF_OR * NS + s] = o.rgb[0]; slot[SF_OG * NS + s] = o.rgb[1]; slot[SF_OB * NS + s] = o.rgb[2];
+                slot[SF_OA0 * NS + s] = o.ambaud; slot[SF_OA1 * NS + s] = o.eyeatt; slot[SF_OU * NS + s] = o.unc;
             }
             __builtin_amdgcn_wave_barrier();
             // ---------------- composite (lz_k_composite_rays, n_step = S): the leader walks its ray's staged samples ----------------
             if (leader && kk > 0) {
-                float ws = slot[SF_WS * 16 + s], d = slot[SF_D * 16 + s], r = slot[SF_R * 16 + s], g = slot[SF_G * 16 + s], b = slot[SF_B * 16 + s];
-                float a0 = slot[SF_A0 * 16 + s], a1 = slot[SF_A1 * 16 + s], u = slot[SF_U * 16 + s], t = slot[SF_T * 16 + s];
+                float ws = slot[SF_WS * NS + s], d = slot[SF_D * NS + s], r = slot[SF_R * NS + s], g = slot[SF_G * NS + s], b = slot[SF_B * NS + s];
+                float a0 = slot[SF_A0 * NS + s], a1 = slot[SF_A1 * NS + s], u = slot[SF_U * NS + s], t = slot[SF_T * NS + s];
                 int step = 0;
                 while (step < kk) {
                     const int sl = s + step;
-                    const float alpha = slot[SF_OSIG * 16 + sl];
+                    const float alpha = slot[SF_OSIG * NS + sl];
                     const float T = 1 - ws;
                     const float w = alpha * T;
                     ws += w;
-                    t = slot[SF_TS * 16 + sl];
+                    t = slot[SF_TS * NS + sl];
                     d = lz_fmaf(w, t, d);
-                    r = lz_fmaf(w, slot[SF_OR * 16 + sl], r);
-                    g = lz_fmaf(w, slot[SF_OG * 16 + sl], g);
-                    b = lz_fmaf(w, slot[SF_OB * 16 + sl], b);
-                    a0 = a0 + slot[SF_OA0 * 16 + sl];
-                    a1 = a1 + slot[SF_OA1 * 16 + sl];
-                    u = lz_fmaf(w, slot[SF_OU * 16 + sl], u);
+                    r = lz_fmaf(w, slot[SF_OR * NS + sl], r);
+                    g = lz_fmaf(w, slot[SF_OG * NS + sl], g);
+                    b = lz_fmaf(w, slot[SF_OB * NS + sl], b);
+                    a0 = a0 + slot[SF_OA0 * NS + sl];
+                    a1 = a1 + slot[SF_OA1 * NS + sl];
+                    u = lz_fmaf(w, slot[SF_OU * NS + sl], u);
                     if (T < F.T_thresh) break;
                     step++;
                 }
-                const int c0 = sloti[SF_CNT * 16 + s];
+                const int c0 = sloti[SF_CNT * NS + s];
                 const int cnt = c0 + kk;                                     // marched samples (renderer semantics: the chunk was marched)
                 const bool cut = step < kk;                                  // T < T_thresh at sample c0 + step + 1
                 const bool short_chunk = kk < min(S, cap - c0);              // the box held fewer samples than the chunk wanted
@@ -614,13 +611,13 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                     const int composited = cut ? c0 + step + 1 : cnt;
                     lzf_ray_end(OUT, ph2, ray, kind, composited, cnt, t, ws, d, r, g, b, a0, a1, u);
                     my_samples += (F.cap_mode ? composited : cnt) - cnt_base;
-                    sloti[SF_RAY * 16 + s] = -1;
+                    sloti[SF_RAY * NS + s] = -1;
                 } else {
-                    slot[SF_T * 16 + s] = t;
-                    slot[SF_WS * 16 + s] = ws; slot[SF_D * 16 + s] = d;
-                    slot[SF_R * 16 + s] = r; slot[SF_G * 16 + s] = g; slot[SF_B * 16 + s] = b;
-                    slot[SF_A0 * 16 + s] = a0; slot[SF_A1 * 16 + s] = a1; slot[SF_U * 16 + s] = u;
-                    sloti[SF_CNT * 16 + s] = cnt;
+                    slot[SF_T * NS + s] = t;
+                    slot[SF_WS * NS + s] = ws; slot[SF_D * NS + s] = d;
+                    slot[SF_R * NS + s] = r; slot[SF_G * NS + s] = g; slot[SF_B * NS + s] = b;
+                    slot[SF_A0 * NS + s] = a0; slot[SF_A1 * NS + s] = a1; slot[SF_U * NS + s] = u;
+                    sloti[SF_CNT * NS + s] = cnt;
                 }
             }
         }
@@ -628,7 +625,6 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
         // S = 1.  ROWS slot rows per wave (NS = 16 ROWS slots, slot l lives on lane l): the march, the refill and the compositing run
         // ONCE for all NS slots, the head runs once per row of 16.  ROWS = 2 is for the f16 head, which is bound by vector-instruction
         // issue: the sections that use 16 of 64 lanes are then shared by two slices (outputs of a row wait for the compositing in LDS).
-        const bool slot_lane = lane < NS;
         const int sl = lane;                       // this lane's slot (slot lanes only)
         for (;;) {
             // f32 heads: refill, march and the gather's address work run at a raised wave priority and the slice drops it once its loads are
@@ -700,51 +696,39 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 if (dry && !__ballot(slot_lane && ray >= 0)) break;     // queue dry and every slot empty: this wave is done
                 continue;                                             // slots still crossing empty space (or waiting for a refill)
             }
-            // ---------------- head: one slice per row of 16 slots, exactly a slice of the stand-alone head kernel ----------------
+            // ---------------- head: exactly a slice of the stand-alone head kernel ----------------
             typename HD::Out o;
-            int row0 = 0;
-            if constexpr (PREC == 1 && ROWS >= 2) {
-#ifndef LZ_NO_ROW_PAIRS
-                if ((have_mask & 0xffffull) && ((have_mask >> 16) & 0xffffull)) {     // wave-uniform: rows 0 and 1 both carry samples
-                    float px2[2], py2[2], pz2[2];
-                    typename HD::ShSlot f2[2] = {typename HD::ShSlot{slot, s, NS}, typename HD::ShSlot{slot, 16 + s, NS}};
-                    typename HD::Out o2[2];
-#pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        px2[r] = __shfl(x, 16 * r + s, 64); py2[r] = __shfl(y, 16 * r + s, 64); pz2[r] = __shfl(z, 16 * r + s, 64);
-                    }
-                    HD::slice2(ctx, lane, px2, py2, pz2, f2, o2);
-                    my_slices += 2;
-#pragma unroll
-                    for (int r = 0; r < 2; r++) {   // every lane group parks its own transcendental (LzHead16Out::own; OSIG, OR, OG, OB are consecutive fields)
-                        const int rs = 16 * r + s;
-                        slot[(SF_OSIG + ((q + 1) & 3)) * NS + rs] = o2[r].own;
-                        if (q == 0) { slot[SF_OA0 * NS + rs] = o2[r].ambaud; slot[SF_OA1 * NS + rs] = o2[r].eyeatt; slot[SF_OU * NS + rs] = o2[r].unc; }
-                    }
-                    row0 = 2;
-                }
-#endif
-            }
-#pragma unroll 1
-            for (int row = row0; row < ROWS; row++) {
-                if (ROWS > 1 && !((have_mask >> (16 * row)) & 0xffffull)) continue;   // no sample in this row
-                const int rs = 16 * row + s;                   // the slot whose sample this lane works on
+            if constexpr (PREC == 1) {
+                // f16: ONE 32-sample slice over both slot rows (lz_head16w_slice: v_mfma_f32_32x32x16_f16, lane = (slot l & 31, half l >> 5)).
+                // A sample's four transcendentals come out two per lane (rgb[0], rgb[2] on half 0; rgb[1], sigma on half 1): every lane parks
+                // its own for the compositing below -- OSIG, OR, OG, OB are consecutive fields -- and nothing crosses lanes
+                const int rs = lane & 31, hh = lane >> 5;
                 const float px = __shfl(x, rs, 64), py = __shfl(y, rs, 64), pz = __shfl(z, rs, 64);
                 HD::slice(ctx, lane, px, py, pz, typename HD::ShSlot{slot, rs, NS}, o);
-                my_slices++;
-                if constexpr (ROWS > 1 && PREC == 1) slot[(SF_OSIG + ((q + 1) & 3)) * NS + rs] = o.own;   // (as in the pair above)
-                if (ROWS > 1 && q == 0) {   // park the row's outputs for the compositing below (lanes q == 0 hold valid bits in both heads)
-                    if constexpr (PREC != 1) {
+                my_slices += 2;
+                slot[(SF_OR + hh) * NS + rs] = o.a;
+                slot[(hh ? SF_OSIG : SF_OB) * NS + rs] = o.b;
+                if (hh == 0) { slot[SF_OA0 * NS + rs] = o.ambaud; slot[SF_OA1 * NS + rs] = o.eyeatt; slot[SF_OU * NS + rs] = o.unc; }
+            } else {
+#pragma unroll 1
+                for (int row = 0; row < ROWS; row++) {     // one slice per row of 16 slots
+                    if (ROWS > 1 && !((have_mask >> (16 * row)) & 0xffffull)) continue;   // no sample in this row
+                    const int rs = 16 * row + s;                   // the slot whose sample this lane works on
+                    const float px = __shfl(x, rs, 64), py = __shfl(y, rs, 64), pz = __shfl(z, rs, 64);
+                    HD::slice(ctx, lane, px, py, pz, typename HD::ShSlot{slot, rs, NS}, o);
+                    my_slices++;
+                    if (ROWS > 1 && q == 0) {   // park the row's outputs for the compositing below (lanes q == 0 hold valid bits)
                         slot[SF_OSIG * NS + rs] = o.sigma;
                         slot[SF_OR * NS + rs] = o.rgb[0]; slot[SF_OG * NS + rs] = o.rgb[1]; slot[SF_OB * NS + rs] = o.rgb[2];
+                        slot[SF_OA0 * NS + rs] = o.ambaud; slot[SF_OA1 * NS + rs] = o.eyeatt; slot[SF_OU * NS + rs] = o.unc;
                     }
-                    slot[SF_OA0 * NS + rs] = o.ambaud; slot[SF_OA1 * NS + rs] = o.eyeatt; slot[SF_OU * NS + rs] = o.unc;
                 }
             }
             __builtin_amdgcn_wave_barrier();     // the parked outputs are read by other lanes of this wave: keep the LDS order
             // ---------------- composite (lz_k_composite_rays, n_step = 1): the slot lanes ----------------
             if (have) {
-                float sg = o.sigma, c0 = o.rgb[0], c1 = o.rgb[1], c2 = o.rgb[2], am0 = o.ambaud, am1 = o.eyeatt, un = o.unc;
+                float sg, c0, c1, c2, am0, am1, un;
+                if constexpr (PREC != 1) { sg = o.sigma; c0 = o.rgb[0]; c1 = o.rgb[1]; c2 = o.rgb[2]; am0 = o.ambaud; am1 = o.eyeatt; un = o.unc; }
                 if (ROWS > 1) {
                     sg = slot[SF_OSIG * NS + sl];
                     c0 = slot[SF_OR * NS + sl]; c1 = slot[SF_OG * NS + sl]; c2 = slot[SF_OB * NS + sl];
@@ -1139,7 +1123,9 @@ static int lzf_launch_persistent(const lz_frame_fused* f, const LzFrameK& K, hip
     if (S == 0) {
         // (round 4, with the batched march: rank 0's tile of a 512^2 frame sharded 8 / 4 ways, f16 kernel ms at S = 1 / 2 / 4: 0.573 / 0.454 /
         // 0.421 and 0.733 / 0.705 / 0.768; f32: 2.22 / 1.57 / 1.30 and 2.97 / 2.57 / 2.53 -- both heads want the rows in flight twice over)
-        const uint64_t want = (uint64_t)n_cu * LZF_WAVES * 16 * 2;
+        // f16 (32 slots per wave): the slots filled 1.5 times over -- with exactly one ray per slot nothing is ever refilled and the frame
+        // ends on emptying slices (round 3: a 2-way tile of 131 072 rays, 1.30 ms on two full rows against 1.17 on one)
+        const uint64_t want = p->precision == 1 ? (uint64_t)n_cu * LZF_WAVES * 48 : (uint64_t)n_cu * LZF_WAVES * 16 * 2;
         S = 1;
         while (S < 16 && (uint64_t)f->N * S < want) S *= 2;
     }
@@ -1159,21 +1145,15 @@ static int lzf_launch_persistent(const lz_frame_fused* f, const LzFrameK& K, hip
         a.offsets = p->offsets; a.packed = reinterpret_cast<const lz_h8*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code;
         a.eye = p->eye; a.bound = p->bound;
         lzf_level_tables(p, a.scale, a.res);
-        // slot rows per wave (f16: bound by vector-instruction issue, and the march / refill / compositing sections cost the same
-        // instructions for 16, 32 or 48 active lanes).  Two rows once the rays fill them; three only when the rays fill them TWICE over:
-        // with most rays resident from the start few slots are ever refilled and the second half of the frame runs on emptying slices
-        // (512^2 dense frame, 262 144 rays on 196 608 slots: 2.21 ms with three rows, 2.10 with two; 1024^2 cfg5: 0.98 vs 1.03 ms).
-        // LZ_FRAME_ROWS=1|2|3 caps the layout (diagnostic)
-        static const int max_rows = getenv("LZ_FRAME_ROWS") ? atoi(getenv("LZ_FRAME_ROWS")) : (getenv("LZ_FRAME_ONE_ROW") ? 1 : 3);
-        static const bool force_rows = getenv("LZ_FRAME_ROWS") != nullptr;
-        if (S == 1 && max_rows >= 3 && (uint64_t)f->N >= (uint64_t)n_cu * LZF_WAVES * 48 * (force_rows ? 1 : 2)) {
-            hipLaunchKernelGGL((lz_k_frame<1, 1, 3>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
-        } else if (S == 1 && max_rows >= 2 && (uint64_t)f->N * 2 >= (uint64_t)n_cu * LZF_WAVES * 32 * (force_rows ? 2 : 3)) {
-            // two rows once the rays fill them 1.5 times over: with exactly one ray per slot nothing is ever refilled and the frame ends on
-            // emptying slices (one rank's tile of a frame sharded two ways, 131 072 rays: 1.30 ms with two rows, 1.17 with one)
-            hipLaunchKernelGGL((lz_k_frame<1, 1, 2>), dim3(grid), dim3(LZF_WG), 0, st, a, K);
-        } else {
-            LZF_SWITCH(1)
+        // f16: two slot rows (32 slots) per wave at every S -- the head works on 32-sample slices (lz_head16w_slice), and the march / refill /
+        // compositing sections cost the same instructions for 16 or 32 active lanes.  (Rounds 2-4 also had one- and three-row layouts on
+        // 16-sample slices; the 32x32x16 slice halves the MFMA issue slots instead: DESIGN 4.1b.)
+        switch (S) {
+            case 1: hipLaunchKernelGGL((lz_k_frame<1, 1, 2>), dim3(grid), dim3(LZF_WG), 0, st, a, K); break;
+            case 2: hipLaunchKernelGGL((lz_k_frame<1, 2, 2>), dim3(grid), dim3(LZF_WG), 0, st, a, K); break;
+            case 4: hipLaunchKernelGGL((lz_k_frame<1, 4, 2>), dim3(grid), dim3(LZF_WG), 0, st, a, K); break;
+            case 8: hipLaunchKernelGGL((lz_k_frame<1, 8, 2>), dim3(grid), dim3(LZF_WG), 0, st, a, K); break;
+            default: hipLaunchKernelGGL((lz_k_frame<1, 16, 2>), dim3(grid), dim3(LZF_WG), 0, st, a, K); break;
         }
     } else {
         LzHeadArgs a;

@@ -83,7 +83,9 @@ typedef float lz_gf2 __attribute__((ext_vector_type(2)));
 // PAIR0: when levels 0..3 are dense (LZ_LVTAB_DENSE0; every lane's first level record), their x / x + 1 corners are adjacent table entries
 // and come with one 8-byte load per row: 30 load instructions per lane instead of 36 and 18 index instructions less.  Same-box A/B on
 // the fused frame: f32 9.05 -> 8.97 ms, f16 2.025 -> 2.04 ms (no gain: the f16 slices keep the one-load-per-corner form)
-template <bool IN_RANGE = false, bool PACK = false, bool YIELD = false, bool PAIR0 = false>
+// LSTRIDE: the lane's three level records are levels q + LSTRIDE mrec (mrec < 3).  4: the 16-sample heads (lane group q of four owns features
+// 4 i + q).  2: the 32-sample f16 head (lz_head_f16w_slice.h), whose lane half h owns 18 features in two calls, q = h and q = 6 + h.
+template <bool IN_RANGE = false, bool PACK = false, bool YIELD = false, bool PAIR0 = false, int LSTRIDE = 4>
 __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], const int* __restrict__ tab, float px, float py, float pz, int q,
                                                float bound, float two_bound, float (&encx)[9]) {
     // the three grid levels this lane touches (level = 4 m + q); read per slice from LDS so that they do not occupy registers during the
@@ -92,7 +94,7 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
     float lv_scale[3];
 #pragma unroll
     for (int mrec = 0; mrec < 3; mrec++) {
-        const int level = 4 * mrec + q;
+        const int level = LSTRIDE * mrec + q;
         lv_off[mrec] = (uint32_t)tab[level];
         lv_scale[mrec] = reinterpret_cast<const float*>(tab)[LZ_LVTAB_SCALE + level];
         lv_strd[mrec] = (uint32_t)tab[LZ_LVTAB_STRIDE + level];
@@ -151,6 +153,7 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
             rowD[rc][mrec][1] = rowD[rc][mrec][0] + lv_strd[mrec];
         }
     float gv[9][4];
+    static_assert(!PAIR0 || LSTRIDE == 4, "PAIR0 pairs the corners of levels 0..3");
     const bool dense0 = PAIR0 && __builtin_amdgcn_readfirstlane(tab[LZ_LVTAB_DENSE0]) != 0;     // workgroup-uniform, a scalar branch
 #pragma unroll
     for (int i = 0; i < 9; i++) {

@@ -64,7 +64,7 @@ class FusedTriplaneHead:
         self.per_level_scale = np.exp2(np.log2(512 * self.bound / 64) / 11)
         self.S = float(np.float32(np.log2(self.per_level_scale)))
         if precision == "f16":
-            self.packed = torch.empty(_lib.load().lz_head_packed_size_f16(), dtype=torch.uint8, device=self.device)
+            self.packed = torch.empty(_lib.load().lz_head_packed_size_f16w(), dtype=torch.uint8, device=self.device)
         else:
             self.packed = torch.empty(_lib.load().lz_head_packed_size(), dtype=torch.float32, device=self.device)
         self.repack()
@@ -78,7 +78,7 @@ class FusedTriplaneHead:
         """(re)build the MFMA A-fragment buffer; call after the weights change"""
         w = self.w
         if self.precision == "f16":
-            call("lz_head_pack_weights_f16", *[ptr(t) for t in w[:9]], int(self.has_eye), int(self.has_ind), ptr(self.packed), stream())
+            call("lz_head_pack_weights_f16w", *[ptr(t) for t in w[:9]], int(self.has_eye), int(self.has_ind), ptr(self.packed), stream())
         else:
             if self.fold_geo:
                 w = list(w)

@@ -76,7 +76,9 @@ def test_full_size_march_counts(scene):
     ro, rd, _ = _rays(dev)
     xyzs, dirs, deltas, rays, ctr, nears, fars = _march(ro, rd, bits)
     M = int(ctr[0].item())
-    assert int(ctr[1].item()) == N_RAYS and xyzs.shape[0] == M and M > 0
+    rows = xyzs.shape[0]                      # padded to a multiple of 128 like the reference's buffers (raymarching.py:246-256)
+    assert int(ctr[1].item()) == N_RAYS and M > 0 and M <= rows <= M + 128 and rows % 128 == 0
+    assert not bool(deltas[M:].any())
     cnt, off = rays[:, 2].long(), rays[:, 1].long()
     assert int(cnt.sum()) == M and int(cnt.max()) <= MAX_STEPS
     order = torch.argsort(off[cnt > 0])

@@ -591,15 +591,21 @@ def test_fused_train_head_f16_forward(params, golden, backward_dtype, exp_eye, i
     outs = net(xyz, d, enc_a, ind, eye)
     live = [k for k in range(5) if outs[k].requires_grad]
     torch.autograd.backward([outs[k] for k in live], [gout[k] for k in live])
-    # ---- the f16 inference kernel: the same rounding sequence in a separately compiled kernel -- bit for bit, now that every f32 result
-    # is materialised before its conversion to half (h_round: no v_fma_mixlo_f16 single rounding that depends on the surrounding code)
+    # ---- the f16 inference kernel: the same rounding sequence, but since round 5 on v_mfma_f32_32x32x16_f16 (lz_head_f16w_slice.h): the f32
+    # accumulation inside a Linear is grouped by 16 k instead of the recording forward's 32 (v_mfma_f32_16x16x32_f16), which the reference
+    # leaves to its GEMM library -- so the two agree to half rounding: the bulk bit-equal, the rest within a few half ulps (rounds 2-4 shared
+    # one slice and agreed bit for bit)
     pi = dict(p) if ind_dim else {k: v for k, v in p.items() if k != "individual_codes"}
     inf = FusedTriplaneHead({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in pi.items()}, bound=1.0, exp_eye=exp_eye, precision="f16")
     oi = inf.forward(xyz, d, dev(enc_a_np), dev(golden["net_ind"]) if ind_dim else None, eye)
     for a, b, nm in zip(outs[:4], oi[:4], ("sigma", "rgb", "amb_aud", "amb_eye")):
         if nm == "amb_eye" and not exp_eye:
             continue
-        assert torch.equal(a.detach().reshape(-1), b.reshape(-1)), nm
+        a, b = a.detach().reshape(-1), b.reshape(-1)
+        rel = (a - b).abs() / (b.abs() + 1e-3)
+        # (||att|| is an f32 sum of 32 squares whose order differs too -- 16 + 16 over two lanes against 8 x 4 over four: equal to f32 rounding)
+        same = float((a == b).float().mean()) if nm != "amb_aud" else float((rel < 1e-6).float().mean())
+        assert same > 0.9 and float(rel.max()) < 2e-2, (nm, same, float(rel.max()))
     # ---- the operator graph under autocast
     encs = []
     for n in ("xy", "yz", "xz"):

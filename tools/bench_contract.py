@@ -13,7 +13,7 @@ TARGET_LINE_BYTES = 4096
 
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                  "dtype", "data", "config")
-CONFIG_KEYS = ("workload", "rays_per_step", "samples_per_step", "parallelism", "mode")
+CONFIG_KEYS = ("workload", "rays_per_step", "rays_per_rank", "samples_per_step", "parallelism", "mode")
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel", "avg_launch_ms")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "s_per_frame", "runs")
 PARITY_KEYS = ("psnr_vs_checker_db", "max_abs_diff_vs_checker", "sample_counts_equal", "parity_sample")
@@ -101,7 +101,6 @@ def compact(result, detail="bench_detail.json"):
         if k in result:
             line[k] = result[k]
     if result.get("n_gpus", 1) > 1:
-        line["config"]["rays_per_rank"] = cfg.get("rays_per_rank")
         for k in ("tiles_contiguous", "tiles_interleaved", "clip_weak_scaling"):
             if k in result:
                 line[k] = {kk: result[k].get(kk) for kk in ("value", "unit", "ms_per_step", "scaling", "frames_per_step")}

@@ -440,7 +440,8 @@ def log(msg):
 
 REF_SCHEDULE = (1, 8)   # renderer.py:513
 PMC_SUMMARY = "r4_final_pmc_summary.json"   # written by tools/profile_bench.sh from rocprofv3 --pmc passes of this same command
-F16_SLICE_MFMAS = 59    # v_mfma_f32_16x16x32_f16 per 16-row slice of lz_k_triplane_head_f16
+F16_SLICE_MFMAS = 30    # v_mfma_f32_32x32x16_f16 per 16 sample rows (60 per 32-sample slice of lz_head16w_slice; rounds 2-4: 59 16x16x32 per 16)
+F16_MFMA_CYCLES = 32    # matrix-pipe cycles of one v_mfma_f32_32x32x16_f16 (MI355X_MICROARCH.md)
 
 
 F16_PMC_SUMMARY = "r4_f16_head_pmc_summary.json"   # tools/profile_bench.sh f16 over the current kernel
@@ -460,23 +461,23 @@ def f16_head_roofline(samples, rows, steps, head_total_ms, n_launch, launches_wi
     v_mfma_f32_16x16x32_f16 per 16-row slice); what holds it is vector-instruction ISSUE (gathers' index arithmetic, conversions, the
     march): the PMC passes (profiles/r4_f16_head_pmc_summary.json, rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VALU_MFMA_MOPS_F16 over this
     same command) give the instructions per slice, and with 4 issue cycles per wave64 VALU instruction and 8 per MFMA
-    (MI355X_MICROARCH.md, cycle constants) the `valu_issue` block prices that stream -- a labelled DIAGNOSTIC of where the time goes,
+    (MI355X_MICROARCH.md, cycle constants; per 16 sample rows = half a 32-sample slice) the `valu_issue` block prices that stream -- a labelled DIAGNOSTIC of where the time goes,
     not a roofline: fewer instructions raise it."""
     t = head_total_ms * 1e-3
     sps = samples * steps / t
     tflops = FLOP_PER_SAMPLE * sps / 1e12
     r = dict(bound="mfma", achieved=round(tflops, 2), peak=F16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tflops / F16_MFMA_PEAK_TFLOPS, 4), traffic=None,
-             kernel="lz_k_frame<1,S,ROWS> (march+f16 head+composite)" if fused else "lz_k_triplane_head_f16",
+             kernel="lz_k_frame<1,S,ROWS> (march+f16 head+composite)" if fused else "lz_k_triplane_head_f16w",
              avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5), avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5),
              launches=n_launch, head_time_share=round(t / dt, 4), head_ms_per_step=round(head_total_ms / steps, 4), rows_per_frame=rows,
              samples_per_s=round(sps, 1), flop_per_sample=FLOP_PER_SAMPLE,
-             matrix_pipe_busy_frac=round(F16_SLICE_MFMAS * 16 * (rows / 16) * steps / (t * 2.4e9 * 1024), 4))
+             matrix_pipe_busy_frac=round(F16_SLICE_MFMAS * F16_MFMA_CYCLES * (rows / 16) * steps / (t * 2.4e9 * 1024), 4))
     if fused and n_rays and packed_bytes:   # 24 B/ray in + ~68 B/ray out + the packed f16 weights every workgroup stages into its LDS once
         r["algorithmic_bytes_per_launch"] = round(92 * n_rays + min(256, (n_rays + 63) // 64) * packed_bytes)
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", F16_PMC_SUMMARY)))
-        k = next(kk for kk in pmc["SQ_INSTS_VALU"] if kk.startswith("lz_k_frame<1,")) if fused else "lz_k_triplane_head_f16"
-        n_mfma = pmc["SQ_INSTS_VALU_MFMA_MOPS_F16"][k]["avg_per_launch"] / 32.0       # MOPS counts 512-FLOP units: 32 per 16x16x32 MFMA
+        k = next(kk for kk in pmc["SQ_INSTS_VALU"] if kk.startswith("lz_k_frame<1,")) if fused else "lz_k_triplane_head_f16w"
+        n_mfma = pmc["SQ_INSTS_VALU_MFMA_MOPS_F16"][k]["avg_per_launch"] / 64.0       # MOPS counts 512-FLOP units: 64 per 32x32x16 MFMA
         slices = n_mfma / F16_SLICE_MFMAS
         valu = pmc["SQ_INSTS_VALU"][k]["avg_per_launch"] - n_mfma
         cyc = (4.0 * valu + 8.0 * n_mfma) / slices                                      # issue-port cycles per 16-row slice
@@ -617,7 +618,7 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
                 leg.update(loop_mode_value=legl["value"], loop_mode_ms_per_step=legl["ms_per_step"], loop_mode_image_equal=bool(torch.equal(img16, img16l)))
             diff = (img16 - image).double()
             mse16 = float((diff ** 2).mean())
-            leg.update(dtype="f16 (f32 accumulate, torch-autocast rounding)", kernel="lz_k_triplane_head_f16",
+            leg.update(dtype="f16 (f32 accumulate, torch-autocast rounding)", kernel="lz_k_triplane_head_f16w",
                        max_abs_diff_vs_f32_image=float(diff.abs().max()), psnr_vs_f32_image_db=round(-10 * np.log10(max(mse16, 1e-300)), 2),
                        reference_schedule_value=leg8["value"], reference_schedule_ms_per_step=leg8["ms_per_step"],
                        reference_schedule_image_equal=bool(torch.equal(img16, img16b)),

@@ -1,7 +1,7 @@
 #!/bin/bash
-# one rank's tile of a frame sharded 2 / 4 / 8 ways on ONE GPU (no collective): tools/shard_sweep.sh [f32|f16] -> gpurun_out/r4_shards_<prec>.log
+# one rank's tile of a frame sharded 2 / 4 / 8 ways on ONE GPU (no collective): tools/shard_sweep.sh [f32|f16] -> gpurun_out/r5_shards_<prec>.log
 PREC=${1:-f32}
-LOG=gpurun_out/r4_shards_$PREC.log
+LOG=gpurun_out/r5_shards_$PREC.log
 : > $LOG
 for so in 1 2 4 8; do for tl in interleaved contiguous; do
   if [ $so = 1 ] && [ $tl = contiguous ]; then continue; fi
