@@ -250,7 +250,7 @@ def main():
     roofline = dict(bound="mfma", achieved=round(achieved_tflops, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved_tflops / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
                     kernel="lz_k_frame<0,S,1> (march+head+composite)" if args.mode == "fused" else "lz_k_triplane_head<false>",
-                    kernel_note="one persistent launch per frame",
+                    kernel_note="the phase-1 persistent launch of each frame (lz_timing pair); the cap's histogram / phase-2 launches are outside it and return at once on this frame (no ray reaches max_steps)",
                     avg_launch_ms=round(head_total_ms / max(launches_with_work, 1), 5),
                     avg_launch_ms_all=round(head_total_ms / max(n_launch, 1), 5), launches=n_launch,
                     launches_with_work=launches_with_work, flop_per_sample=FLOP_PER_SAMPLE,

@@ -667,7 +667,10 @@ typedef struct {
 int lz_occupied_bounds(const uint8_t* bitfield, uint32_t C, uint32_t H, float bound, uint32_t margin, int32_t* workspace,
                        float* aabb6, lz_stream_t stream);
 struct lz_timing;
-/* `timing` (may be NULL): bracket the persistent kernel with one event pair on the launch stream (lz_timing_create) */
+/* `timing` (may be NULL): bracket the PHASE-1 persistent launch with one event pair on the launch stream (lz_timing_create).  Under
+ * cap_mode 1 the histogram / schedule kernels, the phase-2 persistent launch (rays parked at max_steps) and lz_k_frame_counts run behind
+ * the pair and are NOT in it: where the cap binds (max_steps 16, small tiles) the pair understates the frame's kernel time -- time the
+ * whole call (bench.py's ms_per_step) or take the kernel trace there; where it does not bind those launches return at once (~10 us) */
 int lz_frame_render(const lz_frame_fused* f, struct lz_timing* timing, lz_stream_t stream);
 /* cap_mode 1 with defer_finish: schedule replay from cap_ws, phase 2, marched counts (see above); lz_frame_render calls it itself otherwise */
 int lz_frame_finish(const lz_frame_fused* f, lz_stream_t stream);

@@ -360,7 +360,7 @@ template <> struct LzfHead<1> {   // f16: 32-sample slices on v_mfma_f32_32x32x1
     __device__ static __forceinline__ void stage(const Args& P, float* lds, int, Ctx& c) { lz_head16w_stage(P, reinterpret_cast<lz_h8*>(lds), LZF_WG, c); }
     template <typename ShFn>
     __device__ static __forceinline__ void slice(const Ctx& c, int lane, float x, float y, float z, ShFn f, Out& o) {
-        lz_head16w_slice<true>(c, lane, x, y, z, f, o);
+        lz_head16w_slice<true, LZ_F16W_PRIO != 0>(c, lane, x, y, z, f, o);
     }
 };
 
@@ -423,7 +423,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
     if constexpr (S > 1) {
         const int j = s % S, lead = s - j;              // slot s = step j of the ray whose state sits at slot `lead`
         for (;;) {
-            if constexpr (PREC != 1) __builtin_amdgcn_s_setprio(2);   // see the S = 1 loop
+            if constexpr (PREC != 1 || LZ_F16W_PRIO != 0) __builtin_amdgcn_s_setprio(2);   // see the S = 1 loop
             // ---------------- refill + march (group leaders): up to S samples per ray into the staging fields ----------------
             const bool leader = slot_lane && j == 0;
             int ray = leader ? sloti[SF_RAY * NS + s] : -1;
@@ -629,7 +629,7 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
         for (;;) {
             // f32 heads: refill, march and the gather's address work run at a raised wave priority and the slice drops it once its loads are
             // issued (lz_head_gather<YIELD>): a wave that is about to wait on memory gets there first, the matrix phases fill the time
-            if constexpr (PREC != 1) __builtin_amdgcn_s_setprio(2);
+            if constexpr (PREC != 1 || LZ_F16W_PRIO != 0) __builtin_amdgcn_s_setprio(2);
             // ---------------- refill + march: every slot ends with a sample, crossing empty space, or empty with the queue dry ----------------
             int ray = slot_lane ? sloti[SF_RAY * NS + sl] : -1;
             bool have = false;

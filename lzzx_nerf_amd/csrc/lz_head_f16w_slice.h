@@ -116,18 +116,22 @@ __device__ __forceinline__ void lz_head16w_stage(const LzHead16Args& P, lz_h8* w
     hc.unc_const = lz_softplusf(0.0f);   // test mode (network.py:243-249, 278)
 }
 
-template <bool IN_RANGE = false, typename ShFn>   // SH(4) source: LzShFromDir (lz_head_slice.h) or the frame kernel's per-ray LDS copy
+#ifndef LZ_F16W_PRIO
+#define LZ_F16W_PRIO 1   // the frame kernel runs march + gather addresses at a raised wave priority and drops it once a gather call has issued its loads (same-box A/B, three alternations: 1.789 -> 1.783, 1.800 -> 1.791 ms, cfg5 0.770 -> 0.762; -DLZ_F16W_PRIO=0 switches it off)
+#endif
+template <bool IN_RANGE = false, bool YIELD = false, typename ShFn>   // SH(4) source: LzShFromDir (lz_head_slice.h) or the frame kernel's per-ray LDS copy
 __device__ __forceinline__ void lz_head16w_slice(const LzHead16Ctx& hc, int lane, float px, float py, float pz, ShFn shfn, LzHead16wOut& out) {
     const int h = lane >> 5;
     // ---------------- gather (f32, lz_head_gather.h, the f32 kernels' arithmetic): 18 features of this lane's sample, 2 x 36 loads ----------------
     lz_h8 bx[3];
     {
         float e0[9], e1[9];
-        lz_head_gather<IN_RANGE, LZ_GATHER_PACK16, false, false, 2>(hc.emb, hc.tab, px, py, pz, h, hc.bound, hc.two_bound, e0);
+        lz_head_gather<IN_RANGE, LZ_GATHER_PACK16, YIELD, false, 2>(hc.emb, hc.tab, px, py, pz, h, hc.bound, hc.two_bound, e0);
         // h_round2: every f32 feature exists first, then its half (no v_fma_mixlo_f16 with the interpolation's last fma)
         const lz_u4v w0 = {h_round2(e0[0], e0[1]), h_round2(e0[2], e0[3]), h_round2(e0[4], e0[5]), h_round2(e0[6], e0[7])};
         bx[0] = __builtin_bit_cast(lz_h8, w0);
-        lz_head_gather<IN_RANGE, LZ_GATHER_PACK16, false, false, 2>(hc.emb, hc.tab, px, py, pz, 6 + h, hc.bound, hc.two_bound, e1);
+        if constexpr (YIELD) __builtin_amdgcn_s_setprio(2);
+        lz_head_gather<IN_RANGE, LZ_GATHER_PACK16, YIELD, false, 2>(hc.emb, hc.tab, px, py, pz, 6 + h, hc.bound, hc.two_bound, e1);
         const lz_u4v w1 = {h_round2(e0[8], e1[0]), h_round2(e1[1], e1[2]), h_round2(e1[3], e1[4]), h_round2(e1[5], e1[6])};
         const lz_u4v w2 = {h_round2(e1[7], e1[8]), 0u, 0u, 0u};
         bx[1] = __builtin_bit_cast(lz_h8, w1);

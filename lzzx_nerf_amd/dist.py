@@ -193,11 +193,13 @@ class PeerTileGatherer:
         dist.barrier(group=self.group)   # nobody proceeds (or frees) before every import has succeeded
 
     def check(self, synchronize=True):
-        """raise if any wait so far has expired.  synchronize=False looks only at host copies that have already landed (what gather() does)"""
+        """raise if any wait so far has expired.  synchronize=False looks only at host copies that have already landed (what gather() does):
+        the device word is sticky (lz_wait_flags only ever sets it), so whatever copy has reached the pinned host word is read regardless of
+        the newest event -- an EARLIER frame's expired wait is seen even while the newest copy is still in flight"""
         if self._checked is not None:
             if synchronize:
                 self._checked.synchronize()
-            if (synchronize or self._checked.query()) and int(self._timed_out_host[0]) != 0:
+            if int(self._timed_out_host[0]) != 0:
                 raise RuntimeError("PeerTileGatherer: a wait for the peers' tiles expired after %d polls (rank %d, frame <= %d): the frame buffer is torn; "
                                    "raise max_polls or find the stalled peer" % (self.max_polls, self.rank, self.k))
 
@@ -241,9 +243,15 @@ class PeerTileGatherer:
         tile.record_stream(self.comm)
         return self.frame[i]
 
-    def wait(self):
+    def wait(self, check=True):
+        """order the current stream behind the hand-off of the newest frame.  check (default): also block the HOST until that frame's flag
+        wait has reported and raise if it -- or any earlier one -- expired: the caller is about to consume the frame, a torn one must not
+        pass silently (the error used to surface only in the NEXT gather(), never for the last frame).  check=False keeps the
+        stream-only ordering for callers that poll check() themselves."""
         if self.comm is not None:
             torch.cuda.current_stream().wait_stream(self.comm)
+            if check:
+                self.check(synchronize=True)
 
 
 class ShardedFrame:

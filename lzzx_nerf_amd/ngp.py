@@ -111,9 +111,10 @@ class HashgridRenderer:
     """Inference renderer of one FusedHashgridNeRF + occupancy bitfield: the reference's loop (renderer.py:495-548: march n_step samples per
     alive ray, network, composite_rays, drop dead rays, n_step = max(min(budget_factor * N // n_alive, n_step_cap), 1), stop at max_steps)
     with the state on the device; (budget_factor, n_step_cap) = (1, 8) is the reference's schedule -- same pixels under any schedule for
-    rays that end before max_steps, and exactly the reference's cap semantics under (1, 8)."""
+    rays that end before max_steps, and exactly the reference's cap semantics under (1, 8), the default (like TriplaneRenderer /
+    NetworkRenderer; fatter schedules such as (8, 8) are faster and differ on rays that reach max_steps)."""
 
-    def __init__(self, net, density_bitfield, bound=1.0, cascade=None, grid_size=128, aabb=None, min_near=0.05, budget_factor=8, n_step_cap=8):
+    def __init__(self, net, density_bitfield, bound=1.0, cascade=None, grid_size=128, aabb=None, min_near=0.05, budget_factor=1, n_step_cap=8):
         import math
         self.net = net
         self.bound = float(bound)

@@ -19,13 +19,13 @@ _pos = [a for a in sys.argv[1:] if not a.startswith("-")]
 KERNEL = _pos[0] if _pos else "_Z10lz_k_frameILi1ELi1ELi2EEvN7LzfHeadIXT_EE4ArgsE8LzFrameK"
 
 MARKS = {
-    "lz_head_f16_slice.h": [("    float encx[9];\n    lz_head_gather<IN_RANGE", "gather"), ("    lz_h8 bx[2];", "bx"), ("    lz_h8 att16;   // [4 t + r]", "aud"),
-                            ("    float eyeatt = 0.0f;", "eye"), ("    lz_h8 geo16[2];", "sigma"), ("    float rgb[3];\n    {\n        shfn.prepare();", "colour"),
-                            ("    out.sigma = sigma;", "end")],
+    "lz_head_f16w_slice.h": [("    lz_h8 bx[3];\n", "gather"), ("    lz_h8 att16[2];   // [u][j]", "aud"), ("    {   // ambient_aud = || att ||_2", "norm"),
+                             ("    float eyeatt = 0.0f;", "eye"), ("    lz_h8 geo16[4];", "sigma"), ("        lz_h8 b1[6];\n", "colour"),
+                             ("    out.eyeatt = eyeatt;", "end")],
     "lz_head_gather.h": [("    bool oobc[3];", "g_pos"), ("    uint32_t rowH[2][3][2]", "g_rows"), ("    float gv[9][4];", "g_loads"),
                          ('    asm volatile("" ::"v"(gv[0][0])', "g_pin"), ("    if constexpr (PACK) {", "g_interp")],
     "lz_frame.hip": [("            int ray = slot_lane ? sloti[SF_RAY * NS + sl] : -1;\n            bool have = false;", "F_refill_march"),
-                     ("            typename HD::Out o;\n#pragma unroll 1", "F_head"), ("            __builtin_amdgcn_wave_barrier();     // the parked outputs", "F_composite")],
+                     ("            typename HD::Out o;\n            if constexpr (PREC == 1) {", "F_head"), ("            __builtin_amdgcn_wave_barrier();     // the parked outputs", "F_composite")],
 }
 
 

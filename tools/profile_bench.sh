@@ -25,7 +25,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d ${P}_pmc_write -- python3 $REP
 echo "pmc write done"
 cd $REPO
 python3 tools/summarize_pmc.py ${P}_pmc_sq ${P}_pmc_inst ${P}_pmc_fetch ${P}_pmc_write > $OUT/pmc_summary_${PREC}.json
-find ${P}_kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_${PREC}.csv \;
+# per-kernel median / mean without the warm-up launches (rocprofv3's own --stats table averages every launch, warm-ups included)
+python3 tools/kernel_medians.py ${P}_kt --skip 2 > $OUT/kernel_stats_${PREC}.csv
+cp ${P}_kt_bench.json $OUT/bench_under_rocprof_${PREC}.json
 find $OUT -name "*.db" -delete
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -delete
