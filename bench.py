@@ -77,6 +77,8 @@ def parse_args():
                     help="fused training head: f16 = the forward in the reference's autocast arithmetic on the f16 matrix cores (implies f16 records)")
     ap.add_argument("--train-backward", default="f32", choices=["f32", "f16"],
                     help="fused training head: f16 = the data-gradient products on the f16 matrix cores (autocast's half backward; implies f16 records)")
+    ap.add_argument("--train-keep-records", action="store_true",
+                    help="all-f16 training leg: the recorded pair of rounds 2-4 (1 216 B of record + state per sample) instead of the recomputing one (80 B)")
     ap.add_argument("--train-recompute", action="store_true",
                     help="fused training head with record=False: the backward recomputes the forward instead of reading what it recorded")
     ap.add_argument("--train-dp", action="store_true",

@@ -494,6 +494,21 @@ int lz_triplane_head_backward_recorded_dw16(const lz_head_params* p, const float
                                             const lz_head_bwd_out* out, const void* packed_bwd16, uint32_t k_sig0, float* dW_x3,
                                             float* dW_aud1, float* dW_sig0, float* dW_sig1, float* dW_c1h, void* workspace,
                                             lz_stream_t stream);
+/* The same `-O` step with the MLP RECOMPUTED in the backward (ABI 10): nothing travels from the forward to the backward but the enc_x
+ * operand the MLP started from -- encx16: [ceil(M / 16)][5][64] dwords, LZ_ENCX16_BYTES(M) = 80 bytes per sample instead of the 1 216 of
+ * f16 record + state -- and the view directions.  lz_triplane_head_forward_encx_f16 = lz_triplane_head_forward_record_f16 (same arithmetic,
+ * same five outputs, bit for bit) writing encx16 only; lz_triplane_head_backward_encx_dw16 = lz_triplane_head_backward_recorded_dw16 whose
+ * waves first run the f16 forward chain of their slice again (packed_f16: the lz_head_pack_weights_f16 image the forward used; packed_unc:
+ * lz_head_pack_unc_f16) and keep the layer inputs, state pairs and ReLU masks in registers; packed_bwd16 is required (data gradient on the
+ * f16 matrix cores).  Same gradients as the recorded pair, bit for bit.  p->packed: the f32 image (lz_head_pack_weights), training mode. */
+#define LZ_ENCX16_BYTES(M) ((size_t)(((M) + 15u) / 16u) * 1280u)
+int lz_triplane_head_forward_encx_f16(const lz_head_params* p, const void* packed_unc, const float* xyzs, const float* dirs, uint32_t M,
+                                      float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, void* encx16, lz_stream_t stream);
+int lz_triplane_head_backward_encx_dw16(const lz_head_params* p, const void* packed_f16, const void* packed_unc, const void* encx16,
+                                        const float* dirs, uint32_t M, const float* g_sigma, const float* g_rgb, const float* g_amb_aud,
+                                        const float* g_amb_eye, const float* g_unc, const lz_head_bwd_out* out, const void* packed_bwd16,
+                                        uint32_t k_sig0, float* dW_x3, float* dW_aud1, float* dW_sig0, float* dW_sig1, float* dW_c1h,
+                                        void* workspace, lz_stream_t stream);
 
 /* Device-resident inference loop (renderer.py:495-548): no host synchronisation inside the frame, 3 launches per iteration:
  *     lz_loop_march -> lz_triplane_head_forward(count = state words + LZ_LOOP_NEXT + 2) -> lz_loop_composite.

@@ -145,6 +145,9 @@ SIGNATURES = {
     "lz_triplane_plane_coords": [vp, u32, f32, vp, vp],
     "lz_head_pack_unc_f16": [vp, vp, vp, vp],
     "lz_triplane_head_forward_record_f16": [C.POINTER(HeadParams), vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_triplane_head_forward_encx_f16": [C.POINTER(HeadParams), vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp],
+    "lz_triplane_head_backward_encx_dw16": [C.POINTER(HeadParams), vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, C.POINTER(HeadBwdOut), vp, u32, vp, vp, vp, vp, vp,
+                                            vp, vp],
     "lz_triplane_head_grad_w_f16": [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp],
     "lz_triplane_head_backward_recorded_dw16": [C.POINTER(HeadParams), vp, vp, u32, vp, vp, vp, vp, vp, C.POINTER(HeadBwdOut), vp, u32, vp, vp, vp, vp, vp,
                                                 vp, vp],

@@ -33,6 +33,11 @@ struct LzHeadBwdArgs {
     const float *g_sigma, *g_rgb, *g_amb_aud, *g_amb_eye, *g_unc;     // upstream gradients [M], [M,3], [M], [M], [M]
     lz_head_bwd_out o;
     const void* wb16;   // transposed f16 fragments (lz_head_pack_weights_bwd_f16) for the backward on the f16 matrix cores, else null
+    // the recomputing arrangement (lz_k_triplane_head_backward_rec<.., RC>): the forward's f16 weight image (lz_head_pack_weights_f16), unc_net's
+    // five fragments (lz_head_pack_unc_f16) and the samples' view directions; the kernel's `st` argument is then the forward's encx16
+    const void* fw16 = nullptr;
+    const void* unc16 = nullptr;
+    const float* dirs = nullptr;
 };
 
 // dX = W^T dY on the matrix cores from the FORWARD fragments of `LAYER` (see the header comment for the address map)

@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "lz_head_bwd_common.h"
+#include "lz_head_fwd16_chain.h"   // RC: the f16 forward chain, recomputed in the backward
 #include "lz_head_gather.h"
 #include "lz_head_slice.h"
 #include "lzzx_sh_eval.h"
@@ -345,14 +346,25 @@ lz_k_triplane_head_forward_rec(LzHeadArgs P, const float* __restrict__ xyzs, con
 // ends with a second barrier (all reads done) before the next one may write.
 #define LZ_FUSE_AREA_TILES 11                                 // largest segment: c1h, 5 G + 6 X tiles
 #define LZ_FUSE_LDS_FLOATS(NBUF) ((NBUF) * 8 * LZ_FUSE_AREA_TILES * 128)   // buffers x 8 areas x 11 tiles x 512 bytes = 44 KB each
-template <bool H16, bool B16, bool FUSE = false>
+// RC (round 5; with H16, B16, FUSE): NOTHING is read back from the forward but the enc_x operand (80 bytes per sample, `st` = encx16 of
+// lz_triplane_head_forward_encx_f16) and the view directions: the wave recomputes the f16 forward chain of its slice (lz_fwd16_chain, the very
+// function the forward ran: 64 MFMAs) with a sink that keeps the layer inputs, the state pairs and the masks in registers, and goes on as
+// FUSE does.  The f16 forward fragments (59 + 5 KB) take the place of the second G / X buffer in LDS, so every segment pays the second
+// barrier of the single-buffer arrangement.  Per sample and step: 80 B written by the forward and 80 + 40 B read here, instead of
+// 1 216 B of record + state written and read.
+template <bool H16, bool B16, bool FUSE = false, bool RC = false>
 __global__ void __launch_bounds__(LZ_BWD_WG, LZ_BWD_WG / 256)
 lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, uint32_t M, float* __restrict__ parts) {
     static_assert(!FUSE || H16, "the fused weight-gradient products run on half operands (f16 records)");
+    static_assert(!RC || (H16 && B16 && FUSE), "the recomputing arrangement is the all-f16 one with fused weight gradients");
     constexpr int NFRAG = LZ_FRAGS_ALL;
     constexpr int WV = B16 ? LZ_BFRAGS * 128 : NFRAG * 64, TAB = WV + LZ_WV_FLOATS;
-    constexpr uint32_t NBUF = B16 ? 2u : 1u;          // FUSE: LDS buffers of G / X tiles
-    __shared__ __align__(16) float wl[TAB + LZ_LVTAB_WORDS + (FUSE ? LZ_FUSE_LDS_FLOATS(NBUF) : 0)];
+    constexpr uint32_t NBUF = (B16 && !RC) ? 2u : 1u;          // FUSE: LDS buffers of G / X tiles
+    constexpr int FUSE_FLOATS = FUSE ? LZ_FUSE_LDS_FLOATS(NBUF) : 0;
+    constexpr int FW16 = TAB + LZ_LVTAB_WORDS + FUSE_FLOATS;                        // RC: f16 forward fragments, then unc_net's five
+    constexpr int FW16_FLOATS = RC ? (H_FRAGS + LZ_UNC16_FRAGS) * 64 * 4 : 0;
+    static_assert((FW16 + FW16_FLOATS) * 4 <= 163840, "LDS budget of one workgroup per CU");
+    __shared__ __align__(16) float wl[FW16 + FW16_FLOATS];
     const LzHeadArgs& P = A.fwd;
     const lz_head_bwd_out& O = A.o;
     const uint32_t n_slices = (M + 15) / 16;
@@ -366,6 +378,16 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         if (threadIdx.x < LZ_WV_FLOATS) wl[WV + threadIdx.x] = P.packed[LZ_FRAGS_ALL * 64 + threadIdx.x];
         if (threadIdx.x < 32) wl[TAB + LZ_LVTAB_ENCA + threadIdx.x] = P.enc_a[threadIdx.x];
         if (threadIdx.x == 0) reinterpret_cast<int*>(wl + TAB)[LZ_LVTAB_QUEUE] = 0;
+        if constexpr (RC) {   // the forward's weight images and the half tables its chain reads (lz_head16_stage)
+            const float4* f16 = reinterpret_cast<const float4*>(A.fw16);
+            const float4* u16 = reinterpret_cast<const float4*>(A.unc16);
+            float4* d16 = reinterpret_cast<float4*>(wl + FW16);
+            for (int i = threadIdx.x; i < H_FRAGS * 64; i += LZ_BWD_WG) d16[i] = f16[i];
+            for (int i = threadIdx.x; i < LZ_UNC16_FRAGS * 64; i += LZ_BWD_WG) d16[H_FRAGS * 64 + i] = u16[i];
+            int* tab = reinterpret_cast<int*>(wl + TAB);
+            if (threadIdx.x < 16) tab[LZ_LVTAB_ENCA16 + threadIdx.x] = (int)h_cvt2(P.enc_a[2 * threadIdx.x], P.enc_a[2 * threadIdx.x + 1], false);
+            if (threadIdx.x < 2) tab[LZ_LVTAB_IND16 + threadIdx.x] = P.ind_code ? (int)h_cvt2(P.ind_code[2 * threadIdx.x], P.ind_code[2 * threadIdx.x + 1], false) : 0;
+        }
     }
     __syncthreads();
     // one spelling for both matrix paths
@@ -436,6 +458,56 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         in.g_r0 = A.g_rgb[row * 3]; in.g_r1 = A.g_rgb[row * 3 + 1]; in.g_r2 = A.g_rgb[row * 3 + 2];
         return in;
     };
+    // RC: what a slice needs from memory -- its enc_x operand (five dwords per lane), the view direction and the upstream gradients
+    struct InRc {
+        lz_v4 bx0;
+        float bx1, d0, d1, d2;
+        float g_sig, g_aa, g_ae, g_un, g_r0, g_r1, g_r2;
+    };
+    auto fetch_rc = [&](int sl) -> InRc {
+        uint32_t gs = slice_lo + (uint32_t)sl;
+        if (gs >= slice_hi) gs = slice_hi - 1;
+        const uint32_t b = gs * 16 + s;
+        const size_t row = b < M ? b : M - 1;
+        const float* eb = st + (size_t)gs * (5 * 64) + lane;      // encx16 [slice][5][lane]
+        InRc in;
+        in.bx0 = lz_v4{eb[0], eb[64], eb[128], eb[192]};
+        in.bx1 = eb[256];
+        in.d0 = A.dirs[row * 3]; in.d1 = A.dirs[row * 3 + 1]; in.d2 = A.dirs[row * 3 + 2];
+        in.g_sig = A.g_sigma[row]; in.g_aa = A.g_amb_aud[row]; in.g_ae = A.g_amb_eye ? A.g_amb_eye[row] : 0.0f; in.g_un = A.g_unc[row];
+        in.g_r0 = A.g_rgb[row * 3]; in.g_r1 = A.g_rgb[row * 3 + 1]; in.g_r2 = A.g_rgb[row * 3 + 2];
+        return in;
+    };
+    // ... and the sink of the recomputed chain: the words the recording forward stored, kept in registers (constant indices after inlining)
+    // Registers are the budget (256 at two waves per SIMD, 60 of them weight-gradient accumulators): the sink keeps only what cannot be had
+    // again cheaply -- the inputs of sigma_net.1 / .2 and color_net.0's SH columns (X_S1, X_S2C), color_net.1's / unc_net.1's / eye_att_net.1's
+    // inputs and att as packed halves.  sigma_net.0's input is rebuilt from the enc_x operand, att and the eye term where its segment needs it
+    // (a permutation of halves, see rc_sig0_pair), and aud_ch_att_net.1's input by running aud_ch_att_net.0 once more (8 MFMAs).
+    struct RegSink {
+        lz_v4 xp[10];    // X pairs; kept: LZ_R16_X_S1 / 2 .. LZ_R16_X_S2C / 2 + 2 (5 .. 9)
+        lz_v4 sp[6];     // state pairs LZ_S16_C1 / 16 (2, 3), LZ_S16_U1 / 16 (4), LZ_S16_E1 / 16 (5)
+        lz_v2u att16[2]; // att as eight halves (exact: the values are halves)
+        __device__ __forceinline__ void x_pair_h8(int pair, const lz_h8& b) { if (pair >= LZ_R16_X_S1 / 2) xp[pair] = lz_pair_words_h8(b); }
+        __device__ __forceinline__ void x_pair_f(int pair, float l0, float l1, float l2, float l3, float h0, float h1, float h2, float h3) {
+            if (pair >= LZ_R16_X_S1 / 2) xp[pair] = lz_pair_words_f(l0, l1, l2, l3, h0, h1, h2, h3);
+        }
+        __device__ __forceinline__ void s_pair_h8(int pair, const lz_h8& b) { sp[pair] = lz_pair_words_h8(b); }
+        __device__ __forceinline__ void s_att(const lz_v4& w0, const lz_v4& w1) {
+            att16[0] = lz_v2u{h_cvt2(w0[0], w0[1], false), h_cvt2(w0[2], w0[3], false)};
+            att16[1] = lz_v2u{h_cvt2(w1[0], w1[1], false), h_cvt2(w1[2], w1[3], false)};
+        }
+    };
+    LzHead16Ctx hc16;
+    if constexpr (RC) {
+        hc16.wl = reinterpret_cast<const lz_h8*>(wl + FW16);
+        hc16.tab = reinterpret_cast<const int*>(wl + TAB);
+        hc16.lenca = wl + TAB + LZ_LVTAB_ENCA;
+        hc16.emb[0] = hc16.emb[1] = hc16.emb[2] = nullptr;
+        hc16.ind_code = P.ind_code;
+        hc16.bound = P.bound; hc16.two_bound = 2.0f * P.bound;
+        hc16.has_eye = has_eye; hc16.eye_v = eye_v; hc16.unc_const = 0.0f;
+    }
+    const float indq = (RC && P.ind_code) ? P.ind_code[q] : 0.0f;
     // ---- FUSE: accumulators of the tiles this wave owns, the two LDS buffers, the helpers of the five segments --------------------
     const int wave = threadIdx.x >> 6;
     const uint32_t n_local = slice_hi - slice_lo;
@@ -455,7 +527,10 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
     // takes are samples kg, 4 + kg, 8 + kg, 12 + kg -- the k-slot order both operands of lz_k_head_grad_w16 use
     const int rho = 4 * (s & 3) + (s >> 2);
     int slice = FUSE ? wave : grab();       // FUSE: static rounds of 8 slices, slice = 8 round + wave
-    In nx = fetch(slice);
+    In nx;
+    InRc nxr;
+    if constexpr (RC) nxr = fetch_rc(slice);
+    else nx = fetch(slice);
     for (;;) {
         if constexpr (FUSE) {
             if ((uint32_t)(slice - wave) >= n_local) break;                     // workgroup-uniform: the round's first slice
@@ -472,7 +547,31 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         const size_t row = m;
         float* rb = lz_blk(O.rec, gslice, H16 ? LZ_BWD_REC16 / 2 : LZ_BWD_REC, s);   // f16: rows counted in dwords
         float* dencq = O.denc + (size_t)q * M + row;
-        const In in = nx;
+        In in;
+        RegSink rs;
+        lz_v4 rc_bx0 = {0.0f, 0.0f, 0.0f, 0.0f};
+        float rc_bx1 = 0.0f, rc_eyeatt = 0.0f;
+        if constexpr (RC) {
+            // the forward of this slice again, from its enc_x operand: the layer inputs / state pairs land in `rs`, the scalars and masks in `fo`
+            const InRc ir = nxr;
+            lz_h8 bx[2];
+            bx[0] = __builtin_bit_cast(lz_h8, ir.bx0);
+            bx[1] = __builtin_bit_cast(lz_h8, lz_v4{ir.bx1, 0.0f, 0.0f, 0.0f});
+            LzFwd16Out fo;
+            lz_fwd16_chain(hc16, hc16.wl + H_FRAGS * 64, lane, bx, ir.d0, ir.d1, ir.d2, indq, rs, fo);
+            const lz_v4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            in.att0 = z; in.att1 = z;      // RC: att comes from rs.att16 where it is used
+            rc_bx0 = ir.bx0; rc_bx1 = ir.bx1; rc_eyeatt = fo.eyeatt;
+            in.c0 = rs.sp[LZ_S16_C1 / 16]; in.c1 = rs.sp[LZ_S16_C1 / 16 + 1]; in.c2 = z; in.c3 = z;
+            in.u0 = rs.sp[LZ_S16_U1 / 16]; in.u1 = z;
+            in.e = has_eye ? rs.sp[LZ_S16_E1 / 16] : z;
+            const float sc = q == 0 ? fo.norm : (q == 1 ? fo.eyeatt : (q == 2 ? fo.upre : fo.sigma));   // (the state row's arrangement)
+            in.mk = lz_v4{__uint_as_float(fo.mk_a1 | (fo.mk_s1 << 16)), __uint_as_float(fo.mk_s2 | (fo.mk_c1 << 16)), __uint_as_float(fo.mk_u1 | (fo.mk_e1 << 8)), sc};
+            in.clr = lz_v4{fo.cpre[0], fo.cpre[1], fo.cpre[2], 0.0f};
+            in.g_sig = ir.g_sig; in.g_aa = ir.g_aa; in.g_ae = ir.g_ae; in.g_un = ir.g_un; in.g_r0 = ir.g_r0; in.g_r1 = ir.g_r1; in.g_r2 = ir.g_r2;
+        } else {
+            in = nx;
+        }
         const int next = FUSE ? slice + 8 : grab();
         if constexpr (!FUSE) nx = fetch(next);   // FUSE fetches later in the slice (after the sig0 segment): 51 registers less across the chain
         // FUSE helpers (all lanes take part in every LDS access: the transposing read needs EXEC all ones)
@@ -483,7 +582,32 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             if (!valid) w = lz_v2u{0u, 0u};
             *reinterpret_cast<lz_v2u*>(ar + tile * 128 + rho * 8 + 2 * q) = w;
         };
-        auto x_load = [&](int pair) -> lz_v4 { return ld4(rb + 256 * pair + 4 * q); };     // X half of the record: dword j = {tile 2 p, tile 2 p + 1} column 4 q + j
+        auto x_load = [&](int pair) -> lz_v4 {     // X half of the record: dword j = {tile 2 p, tile 2 p + 1} column 4 q + j (RC: the recomputed words)
+            if constexpr (RC) return rs.xp[pair];
+            else return ld4(rb + 256 * pair + 4 * q);
+        };
+        // RC: pair i of sigma_net.0's input as the forward's sink would have written it (lz_fwd16_chain: x_pair_f(LZ_R16_X_SIG0 / 2 + i, ...)):
+        //   pair 0 = {enc_x 2 r | enc_x 2 r + 1} = the enc_x operand's first four dwords as they are
+        //   pair 1 = {enc_x 8 | encw 0}, {eye term | encw 1}, {0 | encw 2}, {0 | encw 3};   pair 2 = {encw 4 + r | 0}   (encw = enc_a * att, halves)
+        auto rc_sig0_pair = [&](int i) -> lz_v4 {
+            if (i == 0) return rc_bx0;
+            const lz_u4 a16 = {rs.att16[0][0], rs.att16[0][1], rs.att16[1][0], rs.att16[1][1]};
+            const lz_u4 ew = __builtin_bit_cast(lz_u4, h_encw(hc16.tab, q, __builtin_bit_cast(lz_h8, a16)));
+            if (i == 2) return __builtin_bit_cast(lz_v4, lz_u4{ew[2] & 0xffffu, ew[2] >> 16, ew[3] & 0xffffu, ew[3] >> 16});
+            const _Float16 et = (has_eye && q == 0) ? h_round(eye_v * rc_eyeatt) : (_Float16)0.0f;
+            const uint32_t etw = (uint32_t)__builtin_bit_cast(uint16_t, et);
+            return __builtin_bit_cast(lz_v4, lz_u4{(__float_as_uint(rc_bx1) & 0xffffu) | (ew[0] << 16), etw | (ew[0] & 0xffff0000u), ew[1] << 16, ew[1] & 0xffff0000u});
+        };
+        // RC: aud_ch_att_net.1's input (two pairs) by running aud_ch_att_net.0 on the enc_x operand again
+        auto rc_a1_pairs = [&](lz_v4& p0, lz_v4& p1) {
+            lz_h8 bx[2];
+            bx[0] = __builtin_bit_cast(lz_h8, rc_bx0);
+            bx[1] = __builtin_bit_cast(lz_h8, lz_v4{rc_bx1, 0.0f, 0.0f, 0.0f});
+            lz_f4 a1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
+            h_layer<H_A1>(hc16.wl, lane, bx, a1);
+            p0 = lz_pair_words_h8(h_pair(a1[0], a1[1], true));
+            p1 = lz_pair_words_h8(h_pair(a1[2], a1[3], true));
+        };
         auto x_put = [&](int tile, const lz_v4& d, bool odd) {                               // one tile of the pair, de-interleaved
             float* ar = my_area0 + (seg & (NBUF - 1u)) * (8 * AREA);
             const uint32_t sel = odd ? 0x07060302u : 0x05040100u;
@@ -588,7 +712,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         const lz_v4 l_att0 = in.att0, l_att1 = in.att1, l_c0 = in.c0, l_c1 = in.c1, l_c2 = in.c2, l_c3 = in.c3, l_u0 = in.u0, l_u1 = in.u1,
                     l_e = in.e, l_mk = in.mk, l_clr = in.clr;
         const float g_sig = in.g_sig, g_aa = in.g_aa, g_ae = in.g_ae, g_un = in.g_un, g_r0 = in.g_r0, g_r1 = in.g_r1, g_r2 = in.g_r2;
-        const float att[8] = {l_att0[0], l_att0[1], l_att0[2], l_att0[3], l_att1[0], l_att1[1], l_att1[2], l_att1[3]};
+        float att[8] = {l_att0[0], l_att0[1], l_att0[2], l_att0[3], l_att1[0], l_att1[1], l_att1[2], l_att1[3]};
         float c1[16], u1[8], e1[4];
         if constexpr (H16) {
             lz_unpack_pair(l_c0, c1, c1 + 4);
@@ -688,7 +812,8 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
                 for (int t = 0; t < 4; t++) g_put(t, ds2[4 * t], ds2[4 * t + 1], ds2[4 * t + 2], ds2[4 * t + 3]);
                 x_put(4, xa[0], false); x_put(5, xa[0], true); x_put(6, xa[1], false); x_put(7, xa[1], true);             // X_S1: 4 tiles
-                xa[0] = x_load(LZ_R16_X_SIG0 / 2); xa[1] = x_load(LZ_R16_X_SIG0 / 2 + 1); xa[2] = x_load(LZ_R16_X_SIG0 / 2 + 2);
+                if constexpr (RC) { xa[0] = rc_sig0_pair(0); xa[1] = rc_sig0_pair(1); xa[2] = rc_sig0_pair(2); }
+                else { xa[0] = x_load(LZ_R16_X_SIG0 / 2); xa[1] = x_load(LZ_R16_X_SIG0 / 2 + 1); xa[2] = x_load(LZ_R16_X_SIG0 / 2 + 2); }
                 seg_sig1();
             } else {
                 if constexpr (H16) {
@@ -706,9 +831,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
                 for (int t = 0; t < 4; t++) g_put(t, ds1[4 * t], ds1[4 * t + 1], ds1[4 * t + 2], ds1[4 * t + 3]);
                 x_put(4, xa[0], false); x_put(5, xa[0], true); x_put(6, xa[1], false); x_put(7, xa[1], true); x_put(8, xa[2], false);   // X_SIG0: 5 tiles
-                xa[0] = x_load(LZ_R16_X_A1 / 2); xa[1] = x_load(LZ_R16_X_A1 / 2 + 1);
+                if constexpr (RC) rc_a1_pairs(xa[0], xa[1]);
+                else { xa[0] = x_load(LZ_R16_X_A1 / 2); xa[1] = x_load(LZ_R16_X_A1 / 2 + 1); }
                 seg_sig0();
-                nx = fetch(next);                    // the next slice's state row and upstream gradients: in flight during the last two segments
+                if constexpr (RC) nxr = fetch_rc(next);   // the next slice's enc_x operand, direction and upstream gradients
+                else nx = fetch(next);               // the next slice's state row and upstream gradients: in flight during the last two segments
             } else {
                 if constexpr (H16) {
                     lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_S1 / 2, ds1, 0);
@@ -727,6 +854,12 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
         }
         float datt[8];
         {
+            if constexpr (RC) {   // att from the packed halves the sink kept
+                const lz_u4 a16 = {rs.att16[0][0], rs.att16[0][1], rs.att16[1][0], rs.att16[1][1]};
+                const lz_h8 ah = __builtin_bit_cast(lz_h8, a16);
+#pragma unroll
+                for (int k = 0; k < 8; k++) att[k] = (float)ah[k];
+            }
             const float inv = norm > 0.0f ? g_aa / norm : 0.0f;
 #pragma unroll
             for (int t = 0; t < 2; t++)
@@ -743,7 +876,8 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 // color_net.1 (3 x 64): G = d loss / d (colour pre-activation) in columns 0 .. 2 of a tile, X = its input c1 (the state row's pairs)
                 g_put(6, q == 0 ? dc[0] : 0.0f, q == 0 ? dc[1] : 0.0f, q == 0 ? dc[2] : 0.0f, 0.0f);
                 x_put(7, l_c0, false); x_put(8, l_c0, true); x_put(9, l_c1, false); x_put(10, l_c1, true);
-                xa[0] = x_load(LZ_R16_X_SIG0 / 2); xa[1] = x_load(LZ_R16_X_SIG0 / 2 + 1);                                  // enc_x again, for x3
+                if constexpr (RC) { xa[0] = rc_sig0_pair(0); xa[1] = rc_sig0_pair(1); }
+                else { xa[0] = x_load(LZ_R16_X_SIG0 / 2); xa[1] = x_load(LZ_R16_X_SIG0 / 2 + 1); }                         // enc_x again, for x3
                 seg_aud1();
             } else {
                 if constexpr (H16) lz_dump_pair_chained(rb + 4 * q, LZ_R16_G_ATT / 2, datt, 0);
@@ -1015,5 +1149,46 @@ extern "C" int lz_triplane_head_backward_recorded_dw16(const lz_head_params* p, 
         hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, false, true>), dim3(grid), dim3(LZ_BWD_WG), 0, lz_st(stream), a, state, M,
                            static_cast<float*>(workspace));
     LZ_CHECK_LAUNCH("triplane_head_backward_recorded_dw16");
+    return lz_head_grad_w_reduce_launch(static_cast<const float*>(workspace), grid, true, k_sig0, dW_x3, dW_aud1, dW_sig0, dW_sig1, dW_c1h, stream);
+}
+
+// The recomputing -O arrangement (round 5): lz_triplane_head_backward_recorded_dw16 without record and state -- the forward
+// (lz_triplane_head_forward_encx_f16) left only the enc_x halves (encx16, 80 bytes per sample); this kernel recomputes the f16 forward chain
+// of every slice from them (packed_f16 / packed_unc: the forward's weight images, dirs: the view directions for SH) and then runs the fused
+// backward: data gradient on the f16 matrix cores (packed_bwd16, required), weight gradients of the wide layers reduced in the kernel.
+// Same outputs as the recorded pair, bit for bit (tests/test_gpu_train_step.py).  p: f32 packed weights (the skinny rows), training mode.
+extern "C" int lz_triplane_head_backward_encx_dw16(const lz_head_params* p, const void* packed_f16, const void* packed_unc, const void* encx16,
+                                                   const float* dirs, uint32_t M, const float* g_sigma, const float* g_rgb, const float* g_amb_aud,
+                                                   const float* g_amb_eye, const float* g_unc, const lz_head_bwd_out* out, const void* packed_bwd16,
+                                                   uint32_t k_sig0, float* dW_x3, float* dW_aud1, float* dW_sig0, float* dW_sig1, float* dW_c1h, void* workspace,
+                                                   lz_stream_t stream) {
+    LZ_REQUIRE(p && packed_f16 && packed_unc && encx16 && dirs && g_sigma && g_rgb && g_amb_aud && g_unc && out && packed_bwd16 && workspace, LZ_ERR_BAD_ARGUMENT,
+               "triplane_head_backward_encx_dw16: null tensor");
+    LZ_REQUIRE(dW_x3 && dW_aud1 && dW_sig0 && dW_sig1 && dW_c1h, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_encx_dw16: null weight-gradient output");
+    LZ_REQUIRE(p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_encx_dw16: incomplete lz_head_params");
+    LZ_REQUIRE(p->precision == 0 && !p->testing, LZ_ERR_UNSUPPORTED, "triplane_head_backward_encx_dw16: training mode, f32 packed weights for the skinny rows");
+    LZ_REQUIRE(k_sig0 == 68 || k_sig0 == 69, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_encx_dw16: sigma_net.0 takes 68 or 69 inputs");
+    const lz_head_bwd_out& o = *out;
+    LZ_REQUIRE(o.denc && o.small, LZ_ERR_BAD_ARGUMENT, "triplane_head_backward_encx_dw16: incomplete lz_head_bwd_out");
+    LZ_REQUIRE((((uintptr_t)encx16 | (uintptr_t)packed_f16 | (uintptr_t)packed_unc | (uintptr_t)packed_bwd16) & 15u) == 0, LZ_ERR_BAD_ARGUMENT,
+               "triplane_head_backward_encx_dw16: encx16 / fragments must be 16-byte aligned");
+    if (M == 0) {   // no sample: the weight gradients are zero
+        hipStream_t st = lz_st(stream);
+        (void)hipMemsetAsync(dW_x3, 0, 112 * 36 * 4, st); (void)hipMemsetAsync(dW_aud1, 0, 32 * 64 * 4, st); (void)hipMemsetAsync(dW_sig0, 0, 64 * k_sig0 * 4, st);
+        (void)hipMemsetAsync(dW_sig1, 0, 64 * 64 * 4, st); (void)hipMemsetAsync(dW_c1h, 0, 65 * 84 * 4, st);
+        return LZ_OK;
+    }
+    LzHeadBwdArgs a;
+    lz_fill_head_args(p, a.fwd);
+    a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.g_amb_aud = g_amb_aud; a.g_amb_eye = g_amb_eye; a.g_unc = g_unc;
+    a.o = o;
+    a.o.rec = nullptr;
+    a.wb16 = packed_bwd16;
+    a.fw16 = packed_f16; a.unc16 = packed_unc; a.dirs = dirs;
+    const uint32_t grid = lz_rec_grid(M, LZ_BWD_WG);
+    LZ_REQUIRE(grid <= LZ_DW_MAX_PARTS, LZ_ERR_UNSUPPORTED, "triplane_head_backward_encx_dw16: more workgroups than partial images");
+    hipLaunchKernelGGL((lz_k_triplane_head_backward_rec<true, true, true, true>), dim3(grid), dim3(LZ_BWD_WG), 0, lz_st(stream), a,
+                       static_cast<const float*>(encx16), M, static_cast<float*>(workspace));
+    LZ_CHECK_LAUNCH("triplane_head_backward_encx_dw16");
     return lz_head_grad_w_reduce_launch(static_cast<const float*>(workspace), grid, true, k_sig0, dW_x3, dW_aud1, dW_sig0, dW_sig1, dW_c1h, stream);
 }

@@ -7,14 +7,10 @@
 // dword on top of the inference slice; 64 MFMAs per 16 samples instead of 379 f32 ones.  The uncertainty net (training only:
 // network.py:241-249) adds five fragments that are packed separately (lz_head_pack_unc_f16), so the inference image and kernels stay
 // as they are.  sigma / rgb / ambient outputs have the bits of lz_k_triplane_head_f16 on the same inputs.
-#include "lz_head_f16_slice.h"
+#include "lz_head_fwd16_chain.h"   // the MLP chain itself, shared with the recomputing backward (lz_head_rec.hip, RC)
 #include "lz_head_bwd_common.h"   // lz_blk / lz_tcol: the blocked record layout
 
-typedef float lz_v4 __attribute__((ext_vector_type(4)));
-typedef uint32_t lz_u4 __attribute__((ext_vector_type(4)));
-
 #define LZ_FREC16_WG 1024
-#define LZ_UNC16_FRAGS 5   // unc_net.0: 2 k-steps x 2 feature tiles; unc_net.1: 1 x 1
 
 extern "C" uint32_t lz_head_packed_unc_size_f16(void) { return (uint32_t)LZ_UNC16_FRAGS * 64u * 16u; }
 
@@ -43,39 +39,39 @@ extern "C" int lz_head_pack_unc_f16(const float* unc0, const float* unc1, void* 
     return LZ_OK;
 }
 
-// a B operand (two tiles: slots 0..3 = low tile registers 0..3, slots 4..7 = high tile) -> the record's pair layout (dword r = {low
-// tile register r, high tile register r}); rowq = the sample's row in dwords + 4 q
-__device__ __forceinline__ void lz_dump_pair_h8(float* __restrict__ rowq, int pair, const lz_h8& b) {
-    const lz_u4 p = __builtin_bit_cast(lz_u4, b);
-    const lz_u4 w = {__builtin_amdgcn_perm(p[2], p[0], 0x05040100u), __builtin_amdgcn_perm(p[2], p[0], 0x07060302u),
-                     __builtin_amdgcn_perm(p[3], p[1], 0x05040100u), __builtin_amdgcn_perm(p[3], p[1], 0x07060302u)};
-    LZ_REC_STORE(__builtin_bit_cast(lz_v4, w), reinterpret_cast<lz_v4*>(rowq + 256 * pair));
-}
-__device__ __forceinline__ float lz_pack_h2f(float lo, float hi) {
-    typedef _Float16 lz_h2 __attribute__((ext_vector_type(2)));
-    const lz_h2 v = {h_round(lo), h_round(hi)};   // the same halves the B operands hold (no fused single rounding)
-    return __builtin_bit_cast(float, v);
-}
-__device__ __forceinline__ void lz_dump_pair_f(float* __restrict__ rowq, int pair, float l0, float l1, float l2, float l3, float h0, float h1,
-                                               float h2, float h3) {
-    lz_v4 w = {lz_pack_h2f(l0, h0), lz_pack_h2f(l1, h1), lz_pack_h2f(l2, h2), lz_pack_h2f(l3, h3)};
-    LZ_REC_STORE(w, reinterpret_cast<lz_v4*>(rowq + 256 * pair));
-}
-// bit 8 p + j of a layer's mask <-> slot j of its B operand p <-> chained index 4 t + r (lz_head_bwd_common.h: lz_mask_pos).  The operand is
-// what ReLU left: halves >= +0, so "positive" is "bit pattern not zero" -- an unsigned 16-bit min with 1 per packed pair, then the
-// eight 0 / 1 halves are folded into one byte (10 instructions; a compare + select + or per half costs 17)
-__device__ __forceinline__ uint32_t lz_mask_h8(const lz_h8& b) {
-    // v_pk_min_u16 spelled out: the compiler expands the vector min against the constant into a compare, a select and a pack per half
-    // (76 compares and 96 selects per slice in the ISA of round 2), four times the instructions of the packed form
-    const lz_u4 w = __builtin_bit_cast(lz_u4, b);   // whole-vector cast only: a bit_cast of a single vector ELEMENT to a 2-vector was miscompiled here (see lz_head_rec.hip)
-    uint32_t q[4];
-#pragma unroll
-    for (int d = 0; d < 4; d++) asm("v_pk_min_u16 %0, %1, %2" : "=v"(q[d]) : "v"(w[d]), "v"(0x00010001u));       // halves 2 d, 2 d + 1 of dword d -> 0 / 1
-    const uint32_t m = q[0] | (q[1] << 2) | (q[2] << 4) | (q[3] << 6);                                          // bits 2 d and 16 + 2 d
-    return (m | (m >> 15)) & 0xffu;
-}
+// the chain's sink of the recording forward: layer inputs into the X half of the sample's record, the state row next to it
+struct LzRec16Sink {
+    float* rbq;      // the sample's record row (dwords) + 4 q
+    float* sbq;      // ... state row + 4 q
+    float* sb;
+    int q;
+    __device__ __forceinline__ void x_pair_h8(int pair, const lz_h8& b) const { LZ_REC_STORE(lz_pair_words_h8(b), reinterpret_cast<lz_v4*>(rbq + 256 * pair)); }
+    __device__ __forceinline__ void x_pair_f(int pair, float l0, float l1, float l2, float l3, float h0, float h1, float h2, float h3) const {
+        LZ_REC_STORE(lz_pair_words_f(l0, l1, l2, l3, h0, h1, h2, h3), reinterpret_cast<lz_v4*>(rbq + 256 * pair));
+    }
+    __device__ __forceinline__ void s_pair_h8(int pair, const lz_h8& b) const { LZ_REC_STORE(lz_pair_words_h8(b), reinterpret_cast<lz_v4*>(sbq + 256 * pair)); }
+    __device__ __forceinline__ void s_att(const lz_v4& w0, const lz_v4& w1) const {
+        LZ_REC_STORE(w0, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_ST_ATT + 4 * q)));
+        LZ_REC_STORE(w1, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_ST_ATT + 16 + 4 * q)));
+    }
+};
+// ... and of the LIGHT forward (RC): nothing is kept but the enc_x operand itself (below)
+struct LzNoSink {
+    __device__ __forceinline__ void x_pair_h8(int, const lz_h8&) const {}
+    __device__ __forceinline__ void x_pair_f(int, float, float, float, float, float, float, float, float) const {}
+    __device__ __forceinline__ void s_pair_h8(int, const lz_h8&) const {}
+    __device__ __forceinline__ void s_att(const lz_v4&, const lz_v4&) const {}
+};
 
-__global__ void __launch_bounds__(LZ_FREC16_WG, 1)
+// RC = false: the recording forward (records + state row per sample).  RC = true: the LIGHT forward of the recomputing arrangement -- the
+// same gather, chain and outputs, and instead of 1 216 bytes of record and state per sample only the enc_x operand the chain started from:
+// encx16 [slice][5][64 lanes] dwords (80 bytes per sample; dwords 0 .. 3 = bx[0], dword 4 = bx[1]'s first), from which
+// lz_triplane_head_backward_encx_dw16 recomputes everything else.
+// Workgroups: the recording forward one of 1024 threads per CU; the light one (82 registers without the record's address and mask work, 66 KB of
+// LDS) TWO of 768 per CU -- six waves per SIMD instead of four to cover its gathers.
+#define LZ_FENCX16_WG 768
+template <bool RC>
+__global__ void __launch_bounds__(RC ? LZ_FENCX16_WG : LZ_FREC16_WG, RC ? 6 : 1)
 lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packed_unc, const float* __restrict__ xyzs,
                                  const float* __restrict__ dirs, uint32_t M, float* __restrict__ sigmas, float* __restrict__ rgbs,
                                  float* __restrict__ amb_aud, float* __restrict__ amb_eye, float* __restrict__ unc_out, float* __restrict__ rec,
@@ -85,10 +81,11 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
     const uint32_t slice_lo = (uint32_t)(((uint64_t)n_slices * blockIdx.x) / gridDim.x);
     const uint32_t slice_hi = (uint32_t)(((uint64_t)n_slices * (blockIdx.x + 1)) / gridDim.x);
     if (slice_lo >= slice_hi) return;
+    constexpr uint32_t WG = RC ? LZ_FENCX16_WG : LZ_FREC16_WG;
     LzHead16Ctx hc;
-    lz_head16_stage(P, wl, LZ_FREC16_WG, hc);
+    lz_head16_stage(P, wl, WG, hc);
     lz_h8* wl_unc = wl + LZ_HEAD16_LDS_H8;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)LZ_UNC16_FRAGS * 64; i += LZ_FREC16_WG) wl_unc[i] = packed_unc[i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)LZ_UNC16_FRAGS * 64; i += WG) wl_unc[i] = packed_unc[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int s = lane & 15, q = lane >> 4;
@@ -115,9 +112,8 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
     }
     for (;;) {
         if (slice_lo + (uint32_t)slice >= slice_hi) break;
+        const uint32_t gslice = slice_lo + (uint32_t)slice;
         const size_t row = row_of(slice);   // lanes past the end repeat the last row: the same values are stored again
-        float* rb = lz_blk(rec, slice_lo + (uint32_t)slice, LZ_BWD_REC16 / 2, s);
-        float* sb = lz_blk(st, slice_lo + (uint32_t)slice, LZ_FWD_STATE16, s);
 
         float encx[9];
         lz_head_gather(hc.emb, hc.tab, px, py, pz, q, hc.bound, hc.two_bound, encx);
@@ -136,144 +132,65 @@ lz_k_triplane_head_forward_rec16(LzHead16Args P, const lz_h8* __restrict__ packe
             bx[0] = __builtin_bit_cast(lz_h8, w0);
             bx[1] = __builtin_bit_cast(lz_h8, w1);
         }
-
-        // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
-        lz_h8 att16;
-        uint32_t mk_a1;
-        {
-            lz_f4 a1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_A1>(hc.wl, lane, bx, a1);
-            const lz_h8 b2[2] = {h_pair(a1[0], a1[1], true), h_pair(a1[2], a1[3], true)};
-            mk_a1 = lz_mask_h8(b2[0]) | (lz_mask_h8(b2[1]) << 8);
-            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_A1 / 2, b2[0]);
-            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_A1 / 2 + 1, b2[1]);
-            lz_f4 a2[2] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_A2>(hc.wl, lane, b2, a2);
-            att16 = h_pair(a2[0], a2[1], false);
-        }
-        {
-            lz_v4 w0 = {(float)att16[0], (float)att16[1], (float)att16[2], (float)att16[3]};
-            lz_v4 w1 = {(float)att16[4], (float)att16[5], (float)att16[6], (float)att16[7]};
-            LZ_REC_STORE(w0, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_ST_ATT + 4 * q)));
-            LZ_REC_STORE(w1, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_ST_ATT + 16 + 4 * q)));
-        }
-        float ss = 0.0f;
+        LzFwd16Out o;
+        if constexpr (RC) {
+            float* eb = rec + (size_t)gslice * (5 * 64) + lane;      // [slice][5][lane]: five coalesced 256-byte rows
+            const lz_u4v w0 = __builtin_bit_cast(lz_u4v, bx[0]);
+            const lz_u4v w1 = __builtin_bit_cast(lz_u4v, bx[1]);
 #pragma unroll
-        for (int k = 0; k < 8; k++) ss = lz_fmaf((float)att16[k], (float)att16[k], ss);
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float norm = h_sqrt32(ss);
-        // ---------------- eye attention ----------------
-        float eyeatt = 0.0f;
-        uint32_t mk_e1 = 0;
-        if (hc.has_eye) {
-            lz_f4 e1[1] = {lz_f4{0, 0, 0, 0}};
-            h_layer<H_E1>(hc.wl, lane, bx, e1);
-            const lz_f4 z = lz_f4{0, 0, 0, 0};
-            const lz_h8 be[1] = {h_pair(e1[0], z, true)};
-            mk_e1 = lz_mask_h8(be[0]) & 0xfu;
-            lz_dump_pair_h8(sb + 4 * q, LZ_S16_E1 / 16, be[0]);
-            lz_f4 e2[1] = {lz_f4{0, 0, 0, 0}};
-            h_layer<H_E2>(hc.wl, lane, be, e2);
-            eyeatt = (float)(_Float16)h_sigmoid((float)(_Float16)e2[0][0]);   // lanes q == 0
-            eyeatt = __shfl(eyeatt, s, 64);
-        }
-        // ---------------- uncertainty (training): 36 -> 32 -> 1, softplus in f32 on the half pre-activation ----------------
-        float upre;
-        uint32_t mk_u1;
-        {
-            lz_f4 u1[2] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer_at<2, 2>(wl_unc, lane, bx, u1);
-            const lz_h8 bu[1] = {h_pair(u1[0], u1[1], true)};
-            mk_u1 = lz_mask_h8(bu[0]);
-            lz_dump_pair_h8(sb + 4 * q, LZ_S16_U1 / 16, bu[0]);
-            lz_f4 u2[1] = {lz_f4{0, 0, 0, 0}};
-            h_layer_at<1, 1>(wl_unc + 4 * 64, lane, bu, u2);
-            upre = __shfl((float)(_Float16)u2[0][0], s, 64);
-        }
-        // ---------------- sigma net ----------------
-        lz_h8 geo16[2];
-        float spre;
-        uint32_t mk_s1, mk_s2;
-        {
-            lz_h8 b1[3];
-            b1[0] = bx[0];
-            b1[1] = bx[1];
-            b1[1][1] = (hc.has_eye && q == 0) ? h_round(hc.eye_v * eyeatt) : (_Float16)0.0f;
-            b1[2] = h_encw(hc.tab, q, att16);
-            // sigma_net.0 input in the record's arrangement (lz_head_rec.hip: tiles 0, 1 enc_x, tile 2 feature 32 + q and the eye term,
-            // tiles 3, 4 enc_a * att); the conversions to half repeat the ones above, value for value
-            lz_dump_pair_f(rb + 4 * q, LZ_R16_X_SIG0 / 2, encx[0], encx[2], encx[4], encx[6], encx[1], encx[3], encx[5], encx[7]);
-            lz_dump_pair_f(rb + 4 * q, LZ_R16_X_SIG0 / 2 + 1, encx[8], (float)b1[1][1], 0.0f, 0.0f, (float)b1[2][0], (float)b1[2][1], (float)b1[2][2],
-                           (float)b1[2][3]);
-            lz_dump_pair_f(rb + 4 * q, LZ_R16_X_SIG0 / 2 + 2, (float)b1[2][4], (float)b1[2][5], (float)b1[2][6], (float)b1[2][7], 0.0f, 0.0f, 0.0f, 0.0f);
-            lz_f4 s1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_S1>(hc.wl, lane, b1, s1);
-            const lz_h8 b2[2] = {h_pair(s1[0], s1[1], true), h_pair(s1[2], s1[3], true)};
-            mk_s1 = lz_mask_h8(b2[0]) | (lz_mask_h8(b2[1]) << 8);
-            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_S1 / 2, b2[0]);
-            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_S1 / 2 + 1, b2[1]);
-            lz_f4 s2[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_S2>(hc.wl, lane, b2, s2);
-            const lz_h8 b3[2] = {h_pair(s2[0], s2[1], true), h_pair(s2[2], s2[3], true)};
-            mk_s2 = lz_mask_h8(b3[0]) | (lz_mask_h8(b3[1]) << 8);
-            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_S2C / 2, b3[0]);
-            lz_dump_pair_h8(rb + 4 * q, LZ_R16_X_S2C / 2 + 1, b3[1]);
-            lz_f4 s3[5] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_S3>(hc.wl, lane, b3, s3);
-            geo16[0] = h_pair(s3[0], s3[1], false);
-            geo16[1] = h_pair(s3[2], s3[3], false);
-            spre = __shfl((float)(_Float16)s3[4][0], s + 48, 64);      // the sigma row sits at row 12 of tile 4: lanes q == 3 (lz_k_head_pack_f16)
-        }
-        const float sigma = h_exp32(spre);
-        // ---------------- colour net ----------------
-        float cpre[3];
-        uint32_t mk_c1;
-        {
-            auto shfn = lz_sh_from_dir([&](float& ox, float& oy, float& oz) { ox = cdx; oy = cdy; oz = cdz; });
-            shfn.prepare();
-            lz_h8 b1[3];
-            {
-                uint32_t shw[2];
-                h_sh_pk(shfn, q, shw);
-                const lz_u4v w = {shw[0], shw[1], q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16] : 0u, q == 0 ? (uint32_t)hc.tab[LZ_LVTAB_IND16 + 1] : 0u};
-                b1[0] = __builtin_bit_cast(lz_h8, w);
-            }
-            b1[1] = geo16[0];
-            b1[2] = geo16[1];
-            // colour_net.0's SH / ind columns as the record keeps them: SH component 4 r + q at column 4 q + r, ind_code[q] at column 4 q
-            lz_dump_pair_f(rb + 4 * q, LZ_R16_X_S2C / 2 + 2, shfn.comp_iq(0, q), shfn.comp_iq(1, q), shfn.comp_iq(2, q), shfn.comp_iq(3, q), indq, 0.0f, 0.0f,
-                           0.0f);
-            lz_f4 c1[4] = {lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}, lz_f4{0, 0, 0, 0}};
-            h_layer<H_C1>(hc.wl, lane, b1, c1);
-            const lz_h8 b2[2] = {h_pair(c1[0], c1[1], true), h_pair(c1[2], c1[3], true)};
-            mk_c1 = lz_mask_h8(b2[0]) | (lz_mask_h8(b2[1]) << 8);
-            lz_dump_pair_h8(sb + 4 * q, LZ_S16_C1 / 16, b2[0]);
-            lz_dump_pair_h8(sb + 4 * q, LZ_S16_C1 / 16 + 1, b2[1]);
-            lz_f4 c2[1] = {lz_f4{0, 0, 0, 0}};
-            h_layer<H_C2>(hc.wl, lane, b2, c2);
-#pragma unroll
-            for (int c = 0; c < 3; c++) cpre[c] = __shfl((float)(_Float16)c2[0][0], s + 16 * c, 64);   // channel c sits at row 4 c: register 0 of lanes q == c
-        }
-        // ---------------- state words, outputs (the four lanes of a sample store the same values) ----------------
-        {
-            const float sc = q == 0 ? norm : (q == 1 ? eyeatt : (q == 2 ? upre : sigma));
-            lz_v4 w = {__uint_as_float(mk_a1 | (mk_s1 << 16)), __uint_as_float(mk_s2 | (mk_c1 << 16)), __uint_as_float(mk_u1 | (mk_e1 << 8)), sc};
+            for (int k = 0; k < 4; k++) eb[64 * k] = __uint_as_float(w0[k]);
+            eb[64 * 4] = __uint_as_float(w1[0]);
+            LzNoSink sink;
+            lz_fwd16_chain(hc, wl_unc, lane, bx, cdx, cdy, cdz, indq, sink, o);
+        } else {
+            float* rb = lz_blk(rec, gslice, LZ_BWD_REC16 / 2, s);
+            float* sb = lz_blk(st, gslice, LZ_FWD_STATE16, s);
+            LzRec16Sink sink{rb + 4 * q, sb + 4 * q, sb, q};
+            lz_fwd16_chain(hc, wl_unc, lane, bx, cdx, cdy, cdz, indq, sink, o);
+            // ---------------- state words (the four lanes of a sample store the same values) ----------------
+            const float sc = q == 0 ? o.norm : (q == 1 ? o.eyeatt : (q == 2 ? o.upre : o.sigma));
+            lz_v4 w = {__uint_as_float(o.mk_a1 | (o.mk_s1 << 16)), __uint_as_float(o.mk_s2 | (o.mk_c1 << 16)), __uint_as_float(o.mk_u1 | (o.mk_e1 << 8)), sc};
             LZ_REC_STORE(w, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_S16_MK + 4 * q)));
-            lz_v4 cw = {cpre[0], cpre[1], cpre[2], 0.0f};
+            lz_v4 cw = {o.cpre[0], o.cpre[1], o.cpre[2], 0.0f};
             LZ_REC_STORE(cw, reinterpret_cast<lz_v4*>(sb + lz_tcol(LZ_S16_CLR)));
-            sigmas[row] = sigma;
-            amb_aud[row] = norm;
-            if (amb_eye) amb_eye[row] = eyeatt;
-            unc_out[row] = lz_softplusf(upre);
+        }
+        // ---------------- outputs ----------------
+        {
+            sigmas[row] = o.sigma;
+            amb_aud[row] = o.norm;
+            if (amb_eye) amb_eye[row] = o.eyeatt;
+            unc_out[row] = lz_softplusf(o.upre);
             const int qc = q < 2 ? q : 2;
-            const float cv = q == 0 ? cpre[0] : (q == 1 ? cpre[1] : cpre[2]);
+            const float cv = q == 0 ? o.cpre[0] : (q == 1 ? o.cpre[1] : o.cpre[2]);
             const _Float16 sg = (_Float16)h_sigmoid(cv);   // network.py:275 in half: sigmoid, * 1.002, - 0.001, each rounded to half
             const _Float16 t1 = h_round((float)sg * 1.002f);
             rgbs[row * 3 + qc] = (float)h_round((float)t1 - 0.001f);
         }
         slice = next;
     }
+}
+
+static int lz_fwd16_launch(bool rc, const char* who, const lz_head_params* p, const void* packed_unc, const float* xyzs, const float* dirs, uint32_t M,
+                           float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, float* rec_or_encx, float* state16, hipStream_t st) {
+    LzHead16Args a;
+    a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
+    a.offsets = p->offsets; a.packed = reinterpret_cast<const lz_h8*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code; a.eye = p->eye;
+    a.bound = p->bound;
+    for (int l = 0; l < 12; l++) {
+        const float sc = exp2f((float)l * p->S) * (float)p->H - 1.0f;
+        a.scale[l] = sc;
+        a.res[l] = (uint32_t)ceilf(sc) + 1u;
+    }
+    const int n_cu = lz_cu_count();   // of the current device, per call (cached per device)
+    const uint32_t wg = rc ? LZ_FENCX16_WG : LZ_FREC16_WG, per_cu = rc ? 2u : 1u;
+    const uint32_t want = lz_div_up(lz_div_up(M, 16), wg / 64);
+    const uint32_t grid = want < per_cu * (uint32_t)n_cu ? want : per_cu * (uint32_t)n_cu;
+    if (rc) hipLaunchKernelGGL(lz_k_triplane_head_forward_rec16<true>, dim3(grid), dim3(LZ_FENCX16_WG), 0, st, a, reinterpret_cast<const lz_h8*>(packed_unc),
+                               xyzs, dirs, M, sigmas, rgbs, amb_aud, amb_eye, unc, rec_or_encx, state16);
+    else hipLaunchKernelGGL(lz_k_triplane_head_forward_rec16<false>, dim3(grid), dim3(LZ_FREC16_WG), 0, st, a, reinterpret_cast<const lz_h8*>(packed_unc),
+                            xyzs, dirs, M, sigmas, rgbs, amb_aud, amb_eye, unc, rec_or_encx, state16);
+    (void)who;
+    return LZ_OK;
 }
 
 extern "C" int lz_triplane_head_forward_record_f16(const lz_head_params* p, const void* packed_unc, const float* xyzs, const float* dirs,
@@ -287,20 +204,26 @@ extern "C" int lz_triplane_head_forward_record_f16(const lz_head_params* p, cons
     LZ_REQUIRE((((uintptr_t)rec16 | (uintptr_t)state16 | (uintptr_t)packed_unc | (uintptr_t)p->packed) & 15u) == 0, LZ_ERR_BAD_ARGUMENT,
                "triplane_head_forward_record_f16: rec / state / packed weights must be 16-byte aligned");
     if (M == 0) return LZ_OK;
-    LzHead16Args a;
-    a.emb[0] = p->emb_xy; a.emb[1] = p->emb_yz; a.emb[2] = p->emb_xz;
-    a.offsets = p->offsets; a.packed = reinterpret_cast<const lz_h8*>(p->packed); a.enc_a = p->enc_a; a.ind_code = p->ind_code; a.eye = p->eye;
-    a.bound = p->bound;
-    for (int l = 0; l < 12; l++) {
-        const float sc = exp2f((float)l * p->S) * (float)p->H - 1.0f;
-        a.scale[l] = sc;
-        a.res[l] = (uint32_t)ceilf(sc) + 1u;
-    }
-    const int n_cu = lz_cu_count();   // of the current device, per call (cached per device)
-    const uint32_t want = lz_div_up(lz_div_up(M, 16), LZ_FREC16_WG / 64);
-    const uint32_t grid = want < (uint32_t)n_cu ? want : (uint32_t)n_cu;
-    hipLaunchKernelGGL(lz_k_triplane_head_forward_rec16, dim3(grid), dim3(LZ_FREC16_WG), 0, lz_st(stream), a,
-                       reinterpret_cast<const lz_h8*>(packed_unc), xyzs, dirs, M, sigmas, rgbs, amb_aud, amb_eye, unc, static_cast<float*>(rec16), state16);
+    lz_fwd16_launch(false, "triplane_head_forward_record_f16", p, packed_unc, xyzs, dirs, M, sigmas, rgbs, amb_aud, amb_eye, unc, static_cast<float*>(rec16), state16,
+                    lz_st(stream));
     LZ_CHECK_LAUNCH("triplane_head_forward_record_f16");
+    return LZ_OK;
+}
+
+// The LIGHT forward of the recomputing -O arrangement (round 5): the same arithmetic and outputs as lz_triplane_head_forward_record_f16, but
+// instead of the records and the state row it leaves only encx16 -- the enc_x halves the MLP started from, LZ_ENCX16_BYTES(M) bytes,
+// 80 per sample -- for lz_triplane_head_backward_encx_dw16, which recomputes every layer input and mask from them.
+extern "C" int lz_triplane_head_forward_encx_f16(const lz_head_params* p, const void* packed_unc, const float* xyzs, const float* dirs, uint32_t M,
+                                                 float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, void* encx16, lz_stream_t stream) {
+    if (M == 0) return LZ_OK;
+    LZ_REQUIRE(p && packed_unc && xyzs && dirs && sigmas && rgbs && amb_aud && unc && encx16, LZ_ERR_BAD_ARGUMENT, "triplane_head_forward_encx_f16: null tensor");
+    LZ_REQUIRE(p->emb_xy && p->emb_yz && p->emb_xz && p->offsets && p->packed && p->enc_a, LZ_ERR_BAD_ARGUMENT,
+               "triplane_head_forward_encx_f16: incomplete lz_head_params");
+    LZ_REQUIRE(p->precision == 1 && !p->testing, LZ_ERR_UNSUPPORTED, "triplane_head_forward_encx_f16: precision 1 (lz_head_pack_weights_f16 image), training mode");
+    LZ_REQUIRE((((uintptr_t)encx16 | (uintptr_t)packed_unc | (uintptr_t)p->packed) & 15u) == 0, LZ_ERR_BAD_ARGUMENT,
+               "triplane_head_forward_encx_f16: encx16 / packed weights must be 16-byte aligned");
+    lz_fwd16_launch(true, "triplane_head_forward_encx_f16", p, packed_unc, xyzs, dirs, M, sigmas, rgbs, amb_aud, amb_eye, unc, static_cast<float*>(encx16), nullptr,
+                    lz_st(stream));
+    LZ_CHECK_LAUNCH("triplane_head_forward_encx_f16");
     return LZ_OK;
 }

@@ -47,10 +47,11 @@ class _FusedHeadTrain(Function):
         dev = xyzs.device
         # opt.train_camera (renderer.py:129-132, 225-230): rays_o / rays_d carry gradients, march_rays_train hands them on to xyzs / dirs
         # and the reference reaches them through the encoders' dy_dx (grid.py:44-84, sphere_harmonics.py:27-58).  Same here, see backward
+        dirs_req = bool(dirs.requires_grad)
         xyzs, dirs = xyzs.detach().float().contiguous(), dirs.detach().float().contiguous()
         M = xyzs.shape[0]
         w = [t.detach().float().contiguous() for t in weights]
-        call("lz_head_pack_weights", *[ptr(t) for t in w], int(mod.has_eye), int(mod.has_ind), ptr(mod.packed), stream())
+        mod._pack("f32", w)
         enc_a_f = enc_a.detach().reshape(-1).float().contiguous()
         ind_f = None if ind_code is None or not mod.has_ind else ind_code.detach().reshape(-1).float().contiguous()
         eye_f = None if eye is None or not mod.has_eye else eye.detach().reshape(-1).float().contiguous()
@@ -58,14 +59,25 @@ class _FusedHeadTrain(Function):
         p = mod._params(emb, enc_a_f, ind_f, eye_f)
         kw = dict(dtype=torch.float32, device=dev)
         sig, rgb, aa, ae, un = torch.empty(M, **kw), torch.empty(M, 3, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw), torch.empty(M, 1, **kw)
-        ctx.rec = ctx.state = None
+        ctx.rec = ctx.state = ctx.encx = None
         ctx.recompute = not mod.record
         Mb = (M + 15) // 16 * 16   # records and state are blocked by 16-sample slice: whole slices
-        if M > 0 and mod.forward_f16:
+        # recompute_mlp (all-f16 arrangement, round 5): the forward leaves only the enc_x halves (80 B per sample) and the backward kernel runs the
+        # MLP again from them.  Gradients to the view directions need color_net.0's output gradient from a record: such a step keeps records
+        use_rc = M > 0 and mod.recompute_mlp and not dirs_req
+        if use_rc:
+            mod._pack("f16", w)
+            mod._pack("unc16", w)
+            p16 = mod._params(emb, enc_a_f, ind_f, eye_f)
+            p16.packed, p16.precision = mod.packed16.data_ptr(), 1
+            ctx.encx = torch.empty(Mb // 16, 320, **kw)          # [slice][5][64 lanes] dwords (LZ_ENCX16_BYTES)
+            call("lz_triplane_head_forward_encx_f16", C.byref(p16), ptr(mod.packed_unc16), ptr(xyzs), ptr(dirs), M, ptr(sig), ptr(rgb), ptr(aa), ptr(ae),
+                 ptr(un), ptr(ctx.encx), stream())
+        elif M > 0 and mod.forward_f16:
             # forward in the reference's autocast arithmetic on the f16 matrix cores (lz_head_rec16.hip); the backward below runs its
             # f32 data-gradient chain from the state this forward records
-            call("lz_head_pack_weights_f16", *[ptr(t) for t in w[:9]], int(mod.has_eye), int(mod.has_ind), ptr(mod.packed16), stream())
-            call("lz_head_pack_unc_f16", ptr(w[9]), ptr(w[10]), ptr(mod.packed_unc16), stream())
+            mod._pack("f16", w)
+            mod._pack("unc16", w)
             p16 = mod._params(emb, enc_a_f, ind_f, eye_f)
             p16.packed, p16.precision = mod.packed16.data_ptr(), 1
             ctx.rec, ctx.state = torch.empty(Mb, _REC16, dtype=torch.float16, device=dev), torch.empty(Mb, _STATE16, **kw)
@@ -84,7 +96,9 @@ class _FusedHeadTrain(Function):
                 # 3.3 KB per sample do not fit: this step runs the recomputing pair instead (same gradients, nothing held)
                 ctx.rec = ctx.state = None
                 ctx.recompute = True
-        if M > 0 and mod.record and not mod.forward_f16 and ctx.rec is not None:
+        if use_rc:
+            pass
+        elif M > 0 and mod.record and not mod.forward_f16 and ctx.rec is not None:
             call("lz_triplane_head_forward_record", C.byref(p), ptr(xyzs), ptr(dirs), M, ptr(sig), ptr(rgb), ptr(aa), ptr(ae), ptr(un),
                  ptr(ctx.rec), ptr(ctx.state), int(mod.record_f16), stream())
         elif M > 0 and not mod.forward_f16:   # an empty batch (every ray missed the box) has empty outputs and zero gradients
@@ -120,19 +134,19 @@ class _FusedHeadTrain(Function):
             return (None, g_x, g_d, g_enc_a, g_ind, None) + tuple(torch.zeros_like(t) for t in emb) + tuple(torch.zeros_like(t) for t in w)
         z = lambda g, shape: (torch.zeros(shape, **kw) if g is None else g.float().contiguous())
         g_sig, g_rgb, g_aa, g_ae, g_un = z(g_sig, (M,)), z(g_rgb, (M, 3)), z(g_aa, (M, 1)), z(g_ae, (M, 1)), z(g_un, (M, 1))
-        if not ctx.recompute and ctx.rec is None:
+        if not ctx.recompute and ctx.rec is None and ctx.encx is None:
             # the record and state of this forward were consumed (and released) by an earlier backward
             raise RuntimeError("FusedTriplaneTrainHead(record=True): a second backward through the same forward needs record=False "
                                "(the recomputing backward keeps nothing between the two)")
         # one record per sample: every layer input / output gradient the reductions need (the X half is there already in record mode)
-        rec = ctx.rec if ctx.rec is not None else torch.empty((M + 15) // 16 * 16, _REC, **kw)
+        rec = ctx.rec if (ctx.rec is not None or ctx.encx is not None) else torch.empty((M + 15) // 16 * 16, _REC, **kw)
         denc = torch.empty(3, 12, M, **kw)          # level-major: the grid backward reads one level at a time
         small = torch.zeros(32 + 4 + 16 + 32 + 192, **kw)   # d_enc_a | d_ind | dW of the three skinny output layers (reduced in the kernel)
         d_enc_a, d_ind, dw_e2, dw_u2, dw_c2 = small[:32], small[32:36], small[36:52], small[52:84], small[84:]
         o = _lib.HeadBwdOut()
-        o.denc, o.small, o.rec = denc.data_ptr(), small.data_ptr(), rec.data_ptr()
-        # `mod.packed` is shared by every forward of this module: re-pack from the weights THIS forward saw
-        call("lz_head_pack_weights", *[ptr(t) for t in w], int(mod.has_eye), int(mod.has_ind), ptr(mod.packed), stream())
+        o.denc, o.small, o.rec = denc.data_ptr(), small.data_ptr(), (rec.data_ptr() if rec is not None else None)
+        # `mod.packed` is shared by every forward of this module: re-pack from the weights THIS forward saw (a no-op when it still holds them)
+        mod._pack("f32", w)
         p = mod._params(emb, enc_a_f, ind_f, eye_f)
         k_sig0, k_col0 = w[4].shape[1], w[7].shape[1]   # 68 without the eye column, 80 without an individual code
         shapes = dict(x3=(112, 36), aud1=(32, 64), sig0=(64, k_sig0), sig1=(64, 64), c1h=(65, 84))
@@ -141,13 +155,24 @@ class _FusedHeadTrain(Function):
             mod._gw_ws = torch.empty(_lib.load().lz_triplane_head_grad_w_workspace() // 4, **kw)
         need_x, need_d = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         # d loss / d dirs starts from color_net.0's output gradient, which only the two-pass arrangements leave behind (record slot G_C1H)
-        fused_dw = ctx.state is not None and mod.fuse_dw and rec.dtype == torch.float16 and not need_d
-        if fused_dw:
+        fused_dw = ctx.encx is not None or (ctx.state is not None and mod.fuse_dw and rec.dtype == torch.float16 and not need_d)
+        if ctx.encx is not None:
+            # the recomputing all-f16 backward: MLP forward chain again from the enc_x halves, data gradient + weight-gradient products in one kernel
+            if need_d:
+                raise RuntimeError("FusedTriplaneTrainHead(recompute_mlp=True): gradients to the view directions need a recorded step")
+            mod._pack("f16", w)
+            mod._pack("unc16", w)
+            mod._pack("bwd16", w)
+            o.rec = None
+            call("lz_triplane_head_backward_encx_dw16", C.byref(p), ptr(mod.packed16), ptr(mod.packed_unc16), ptr(ctx.encx), ptr(dirs), M, ptr(g_sig),
+                 ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un), C.byref(o), ptr(mod.packed_bwd16), k_sig0,
+                 *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")], ptr(mod._gw_ws), stream())
+            ctx.encx = None
+        elif fused_dw:
             # the whole backward over half records in one kernel: data-gradient chain (f16 or f32 matrix path) + the weight-gradient products
             wb16 = None
             if mod.backward_f16:
-                call("lz_head_pack_weights_bwd_f16", ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[4]), ptr(w[5]), ptr(w[6]), ptr(w[7]), int(mod.has_eye),
-                     int(mod.has_ind), ptr(mod.packed_bwd16), stream())
+                mod._pack("bwd16", w)
                 wb16 = ptr(mod.packed_bwd16)
             call("lz_triplane_head_backward_recorded_dw16", C.byref(p), ptr(ctx.state), ptr(rec), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae),
                  ptr(g_un), C.byref(o), wb16, k_sig0, *[ptr(red[n]) for n in ("x3", "aud1", "sig0", "sig1", "c1h")],
@@ -156,8 +181,7 @@ class _FusedHeadTrain(Function):
         elif ctx.state is not None:
             wb16 = None
             if mod.backward_f16:   # transposed half fragments of the weights THIS forward saw
-                call("lz_head_pack_weights_bwd_f16", ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[4]), ptr(w[5]), ptr(w[6]), ptr(w[7]), int(mod.has_eye),
-                     int(mod.has_ind), ptr(mod.packed_bwd16), stream())
+                mod._pack("bwd16", w)
                 wb16 = ptr(mod.packed_bwd16)
             call("lz_triplane_head_backward_recorded", C.byref(p), ptr(ctx.state), M, ptr(g_sig), ptr(g_rgb), ptr(g_aa), ptr(g_ae), ptr(g_un),
                  C.byref(o), int(mod.record_f16), wb16, stream())
@@ -215,7 +239,7 @@ class _FusedHeadTrain(Function):
 
 class FusedTriplaneTrainHead(nn.Module):
     def __init__(self, state_dict=None, bound=1.0, exp_eye=True, ind_dim=4, record=True, record_dtype="f32", forward_dtype="f32",
-                 backward_dtype="f32", fuse_dw=True):
+                 backward_dtype="f32", fuse_dw=True, recompute_mlp=None):
         super().__init__()
         if record_dtype not in ("f32", "f16") or forward_dtype not in ("f32", "f16") or backward_dtype not in ("f32", "f16"):
             raise ValueError("record_dtype / forward_dtype / backward_dtype must be 'f32' or 'f16'")
@@ -241,6 +265,13 @@ class FusedTriplaneTrainHead(nn.Module):
         # (lz_triplane_head_backward_recorded_dw16) instead of in a second pass over the records, and the G half of the records is
         # never written.  Two LDS buffers of operand tiles with the f16 data gradient, one (an extra barrier per segment) with the f32 chain
         self.fuse_dw = bool(fuse_dw) and self.record_f16
+        # recompute_mlp (default: on for forward_dtype = backward_dtype = "f16" with fuse_dw): the forward keeps ONLY the enc_x halves the MLP
+        # started from (80 bytes per sample instead of 1 216 of record + state) and the backward kernel recomputes every layer input, mask and
+        # pre-activation from them with the forward's own code (csrc/lz_head_fwd16_chain.h) -- same outputs and gradients bit for bit
+        all16 = self.forward_f16 and self.backward_f16 and self.fuse_dw
+        if recompute_mlp and not all16:
+            raise ValueError("recompute_mlp goes with forward_dtype = backward_dtype = 'f16' and fuse_dw")
+        self.recompute_mlp = all16 if recompute_mlp is None else bool(recompute_mlp)
         mk = lambda: GridEncoder(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=14,
                                  desired_resolution=512 * bound)
         self.encoder_xy, self.encoder_yz, self.encoder_xz = mk(), mk(), mk()                       # network.py:131-133
@@ -257,6 +288,7 @@ class FusedTriplaneTrainHead(nn.Module):
         # diagnostics: with keep_denc set, the last backward leaves d loss / d enc_x (level-major [3, 12, M], what the table scatter consumed)
         # in last_denc -- tests/test_gpu_train_fullsize.py checks the scatter against it (per-level sums, the checker's scatter)
         self.keep_denc, self.last_denc = False, None
+        self._packed_token = {}    # weight image -> ((data_ptr, version) of the tensors it was packed from)
         if self.backward_f16:
             self.register_buffer("packed_bwd16", torch.empty(_lib.load().lz_head_packed_bwd_size_f16(), dtype=torch.uint8), persistent=False)
         if self.forward_f16:
@@ -269,6 +301,26 @@ class FusedTriplaneTrainHead(nn.Module):
     @property
     def offsets(self):
         return self.encoder_xy.offsets
+
+    def _pack(self, kind, w):
+        """(re)build one of the weight images from the tensors `w` unless it already holds exactly these (same storage, same version): the
+        images are shared by every forward / backward of the module, so a backward re-packs only when something else packed in between or a
+        weight changed since its forward"""
+        token = tuple((t.data_ptr(), t._version) for t in w) + (str(w[0].device),)
+        if self._packed_token.get(kind) == token:
+            return
+        if kind == "f32":
+            call("lz_head_pack_weights", *[ptr(t) for t in w], int(self.has_eye), int(self.has_ind), ptr(self.packed), stream())
+        elif kind == "f16":
+            call("lz_head_pack_weights_f16", *[ptr(t) for t in w[:9]], int(self.has_eye), int(self.has_ind), ptr(self.packed16), stream())
+        elif kind == "unc16":
+            call("lz_head_pack_unc_f16", ptr(w[9]), ptr(w[10]), ptr(self.packed_unc16), stream())
+        elif kind == "bwd16":
+            call("lz_head_pack_weights_bwd_f16", ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[4]), ptr(w[5]), ptr(w[6]), ptr(w[7]), int(self.has_eye),
+                 int(self.has_ind), ptr(self.packed_bwd16), stream())
+        else:
+            raise KeyError(kind)
+        self._packed_token[kind] = token
 
     def _weights(self):
         n = lambda m, i: m.net[i].weight

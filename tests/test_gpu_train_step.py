@@ -926,3 +926,55 @@ def test_fused_train_head_camera_gradients(params, golden, arr):
             go[1][i] += dl_np[s, 1] * want_x[s] + want_d[s]
     close(ro_t.grad / scale, go[0], "rays_o", 3e-2 if half else 2e-3)
     close(rd_t.grad / scale, go[1], "rays_d", 3e-2 if half else 2e-3)
+
+
+@pytest.mark.parametrize("exp_eye,ind_dim", [(True, 4), (False, 4), (True, 0)])
+def test_recomputing_f16_step_equals_the_recorded_one(params, golden, exp_eye, ind_dim):
+    """recompute_mlp (round 5, the default of the all-f16 arrangement): the forward keeps only the enc_x halves (80 B per sample), the backward
+    kernel runs the MLP again from them with the forward's own code (csrc/lz_head_fwd16_chain.h) and a sink that keeps in registers what the
+    recording forward stored.  Same arithmetic in the same order, so the five outputs and EVERY gradient (11 weight matrices, 3 tables,
+    enc_a, ind_code) equal the recorded pair's bit for bit -- ragged last slice, a workgroup's last round with idle waves included."""
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    rng = np.random.default_rng(77)
+    p = dict(params)
+    p["sigma_net.net.0.weight"] = np.ascontiguousarray(params["sigma_net.net.0.weight"][:, :68 + int(exp_eye)])
+    p["color_net.net.0.weight"] = np.ascontiguousarray(params["color_net.net.0.weight"][:, :80 + ind_dim])
+    for n in ("xy", "yz", "xz"):
+        p[f"encoder_{n}.embeddings"] = params[f"encoder_{n}.embeddings"] * np.float32(30.0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for M in (16 * 4321 + 5, 37):
+        xyz = torch.from_numpy(rng.uniform(-1, 1, (M, 3)).astype(np.float32)).cuda()
+        d = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)), dim=-1).cuda()
+        gout = [torch.from_numpy(rng.normal(size=sh).astype(np.float32)).cuda() for sh in ((M,), (M, 3), (M, 1), (M, 1), (M, 1))]
+        gout[0] *= 1e-2
+        res = []
+        for rc in (False, True):
+            net = FusedTriplaneTrainHead(p, bound=1.0, exp_eye=exp_eye, ind_dim=ind_dim, forward_dtype="f16", backward_dtype="f16", recompute_mlp=rc).cuda()
+            assert net.recompute_mlp is rc
+            enc_a = dev(golden["net_enc_a"]).requires_grad_(True)
+            ind = dev(golden["net_ind"]).requires_grad_(True) if ind_dim else None
+            eye = dev(golden["net_eye"]) if exp_eye else None
+            outs = net(xyz, d, enc_a, ind, eye)
+            live = [k for k in range(5) if outs[k].requires_grad]
+            torch.autograd.backward([outs[k] for k in live], [gout[k] for k in live])
+            g = {n: t.grad.clone() for n, t in net.named_parameters()}
+            g["enc_a"] = enc_a.grad.clone()
+            if ind is not None:
+                g["ind"] = ind.grad.clone()
+            res.append(([o.detach().clone() for o in outs], g))
+        (o0, g0), (o1, g1) = res
+        for a, b, nm in zip(o0, o1, ("sigma", "rgb", "amb_aud", "amb_eye", "unc")):
+            assert torch.equal(a, b), (M, nm)
+        assert set(g0) == set(g1)
+        for n in g0:
+            assert bool(torch.isfinite(g1[n]).all()) and float(g1[n].abs().max()) > 0 or n.startswith("eye_att") and not exp_eye, (M, n)
+            # float atomics in a free order: the table scatter's flush, and the per-workgroup sums of the skinny layers / enc_a / ind_code
+            if "embeddings" in n or n in ("enc_a", "ind") or n.endswith(("eye_att_net.net.1.weight", "unc_net.net.1.weight", "color_net.net.1.weight")):
+                assert float((g0[n] - g1[n]).abs().max()) <= 1e-5 * float(g0[n].abs().max()), (M, n)
+            else:
+                assert torch.equal(g0[n], g1[n]), (M, n, float((g0[n] - g1[n]).abs().max()))
+    # the default of the all-f16 arrangement, and what it refuses
+    assert FusedTriplaneTrainHead(p, exp_eye=exp_eye, ind_dim=ind_dim, forward_dtype="f16", backward_dtype="f16").recompute_mlp is True
+    assert FusedTriplaneTrainHead(p, exp_eye=exp_eye, ind_dim=ind_dim, forward_dtype="f16").recompute_mlp is False
+    with pytest.raises(ValueError, match="recompute_mlp"):
+        FusedTriplaneTrainHead(p, exp_eye=exp_eye, ind_dim=ind_dim, recompute_mlp=True)

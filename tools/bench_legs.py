@@ -199,7 +199,9 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
     ro, rd, target = ro[sel[lo:hi]].contiguous(), rd[sel[lo:hi]].contiguous(), target[lo:hi].contiguous()
     if args.train_mlp == "fused":   # one kernel forward, one kernel for the backward data chain (lzzx_nerf_amd/head_train.py)
         from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
-        net = FusedTriplaneTrainHead(P, bound=1.0, record=not args.train_recompute, record_dtype=args.train_records, forward_dtype=args.train_forward, backward_dtype=args.train_backward).to(device)
+        all16 = args.train_forward == "f16" and args.train_backward == "f16"
+        net = FusedTriplaneTrainHead(P, bound=1.0, record=not args.train_recompute, record_dtype=args.train_records, forward_dtype=args.train_forward,
+                                     backward_dtype=args.train_backward, recompute_mlp=(not getattr(args, "train_keep_records", False)) if all16 else None).to(device)
     else:
         net = TriplaneTrainNet(P, device, mlp=args.train_mlp)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-15, fused=True)
@@ -288,7 +290,7 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
                 device_allocations_in_timed_region=dev_allocs, device_frees_in_timed_region=dev_frees,
                 ms_per_step_median=round(per_step[len(per_step) // 2], 3), ms_per_step_min=round(per_step[0], 3), ms_per_step_max=round(per_step[-1], 3),
                 ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
-                loss=float(loss.detach()), dtype=train_dtype(args), mlp={"fused": "fused head forward + backward kernels, " + ("activations recomputed in the backward (csrc/lz_head.hip, lz_head_bwd.hip)" if args.train_recompute else "forward records, backward starts from the record (csrc/lz_head_rec.hip" + (", lz_head_rec16.hip" if args.train_forward == "f16" else "") + "), " + ("f16" if "f16" in (args.train_forward, args.train_backward) else args.train_records) + " records"), "lz": "csrc/lz_linear.hip (MFMA f32)",
+                loss=float(loss.detach()), dtype=train_dtype(args), mlp={"fused": "fused head forward + backward kernels, " + ("activations recomputed in the backward (csrc/lz_head.hip, lz_head_bwd.hip)" if args.train_recompute else ("the forward keeps only the enc_x halves (80 B per sample), the backward kernel recomputes the MLP from them (csrc/lz_head_fwd16_chain.h, lz_head_rec.hip RC)" if (args.train_forward == "f16" and args.train_backward == "f16" and not getattr(args, "train_keep_records", False)) else "forward records, backward starts from the record (csrc/lz_head_rec.hip" + (", lz_head_rec16.hip" if args.train_forward == "f16" else "") + "), " + ("f16" if "f16" in (args.train_forward, args.train_backward) else args.train_records) + " records")), "lz": "csrc/lz_linear.hip (MFMA f32)",
                      "torch": "torch/rocBLAS"}[args.train_mlp])
 
 

@@ -10,7 +10,8 @@ mkdir -p $OUT
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $REPO/bench.py --train-only --steps 12 --warmup 2 "$@" > $OUT/prof_${TAG}_bench.json 2> $OUT/prof_$TAG.err
 cd $REPO
-find $OUT/prof_$TAG -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
+# per-kernel median / mean without the warm-up steps (rocprofv3's own --stats table averages every launch, warm-ups included)
+python3 tools/kernel_medians.py $OUT/prof_$TAG --skip 2 > $OUT/${TAG}_kernel_stats.csv
 find $OUT/prof_$TAG -name "*.db" -delete
 find $OUT/prof_$TAG -name "*kernel_trace.csv" -delete
 cut -c1-160 $OUT/${TAG}_kernel_stats.csv | head -40
