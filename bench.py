@@ -124,6 +124,10 @@ def parse_args():
     ap.add_argument("--gather-via", default="collective", choices=["collective", "peer"],
                     help="N > 1, --shard frame: 'collective' = one RCCL all_gather_into_tensor per frame; 'peer' = every rank copies its tile "
                          "straight into each peer's frame buffer (one xGMI hop per tile, IPC-mapped buffers, device-side flag wait)")
+    ap.add_argument("--verify-frames", type=int, default=0, metavar="K",
+                    help="N > 1, --shard frame: after the timed region run K more steps and compare the CONTENTS of every gathered frame on every "
+                         "rank with the frame of the timed region's last step, with no barrier between the steps (the check --gather-via peer "
+                         "needs: a stale cache line or a torn hand-off shows up as a mismatch count in `verify_frames`)")
     ap.add_argument("--gather", default="f32", choices=["f32", "rgb24"],
                     help="what the per-step all-gather moves: f32 RGB tiles, or the video pipe's RGB24 quantised on device (4x fewer bytes)")
     args = ap.parse_args()
@@ -181,6 +185,7 @@ def main():
     # ---- headline ----
     job = make_job(args.shard, args.tiles, shard_of=args.shard_of)
     dt, head_ms, out, tiles = timed(job, args.steps, args.warmup, world, device)
+    dt_own = job.dt_own
     samples_per_step, iters_per_frame, rows_per_step = frame_stats(out, world, device)
     log(f"headline: {dt / args.steps * 1e3:.3f} ms/step")
     frames_per_step = world if (world > 1 and args.shard == "clip") else 1
@@ -217,10 +222,29 @@ def main():
     train_dp = None
     if world > 1 and args.train_dp:   # every rank takes part: one gradient all-reduce per step
         train_dp = train_bench(args, device, P, golden, bits, rank, world)
+    # per-rank tile times (every rank's own clock and its persistent-kernel time per step), for the first SCALE record to read load balance from
+    rank_tile_ms = None
+    if world > 1:
+        mine_ms = torch.tensor([dt_own / args.steps * 1e3, float(np.sum(head_ms)) / max(args.steps, 1)], dtype=torch.float64, device=device)
+        allms = [torch.zeros_like(mine_ms) for _ in range(world)]
+        torch.distributed.all_gather(allms, mine_ms)
+        rank_tile_ms = dict(step=[round(float(t[0]), 4) for t in allms], kernel=[round(float(t[1]), 4) for t in allms])
     # correctness of the gathered frame on every rank: the assembled tiles equal this rank's own tile where they overlap
-    gather_ok = gather_equals_unsharded = None
+    gather_ok = gather_equals_unsharded = verify = None
     if world > 1 and args.shard == "frame":
         job.sf.wait()
+        if args.verify_frames > 0:
+            # K more frames of the same pose, NO barrier between them: every rank compares every gathered frame, word for word, with the frame
+            # the timed region ended on (whose own check against the unsharded reference loop follows below)
+            want = tiles.clone()
+            bad = 0
+            for _ in range(args.verify_frames):
+                _, t2 = job.step()
+                job.sf.wait()
+                bad += int(not torch.equal(t2, want))
+            vb = torch.tensor([float(bad)], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(vb)
+            verify = dict(steps=args.verify_frames, mismatching_frames_over_all_ranks=int(vb.item()), barrier_between_steps=False, via=args.gather_via)
         frame = job.sf.assemble(tiles)
         mine = frame[job.sf.pixels]
         own = out["image_rgb24"] if args.gather == "rgb24" else out["image"]
@@ -320,6 +344,10 @@ def main():
         result["gathered_frame_ok"] = gather_ok
     if gather_equals_unsharded is not None:
         result["gathered_frame_equals_unsharded_reference_loop"] = gather_equals_unsharded
+    if verify is not None:
+        result["verify_frames"] = verify
+    if rank_tile_ms is not None:
+        result["rank_tile_ms"] = rank_tile_ms
     result.update(multi)
     if train_dp is not None:
         result["train_step"] = train_dp

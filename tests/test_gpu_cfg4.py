@@ -101,7 +101,7 @@ def test_device_built_ellipsoid_bitfield_equals_checker():
     assert np.array_equal(bits.cpu().numpy(), bits_o) and np.array_equal(grid.cpu().numpy(), grid_o)
 
 
-@pytest.mark.parametrize("extra", [["--max-steps", "64"], ["--max-steps", "16", "--scene", "ellipsoid"]])
+@pytest.mark.parametrize("extra", [["--max-steps", "64", "--verify-frames", "3"], ["--max-steps", "16", "--scene", "ellipsoid"]])
 def test_bench_self_spawns_two_ranks_and_prints_the_contract_line(tmp_path, extra):
     """(second case: the reference's deployed max_steps, where the cap binds -- the two ranks all-reduce the cap histogram between the two
     phases of every frame, and rank 0's check of the gathered frame against its own tile still holds)"""
@@ -124,6 +124,9 @@ def test_bench_self_spawns_two_ranks_and_prints_the_contract_line(tmp_path, extr
     assert len(lines[0]) < MAX_LINE_BYTES // 2, len(lines[0])
     assert set(CONTRACT_KEYS) <= set(r) and set(CONFIG_KEYS) <= set(r["config"]) and set(ROOFLINE_KEYS) <= set(r["roofline"])
     assert p.stdout.strip().splitlines()[-1] == lines[0]
+    assert len(r["rank_tile_ms"]["step"]) == 2 and len(r["rank_tile_ms"]["kernel"]) == 2 and min(r["rank_tile_ms"]["step"]) > 0
+    if "--verify-frames" in extra:   # K more frames compared word for word on every rank, no barrier between them
+        assert r["verify_frames"]["steps"] == 3 and r["verify_frames"]["mismatching_frames_over_all_ranks"] == 0
     detail = json.load(open(os.path.join(ROOT, r["detail"])))
     assert detail["value"] == r["value"] and "schedule" in detail["config"]
 

@@ -345,6 +345,7 @@ def timed(job, steps, warmup, world, device, timing=True):
     dt = time.perf_counter() - t0
     gc.enable()
     head_ms = job.r.timing_stop() if timing else []
+    job.dt_own = dt            # this rank's own clock (the return value is the max over the ranks)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
