@@ -703,7 +703,13 @@ lz_k_frame(typename LzfHead<PREC>::Args P, LzFrameK F) {
                 // A sample's four transcendentals come out two per lane (rgb[0], rgb[2] on half 0; rgb[1], sigma on half 1): every lane parks
                 // its own for the compositing below -- OSIG, OR, OG, OB are consecutive fields -- and nothing crosses lanes
                 const int rs = lane & 31, hh = lane >> 5;
-                const float px = __shfl(x, rs, 64), py = __shfl(y, rs, 64), pz = __shfl(z, rs, 64);
+                // the slot lanes' positions to both lane halves: v_permlane32_swap(a, a) leaves a's low half in both (one VALU instruction where
+                // a ds_bpermute costs an address, an LDS round trip and a wait)
+                auto lo2 = [](float v) -> float {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                    return __uint_as_float(r[0]);
+                };
+                const float px = lo2(x), py = lo2(y), pz = lo2(z);
                 HD::slice(ctx, lane, px, py, pz, typename HD::ShSlot{slot, rs, NS}, o);
                 my_slices += 2;
                 slot[(SF_OR + hh) * NS + rs] = o.a;

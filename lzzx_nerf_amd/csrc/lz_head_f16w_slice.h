@@ -125,13 +125,14 @@ __device__ __forceinline__ void lz_head16w_slice(const LzHead16Ctx& hc, int lane
     // ---------------- gather (f32, lz_head_gather.h, the f32 kernels' arithmetic): 18 features of this lane's sample, 2 x 36 loads ----------------
     lz_h8 bx[3];
     {
-        float e0[9], e1[9];
-        lz_head_gather<IN_RANGE, LZ_GATHER_PACK16, YIELD, false, 2>(hc.emb, hc.tab, px, py, pz, h, hc.bound, hc.two_bound, e0);
+        float e0[9], e1[9], c01[3];
+        lz_head_map01(px, py, pz, hc.bound, hc.two_bound, c01);      // once for both calls
+        lz_head_gather<IN_RANGE, LZ_GATHER_PACK16, YIELD, false, 2, true>(hc.emb, hc.tab, c01[0], c01[1], c01[2], h, hc.bound, hc.two_bound, e0);
         // h_round2: every f32 feature exists first, then its half (no v_fma_mixlo_f16 with the interpolation's last fma)
         const lz_u4v w0 = {h_round2(e0[0], e0[1]), h_round2(e0[2], e0[3]), h_round2(e0[4], e0[5]), h_round2(e0[6], e0[7])};
         bx[0] = __builtin_bit_cast(lz_h8, w0);
         if constexpr (YIELD) __builtin_amdgcn_s_setprio(2);
-        lz_head_gather<IN_RANGE, LZ_GATHER_PACK16, YIELD, false, 2>(hc.emb, hc.tab, px, py, pz, 6 + h, hc.bound, hc.two_bound, e1);
+        lz_head_gather<IN_RANGE, LZ_GATHER_PACK16, YIELD, false, 2, true>(hc.emb, hc.tab, c01[0], c01[1], c01[2], 6 + h, hc.bound, hc.two_bound, e1);
         const lz_u4v w1 = {h_round2(e0[8], e1[0]), h_round2(e1[1], e1[2]), h_round2(e1[3], e1[4]), h_round2(e1[5], e1[6])};
         const lz_u4v w2 = {h_round2(e1[7], e1[8]), 0u, 0u, 0u};
         bx[1] = __builtin_bit_cast(lz_h8, w1);

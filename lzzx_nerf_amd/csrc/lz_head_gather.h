@@ -85,7 +85,24 @@ typedef float lz_gf2 __attribute__((ext_vector_type(2)));
 // the fused frame: f32 9.05 -> 8.97 ms, f16 2.025 -> 2.04 ms (no gain: the f16 slices keep the one-load-per-corner form)
 // LSTRIDE: the lane's three level records are levels q + LSTRIDE mrec (mrec < 3).  4: the 16-sample heads (lane group q of four owns features
 // 4 i + q).  2: the 32-sample f16 head (lz_head_f16w_slice.h), whose lane half h owns 18 features in two calls, q = h and q = 6 + h.
-template <bool IN_RANGE = false, bool PACK = false, bool YIELD = false, bool PAIR0 = false, int LSTRIDE = 4>
+// (x + bound) / (2 bound) of a sample, grid.py:143 -- what lz_head_gather starts with; a caller that gathers one sample in several calls
+// (the 32-sample f16 slice) maps it once and passes MAPPED = true
+__device__ __forceinline__ void lz_head_map01(float px, float py, float pz, float bound, float two_bound, float (&c01)[3]) {
+    // When 2 bound is a power of two (bound 1, 2, 4 ...: every scene of the reference) the division equals the multiplication by its exact
+    // reciprocal bit for bit, and an IEEE division is ~11 VALU instructions (readfirstlane: `two_bound` reaches this point in a vector
+    // register, and a condition computed from it counts as divergent -- the compiler then evaluates BOTH sides below, three IEEE division
+    // sequences of ~10 instructions each per slice, and selects; as a scalar it is a branch)
+    const uint32_t tb_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(two_bound));
+    const bool pow2 = (tb_bits & 0x007fffffu) == 0u && tb_bits > 0x00800000u && tb_bits < 0x7f000000u;   // wave-uniform
+    if (pow2) {
+        const float inv = __uint_as_float(0x7f000000u - tb_bits);    // 2^-k for two_bound = 2^k
+        c01[0] = (px + bound) * inv; c01[1] = (py + bound) * inv; c01[2] = (pz + bound) * inv;
+    } else {
+        c01[0] = (px + bound) / two_bound; c01[1] = (py + bound) / two_bound; c01[2] = (pz + bound) / two_bound;
+    }
+}
+
+template <bool IN_RANGE = false, bool PACK = false, bool YIELD = false, bool PAIR0 = false, int LSTRIDE = 4, bool MAPPED = false>
 __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], const int* __restrict__ tab, float px, float py, float pz, int q,
                                                float bound, float two_bound, float (&encx)[9]) {
     // the three grid levels this lane touches (level = 4 m + q); read per slice from LDS so that they do not occupy registers during the
@@ -101,19 +118,9 @@ __device__ __forceinline__ void lz_head_gather(const float* const (&emb)[3], con
         lv_hmul[mrec] = (uint32_t)tab[LZ_LVTAB_HMUL + level];
         lv_mask[mrec] = (uint32_t)tab[LZ_LVTAB_MASK + level];
     }
-    // (x + bound) / (2 bound), grid.py:143.  When 2 bound is a power of two (bound 1, 2, 4 ...: every scene of the reference) the
-    // division equals the multiplication by its exact reciprocal bit for bit, and an IEEE division is ~11 VALU instructions
-    // (readfirstlane: `two_bound` reaches this point in a vector register, and a condition computed from it counts as divergent -- the compiler
-    // then evaluates BOTH sides below, three IEEE division sequences of ~10 instructions each per slice, and selects; as a scalar it is a branch)
-    const uint32_t tb_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(two_bound));
-    const bool pow2 = (tb_bits & 0x007fffffu) == 0u && tb_bits > 0x00800000u && tb_bits < 0x7f000000u;   // wave-uniform
     float c01[3];
-    if (pow2) {
-        const float inv = __uint_as_float(0x7f000000u - tb_bits);    // 2^-k for two_bound = 2^k
-        c01[0] = (px + bound) * inv; c01[1] = (py + bound) * inv; c01[2] = (pz + bound) * inv;
-    } else {
-        c01[0] = (px + bound) / two_bound; c01[1] = (py + bound) / two_bound; c01[2] = (pz + bound) / two_bound;
-    }
+    if constexpr (MAPPED) { c01[0] = px; c01[1] = py; c01[2] = pz; }      // the caller ran lz_head_map01
+    else lz_head_map01(px, py, pz, bound, two_bound, c01);
     // Branch-free: out-of-range coordinates are clamped for ADDRESSING only and the feature is zeroed by a select
     // (gridencoder.cu:98-122), so all 36 gathers of a sample are independent loads.  Two passes so that the 36 table reads are IN
     // FLIGHT TOGETHER (one L2 round trip per slice instead of one per read): pass 1 computes fractions + table indices and issues
