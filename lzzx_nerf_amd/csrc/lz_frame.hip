@@ -1130,10 +1130,14 @@ static int lzf_launch_persistent(const lz_frame_fused* f, const LzFrameK& K, hip
         // (round 4, with the batched march: rank 0's tile of a 512^2 frame sharded 8 / 4 ways, f16 kernel ms at S = 1 / 2 / 4: 0.573 / 0.454 /
         // 0.421 and 0.733 / 0.705 / 0.768; f32: 2.22 / 1.57 / 1.30 and 2.97 / 2.57 / 2.53 -- both heads want the rows in flight twice over)
         // f16 (32 slots per wave): the slots filled 1.5 times over -- with exactly one ray per slot nothing is ever refilled and the frame
-        // ends on emptying slices (round 3: a 2-way tile of 131 072 rays, 1.30 ms on two full rows against 1.17 on one)
-        const uint64_t want = p->precision == 1 ? (uint64_t)n_cu * LZF_WAVES * 48 : (uint64_t)n_cu * LZF_WAVES * 16 * 2;
+        // ends on emptying slices -- for S <= 2, once over from S = 4 on (round 5, tools/spp_sweep.sh, rank 0's interleaved tile of a 512^2
+        // frame, ms at S = 1 / 2 / 4 / 8 / 16: 2-way 1.12 / 1.07 / 1.12 / 1.29 / 1.91, 4-way 0.80 / 0.67 / 0.63 / 0.72 / 1.05, 8-way 0.64 / 0.49 /
+        // 0.39 / 0.41 / 0.58, 16-way 0.60 / 0.41 / 0.32 / 0.28 / 0.37: the rule picks the best S at every size)
+        const uint64_t slots = (uint64_t)n_cu * LZF_WAVES * 32;
+        const uint64_t want = p->precision == 1 ? slots * 3 / 2 : (uint64_t)n_cu * LZF_WAVES * 16 * 2;
         S = 1;
         while (S < 16 && (uint64_t)f->N * S < want) S *= 2;
+        if (p->precision == 1 && S >= 8 && (uint64_t)f->N * (S / 2) >= slots) S /= 2;
     }
     LZ_REQUIRE(S == 1 || S == 2 || S == 4 || S == 8 || S == 16, LZ_ERR_BAD_ARGUMENT, "frame_render: steps_per_pass must be 0 (auto), 1, 2, 4, 8 or 16");
 #define LZF_LAUNCH(PREC, SS) hipLaunchKernelGGL((lz_k_frame<PREC, SS, 1>), dim3(grid), dim3(LZF_WG), 0, st, a, K)

@@ -248,7 +248,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
                     float v = wv[LZ_WV_C2 + f] * dc[0];
                     v = lz_fmaf(wv[LZ_WV_C2 + 64 + f], dc[1], v);
                     v = lz_fmaf(wv[LZ_WV_C2 + 128 + f], dc[2], v);
-                    dc1[k] = ((mk_c1 >> k) & 1u) ? v : 0.0f;
+                    dc1[k] = lz_mask_keep(mk_c1, k, v);
                 }
             if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_G_C1H, dc1);
             float dxc[21];
@@ -273,13 +273,13 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
                 for (int r = 0; r < 4; r++) {
                     const int k = 4 * t + r;
                     const float v = lz_fmaf(wv[LZ_WV_SIG + 16 * t + 4 * q + r], dh0, ds2[k]);
-                    ds2[k] = ((mk_s2 >> k) & 1u) ? v : 0.0f;
+                    ds2[k] = lz_mask_keep(mk_s2, k, v);
                 }
             if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_G_S2, ds2);
             float ds1[16];
             lz_layer_bwd<LZ_L_S2>(wl, lane, ds2, ds1);
 #pragma unroll
-            for (int k = 0; k < 16; k++) ds1[k] = ((mk_s1 >> k) & 1u) ? ds1[k] : 0.0f;
+            for (int k = 0; k < 16; k++) ds1[k] = lz_mask_keep(mk_s1, k, ds1[k]);
             if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_G_S1, ds1);
             float dxs[18];
             lz_layer_bwd<LZ_L_S1>(wl, lane, ds1, dxs);
@@ -314,7 +314,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
             }
             float de1[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) de1[r] = ((mk_e1 >> r) & 1u) ? wv[LZ_WV_E2 + 4 * q + r] * de2 : 0.0f;
+            for (int r = 0; r < 4; r++) de1[r] = lz_mask_keep(mk_e1, r, wv[LZ_WV_E2 + 4 * q + r] * de2);
             if (valid) lz_dump_chained<1>(rb, q, LZ_BWD_G_X + 64, de1);
             float dxe[9];
             lz_layer_bwd<LZ_L_E1>(wl, lane, de1, dxe);
@@ -329,7 +329,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
             float da1[16];
             lz_layer_bwd<LZ_L_A2>(wl, lane, datt, da1);
 #pragma unroll
-            for (int k = 0; k < 16; k++) da1[k] = ((mk_a1 >> k) & 1u) ? da1[k] : 0.0f;
+            for (int k = 0; k < 16; k++) da1[k] = lz_mask_keep(mk_a1, k, da1[k]);
             if (valid) lz_dump_chained<4>(rb, q, LZ_BWD_G_X, da1);
             float dxa[9];
             lz_layer_bwd<LZ_L_A1>(wl, lane, da1, dxa);
@@ -344,7 +344,7 @@ lz_k_triplane_head_backward(LzHeadBwdArgs A, const float* __restrict__ xyzs, con
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int k = 4 * t + r;
-                    du1[k] = ((mk_u1 >> k) & 1u) ? wv[LZ_WV_U2 + 16 * t + 4 * q + r] * du : 0.0f;
+                    du1[k] = lz_mask_keep(mk_u1, k, wv[LZ_WV_U2 + 16 * t + 4 * q + r] * du);
                 }
             if (valid) lz_dump_chained<2>(rb, q, LZ_BWD_G_X + 80, du1);
         }

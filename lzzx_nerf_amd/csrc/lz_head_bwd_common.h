@@ -130,6 +130,15 @@ __device__ __forceinline__ void lz_dump_chained(float* __restrict__ rb, int q, i
     }
 }
 
+// v where bit k of the ReLU mask is set, +0 elsewhere: the bit sign-extended to a word (v_bfe_i32) and one AND -- two instructions per value
+// where the compare + select form the compiler makes of `(mk >> k) & 1 ? v : 0` costs three (76 values per slice of the backward kernels,
+// which are bound by vector-instruction issue); the same bits in every case (a kept value is untouched, a dropped one is +0)
+__device__ __forceinline__ float lz_mask_keep(uint32_t mk, int k, float v) {
+    return __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)mk, (uint32_t)k, 1u));
+}
+// (the recomputing backward sits at its register limit and spills nine more values with the AND form: it keeps the select)
+#define LZ_MASK_KEEP(SELECT, mk, k, v) ((SELECT) ? ((((mk) >> (k)) & 1u) ? (v) : 0.0f) : lz_mask_keep((mk), (k), (v)))
+
 template <int N>
 __device__ __forceinline__ uint32_t lz_mask_pos(const float (&v)[N]) {
     uint32_t mk = 0;

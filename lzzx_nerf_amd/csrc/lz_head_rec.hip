@@ -765,7 +765,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                     float v = wv[LZ_WV_C2 + f] * dc[0];
                     v = lz_fmaf(wv[LZ_WV_C2 + 64 + f], dc[1], v);
                     v = lz_fmaf(wv[LZ_WV_C2 + 128 + f], dc[2], v);
-                    dc1[k] = ((mk_c1 >> k) & 1u) ? v : 0.0f;
+                    dc1[k] = LZ_MASK_KEEP(RC, mk_c1, k, v);
                 }
             if constexpr (FUSE) {
 #pragma unroll
@@ -806,7 +806,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 for (int r = 0; r < 4; r++) {
                     const int k = 4 * t + r;
                     const float v = lz_fmaf(wv[LZ_WV_SIG + 16 * t + 4 * q + r], dh0, ds2[k]);
-                    ds2[k] = ((mk_s2 >> k) & 1u) ? v : 0.0f;
+                    ds2[k] = LZ_MASK_KEEP(RC, mk_s2, k, v);
                 }
             if constexpr (FUSE) {
 #pragma unroll
@@ -826,7 +826,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             float ds1[16];
             layer_bwd(std::integral_constant<int, LZ_L_S2>{}, ds2, ds1);
 #pragma unroll
-            for (int k = 0; k < 16; k++) ds1[k] = ((mk_s1 >> k) & 1u) ? ds1[k] : 0.0f;
+            for (int k = 0; k < 16; k++) ds1[k] = LZ_MASK_KEEP(RC, mk_s1, k, ds1[k]);
             if constexpr (FUSE) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) g_put(t, ds1[4 * t], ds1[4 * t + 1], ds1[4 * t + 2], ds1[4 * t + 3]);
@@ -891,7 +891,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int k = 4 * t + r;
-                du1[k] = ((mk_u1 >> k) & 1u) ? wv[LZ_WV_U2 + 16 * t + 4 * q + r] * du : 0.0f;
+                du1[k] = LZ_MASK_KEEP(RC, mk_u1, k, wv[LZ_WV_U2 + 16 * t + 4 * q + r] * du);
             }
         float de1[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // stays zero without an eye input: the stacked reduction over G_x reads these columns
         if (has_eye) {
@@ -903,7 +903,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
                 for (int r = 0; r < 4; r++) acc_e2[r] = lz_fmaf(de2, e1[r], acc_e2[r]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++) de1[r] = ((mk_e1 >> r) & 1u) ? wv[LZ_WV_E2 + 4 * q + r] * de2 : 0.0f;
+            for (int r = 0; r < 4; r++) de1[r] = LZ_MASK_KEEP(RC, mk_e1, r, wv[LZ_WV_E2 + 4 * q + r] * de2);
             float dxe[9];
             layer_bwd(std::integral_constant<int, LZ_L_E1>{}, de1, dxe);
 #pragma unroll
@@ -926,7 +926,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             float da1[16];
             layer_bwd(std::integral_constant<int, LZ_L_A2>{}, datt, da1);
 #pragma unroll
-            for (int k = 0; k < 16; k++) da1[k] = ((mk_a1 >> k) & 1u) ? da1[k] : 0.0f;
+            for (int k = 0; k < 16; k++) da1[k] = LZ_MASK_KEEP(RC, mk_a1, k, da1[k]);
             if constexpr (FUSE) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) g_put(t, da1[4 * t], da1[4 * t + 1], da1[4 * t + 2], da1[4 * t + 3]);
