@@ -45,7 +45,9 @@
 #include "lz_head_f16_slice.h"
 #include "lz_head_f16w_slice.h"
 
-#define LZF_WG 1024
+#ifndef LZF_WG
+#define LZF_WG 1024   // (-DLZF_WG=768: three waves per SIMD, 168 registers -- the LZ_F16W_G72 experiment)
+#endif
 #define LZF_WAVES (LZF_WG / 64)
 #define LZF_BINS 256
 #define LZF_LUT 256          // Morton bit-spread table in LDS, for grids up to 256^3 (the reference hard-codes 128, renderer.py:94)
