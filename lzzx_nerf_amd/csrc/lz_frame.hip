@@ -46,7 +46,7 @@
 #include "lz_head_f16w_slice.h"
 
 #ifndef LZF_WG
-#define LZF_WG 1024   // (-DLZF_WG=768: three waves per SIMD, 168 registers -- the LZ_F16W_G72 experiment)
+#define LZF_WG 1024   // (-DLZF_WG=768: three waves per SIMD, 168 registers; round 5 tried the f16 slice with ONE 72-load gather there: 1.84 ms against 1.77, and 2.33 at 1024 threads)
 #endif
 #define LZF_WAVES (LZF_WG / 64)
 #define LZF_BINS 256

@@ -116,77 +116,6 @@ __device__ __forceinline__ void lz_head16w_stage(const LzHead16Args& P, lz_h8* w
     hc.unc_const = lz_softplusf(0.0f);   // test mode (network.py:243-249, 278)
 }
 
-// The lane's 18 features in ONE pass (LZ_F16W_G72): levels h, h + 2, .., h + 10 of the three planes, all 72 table reads in flight together
-// (lz_head_gather's arithmetic, feature by feature: pos = fma(x, scale, 0.5), one index formula for dense and hashed levels, corner
-// weights in corner order, fma accumulation).  c01: the sample mapped by lz_head_map01.  encx[6 p + m] = plane p, level 2 m + h.
-template <bool IN_RANGE, bool YIELD>
-__device__ __forceinline__ void lz_head_gather18(const float* const (&emb)[3], const int* __restrict__ tab, const float (&c01)[3], int h, float (&encx)[18]) {
-    bool oobc[3];
-    float cc[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        oobc[d] = IN_RANGE ? false : (c01[d] < 0 || c01[d] > 1);
-        cc[d] = IN_RANGE ? c01[d] : lz_fminf(lz_fmaxf(c01[d], 0.0f), 1.0f);
-    }
-    float gv[18][4], fr[6][3], om[6][3];
-#pragma unroll
-    for (int m = 0; m < 6; m++) {
-        const int level = 2 * m + h;
-        const uint32_t off = (uint32_t)tab[level], strd = (uint32_t)tab[LZ_LVTAB_STRIDE + level], hmul = (uint32_t)tab[LZ_LVTAB_HMUL + level],
-                       mask = (uint32_t)tab[LZ_LVTAB_MASK + level];
-        const float scale = reinterpret_cast<const float*>(tab)[LZ_LVTAB_SCALE + level];
-        uint32_t cell[3];
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const float p = lz_fmaf(cc[d], scale, 0.5f);
-            cell[d] = (uint32_t)p;
-            fr[m][d] = __builtin_amdgcn_fractf(p);
-            om[m][d] = 1 - fr[m][d];
-        }
-        uint32_t rowH[2][2], rowD[2][2];     // [row coordinate: 0 = y, 1 = z][lower / upper corner]
-#pragma unroll
-        for (int rc = 0; rc < 2; rc++) {
-            const uint32_t g1 = cell[1 + rc];
-            rowH[rc][0] = __umul24(g1, hmul);
-            rowH[rc][1] = rowH[rc][0] + hmul;
-            rowD[rc][0] = __umul24(g1, strd) + off;
-            rowD[rc][1] = rowD[rc][0] + strd;
-        }
-#pragma unroll
-        for (int plane = 0; plane < 3; plane++) {
-            const int cd = plane == 1 ? 1 : 0, rc = plane == 0 ? 0 : 1;          // column coordinate (x, y, x), row coordinate (y, z, z)
-            const char* gb = reinterpret_cast<const char*>(emb[plane]);
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const uint32_t c0 = cell[cd] + (c & 1);
-                const uint32_t index = ((c0 ^ rowH[rc][c >> 1]) & mask) + rowD[rc][c >> 1];
-                gv[6 * plane + m][c] = *reinterpret_cast<const float*>(gb + (index << 2));
-            }
-        }
-    }
-    if constexpr (YIELD) __builtin_amdgcn_s_setprio(0);
-    // every read issued before the first use: the values pass through empty asm statements (in and out), behind a scheduling barrier
-#pragma unroll
-    for (int i = 0; i < 18; i++) asm volatile("" : "+v"(gv[i][0]), "+v"(gv[i][1]), "+v"(gv[i][2]), "+v"(gv[i][3]));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 18; i++) {
-        const int plane = i / 6, m = i % 6;
-        const int cd = plane == 1 ? 1 : 0, rd = plane == 0 ? 1 : 2;
-        float acc = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float w = ((c & 1) ? fr[m][cd] : om[m][cd]) * ((c >> 1) ? fr[m][rd] : om[m][rd]);
-            acc = lz_fmaf(w, gv[i][c], acc);
-        }
-        if constexpr (!IN_RANGE) {
-            const bool oob = plane == 0 ? (oobc[0] || oobc[1]) : (plane == 1 ? (oobc[1] || oobc[2]) : (oobc[0] || oobc[2]));
-            acc = oob ? 0.0f : acc;
-        }
-        encx[i] = acc;
-    }
-}
-
 #ifndef LZ_F16W_PRIO
 #define LZ_F16W_PRIO 1   // the frame kernel runs march + gather addresses at a raised wave priority and drops it once a gather call has issued its loads (same-box A/B, three alternations: 1.789 -> 1.783, 1.800 -> 1.791 ms, cfg5 0.770 -> 0.762; -DLZ_F16W_PRIO=0 switches it off)
 #endif
@@ -196,17 +125,6 @@ __device__ __forceinline__ void lz_head16w_slice(const LzHead16Ctx& hc, int lane
     // ---------------- gather (f32, lz_head_gather.h, the f32 kernels' arithmetic): 18 features of this lane's sample, 2 x 36 loads ----------------
     lz_h8 bx[3];
     {
-#if LZ_F16W_G72
-        float e[18], c01[3];
-        lz_head_map01(px, py, pz, hc.bound, hc.two_bound, c01);
-        lz_head_gather18<IN_RANGE, YIELD>(hc.emb, hc.tab, c01, h, e);
-        const lz_u4v w0 = {h_round2(e[0], e[1]), h_round2(e[2], e[3]), h_round2(e[4], e[5]), h_round2(e[6], e[7])};
-        const lz_u4v w1 = {h_round2(e[8], e[9]), h_round2(e[10], e[11]), h_round2(e[12], e[13]), h_round2(e[14], e[15])};
-        const lz_u4v w2 = {h_round2(e[16], e[17]), 0u, 0u, 0u};
-        bx[0] = __builtin_bit_cast(lz_h8, w0);
-        bx[1] = __builtin_bit_cast(lz_h8, w1);
-        bx[2] = __builtin_bit_cast(lz_h8, w2);
-#else
         float e0[9], e1[9], c01[3];
         lz_head_map01(px, py, pz, hc.bound, hc.two_bound, c01);      // once for both calls
         lz_head_gather<IN_RANGE, LZ_GATHER_PACK16, YIELD, false, 2, true>(hc.emb, hc.tab, c01[0], c01[1], c01[2], h, hc.bound, hc.two_bound, e0);
@@ -219,7 +137,6 @@ __device__ __forceinline__ void lz_head16w_slice(const LzHead16Ctx& hc, int lane
         const lz_u4v w2 = {h_round2(e1[7], e1[8]), 0u, 0u, 0u};
         bx[1] = __builtin_bit_cast(lz_h8, w1);
         bx[2] = __builtin_bit_cast(lz_h8, w2);
-#endif
     }
     // ---------------- audio channel attention: 36 -> 64 -> 32 ----------------
     lz_h8 att16[2];   // [u][j] = feature 16 u + 8 (j >> 2) + 4 h + (j & 3)
