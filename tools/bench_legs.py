@@ -442,12 +442,12 @@ def log(msg):
 
 
 REF_SCHEDULE = (1, 8)   # renderer.py:513
-PMC_SUMMARY = "r4_final_pmc_summary.json"   # written by tools/profile_bench.sh from rocprofv3 --pmc passes of this same command
+PMC_SUMMARY = "r5_final_pmc_summary.json"   # written by tools/profile_bench.sh from rocprofv3 --pmc passes of this same command
 F16_SLICE_MFMAS = 30    # v_mfma_f32_32x32x16_f16 per 16 sample rows (60 per 32-sample slice of lz_head16w_slice; rounds 2-4: 59 16x16x32 per 16)
 F16_MFMA_CYCLES = 32    # matrix-pipe cycles of one v_mfma_f32_32x32x16_f16 (MI355X_MICROARCH.md)
 
 
-F16_PMC_SUMMARY = "r4_f16_head_pmc_summary.json"   # tools/profile_bench.sh f16 over the current kernel
+F16_PMC_SUMMARY = "r5_f16_head_pmc_summary.json"   # tools/profile_bench.sh f16 over the current kernel
 F16_MFMA_PEAK_TFLOPS = 2500.0                      # dense f16 (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 
 
