@@ -21,6 +21,7 @@ ISSUED_FLOP_PER_ROW = 361 * 2048 // 16   # the head issues 361 v_mfma_f32_16x16x
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
 GRID_ORDERED_PMC_SUMMARY = "r4_grid_ordered_pmc_summary.json"   # tools/profile_grid_ordered.sh
+GRID_REQ_SUMMARY = "r5_grid_request_rate.json"   # tools/profile_grid_req.sh: L1 -> L2 requests / lane accesses per launch of the ordered cfg2 gather legs + the probe's peaks
 GRID_PMC_SUMMARY = "r3_grid_pmc_summary.json"   # tools/profile_grid.sh over the CURRENT kernels (a summary of an older round describes code that no longer exists)
 
 
@@ -61,6 +62,27 @@ def _grid_traffic(tag, B):
                 kib += 2 * f["avg_per_launch"] + w["avg_per_launch"]
         return round(kib * 1024 / b_prof * B)
     except (KeyError, ValueError):
+        return None
+
+
+def _grid_request_rate(tag, ms):
+    """the cfg2 gather against REQUEST-rate yardsticks (with half tables the byte roofline is the wrong one -- the kernel
+    makes the f32 kernel's line fills and lane accesses for half the bytes): lane loads per second against the chip's L1-hit scatter peak and
+    line fills per second against its L2-resident fill peak, both measured by tools/probes/l1_fill_probe.hip; counters per launch from the
+    committed PMC pass of the same case (one process per case, tools/profile_grid_req.sh).  None when the summary is absent."""
+    case = ("march" if tag.endswith("_march_order") else "ray" if tag.endswith("_ray_ordered") else None)
+    if case is None:
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", GRID_REQ_SUMMARY)))
+        c, pk = d["cases"][case + ("_f16" if "f16" in tag else "_f32")], d["peaks"]
+        acc, fills = c["TCP_TOTAL_ACCESSES_per_launch"] / (ms * 1e-3), c["TCP_TCC_READ_REQ_per_launch"] / (ms * 1e-3)
+        return dict(bound="l1 lane-address rate", achieved=round(acc, -7), peak=pk["l1_hit_scatter_lane_loads_per_s"], unit="lane loads/s",
+                    frac=round(acc / pk["l1_hit_scatter_lane_loads_per_s"], 4), line_fills_per_s=round(fills, -7),
+                    frac_of_l2_resident_fill_peak=round(fills / pk["l2_resident_line_fills_per_s"], 4),
+                    lane_loads_per_launch=c["TCP_TOTAL_ACCESSES_per_launch"], line_fills_per_launch=c["TCP_TCC_READ_REQ_per_launch"],
+                    source="profiles/" + GRID_REQ_SUMMARY)
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
 
@@ -125,6 +147,9 @@ def grid_roofline(device):
         gbs = bytes_per_sample * B / (ms * 1e-3) / 1e9
         res[tag] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                         traffic=_grid_traffic(tag, B), samples=B, ms=round(ms, 4), bytes_per_sample=bytes_per_sample)
+        rr = _grid_request_rate(tag, ms)
+        if rr is not None:
+            res[tag]["request_rate"] = rr
         del enc, x
     return res
 
