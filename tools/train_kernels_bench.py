@@ -22,6 +22,9 @@ from lzzx_nerf_amd.utils import frame_rays
 pose, intr = synthetic_camera(512, 512)
 ro, rd = frame_rays(torch.from_numpy(np.ascontiguousarray(pose)).to(dev), intr, 512, 512)
 sel = torch.randperm(512 * 512, device=dev, generator=g)[:65536]
+if "--sorted" in sys.argv:      # the same random rays presented in pixel order
+    sel = sel.sort().values
+    sys.argv.remove("--sorted")
 ro, rd = ro[sel].contiguous(), rd[sel].contiguous()
 aabb = torch.tensor([-1, -0.5, -1, 1, 0.5, 1], dtype=torch.float32, device=dev)
 nears, fars = R.near_far_from_aabb(ro, rd, aabb, 0.05)
