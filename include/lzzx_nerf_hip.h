@@ -107,7 +107,10 @@ int lz_morton3D_dilation(const float* grid, uint32_t C, uint32_t H, float* grid_
 
 /* raymarching.h:14.  counter [2] i32 = (points, rays), accumulated from its current contents like the
  * reference's atomicAdd; ray rows are emitted in ray-id order (deterministic; one admissible outcome of the
- * reference's unordered atomics, raymarching.cu:446-454).  workspace: >= (N + 2) * 4 bytes of device scratch. */
+ * reference's unordered atomics, raymarching.cu:446-454).  workspace: >= (N + 2) * 4 bytes of device scratch.
+ * Every row of xyzs / dirs / deltas [M, ...] that the call does not write (behind the last sample, in front of the first when the
+ * counter did not start at 0, the rows of a ray dropped for lack of room) is set to ZERO by the call itself: the reference's wrapper
+ * pre-fills the buffers with torch.zeros (raymarching.py:246-248); here the caller may pass uninitialised memory. */
 int lz_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                         const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,

@@ -563,6 +563,21 @@ lz_k_march_train_write(const float* __restrict__ rays_o, const float* __restrict
         rays[(size_t)ray_index * 3 + 2] = (int)num_steps;
         if (num_steps == 0 || point_index + num_steps > M) active = false;     // nothing marched / dropped for lack of room (raymarching.cu:457)
     }
+    // Rows nobody writes read ZERO, as the reference's wrapper left them (torch.zeros, raymarching.py:246-248) -- written here, so that the
+    // caller need not fill three sample buffers first (round 5: 3 of the 19 fill launches of a training step, ~190 MB): the rows of a ray that
+    // was dropped for lack of room, and (below) the tail behind the step's last row and anything in front of its first
+    auto zero_row = [&](uint32_t r) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { xyzs[(size_t)r * 3 + k] = 0.0f; dirs[(size_t)r * 3 + k] = 0.0f; }
+        deltas[(size_t)r * 2] = 0.0f; deltas[(size_t)r * 2 + 1] = 0.0f;
+    };
+    if (n < N && num_steps != 0 && point_index + num_steps > M)
+        for (uint32_t r = point_index; r < M; r++) zero_row(r);
+    {
+        const uint32_t first = (uint32_t)base[0] < M ? (uint32_t)base[0] : M, last = (uint32_t)total[0] < M ? (uint32_t)total[0] : M;
+        const uint32_t nthreads = gridDim.x * blockDim.x, span = first + (M - last);
+        for (uint32_t i = n; i < span; i += nthreads) zero_row(i < first ? i : last + (i - first));
+    }
     LzMarch m;
     const uint32_t nc = n < N ? n : N - 1;
     m.init(rays_o + (size_t)nc * 3, rays_d + (size_t)nc * 3, bound, dt_gamma, max_steps, C, H, grid);

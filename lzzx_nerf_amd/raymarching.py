@@ -134,9 +134,10 @@ class _march_rays_train(Function):
                 mean_count += align - mean_count % align
             M = mean_count
         dev = rays_o.device
-        xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
-        dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
-        deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
+        # (the reference fills these with torch.zeros, raymarching.py:246-248; lz_march_rays_train itself zeroes every row it does not write)
+        xyzs = torch.empty(M, 3, dtype=rays_o.dtype, device=dev) if N > 0 else torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+        dirs = torch.empty(M, 3, dtype=rays_o.dtype, device=dev) if N > 0 else torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+        deltas = torch.empty(M, 2, dtype=rays_o.dtype, device=dev) if N > 0 else torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
         rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)

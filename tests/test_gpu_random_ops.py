@@ -167,7 +167,8 @@ def test_march_rays_train_on_random_rays(seed):
     for M in sorted({total + 128 - total % 128, max(total // 2, 1), total + 7}):
         xo, do, lo, ro_ = O.march_rays_train(ro, rd, bound, bits, cascade, 128, nears, fars, np.zeros(2, np.int32), M, noises, -1, False, dt_gamma, max_steps)
         assert xo.shape[0] == M
-        xt, dt_, lt = torch.zeros(M, 3, device="cuda"), torch.zeros(M, 3, device="cuda"), torch.zeros(M, 2, device="cuda")
+        # NaN-filled buffers: the entry zeroes every row it does not write itself (tail, dropped rays) -- the caller no longer has to
+        xt, dt_, lt = (torch.full(sh, float("nan"), device="cuda") for sh in ((M, 3), (M, 3), (M, 2)))
         rt = torch.empty(N, 3, dtype=torch.int32, device="cuda")
         ctr = torch.zeros(2, dtype=torch.int32, device="cuda")
         ws = torch.empty(N + 2, dtype=torch.int32, device="cuda")
