@@ -213,8 +213,10 @@ class _FusedHeadTrain(Function):
         x01 = torch.empty(3, M, 2, **kw)
         call("lz_triplane_plane_coords", ptr(xyzs), M, mod.bound, ptr(x01), stream())
         demb, dx01 = [], []
-        for c, e, g in zip(x01, emb, denc):
-            ge = torch.zeros_like(e)
+        same = all(t.shape == emb[0].shape for t in emb)
+        ge_all = torch.zeros((3,) + tuple(emb[0].shape), **kw) if same else None     # one fill for the three planes' gradients
+        for p_, (c, e, g) in enumerate(zip(x01, emb, denc)):
+            ge = ge_all[p_] if same else torch.zeros_like(e)
             jac = gin = None
             if need_x:
                 # the grid encoder's dy_dx (gridencoder.cu:179-222) is recomputed here instead of being held from the forward (96 B per
@@ -301,6 +303,11 @@ class FusedTriplaneTrainHead(nn.Module):
     @property
     def offsets(self):
         return self.encoder_xy.offsets
+
+    def invalidate_packs(self):
+        """forget which tensors the weight images were packed from (call after changing a weight behind autograd's back, e.g. through
+        `.data`, which bumps no version counter)"""
+        self._packed_token.clear()
 
     def _pack(self, kind, w):
         """(re)build one of the weight images from the tensors `w` unless it already holds exactly these (same storage, same version): the
