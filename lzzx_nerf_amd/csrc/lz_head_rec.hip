@@ -526,6 +526,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
     // a 16 x 16 half tile in LDS: [row][16 halves], row = rho(sample) so that the four rows one lane group of the transposing read
     // takes are samples kg, 4 + kg, 8 + kg, 12 + kg -- the k-slot order both operands of lz_k_head_grad_w16 use
     const int rho = 4 * (s & 3) + (s >> 2);
+    // ... and inside a row the 8-byte column block q sits at q ^ (rho / 4) (= q ^ (s & 3)): a tile row is 8 dwords, so rows r, r + 4, r + 8, r + 12
+    // start at the same bank and the 16 lanes of a ds_write_b64 group (q fixed, 16 rows) collided four ways -- 589 LDS conflict cycles per
+    // slice (round 5, SQ_LDS_BANK_CONFLICT: 31 % of the LDS-active cycles of the backward).  With the swizzle the four rows of a bank group
+    // write four different blocks; the transposing read takes 4 consecutive rows per lane group, conflict-free under any block order
+    const int qsw = q ^ (s & 3);
     int slice = FUSE ? wave : grab();       // FUSE: static rounds of 8 slices, slice = 8 round + wave
     In nx;
     InRc nxr;
@@ -580,7 +585,7 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             float* ar = my_area0 + (seg & (NBUF - 1u)) * (8 * AREA);
             lz_v2u w = {__float_as_uint(lz_pack_h2(v0, v1)), __float_as_uint(lz_pack_h2(v2, v3))};
             if (!valid) w = lz_v2u{0u, 0u};
-            *reinterpret_cast<lz_v2u*>(ar + tile * 128 + rho * 8 + 2 * q) = w;
+            *reinterpret_cast<lz_v2u*>(ar + tile * 128 + rho * 8 + 2 * qsw) = w;
         };
         auto x_load = [&](int pair) -> lz_v4 {     // X half of the record: dword j = {tile 2 p, tile 2 p + 1} column 4 q + j (RC: the recomputed words)
             if constexpr (RC) return rs.xp[pair];
@@ -614,11 +619,11 @@ lz_k_triplane_head_backward_rec(LzHeadBwdArgs A, const float* __restrict__ st, u
             lz_v2u w = {__builtin_amdgcn_perm(__float_as_uint(d[1]), __float_as_uint(d[0]), sel),
                         __builtin_amdgcn_perm(__float_as_uint(d[3]), __float_as_uint(d[2]), sel)};
             if (!valid) w = lz_v2u{0u, 0u};                                                  // padding rows of the record are never written: not even NaN may pass
-            *reinterpret_cast<lz_v2u*>(ar + tile * 128 + rho * 8 + 2 * q) = w;
+            *reinterpret_cast<lz_v2u*>(ar + tile * 128 + rho * 8 + 2 * qsw) = w;
         };
         auto tr = [&](const float* ar, int tile) -> lz_bh4 {     // lane (i, kg): column i, rows 4 kg .. 4 kg + 3 of the tile image
             const int l16 = lane & 15;
-            const _Float16* ph = reinterpret_cast<const _Float16*>(ar + tile * 128) + (4 * (lane >> 4) + (l16 >> 2)) * 16 + 4 * (l16 & 3);
+            const _Float16* ph = reinterpret_cast<const _Float16*>(ar + tile * 128) + (4 * (lane >> 4) + (l16 >> 2)) * 16 + 4 * ((l16 & 3) ^ (lane >> 4));   // (column block swizzled by row / 4: see qsw)
             typedef short lz_s4 __attribute__((ext_vector_type(4)));
             return __builtin_bit_cast(lz_bh4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lz_s4*)ph));
         };
