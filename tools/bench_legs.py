@@ -764,7 +764,10 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
                     hr = HashgridRenderer(fnet, bits2, bound=1.0, aabb=aabb2, budget_factor=sched[0], n_step_cap=sched[1])
                     ms4, o4 = time2(lambda: hr.render(ro2, rd2, max_steps=128))
                     st4 = o4["state"].cpu().numpy()
-                    d4 = dict(ms_per_frame=round(ms4, 3), rays_per_s=round(65536 / ms4 * 1e3, 1), samples_per_frame=int(st4[5]),
+                    # rays that still had samples to take at max_steps: only THEY see the schedule (the reference hands them its C_eff); 0 = the
+                    # frame is the reference schedule's under any schedule
+                    at_cap = int((hr.render(ro2, rd2, max_steps=128, count_samples=True)["ray_counts"] >= 128).sum())
+                    d4 = dict(rays_at_max_steps=at_cap, ms_per_frame=round(ms4, 3), rays_per_s=round(65536 / ms4 * 1e3, 1), samples_per_frame=int(st4[5]),
                               samples_per_s=round(int(st4[5]) / ms4 * 1e3, 1), iterations_per_frame=int(st4[6]), sample_rows_per_frame=int(st4[72]),
                               schedule=f"n_step = max(min({sched[0]} * N // n_alive, {sched[1]}), 1)" + (" (the reference's)" if sched == (1, 8) else ""),
                               max_abs_diff_vs_reference_loop_image=float((o4["image"] - img_ref).abs().max()))
@@ -779,6 +782,7 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
                                     "lz_k_ngp_head (both MLPs + SH + activations on v_mfma_f32_16x16x4_f32) -> composite; pixels differ from the "
                                     "operator-API network only by the Linear layers' summation order",
                                     fastest_schedule=best[1]["schedule"], fastest_schedule_ms_per_frame=best[1]["ms_per_frame"],
+                                    fastest_schedule_rays_at_max_steps=best[1]["rays_at_max_steps"],
                                     differs_from_reference_loop_image=bool(ref_leg["max_abs_diff_vs_reference_loop_image"] > 1e-4))
                 best = (ref_leg["ms_per_frame"], ref_leg)
                 # roofline of the leg: the gather's algorithmic bytes (1 164 B per sample f32 tables, 588 B f16) over the whole frame time
