@@ -79,6 +79,9 @@ def parse_args():
                     help="fused training head: f16 = the data-gradient products on the f16 matrix cores (autocast's half backward; implies f16 records)")
     ap.add_argument("--train-keep-records", action="store_true",
                     help="all-f16 training leg: the recorded pair of rounds 2-4 (1 216 B of record + state per sample) instead of the recomputing one (80 B)")
+    ap.add_argument("--train-layout", default="step", choices=["step", "ray"],
+                    help="training legs: sample rows of march_rays_train -- 'step' = step-major groups of 64 neighbouring rays (round 5, "
+                         "lz_march_rays_train_grouped), 'ray' = the reference's ray-major rows")
     ap.add_argument("--train-recompute", action="store_true",
                     help="fused training head with record=False: the backward recomputes the forward instead of reading what it recorded")
     ap.add_argument("--train-dp", action="store_true",

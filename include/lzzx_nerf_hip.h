@@ -187,10 +187,12 @@ int lz_composite_rays_triplane(uint32_t n_alive, uint32_t n_step, float T_thresh
 /* The same compositing with the channel variant as data: one entry per direction; the reference's five channel variants
  *   plain (raymarching.h:16-17,20)  ambient (:21)  sigma (:24-27)  uncertainty (:31-33)  triplane (:36-38)
  * are selected by (n_amb, amb_weighted, has_unc) = plain (0,0,0) [inference only], ambient (1,0,0),
- * sigma (1,1,0), uncertainty (1,0,1), triplane (2,0,1).  Unused channel pointers may be NULL. */
+ * sigma (1,1,0), uncertainty (1,0,1), triplane (2,0,1).  Unused channel pointers may be NULL.
+ * layout: 0 = the reference's ray-major sample rows (the named entries above); 1 = the step-major groups lz_march_rays_train_grouped
+ * writes (below).  Per ray the arithmetic and its order are the same under both. */
 int lz_composite_train_forward_v(const float* sigmas, const float* rgbs, const float* amb0, const float* amb1,
                                     const float* unc, const float* deltas, const int32_t* rays, uint32_t M, uint32_t N,
-                                    float T_thresh, int n_amb, int amb_weighted, int has_unc, float* weights_sum,
+                                    float T_thresh, int n_amb, int amb_weighted, int has_unc, int layout, float* weights_sum,
                                     float* amb0_sum, float* amb1_sum, float* unc_sum, float* depth, float* image,
                                     lz_stream_t stream);
 /* grad_* outputs pre-zeroed by the caller (raymarching.py:332-334, 649-653) */
@@ -199,9 +201,28 @@ int lz_composite_train_backward_v(const float* grad_weights_sum, const float* gr
                                      const float* rgbs, const float* amb0, const float* amb1, const float* unc,
                                      const float* deltas, const int32_t* rays, const float* weights_sum,
                                      const float* amb0_sum, const float* unc_sum, const float* image, uint32_t M,
-                                     uint32_t N, float T_thresh, int n_amb, int amb_weighted, int has_unc,
+                                     uint32_t N, float T_thresh, int n_amb, int amb_weighted, int has_unc, int layout,
                                      float* grad_sigmas, float* grad_rgbs, float* grad_amb0, float* grad_amb1,
                                      float* grad_unc, lz_stream_t stream);
+
+/* STEP-MAJOR sample rows for training (no reference counterpart: the reference leaves the row order to its atomics, raymarching.cu:446-454,
+ * and nothing but rays[] = (ray id, offset, count) says which rows a ray owns).  Rays are taken in `order` (int32 [N], a permutation of
+ * 0..N-1; NULL = ray-id order) and GROUPED by G = lz_train_group_size() (a build constant: 16, 32 or 64 lanes of a wave): group g = rays[]
+ * rows G g .. G g + G - 1 owns the rows the ray-major layout would give it, ordered by step first:
+ *   row(j, k) = o_g + sum_i min(c_i, k) + #{ i < j : c_i > k }   (j = place in the group, k = step, c = counts, o_g = rays[G g].offset).  rays[i] = (order[i], ray-major offset o_i, c_i): the drop rule o_i + c_i > M is the reference's.  A wave of
+ * the consumers then holds neighbouring rays at the same step (64 / G steps of G rays) instead of 64 consecutive samples of one ray (head forward of the cfg3
+ * step 1.36 -> 0.71 ms).  Consumers: lz_composite_train_{forward,backward}_v with layout = 1, lz_march_rays_train_backward_grouped; the
+ * heads and encoders are per-row operators and do not care.  Everything else as lz_march_rays_train (counter, zeroed rows, workspace). */
+int lz_march_rays_train_grouped(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                const float* noises, const int32_t* order, void* workspace, lz_stream_t stream);
+int lz_train_group_size(void);
+int lz_march_rays_train_backward_grouped(const float* grad_xyzs, const float* grad_dirs, const int32_t* rays, const float* deltas,
+                                         uint32_t N, uint32_t M, float* grad_rays_o, float* grad_rays_d, lz_stream_t stream);
+/* a sort key per ray that puts neighbouring pixels next to each other (direction: octahedral map, 12 + 12 bits Morton-interleaved; origin:
+ * 2 bits per axis on top): sort it (stable) to get `order`.  Any permutation is a valid order; this one is the locality heuristic. */
+int lz_ray_sort_keys(const float* rays_o, const float* rays_d, uint32_t N, float bound, int32_t* keys, lz_stream_t stream);
 /* in place on rays_alive, rays_t and the per-ray accumulators */
 int lz_composite_rays_v(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
                       const float* sigmas, const float* rgbs, const float* deltas, const float* amb0, const float* amb1,

@@ -84,8 +84,12 @@ SIGNATURES = {
     "lz_march_rays_train": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lz_march_rays_train_backward": [vp, vp, vp, vp, u32, u32, vp, vp, vp],
     "lz_march_rays": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
-    "lz_composite_train_forward_v": [vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
-    "lz_composite_train_backward_v": [vp] * 16 + [u32, u32, f32, i32, i32, i32] + [vp] * 6,
+    "lz_composite_train_forward_v": [vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "lz_composite_train_backward_v": [vp] * 16 + [u32, u32, f32, i32, i32, i32, i32] + [vp] * 6,
+    # step-major sample rows for training (round 5): 64 neighbouring rays at the same step per wave of the consumers
+    "lz_march_rays_train_grouped": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lz_march_rays_train_backward_grouped": [vp, vp, vp, vp, u32, u32, vp, vp, vp],
+    "lz_ray_sort_keys": [vp, vp, u32, f32, vp, vp],
     "lz_composite_rays_v": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     # the reference's 13 compositing entry points by name (thin wrappers over the three *_v entries above)
     "lz_composite_rays_train_forward": [vp] * 5 + [u32, u32, f32] + [vp] * 5,
@@ -153,12 +157,12 @@ SIGNATURES = {
                                                 vp, vp],
     "lz_triplane_head_grad_w": [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp],
 }
-PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32),
+PLAIN = {"lz_last_error": ([], C.c_char_p), "lz_abi_version": ([], i32), "lz_device_ok": ([], i32), "lz_train_group_size": ([], i32),
          "lz_head_packed_size": ([], u32), "lz_head_packed_size_f16": ([], u32), "lz_head_packed_size_f16w": ([], u32), "lz_head_packed_unc_size_f16": ([], u32), "lz_head_packed_bwd_size_f16": ([], u32),
          "lz_triplane_head_grad_w_workspace": ([], C.c_size_t)}
 
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
-ABI_VERSION = 10  # lz_abi_version() of the library this binding table describes (include/lzzx_nerf_hip.h)
+ABI_VERSION = 11  # lz_abi_version() of the library this binding table describes (include/lzzx_nerf_hip.h)
 
 _lib = None
 

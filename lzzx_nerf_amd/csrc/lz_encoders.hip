@@ -27,7 +27,7 @@ void lz_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* lz_last_error(void) { return g_lz_err; }
-extern "C" int lz_abi_version(void) { return 10; }
+extern "C" int lz_abi_version(void) { return 11; }
 
 extern "C" int lz_device_ok(void) {
     int n = 0;

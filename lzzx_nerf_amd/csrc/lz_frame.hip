@@ -188,6 +188,9 @@ __global__ void __launch_bounds__(LZF_PREP_WG) lz_k_frame_prepare(LzFrameK F) {
             const float est = lz_fminf((far - t) / dt + 1.0f, (float)F.max_steps);
             key = (int)(est * 255.0f / (float)F.max_steps);
             key = key < 1 ? 1 : (key > 255 ? 255 : key);
+#ifdef LZF_KEY_MERGE      /* experiment: 2^LZF_KEY_MERGE neighbouring length bins share a queue stretch (order inside: ray order) */
+            key |= (1 << LZF_KEY_MERGE) - 1;
+#endif
             atomicAdd(&hist[key], 1);
         } else {
             lzf_write_pixel(lzf_out<0>(), (int)n, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0);   // no sample on this ray: background

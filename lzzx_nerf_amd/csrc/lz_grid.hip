@@ -977,43 +977,37 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
     // registers, so pass 2 reads only the inputs again (12 instead of 16 bytes per sample and level).
     constexpr bool kKeep = (C == 1);
     float gkeep[kKeep ? LZ_GRID_FX_KEEP : 1];
-    const bool kept = kKeep && blockDim.x == 1024 && (b1 - b0) <= LZ_GRID_FX_KEEP * 1024u;   // workgroup-uniform
+    const bool kept = kKeep && D == 2 && blockDim.x == 1024 && (b1 - b0) <= LZ_GRID_FX_KEEP * 1024u;   // workgroup-uniform
     float gm = 0.0f;
-    // kept path: which sample of a 1024-sample block a thread takes.  Consecutive samples are one ray's (march order) and project onto the
-    // SAME cell of a plane the ray is normal to (a camera looking along z: the xy plane) -- a wave of 64 consecutive samples then issues
-    // 64-way same-address LDS atomics, which retire at about one lane per cycle: 0.78 ms for the xy plane against 0.30 ms for the other
-    // two of a cfg3 step.  The spread map deals a wave 16 groups of 4 consecutive samples, 64 samples apart (<= 4 lanes per ray segment),
-    // at the price of 16-byte pieces instead of whole lines per load instruction: xy plane 0.83 -> 0.42 ms, the others 0.30 -> 0.40.  So
-    // the workgroup looks first: on its first 1024 samples, how many lanes sit in the same cell of THIS level as their neighbour?  More
-    // than half -> spread.  The sums are exact integers: the same bits under either map.
-    uint32_t tperm = threadIdx.x;
-    if constexpr (kKeep && D == 2) {
-        __shared__ int run_votes;
-        if (threadIdx.x == 0) run_votes = 0;
-        __syncthreads();
-        const uint32_t bb = b0 + threadIdx.x < b1 ? b0 + threadIdx.x : b1 - 1;
-        const float sx = lz_fmaf(inputs[(size_t)bb * 2], scale_l, align_corners ? 0.0f : 0.5f);
-        const float sy = lz_fmaf(inputs[(size_t)bb * 2 + 1], scale_l, align_corners ? 0.0f : 0.5f);
-        const int cx = (int)floorf(sx), cy = (int)floorf(sy);
-        const bool same = cx == __shfl_down(cx, 1, 64) && cy == __shfl_down(cy, 1, 64) && (threadIdx.x & 63u) != 63u;
-        const int cnt = __popcll(__ballot(same));
-        if ((threadIdx.x & 63u) == 0u && cnt) atomicAdd(&run_votes, cnt);
-        __syncthreads();
-#ifndef LZ_GRID_FX_GROUP
-#define LZ_GRID_FX_GROUP 4     /* consecutive samples a wave keeps together: 4 -> xy plane 0.46 ms, the others unchanged (tools: build.py --variant) */
-#endif
-        if (LZ_GRID_FX_GROUP < 64 && run_votes * 2 > (int)blockDim.x) {
-            constexpr uint32_t G = LZ_GRID_FX_GROUP;
-            const uint32_t l = threadIdx.x & 63u, w = threadIdx.x >> 6;
-            tperm = (l / G) * (16u * G) + w * G + (l % G);
-        }
-    }
+    // kept path, WHICH rows a thread takes: LANE-MAJOR segments.  The 64 lanes of a wave-instruction must not sit in the same cell -- same-
+    // address LDS atomics retire one lane at a time -- and consecutive rows do exactly that: ray-major rows are one ray's consecutive steps
+    // (the same cell of a plane the ray is normal to: the xy plane of a camera looking along z ran 0.44 ms against 0.29 for the others),
+    // step-major rows (lz_march_rays_train_grouped) are neighbouring rays at one step (every plane, every coarse level: 0.57 - 0.70 ms).
+    // So the chunk is cut into 64 segments of SEG = 64 T rows (T <= 18), lane l walks segment l, and inside it the 16 waves x 4 rows x T
+    // trips cover the segment:  row = b0 + l SEG + (16 k + w) 4 + i.  The lanes of an instruction are SEG rows apart -- different rays AND
+    // different steps under either layout -- while a thread's four rows per trip are consecutive (one 16-byte load of gradients, two of
+    // inputs) and the 16 waves of the workgroup read the neighbouring pieces of the same lines in the same trip.  (Rounds 3-4 voted per
+    // workgroup between whole-line loads and a 4-row spread inside 1 024-row tiles; that could not separate the lanes of a step-major tile.)
+    const uint32_t fx_T = kept ? (b1 - b0 + 4095u) / 4096u : 0u, fx_seg = 64u * fx_T;
+    const uint32_t fx_row0 = b0 + (threadIdx.x & 63u) * fx_seg + (threadIdx.x >> 6) * 4u;       // + 64 k + i
+    const float* gbase = grad + (sample_major ? (size_t)level * C : (size_t)level * B * C);     // C == 1 on this path
+    const bool g_vec = !sample_major && (((uintptr_t)(gbase + b0) & 15u) == 0u) && (fx_seg % 4u == 0u);
     if (kept) {
 #pragma unroll
-        for (uint32_t k = 0; k < (kKeep ? LZ_GRID_FX_KEEP : 1); k++) {
-            const uint32_t b = b0 + tperm + k * 1024u;
-            gkeep[k] = b < b1 ? grad[sample_major ? ((size_t)b * L + level) * C : ((size_t)level * B + b) * C] : 0.0f;
-            gm = fmaxf(gm, lz_abs_nan_inf(gkeep[k]));
+        for (uint32_t k = 0; k < (kKeep ? LZ_GRID_FX_KEEP / 4 : 0); k++) {
+            const uint32_t r = fx_row0 + 64u * k;
+            float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (k < fx_T) {
+                if (g_vec && r + 4u <= b1) g4 = *reinterpret_cast<const float4*>(gbase + r);
+                else {
+                    if (r < b1) g4.x = gbase[sample_major ? (size_t)r * L : r];
+                    if (r + 1 < b1) g4.y = gbase[sample_major ? (size_t)(r + 1) * L : r + 1];
+                    if (r + 2 < b1) g4.z = gbase[sample_major ? (size_t)(r + 2) * L : r + 2];
+                    if (r + 3 < b1) g4.w = gbase[sample_major ? (size_t)(r + 3) * L : r + 3];
+                }
+            }
+            gkeep[4 * k] = g4.x; gkeep[4 * k + 1] = g4.y; gkeep[4 * k + 2] = g4.z; gkeep[4 * k + 3] = g4.w;
+            gm = fmaxf(fmaxf(gm, lz_abs_nan_inf(g4.x)), fmaxf(lz_abs_nan_inf(g4.y), fmaxf(lz_abs_nan_inf(g4.z), lz_abs_nan_inf(g4.w))));
         }
     } else {
         for (uint32_t b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
@@ -1040,14 +1034,11 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
     int e = 62 - hb - ex;
     e = e > 100 ? 100 : (e < -100 ? -100 : e);
     const float fx = ldexpf(1.0f, e), inv = ldexpf(1.0f, -e);
-    auto scatter = [&](uint32_t b, const float (&gcur)[C]) {
-        float x[D];
+    auto scatter_at = [&](const float (&x)[D], const float (&gcur)[C]) {
         bool oob = false;
 #pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            x[d] = inputs[(size_t)b * D + d];
+        for (uint32_t d = 0; d < D; d++)
             if (x[d] < 0 || x[d] > 1) oob = true;
-        }
         if (oob) return;
         float pos[D];
         uint32_t pg[D];
@@ -1110,14 +1101,41 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
             }
         }
     };
-    if (kept) {
+    auto scatter = [&](uint32_t b, const float (&gcur)[C]) {
+        float x[D];
 #pragma unroll
-        for (uint32_t k = 0; k < (kKeep ? LZ_GRID_FX_KEEP : 1); k++) {
-            const uint32_t b = b0 + tperm + k * 1024u;
-            if (b < b1) {
-                float gcur[C];
-                gcur[0] = gkeep[k];
-                scatter(b, gcur);
+        for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+        scatter_at(x, gcur);
+    };
+    if (kept) {
+        if constexpr (D == 2) {
+            const bool x_vec = (((uintptr_t)(inputs + (size_t)b0 * 2) & 15u) == 0u) && (fx_seg % 2u == 0u);
+#pragma unroll
+            for (uint32_t k = 0; k < (kKeep ? LZ_GRID_FX_KEEP / 4 : 0); k++) {
+                const uint32_t r = fx_row0 + 64u * k;
+                if (k < fx_T && r < b1) {
+                    float xy[8];
+                    if (x_vec && r + 4u <= b1) {
+                        const float4 p = *reinterpret_cast<const float4*>(inputs + (size_t)r * 2), q = *reinterpret_cast<const float4*>(inputs + (size_t)r * 2 + 4);
+                        xy[0] = p.x; xy[1] = p.y; xy[2] = p.z; xy[3] = p.w; xy[4] = q.x; xy[5] = q.y; xy[6] = q.z; xy[7] = q.w;
+                    } else {
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) {
+                            const bool in = r + i < b1;
+                            xy[2 * i] = in ? inputs[(size_t)(r + i) * 2] : -1.0f;          // out of range: skipped like an out-of-bounds input
+                            xy[2 * i + 1] = in ? inputs[(size_t)(r + i) * 2 + 1] : -1.0f;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) {
+                        if (r + i < b1) {
+                            const float x[D] = {xy[2 * i], xy[2 * i + 1]};
+                            float gcur[C];
+                            gcur[0] = gkeep[4 * k + i];
+                            scatter_at(x, gcur);
+                        }
+                    }
+                }
             }
         }
     } else {
@@ -1149,7 +1167,7 @@ static void lz_grid_bwd_lds_launch(const float* grad, const float* inputs, const
         const uint32_t per_round = 256, down = (n_chunks * L / per_round) * per_round / L;
         if (down >= 1 && down >= fit && down * L >= per_round) n_chunks = down;
     }
-    const uint32_t chunk = lz_div_up(B, n_chunks);
+    const uint32_t chunk = (lz_div_up(B, n_chunks) + 63u) & ~63u;      // whole 64-row blocks: the kept path's 16-byte loads stay aligned
     n_chunks = lz_div_up(B, chunk);
     static bool attr_set = false;   // per instantiation: more than 64 KB of dynamic LDS has to be requested once
     if (!attr_set) {

@@ -433,12 +433,13 @@ __global__ void __launch_bounds__(256)
 lz_k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
                        float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                        const float* __restrict__ nears, const float* __restrict__ fars, const float* __restrict__ noises,
-                       int* __restrict__ counts) {
+                       int* __restrict__ counts, const int* __restrict__ order = nullptr) {
     __shared__ uint32_t mlut[LZ_MORTON_LUT];     // Morton bit-spread table: three LDS reads per probe instead of 24 vector instructions
     lz_morton_lut_stage(mlut);
     __syncthreads();
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t n = order ? (uint32_t)order[i] : i;      // step-major layout: counts in PROCESSING order (counts[i] of ray order[i])
     LzMarch m;
     m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
     if (H <= LZ_MORTON_LUT) m.morton_lut = mlut;
@@ -450,7 +451,7 @@ lz_k_march_train_count(const float* __restrict__ rays_o, const float* __restrict
     while (t < far && num_steps < max_steps) {
         if (m.probe(t, x, y, z, dt)) { num_steps++; t += dt; }
     }
-    counts[n] = (int)num_steps;
+    counts[i] = (int)num_steps;
 }
 
 // exclusive scan of counts[0..N) by ONE 1024-thread workgroup -> offsets written in place; totals to counter.
@@ -676,6 +677,221 @@ extern "C" int lz_march_rays_train_backward(const float* grad_xyzs, const float*
     if (N == 0) return LZ_OK;
     hipLaunchKernelGGL(lz_k_march_train_backward, dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), grad_xyzs, grad_dirs, rays, deltas, N, M, grad_rays_o, grad_rays_d);
     LZ_CHECK_LAUNCH("march_rays_train_backward");
+    return LZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// STEP-MAJOR sample layout for training (round 5; `layout = 1` of the *_v / *_grouped entries)
+// ------------------------------------------------------------------------------------------------
+// The reference packs a ray's samples in consecutive rows, rays in the order their atomicAdd happened to land (raymarching.cu:446-454):
+// nothing downstream depends on WHICH rows a ray got, only on rays[] = (ray id, offset, count) saying so.  Ray-major rows are the worst
+// order for everything that follows: the 64 lanes of a wave hold 64 consecutive samples of ONE ray, a line across the volume -- the
+// table gathers of the head touch up to 64 different cache lines per load (the cfg3 step's forward ran at the texture addresser's
+// per-lane rate, 1.27 ms), and compositing has every lane walk its own ray (stride = the ray's length).
+// Here a GROUP = the 64 rays at rows 64 g .. 64 g + 63 of rays[] (one wave).  The group owns the same rows [o_g, o_g + sum c_j) the
+// ray-major layout would give it, ordered by step first:
+//     row(j, k) = o_g + sum_i min(c_i, k) + #{ i < j : c_i > k }          (j = ray's place in the group, k = its step, c = counts)
+// i.e. first samples of all 64 rays, then the second samples of those that have one, ...  Rays enter in the caller's `order` (neighbouring
+// pixels next to each other: lz_ray_sort_keys), so a wave of the head sees 64 NEIGHBOURING rays at the same step -- the access shape of the
+// fused frame kernel.  Measured on the cfg3 step (65 536 random rays, 5.99 M samples): light f16 forward 1.36 -> 0.71 ms, inference f16
+// head 1.31 -> 0.59 ms.  rays[i] = (ray id, o_i, c_i) with o_i the RAY-MAJOR offset (exclusive scan in processing order): the drop rule
+// (o_i + c_i > M, raymarching.cu:457) is unchanged and the dropped rays are a suffix, so a partly dropped group still fits its rows.
+// Compositing and the march's backward walk a group with one ballot per step: alive = ballot(k < c), row = o_g + S + popc(alive & lanes
+// below), S += popc(alive) -- loads and stores of consecutive lanes are consecutive rows.
+
+#ifndef LZ_TRAIN_GROUP
+#define LZ_TRAIN_GROUP 64       /* rays per group of the step-major layout: 16, 32 or 64 (lz_train_group_size()) */
+#endif
+static_assert(LZ_TRAIN_GROUP == 16 || LZ_TRAIN_GROUP == 32 || LZ_TRAIN_GROUP == 64, "group = 16, 32 or 64 lanes of a wave");
+// lanes of this lane's group / those of them below this lane
+__device__ __forceinline__ unsigned long long lz_tg_mask(uint32_t lane) {
+    return LZ_TRAIN_GROUP == 64 ? ~0ull : (((1ull << LZ_TRAIN_GROUP) - 1ull) << (lane & ~(uint32_t)(LZ_TRAIN_GROUP - 1)));
+}
+// the group's first row: rays[] offset of the group's first lane (that lane always holds a ray when any lane of the group does)
+__device__ __forceinline__ uint32_t lz_tg_base(uint32_t offset, uint32_t lane) {
+    if (LZ_TRAIN_GROUP == 64) return (uint32_t)__builtin_amdgcn_readfirstlane((int)offset);
+    return (uint32_t)__shfl((int)offset, (int)(lane & ~(uint32_t)(LZ_TRAIN_GROUP - 1)), 64);
+}
+extern "C" int lz_train_group_size(void) { return LZ_TRAIN_GROUP; }
+
+// sort key of a ray: rays of one camera by direction (octahedral map, 12 + 12 bits, Morton-interleaved), cameras apart by 2 bits per axis
+// of the origin.  Any key gives a valid layout; this one puts neighbouring pixels next to each other.
+__global__ void __launch_bounds__(256)
+lz_k_ray_sort_keys(const float* __restrict__ rays_o, const float* __restrict__ rays_d, uint32_t N, float bound, int* __restrict__ keys) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float dx = rays_d[(size_t)n * 3], dy = rays_d[(size_t)n * 3 + 1], dz = rays_d[(size_t)n * 3 + 2];
+    const float l1 = fabsf(dx) + fabsf(dy) + fabsf(dz);
+    const float r = l1 > 0.0f ? 1.0f / l1 : 0.0f;
+    float u = dx * r, v = dy * r;
+    if (dz < 0.0f) {
+        const float uu = (1.0f - fabsf(v)) * (u < 0.0f ? -1.0f : 1.0f), vv = (1.0f - fabsf(u)) * (v < 0.0f ? -1.0f : 1.0f);
+        u = uu; v = vv;
+    }
+    const uint32_t qu = (uint32_t)lz_clampf((u * 0.5f + 0.5f) * 4095.0f, 0.0f, 4095.0f), qv = (uint32_t)lz_clampf((v * 0.5f + 0.5f) * 4095.0f, 0.0f, 4095.0f);
+    auto spread = [](uint32_t x) {          // 12 bits -> every other bit of 24
+        x = (x | (x << 8)) & 0x00ff00ffu;
+        x = (x | (x << 4)) & 0x0f0f0f0fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        x = (x | (x << 1)) & 0x55555555u;
+        return x;
+    };
+    uint32_t ok = 0;
+    const float rb = bound > 0.0f ? 0.125f / bound : 0.0f;     // origins within 4 bounds of the centre: 4 cells per axis
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float o = rays_o[(size_t)n * 3 + k];
+        const uint32_t q = (uint32_t)lz_clampf((o * rb + 0.5f) * 4.0f, 0.0f, 3.0f);
+        ok = (ok << 2) | (o == o ? q : 0u);
+    }
+    keys[n] = (int)((ok << 24) | spread(qu) | (spread(qv) << 1));
+}
+
+extern "C" int lz_ray_sort_keys(const float* rays_o, const float* rays_d, uint32_t N, float bound, int32_t* keys, lz_stream_t stream) {
+    if (N == 0) return LZ_OK;
+    LZ_REQUIRE(rays_o && rays_d && keys, LZ_ERR_BAD_ARGUMENT, "ray_sort_keys: null tensor");
+    hipLaunchKernelGGL(lz_k_ray_sort_keys, dim3(lz_div_up(N, 256)), dim3(256), 0, lz_st(stream), rays_o, rays_d, N, bound, keys);
+    LZ_CHECK_LAUNCH("ray_sort_keys");
+    return LZ_OK;
+}
+
+// pass 2 of the march, step-major: lane j of a wave = ray order[64 g + j]; every trip of the loop yields the next sample of every ray that
+// still has one (a lane crossing empty space probes until it stands in an occupied cell again -- the count pass ran the same arithmetic,
+// so the sample exists), written straight to its row: consecutive lanes, consecutive rows.
+__global__ void __launch_bounds__(256)
+lz_k_march_train_write_grouped(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+                               float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                               const float* __restrict__ nears, const float* __restrict__ fars, const float* __restrict__ noises,
+                               const int* __restrict__ offsets, const int* __restrict__ order, const int* __restrict__ base,
+                               const int* __restrict__ total, float* __restrict__ xyzs, float* __restrict__ dirs,
+                               float* __restrict__ deltas, int* __restrict__ rays) {
+    __shared__ uint32_t mlut[LZ_MORTON_LUT];
+    lz_morton_lut_stage(mlut);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ic = i < N ? i : N - 1;
+    const uint32_t n = order ? (uint32_t)order[ic] : ic;
+    uint32_t c = 0, point_index = 0;
+    if (i < N) {
+        const uint32_t off = (uint32_t)offsets[i];
+        const uint32_t nxt = (i + 1 < N) ? (uint32_t)offsets[i + 1] : (uint32_t)(total[0] - base[0]);
+        const uint32_t num_steps = nxt - off;
+        point_index = (uint32_t)base[0] + off;
+        const uint32_t ray_index = (uint32_t)base[1] + i;
+        rays[(size_t)ray_index * 3] = (int)n;
+        rays[(size_t)ray_index * 3 + 1] = (int)point_index;
+        rays[(size_t)ray_index * 3 + 2] = (int)num_steps;
+        if (num_steps != 0 && point_index + num_steps <= M) c = num_steps;      // else: nothing marched / dropped for lack of room (raymarching.cu:457)
+        else if (num_steps != 0)                                                // the first dropped ray clears what is left of the buffer
+            for (uint32_t r = point_index; r < M; r++) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { xyzs[(size_t)r * 3 + k] = 0.0f; dirs[(size_t)r * 3 + k] = 0.0f; }
+                deltas[(size_t)r * 2] = 0.0f; deltas[(size_t)r * 2 + 1] = 0.0f;
+            }
+    }
+    {   // rows in front of the step's first and behind its last: zero (see lz_k_march_train_write)
+        const uint32_t first = (uint32_t)base[0] < M ? (uint32_t)base[0] : M, last = (uint32_t)total[0] < M ? (uint32_t)total[0] : M;
+        const uint32_t nthreads = gridDim.x * blockDim.x, span = first + (M - last);
+        for (uint32_t q = i; q < span; q += nthreads) {
+            const uint32_t r = q < first ? q : last + (q - first);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { xyzs[(size_t)r * 3 + k] = 0.0f; dirs[(size_t)r * 3 + k] = 0.0f; }
+            deltas[(size_t)r * 2] = 0.0f; deltas[(size_t)r * 2 + 1] = 0.0f;
+        }
+    }
+    const uint32_t gb = lz_tg_base(point_index, lane);
+    LzMarch m;
+    m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
+    if (H <= LZ_MORTON_LUT) m.morton_lut = mlut;
+    const float far = fars[n];
+    float t = nears[n];
+    t = lz_fmaf(lz_clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
+    const unsigned long long gm = lz_tg_mask(lane), below = ((1ull << lane) - 1ull) & gm;
+    uint32_t S = 0;
+    for (uint32_t k = 0;; k++) {
+        const bool want = k < c;
+        const unsigned long long all = __ballot(want), alive = all & gm;
+        if (!all) break;
+        if (want) {
+            float x = 0.0f, y = 0.0f, z = 0.0f, dt = 0.0f;
+            bool found = false;
+            while (!found && t < far) found = m.probe(t, x, y, z, dt);
+            t += dt;
+            const size_t row = (size_t)gb + S + (uint32_t)__popcll(alive & below);
+            xyzs[row * 3] = x; xyzs[row * 3 + 1] = y; xyzs[row * 3 + 2] = z;
+            dirs[row * 3] = m.dx; dirs[row * 3 + 1] = m.dy; dirs[row * 3 + 2] = m.dz;
+            *reinterpret_cast<float2*>(deltas + row * 2) = make_float2(dt, t);
+        }
+        S += (uint32_t)__popcll(alive);
+    }
+}
+
+extern "C" int lz_march_rays_train_grouped(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                           uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                           const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                           const float* noises, const int32_t* order, void* workspace, lz_stream_t stream) {
+    LZ_REQUIRE(C >= 1 && C <= 8 && H > 0, LZ_ERR_BAD_ARGUMENT, "march_rays_train_grouped: cascade must be in [1, 8]");
+    if (N == 0) return LZ_OK;
+    LZ_REQUIRE(workspace, LZ_ERR_BAD_ARGUMENT, "march_rays_train_grouped: workspace of (N + 2) * 4 bytes required");
+    LZ_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises, LZ_ERR_BAD_ARGUMENT, "march_rays_train_grouped: null tensor");
+    LZ_REQUIRE(M == 0 || (xyzs && dirs && deltas), LZ_ERR_BAD_ARGUMENT, "march_rays_train_grouped: null sample buffers with M > 0");
+    int* counts = reinterpret_cast<int*>(workspace);
+    int* base = counts + N;
+    hipStream_t st = lz_st(stream);
+    hipLaunchKernelGGL(lz_k_march_train_count, dim3(lz_div_up(N, 256)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, counts, order);
+    hipLaunchKernelGGL(lz_k_exclusive_scan_1wg, dim3(1), dim3(1024), 0, st, counts, N, counter, base);
+    hipLaunchKernelGGL(lz_k_march_train_write_grouped, dim3(lz_div_up(N, 256)), dim3(256), 0, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, noises, counts, order, base, counter, xyzs, dirs, deltas, rays);
+    LZ_CHECK_LAUNCH("march_rays_train_grouped");
+    return LZ_OK;
+}
+
+__global__ void __launch_bounds__(64)
+lz_k_march_train_backward_grouped(const float* __restrict__ grad_xyzs, const float* __restrict__ grad_dirs, const int* __restrict__ rays,
+                                  const float* __restrict__ deltas, uint32_t N, uint32_t M, float* __restrict__ grad_rays_o,
+                                  float* __restrict__ grad_rays_d) {
+    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+    uint32_t n = 0, offset = 0, c = 0;
+    if (i < N) {
+        n = (uint32_t)rays[(size_t)i * 3];
+        offset = (uint32_t)rays[(size_t)i * 3 + 1];
+        c = (uint32_t)rays[(size_t)i * 3 + 2];
+        if (offset + c > M) c = 0;
+    }
+    const uint32_t gb = lz_tg_base(offset, lane);
+    float go[3] = {0, 0, 0}, gd[3] = {0, 0, 0};
+    if (c > 0)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { go[k] = grad_rays_o[(size_t)n * 3 + k]; gd[k] = grad_rays_d[(size_t)n * 3 + k]; }
+    const unsigned long long gm = lz_tg_mask(lane), below = ((1ull << lane) - 1ull) & gm;
+    uint32_t S = 0;
+    for (uint32_t s = 0;; s++) {
+        const bool want = s < c;
+        const unsigned long long all = __ballot(want), alive = all & gm;
+        if (!all) break;
+        if (want) {
+            const size_t row = (size_t)gb + S + (uint32_t)__popcll(alive & below);
+            const float tt = deltas[row * 2 + 1];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float gx = grad_xyzs[row * 3 + k];
+                go[k] += gx;
+                gd[k] += lz_fmaf(gx, tt, grad_dirs[row * 3 + k]);
+            }
+        }
+        S += (uint32_t)__popcll(alive);
+    }
+    if (c > 0)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { grad_rays_o[(size_t)n * 3 + k] = go[k]; grad_rays_d[(size_t)n * 3 + k] = gd[k]; }
+}
+
+extern "C" int lz_march_rays_train_backward_grouped(const float* grad_xyzs, const float* grad_dirs, const int32_t* rays, const float* deltas,
+                                                    uint32_t N, uint32_t M, float* grad_rays_o, float* grad_rays_d, lz_stream_t stream) {
+    LZ_REQUIRE(N == 0 || (grad_xyzs && grad_dirs && rays && deltas && grad_rays_o && grad_rays_d), LZ_ERR_BAD_ARGUMENT, "march_rays_train_backward_grouped: null tensor");
+    if (N == 0) return LZ_OK;
+    hipLaunchKernelGGL(lz_k_march_train_backward_grouped, dim3(lz_div_up(N, 64)), dim3(64), 0, lz_st(stream), grad_xyzs, grad_dirs, rays, deltas, N, M, grad_rays_o, grad_rays_d);
+    LZ_CHECK_LAUNCH("march_rays_train_backward_grouped");
     return LZ_OK;
 }
 
@@ -1013,6 +1229,161 @@ lz_k_composite_train_bwd(const float* __restrict__ grad_weights_sum, const float
     }
 }
 
+// compositing over the STEP-MAJOR layout (see lz_k_march_train_write_grouped): lane j = ray 64 g + j of rays[]; per step one ballot gives
+// every lane its row, the loads of a step are consecutive rows across the lanes (no LDS transposition), eight steps are fetched ahead of
+// the sequential T chain.  Same arithmetic in the same order as the ray-major kernels above.
+template <int NAMB, bool AMBW, bool UNC>
+__global__ void __launch_bounds__(64)
+lz_k_composite_train_fwd_g(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ amb0,
+                           const float* __restrict__ amb1, const float* __restrict__ unc, const float* __restrict__ deltas,
+                           const int* __restrict__ rays, uint32_t M, uint32_t N, float T_thresh, float* __restrict__ weights_sum,
+                           float* __restrict__ amb0_sum, float* __restrict__ amb1_sum, float* __restrict__ unc_sum,
+                           float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t lane = threadIdx.x, n = blockIdx.x * 64 + lane;
+    const bool have = n < N;
+    uint32_t index = 0, offset = 0, ns = 0;
+    if (have) {
+        index = (uint32_t)rays[(size_t)n * 3];
+        offset = (uint32_t)rays[(size_t)n * 3 + 1];
+        ns = (uint32_t)rays[(size_t)n * 3 + 2];
+        if (ns == 0 || offset + ns > M) ns = 0;   // dropped ray (raymarching.cu:1905): zero outputs
+    }
+    const uint32_t gb = lz_tg_base(offset, lane);
+    const unsigned long long gm = lz_tg_mask(lane), below = ((1ull << lane) - 1ull) & gm;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0, a0 = 0, a1 = 0, u = 0;
+    bool live = ns > 0;
+    uint32_t S = 0;
+    for (uint32_t base = 0; __any(live && base < ns); base += LZ_CT_CHUNK) {
+        float v[LZ_CT_CHUNK][LZ_CT_FWD_NF];
+#pragma unroll
+        for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
+            const bool has = base + k < ns;
+            const unsigned long long alive = __ballot(has) & gm;
+            if (has && live) {
+                const size_t i = (size_t)gb + S + (uint32_t)__popcll(alive & below);
+                const float2 dl = *reinterpret_cast<const float2*>(deltas + i * 2);
+                v[k][0] = sigmas[i]; v[k][1] = dl.x; v[k][2] = dl.y;
+                v[k][3] = rgbs[i * 3]; v[k][4] = rgbs[i * 3 + 1]; v[k][5] = rgbs[i * 3 + 2];
+                if (NAMB > 0) v[k][6] = amb0[i];
+                if (NAMB > 1) v[k][7] = amb1[i];
+                if (UNC) v[k][8] = unc[i];
+            }
+            S += (uint32_t)__popcll(alive);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
+            if (live && base + k < ns) {
+                const float alpha = 1.0f - lz_expf(-v[k][0] * v[k][1]);
+                const float weight = alpha * T;
+                r = lz_fmaf(weight, v[k][3], r);
+                g = lz_fmaf(weight, v[k][4], g);
+                b = lz_fmaf(weight, v[k][5], b);
+                d = lz_fmaf(weight, v[k][2], d);
+                ws += weight;
+                if (NAMB > 0) a0 = AMBW ? lz_fmaf(weight, v[k][6], a0) : a0 + v[k][6];
+                if (NAMB > 1) a1 = AMBW ? lz_fmaf(weight, v[k][7], a1) : a1 + v[k][7];
+                if (UNC) u = lz_fmaf(weight, v[k][8], u);
+                T *= 1.0f - alpha;
+                if (T < T_thresh) live = false;
+            }
+        }
+    }
+    if (!have) return;
+    weights_sum[index] = ws;
+    if (NAMB > 0) amb0_sum[index] = a0;
+    if (NAMB > 1) amb1_sum[index] = a1;
+    if (UNC) unc_sum[index] = u;
+    depth[index] = d;
+    image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+}
+
+template <int NAMB, bool AMBW, bool UNC>
+__global__ void __launch_bounds__(64)
+lz_k_composite_train_bwd_g(const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_amb0_sum,
+                           const float* __restrict__ grad_amb1_sum, const float* __restrict__ grad_unc_sum,
+                           const float* __restrict__ grad_image, const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                           const float* __restrict__ amb0, const float* __restrict__ unc, const float* __restrict__ deltas,
+                           const int* __restrict__ rays, const float* __restrict__ weights_sum, const float* __restrict__ amb0_sum,
+                           const float* __restrict__ unc_sum, const float* __restrict__ image, uint32_t M, uint32_t N, float T_thresh,
+                           float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs, float* __restrict__ grad_amb0,
+                           float* __restrict__ grad_amb1, float* __restrict__ grad_unc) {
+    const uint32_t lane = threadIdx.x, n = blockIdx.x * 64 + lane;
+    uint32_t index = 0, offset = 0, ns = 0;
+    if (n < N) {
+        index = (uint32_t)rays[(size_t)n * 3];
+        offset = (uint32_t)rays[(size_t)n * 3 + 1];
+        ns = (uint32_t)rays[(size_t)n * 3 + 2];
+        if (ns == 0 || offset + ns > M) ns = 0;   // dropped ray: its gradients stay as the caller initialised them
+    }
+    const uint32_t gb = lz_tg_base(offset, lane);
+    const unsigned long long gm = lz_tg_mask(lane), below = ((1ull << lane) - 1ull) & gm;
+    float gi0 = 0, gi1 = 0, gi2 = 0, gws = 0, ga0 = 0, ga1 = 0, gu = 0, r_final = 0, g_final = 0, b_final = 0, ws_final = 0, amb_final = 0,
+          unc_final = 0;
+    if (ns > 0) {
+        gi0 = grad_image[(size_t)index * 3]; gi1 = grad_image[(size_t)index * 3 + 1]; gi2 = grad_image[(size_t)index * 3 + 2];
+        gws = grad_weights_sum[index];
+        if (NAMB > 0) ga0 = grad_amb0_sum[index];
+        if (NAMB > 1) ga1 = grad_amb1_sum[index];
+        if (UNC) gu = grad_unc_sum[index];
+        r_final = image[(size_t)index * 3]; g_final = image[(size_t)index * 3 + 1]; b_final = image[(size_t)index * 3 + 2];
+        ws_final = weights_sum[index];
+        if (NAMB > 0 && AMBW) amb_final = amb0_sum[index];
+        if (UNC) unc_final = unc_sum[index];
+    }
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, amb = 0, u = 0;
+    bool live = ns > 0;
+    uint32_t S = 0;
+    for (uint32_t base = 0; __any(live && base < ns); base += LZ_CT_CHUNK) {
+        float v[LZ_CT_CHUNK][LZ_CT_BWD_NF];
+        uint32_t row[LZ_CT_CHUNK];
+#pragma unroll
+        for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
+            const bool has = base + k < ns;
+            const unsigned long long alive = __ballot(has) & gm;
+            row[k] = gb + S + (uint32_t)__popcll(alive & below);
+            if (has && live) {
+                const size_t i = row[k];
+                v[k][0] = sigmas[i]; v[k][1] = deltas[i * 2];
+                v[k][2] = rgbs[i * 3]; v[k][3] = rgbs[i * 3 + 1]; v[k][4] = rgbs[i * 3 + 2];
+                if (NAMB > 0 && AMBW) v[k][5] = amb0[i];
+                if (UNC) v[k][6] = unc[i];
+            }
+            S += (uint32_t)__popcll(alive);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < LZ_CT_CHUNK; k++) {
+            if (live && base + k < ns) {
+                const size_t i = row[k];
+                const float dl0 = v[k][1], c0 = v[k][2], c1 = v[k][3], c2 = v[k][4];
+                const float alpha = 1.0f - lz_expf(-v[k][0] * dl0);
+                const float weight = alpha * T;
+                r = lz_fmaf(weight, c0, r);
+                g = lz_fmaf(weight, c1, g);
+                b = lz_fmaf(weight, c2, b);
+                float av = 0.0f, uv = 0.0f;
+                if (NAMB > 0 && AMBW) { av = v[k][5]; amb = lz_fmaf(weight, av, amb); }
+                if (UNC) { uv = v[k][6]; u = lz_fmaf(weight, uv, u); }
+                ws += weight;
+                T *= 1.0f - alpha;
+                grad_rgbs[i * 3] = gi0 * weight;
+                grad_rgbs[i * 3 + 1] = gi1 * weight;
+                grad_rgbs[i * 3 + 2] = gi2 * weight;
+                if (NAMB > 0) grad_amb0[i] = AMBW ? ga0 * weight : ga0;
+                if (NAMB > 1) grad_amb1[i] = ga1;
+                if (UNC) grad_unc[i] = gu * weight;
+                float s = gi0 * lz_fmaf(T, c0, -(r_final - r));
+                s = lz_fmaf(gi1, lz_fmaf(T, c1, -(g_final - g)), s);
+                s = lz_fmaf(gi2, lz_fmaf(T, c2, -(b_final - b)), s);
+                if (NAMB > 0 && AMBW) s = lz_fmaf(ga0, lz_fmaf(T, av, -(amb_final - amb)), s);
+                if (UNC) s = lz_fmaf(gu, lz_fmaf(T, uv, -(unc_final - u)), s);
+                s = lz_fmaf(gws, 1 - ws_final, s);
+                grad_sigmas[i] = dl0 * s;
+                if (T < T_thresh) live = false;
+            }
+        }
+    }
+}
+
 template <int NAMB, bool AMBW, bool UNC, bool STATE>
 __global__ void __launch_bounds__(256)
 lz_k_composite_rays(uint32_t n_alive_h, uint32_t n_step_h, const lz_loop_state* __restrict__ state, float T_thresh,
@@ -1098,9 +1469,10 @@ lz_k_composite_rays(uint32_t n_alive_h, uint32_t n_step_h, const lz_loop_state* 
 
 extern "C" int lz_composite_train_forward_v(const float* sigmas, const float* rgbs, const float* amb0, const float* amb1,
                                                const float* unc, const float* deltas, const int32_t* rays, uint32_t M, uint32_t N,
-                                               float T_thresh, int n_amb, int amb_weighted, int has_unc, float* weights_sum,
+                                               float T_thresh, int n_amb, int amb_weighted, int has_unc, int layout, float* weights_sum,
                                                float* amb0_sum, float* amb1_sum, float* unc_sum, float* depth, float* image,
                                                lz_stream_t stream) {
+    LZ_REQUIRE(layout == 0 || layout == 1, LZ_ERR_BAD_ARGUMENT, "composite_rays_train_forward: layout must be 0 (ray-major) or 1 (step-major groups)");
     LZ_REQUIRE(N == 0 || (sigmas && rgbs && deltas && rays && weights_sum && depth && image), LZ_ERR_BAD_ARGUMENT, "composite_rays_train_forward: null tensor");
     LZ_REQUIRE(n_amb >= 0 && n_amb <= 2, LZ_ERR_BAD_ARGUMENT, "composite_rays_train_forward: n_amb must be 0, 1 or 2");
     LZ_REQUIRE(N == 0 || ((n_amb < 1 || (amb0 && amb0_sum)) && (n_amb < 2 || (amb1 && amb1_sum)) && (!has_unc || (unc && unc_sum))), LZ_ERR_BAD_ARGUMENT,
@@ -1108,7 +1480,11 @@ extern "C" int lz_composite_train_forward_v(const float* sigmas, const float* rg
     if (N == 0) return LZ_OK;
     dim3 grid(lz_div_up(N, 64)), block(64);   // one wave per workgroup (wave-local barriers)
     hipStream_t st = lz_st(stream);
-#define CALL(NA, AW, HU) hipLaunchKernelGGL((lz_k_composite_train_fwd<NA, AW, HU>), grid, block, 0, st, sigmas, rgbs, amb0, amb1, unc, deltas, rays, M, N, T_thresh, weights_sum, amb0_sum, amb1_sum, unc_sum, depth, image)
+#define CALL(NA, AW, HU)                                                                                                             \
+    do {                                                                                                                             \
+        if (layout == 1) hipLaunchKernelGGL((lz_k_composite_train_fwd_g<NA, AW, HU>), grid, block, 0, st, sigmas, rgbs, amb0, amb1, unc, deltas, rays, M, N, T_thresh, weights_sum, amb0_sum, amb1_sum, unc_sum, depth, image); \
+        else hipLaunchKernelGGL((lz_k_composite_train_fwd<NA, AW, HU>), grid, block, 0, st, sigmas, rgbs, amb0, amb1, unc, deltas, rays, M, N, T_thresh, weights_sum, amb0_sum, amb1_sum, unc_sum, depth, image); \
+    } while (0)
     LZ_VARIANT_SWITCH(n_amb, amb_weighted, has_unc, CALL);
 #undef CALL
     LZ_CHECK_LAUNCH("composite_rays_train_forward");
@@ -1120,9 +1496,10 @@ extern "C" int lz_composite_train_backward_v(const float* grad_weights_sum, cons
                                                 const float* rgbs, const float* amb0, const float* amb1, const float* unc,
                                                 const float* deltas, const int32_t* rays, const float* weights_sum,
                                                 const float* amb0_sum, const float* unc_sum, const float* image, uint32_t M,
-                                                uint32_t N, float T_thresh, int n_amb, int amb_weighted, int has_unc,
+                                                uint32_t N, float T_thresh, int n_amb, int amb_weighted, int has_unc, int layout,
                                                 float* grad_sigmas, float* grad_rgbs, float* grad_amb0, float* grad_amb1,
                                                 float* grad_unc, lz_stream_t stream) {
+    LZ_REQUIRE(layout == 0 || layout == 1, LZ_ERR_BAD_ARGUMENT, "composite_rays_train_backward: layout must be 0 (ray-major) or 1 (step-major groups)");
     LZ_REQUIRE(N == 0 || (grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs),
                LZ_ERR_BAD_ARGUMENT, "composite_rays_train_backward: null tensor");
     LZ_REQUIRE(n_amb >= 0 && n_amb <= 2, LZ_ERR_BAD_ARGUMENT, "composite_rays_train_backward: n_amb must be 0, 1 or 2");
@@ -1133,7 +1510,11 @@ extern "C" int lz_composite_train_backward_v(const float* grad_weights_sum, cons
     if (N == 0) return LZ_OK;
     dim3 grid(lz_div_up(N, 64)), block(64);
     hipStream_t st = lz_st(stream);
-#define CALL(NA, AW, HU) hipLaunchKernelGGL((lz_k_composite_train_bwd<NA, AW, HU>), grid, block, 0, st, grad_weights_sum, grad_amb0_sum, grad_amb1_sum, grad_unc_sum, grad_image, sigmas, rgbs, amb0, unc, deltas, rays, weights_sum, amb0_sum, unc_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, grad_amb0, grad_amb1, grad_unc)
+#define CALL(NA, AW, HU)                                                                                                             \
+    do {                                                                                                                             \
+        if (layout == 1) hipLaunchKernelGGL((lz_k_composite_train_bwd_g<NA, AW, HU>), grid, block, 0, st, grad_weights_sum, grad_amb0_sum, grad_amb1_sum, grad_unc_sum, grad_image, sigmas, rgbs, amb0, unc, deltas, rays, weights_sum, amb0_sum, unc_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, grad_amb0, grad_amb1, grad_unc); \
+        else hipLaunchKernelGGL((lz_k_composite_train_bwd<NA, AW, HU>), grid, block, 0, st, grad_weights_sum, grad_amb0_sum, grad_amb1_sum, grad_unc_sum, grad_image, sigmas, rgbs, amb0, unc, deltas, rays, weights_sum, amb0_sum, unc_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, grad_amb0, grad_amb1, grad_unc); \
+    } while (0)
     LZ_VARIANT_SWITCH(n_amb, amb_weighted, has_unc, CALL);
 #undef CALL
     LZ_CHECK_LAUNCH("composite_rays_train_backward");
@@ -1164,7 +1545,7 @@ extern "C" int lz_composite_rays_v(uint32_t n_alive, uint32_t n_step, float T_th
     extern "C" int NAME(const float* sigmas, const float* rgbs, const float* ambient, const float* deltas, const int32_t* rays,     \
                         uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* ambient_sum, float* depth, float* image, \
                         lz_stream_t stream) {                                                                                        \
-        return lz_composite_train_forward_v(sigmas, rgbs, ambient, nullptr, nullptr, deltas, rays, M, N, T_thresh, NA, AW, 0, weights_sum, \
+        return lz_composite_train_forward_v(sigmas, rgbs, ambient, nullptr, nullptr, deltas, rays, M, N, T_thresh, NA, AW, 0, 0, weights_sum, \
                                             ambient_sum, nullptr, nullptr, depth, image, stream);                                    \
     }
 #define LZ_TRAIN_BWD(NAME, NA, AW)                                                                                                   \
@@ -1174,7 +1555,7 @@ extern "C" int lz_composite_rays_v(uint32_t n_alive, uint32_t n_step, float T_th
                         float* grad_rgbs, float* grad_ambient, lz_stream_t stream) {                                                 \
         return lz_composite_train_backward_v(grad_weights_sum, grad_ambient_sum, nullptr, nullptr, grad_image, sigmas, rgbs, ambient, \
                                              nullptr, nullptr, deltas, rays, weights_sum, ambient_sum, nullptr, image, M, N, T_thresh, \
-                                             NA, AW, 0, grad_sigmas, grad_rgbs, grad_ambient, nullptr, nullptr, stream);             \
+                                             NA, AW, 0, 0, grad_sigmas, grad_rgbs, grad_ambient, nullptr, nullptr, stream);          \
     }
 #define LZ_INFER_AMB(NAME, AW)                                                                                                       \
     extern "C" int NAME(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t, const float* sigmas,  \
@@ -1202,7 +1583,7 @@ extern "C" int lz_composite_rays_train_uncertainty_forward(const float* sigmas, 
                                                            const float* deltas, const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
                                                            float* weights_sum, float* ambient_sum, float* uncertainty_sum, float* depth,
                                                            float* image, lz_stream_t stream) {
-    return lz_composite_train_forward_v(sigmas, rgbs, ambient, nullptr, uncertainty, deltas, rays, M, N, T_thresh, 1, 0, 1, weights_sum, ambient_sum,
+    return lz_composite_train_forward_v(sigmas, rgbs, ambient, nullptr, uncertainty, deltas, rays, M, N, T_thresh, 1, 0, 1, 0, weights_sum, ambient_sum,
                                         nullptr, uncertainty_sum, depth, image, stream);
 }
 extern "C" int lz_composite_rays_train_uncertainty_backward(const float* grad_weights_sum, const float* grad_ambient_sum,
@@ -1213,7 +1594,7 @@ extern "C" int lz_composite_rays_train_uncertainty_backward(const float* grad_we
                                                             uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas, float* grad_rgbs,
                                                             float* grad_ambient, float* grad_uncertainty, lz_stream_t stream) {
     return lz_composite_train_backward_v(grad_weights_sum, grad_ambient_sum, nullptr, grad_uncertainty_sum, grad_image, sigmas, rgbs, ambient, nullptr,
-                                         uncertainty, deltas, rays, weights_sum, ambient_sum, uncertainty_sum, image, M, N, T_thresh, 1, 0, 1,
+                                         uncertainty, deltas, rays, weights_sum, ambient_sum, uncertainty_sum, image, M, N, T_thresh, 1, 0, 1, 0,
                                          grad_sigmas, grad_rgbs, grad_ambient, nullptr, grad_uncertainty, stream);
 }
 extern "C" int lz_composite_rays_uncertainty(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
@@ -1228,7 +1609,7 @@ extern "C" int lz_composite_rays_train_triplane_forward(const float* sigmas, con
                                                         uint32_t N, float T_thresh, float* weights_sum, float* amb_aud_sum,
                                                         float* amb_eye_sum, float* uncertainty_sum, float* depth, float* image,
                                                         lz_stream_t stream) {
-    return lz_composite_train_forward_v(sigmas, rgbs, amb_aud, amb_eye, uncertainty, deltas, rays, M, N, T_thresh, 2, 0, 1, weights_sum, amb_aud_sum,
+    return lz_composite_train_forward_v(sigmas, rgbs, amb_aud, amb_eye, uncertainty, deltas, rays, M, N, T_thresh, 2, 0, 1, 0, weights_sum, amb_aud_sum,
                                         amb_eye_sum, uncertainty_sum, depth, image, stream);
 }
 extern "C" int lz_composite_rays_train_triplane_backward(const float* grad_weights_sum, const float* grad_amb_aud_sum,
@@ -1242,7 +1623,7 @@ extern "C" int lz_composite_rays_train_triplane_backward(const float* grad_weigh
                                                          float* grad_uncertainty, lz_stream_t stream) {
     (void)amb_eye_sum;   // the ambient sums are unweighted: their gradient is constant on the visited samples (raymarching.cu:2088-2089)
     return lz_composite_train_backward_v(grad_weights_sum, grad_amb_aud_sum, grad_amb_eye_sum, grad_uncertainty_sum, grad_image, sigmas, rgbs, amb_aud,
-                                         amb_eye, uncertainty, deltas, rays, weights_sum, amb_aud_sum, uncertainty_sum, image, M, N, T_thresh, 2, 0, 1,
+                                         amb_eye, uncertainty, deltas, rays, weights_sum, amb_aud_sum, uncertainty_sum, image, M, N, T_thresh, 2, 0, 1, 0,
                                          grad_sigmas, grad_rgbs, grad_amb_aud, grad_amb_eye, grad_uncertainty, stream);
 }
 extern "C" int lz_composite_rays_triplane(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,

@@ -118,11 +118,50 @@ morton3D_dilation = _morton3D_dilation.apply
 # ----------------------------------------
 # train functions
 # ----------------------------------------
+# ---- sample-row layout of the training path (round 5) ----------------------------------------------------------------------------
+# "ray"  : the reference's -- a ray's samples in consecutive rows (raymarching.cu:446-517), rays in ray-id order;
+# "step" : step-major groups of 64 rays taken in a locality order (include/lzzx_nerf_hip.h: lz_march_rays_train_grouped) -- the rows a
+#          wave of the head / encoders / compositing works on are 64 NEIGHBOURING rays at the same step instead of 64 consecutive
+#          samples of one ray.  Nothing downstream of the reference's run_cuda depends on which rows a ray got (its own atomics leave
+#          that open); the two operators that do -- compositing and the march's backward -- read the layout off the `rays` tensor
+#          march_rays_train returned (attribute `lz_layout`), or take the module default when handed a copy of it.
+_TRAIN_LAYOUT = "ray"
+_LAYOUTS = {"ray": 0, "step": 1}
+
+
+def set_train_layout(layout):
+    """module default for march_rays_train(layout=None) and for compositing a `rays` tensor that carries no layout tag; returns the previous one"""
+    global _TRAIN_LAYOUT
+    if layout not in _LAYOUTS:
+        raise ValueError(f"layout must be one of {sorted(_LAYOUTS)}, got {layout!r}")
+    prev, _TRAIN_LAYOUT = _TRAIN_LAYOUT, layout
+    return prev
+
+
+def train_layout():
+    return _TRAIN_LAYOUT
+
+
+def _layout_of(rays):
+    return _LAYOUTS[getattr(rays, "lz_layout", None) or _TRAIN_LAYOUT]
+
+
+def ray_order(rays_o, rays_d, bound):
+    """the locality order of the step-major layout: int32 [N] permutation, neighbouring pixels next to each other (stable sort of
+    lz_ray_sort_keys: direction by octahedral Morton code, cameras apart)"""
+    rays_o = _cuda(rays_o).contiguous().view(-1, 3).float()
+    rays_d = _cuda(rays_d).contiguous().view(-1, 3).float()
+    N = rays_o.shape[0]
+    keys = torch.empty(N, dtype=torch.int32, device=rays_o.device)
+    call("lz_ray_sort_keys", ptr(rays_o), ptr(rays_d), N, float(bound), ptr(keys), stream())
+    return torch.sort(keys, stable=True).indices.to(torch.int32)
+
+
 class _march_rays_train(Function):
     @staticmethod
     @_fwd32
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False,
-                align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+                align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, layout="ray", order=None):
         rays_o = _cuda(rays_o).contiguous().view(-1, 3)
         rays_d = _cuda(rays_d).contiguous().view(-1, 3)
         density_bitfield = _cuda(density_bitfield).contiguous()
@@ -144,9 +183,23 @@ class _march_rays_train(Function):
         noises = torch.rand(N, dtype=rays_o.dtype, device=dev) if perturb else torch.zeros(N, dtype=rays_o.dtype, device=dev)
         workspace = torch.empty(N + 2, dtype=torch.int32, device=dev)
         nears, fars = nears.contiguous(), fars.contiguous()   # two live names: a freed temporary's block could be handed to the next one
-        call("lz_march_rays_train", ptr(rays_o), ptr(rays_d), ptr(density_bitfield), float(bound), float(dt_gamma), int(max_steps), N,
-             int(C), int(H), M, ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays),
-             ptr(step_counter), ptr(noises), ptr(workspace), stream())
+        ctx.layout = _LAYOUTS[layout]
+        if ctx.layout == 1:
+            if order is None and N > 0:
+                order = ray_order(rays_o, rays_d, bound)
+            elif order is False:
+                order = None                                  # groups of 64 in ray-id order
+            if order is not None:
+                order = _cuda(order).to(torch.int32).contiguous()
+                if order.numel() != N:
+                    raise ValueError(f"march_rays_train: order has {order.numel()} entries for {N} rays")
+            call("lz_march_rays_train_grouped", ptr(rays_o), ptr(rays_d), ptr(density_bitfield), float(bound), float(dt_gamma), int(max_steps), N,
+                 int(C), int(H), M, ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays),
+                 ptr(step_counter), ptr(noises), ptr(order), ptr(workspace), stream())
+        else:
+            call("lz_march_rays_train", ptr(rays_o), ptr(rays_d), ptr(density_bitfield), float(bound), float(dt_gamma), int(max_steps), N,
+                 int(C), int(H), M, ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays),
+                 ptr(step_counter), ptr(noises), ptr(workspace), stream())
         if force_all_rays or mean_count <= 0:
             m = step_counter[0].item()  # D2H copy, as in the reference (raymarching.py:249)
             if align > 0:
@@ -163,14 +216,26 @@ class _march_rays_train(Function):
         grad_rays_o = torch.zeros(N, 3, device=rays.device)
         grad_rays_d = torch.zeros(N, 3, device=rays.device)
         gx, gd, deltas = grad_xyzs.float().contiguous(), grad_dirs.float().contiguous(), deltas.contiguous()
-        call("lz_march_rays_train_backward", ptr(gx), ptr(gd), ptr(rays), ptr(deltas), N, M, ptr(grad_rays_o), ptr(grad_rays_d), stream())
-        return (grad_rays_o, grad_rays_d) + (None,) * 13
+        call("lz_march_rays_train_backward_grouped" if ctx.layout == 1 else "lz_march_rays_train_backward", ptr(gx), ptr(gd), ptr(rays), ptr(deltas),
+             N, M, ptr(grad_rays_o), ptr(grad_rays_d), stream())
+        return (grad_rays_o, grad_rays_d) + (None,) * 15
 
 
-march_rays_train = _march_rays_train.apply
+def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False,
+                     align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, layout=None, order=None):
+    """raymarching.py:186-280, plus `layout` ("ray" | "step" | None = the module default, see set_train_layout) and, for "step", `order`
+    (an int32 permutation of the rays; None = ray_order(rays_o, rays_d, bound); False = ray-id order).  The returned `rays` carries the
+    layout (`rays.lz_layout`) for compositing."""
+    layout = layout or _TRAIN_LAYOUT
+    if layout not in _LAYOUTS:
+        raise ValueError(f"layout must be one of {sorted(_LAYOUTS)}, got {layout!r}")
+    out = _march_rays_train.apply(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter, mean_count, perturb, align,
+                                  force_all_rays, dt_gamma, max_steps, layout, order)
+    out[3].lz_layout = layout
+    return out
 
 
-def _composite_train_fwd(variant, sigmas, rgbs, amb0, amb1, unc, deltas, rays, T_thresh):
+def _composite_train_fwd(variant, sigmas, rgbs, amb0, amb1, unc, deltas, rays, T_thresh, layout=0):
     na, aw, hu = variant
     M, N = sigmas.shape[0], rays.shape[0]
     kw = dict(dtype=sigmas.dtype, device=sigmas.device)
@@ -179,12 +244,12 @@ def _composite_train_fwd(variant, sigmas, rgbs, amb0, amb1, unc, deltas, rays, T
     a1s = torch.empty(N, **kw) if na > 1 else None
     us = torch.empty(N, **kw) if hu else None
     call("lz_composite_train_forward_v", ptr(sigmas), ptr(rgbs), ptr(amb0), ptr(amb1), ptr(unc), ptr(deltas), ptr(rays), M, N,
-         float(T_thresh), na, aw, hu, ptr(weights_sum), ptr(a0s), ptr(a1s), ptr(us), ptr(depth), ptr(image), stream())
+         float(T_thresh), na, aw, hu, int(layout), ptr(weights_sum), ptr(a0s), ptr(a1s), ptr(us), ptr(depth), ptr(image), stream())
     return weights_sum, a0s, a1s, us, depth, image
 
 
 def _composite_train_bwd(variant, g_ws, g_a0, g_a1, g_u, g_img, sigmas, rgbs, amb0, amb1, unc, deltas, rays, weights_sum, a0s, us,
-                         image, T_thresh):
+                         image, T_thresh, layout=0):
     na, aw, hu = variant
     M, N = sigmas.shape[0], rays.shape[0]
     grad_sigmas, grad_rgbs = torch.zeros_like(sigmas), torch.zeros_like(rgbs)
@@ -193,7 +258,7 @@ def _composite_train_bwd(variant, g_ws, g_a0, g_a1, g_u, g_img, sigmas, rgbs, am
     gu = torch.zeros_like(unc) if hu else None
     call("lz_composite_train_backward_v", ptr(g_ws), ptr(g_a0), ptr(g_a1), ptr(g_u), ptr(g_img), ptr(sigmas), ptr(rgbs), ptr(amb0),
          ptr(amb1), ptr(unc), ptr(deltas), ptr(rays), ptr(weights_sum), ptr(a0s), ptr(us), ptr(image), M, N, float(T_thresh), na, aw, hu,
-         ptr(grad_sigmas), ptr(grad_rgbs), ptr(ga0), ptr(ga1), ptr(gu), stream())
+         int(layout), ptr(grad_sigmas), ptr(grad_rgbs), ptr(ga0), ptr(ga1), ptr(gu), stream())
     return grad_sigmas, grad_rgbs, ga0, ga1, gu
 
 
@@ -206,7 +271,8 @@ def _make_train_1amb(variant):
         def forward(ctx, sigmas, rgbs, ambient, deltas, rays, T_thresh=1e-4):
             sigmas, rgbs, ambient = sigmas.contiguous(), rgbs.contiguous(), ambient.contiguous()
             deltas = deltas.contiguous()
-            ws, a0s, _, _, depth, image = _composite_train_fwd(variant, sigmas, rgbs, ambient, None, None, deltas, rays, T_thresh)
+            ctx.layout = _layout_of(rays)
+            ws, a0s, _, _, depth, image = _composite_train_fwd(variant, sigmas, rgbs, ambient, None, None, deltas, rays, T_thresh, ctx.layout)
             ctx.save_for_backward(sigmas, rgbs, ambient, deltas, rays, ws, a0s, depth, image)
             ctx.T_thresh = T_thresh
             return ws, a0s, depth, image
@@ -218,7 +284,7 @@ def _make_train_1amb(variant):
             sigmas, rgbs, ambient, deltas, rays, ws, a0s, depth, image = ctx.saved_tensors
             gs, gr, ga, _, _ = _composite_train_bwd(variant, grad_weights_sum.contiguous(), grad_ambient_sum.contiguous(), None, None,
                                                    grad_image.contiguous(), sigmas, rgbs, ambient, None, None, deltas, rays, ws, a0s,
-                                                   None, image, ctx.T_thresh)
+                                                   None, image, ctx.T_thresh, ctx.layout)
             return gs, gr, ga, None, None, None
 
     return _Fn
@@ -236,7 +302,8 @@ class _composite_rays_train_uncertainty(Function):  # raymarching.py:516-578
     def forward(ctx, sigmas, rgbs, ambient, uncertainty, deltas, rays, T_thresh=1e-4):
         sigmas, rgbs, ambient, uncertainty = sigmas.contiguous(), rgbs.contiguous(), ambient.contiguous(), uncertainty.contiguous()
         deltas = deltas.contiguous()
-        ws, a0s, _, us, depth, image = _composite_train_fwd((1, 0, 1), sigmas, rgbs, ambient, None, uncertainty, deltas, rays, T_thresh)
+        ctx.layout = _layout_of(rays)
+        ws, a0s, _, us, depth, image = _composite_train_fwd((1, 0, 1), sigmas, rgbs, ambient, None, uncertainty, deltas, rays, T_thresh, ctx.layout)
         ctx.save_for_backward(sigmas, rgbs, ambient, uncertainty, deltas, rays, ws, a0s, us, depth, image)
         ctx.T_thresh = T_thresh
         return ws, a0s, us, depth, image
@@ -247,7 +314,7 @@ class _composite_rays_train_uncertainty(Function):  # raymarching.py:516-578
         sigmas, rgbs, ambient, uncertainty, deltas, rays, ws, a0s, us, depth, image = ctx.saved_tensors
         gs, gr, ga, _, gu = _composite_train_bwd((1, 0, 1), grad_weights_sum.contiguous(), grad_ambient_sum.contiguous(), None,
                                                  grad_uncertainty_sum.contiguous(), grad_image.contiguous(), sigmas, rgbs, ambient, None,
-                                                 uncertainty, deltas, rays, ws, a0s, us, image, ctx.T_thresh)
+                                                 uncertainty, deltas, rays, ws, a0s, us, image, ctx.T_thresh, ctx.layout)
         return gs, gr, ga, gu, None, None, None
 
 
@@ -261,7 +328,8 @@ class _composite_rays_train_triplane(Function):  # raymarching.py:594-660
         sigmas, rgbs = sigmas.contiguous(), rgbs.contiguous()
         amb_aud, amb_eye, uncertainty = amb_aud.contiguous(), amb_eye.contiguous(), uncertainty.contiguous()
         deltas = deltas.contiguous()
-        ws, a0s, a1s, us, depth, image = _composite_train_fwd((2, 0, 1), sigmas, rgbs, amb_aud, amb_eye, uncertainty, deltas, rays, T_thresh)
+        ctx.layout = _layout_of(rays)
+        ws, a0s, a1s, us, depth, image = _composite_train_fwd((2, 0, 1), sigmas, rgbs, amb_aud, amb_eye, uncertainty, deltas, rays, T_thresh, ctx.layout)
         ctx.save_for_backward(sigmas, rgbs, amb_aud, amb_eye, uncertainty, deltas, rays, ws, a0s, a1s, us, depth, image)
         ctx.T_thresh = T_thresh
         return ws, a0s, a1s, us, depth, image
@@ -273,7 +341,7 @@ class _composite_rays_train_triplane(Function):  # raymarching.py:594-660
         gs, gr, ga0, ga1, gu = _composite_train_bwd((2, 0, 1), grad_weights_sum.contiguous(), grad_amb_aud_sum.contiguous(),
                                                     grad_amb_eye_sum.contiguous(), grad_uncertainty_sum.contiguous(),
                                                     grad_image.contiguous(), sigmas, rgbs, amb_aud, amb_eye, uncertainty, deltas, rays,
-                                                    ws, a0s, us, image, ctx.T_thresh)
+                                                    ws, a0s, us, image, ctx.T_thresh, ctx.layout)
         return gs, gr, ga0, ga1, gu, None, None, None
 
 

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(_lib.ALL_SYMBOLS) == _declared()
     bound = _lib.load()
-    assert bound.lz_abi_version() == _lib.ABI_VERSION == 10
+    assert bound.lz_abi_version() == _lib.ABI_VERSION == 11
     assert bound.lz_head_packed_size() == 24576 and bound.lz_head_packed_size_f16() == 60416 and bound.lz_head_packed_size_f16w() == 61440
 
 
@@ -167,7 +167,7 @@ def test_zero_work_items_are_no_ops_without_touching_the_arrays():
     # entries whose zero-count call needs valid shape parameters next to the count: (name, {argument index: value})
     shaped = {
         "lz_sh_encode_forward": {3: 3, 4: 4}, "lz_sh_encode_backward": {3: 3, 4: 4},
-        "lz_march_rays_train": {7: 1, 8: 128}, "lz_march_rays": {9: 1, 10: 128}, "lz_loop_march": {13: 1, 14: 128},
+        "lz_march_rays_train": {7: 1, 8: 128}, "lz_march_rays_train_grouped": {7: 1, 8: 128}, "lz_march_rays": {9: 1, 10: 128}, "lz_loop_march": {13: 1, 14: 128},
         "lz_grid_encode_forward": {5: 3, 6: 2, 7: 16, 9: 16}, "lz_grid_encode_backward": {6: 3, 7: 2, 8: 16, 10: 16},
         "lz_grid_corner_indices": {4: 3, 5: 2, 6: 16, 8: 16}, "lz_grid_encode_forward_tiled": {7: 3, 8: 2, 9: 16, 11: 16},
         "lz_freq_encode_forward": {2: 3, 3: 4, 4: 27}, "lz_freq_encode_backward": {3: 3, 4: 4, 5: 27},
@@ -202,7 +202,7 @@ def test_null_arrays_are_rejected_before_any_launch():
     vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_float
     shaped = {
         "lz_sh_encode_forward": {3: 3, 4: 4}, "lz_sh_encode_backward": {3: 3, 4: 4},
-        "lz_march_rays_train": {7: 1, 8: 128}, "lz_march_rays": {9: 1, 10: 128}, "lz_loop_march": {13: 1, 14: 128},
+        "lz_march_rays_train": {7: 1, 8: 128}, "lz_march_rays_train_grouped": {7: 1, 8: 128}, "lz_march_rays": {9: 1, 10: 128}, "lz_loop_march": {13: 1, 14: 128},
         "lz_grid_encode_forward": {5: 3, 6: 2, 7: 16, 9: 16}, "lz_grid_encode_backward": {6: 3, 7: 2, 8: 16, 10: 16},
         "lz_grid_corner_indices": {4: 3, 5: 2, 6: 16, 8: 16}, "lz_grid_encode_forward_tiled": {7: 3, 8: 2, 9: 16, 11: 16},
         "lz_freq_encode_forward": {2: 3, 3: 4, 4: 27}, "lz_freq_encode_backward": {3: 3, 4: 4, 5: 27},

@@ -244,12 +244,13 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
     mean_count = [-1]
     half = args.train_mlp == "fused" and "f16" in (args.train_records, args.train_forward, args.train_backward)
     scaler = torch.amp.GradScaler("cuda", init_scale=65536.0) if (half and world == 1) else None
+    layout = getattr(args, "train_layout", "step")
 
     def step():
         nears, fars = R.near_far_from_aabb(ro, rd, aabb, 0.05)
         ctr.zero_()
         xyzs, dirs, deltas, rays = R.march_rays_train(ro, rd, 1.0, bitfield, 1, 128, nears, fars, ctr, mean_count[0], True, 128,
-                                                      mean_count[0] <= 0, 1 / 256, args.max_steps)
+                                                      mean_count[0] <= 0, 1 / 256, args.max_steps, layout=layout)
         if mean_count[0] <= 0:
             mean_count[0] = int(xyzs.shape[0]) + n_rays // 64   # margin: a perturbed ray gains or loses at most one sample
         sigma, rgb, a0, a1, unc = net(xyzs, dirs, enc_a, ind, eye)
@@ -311,12 +312,35 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
                 workload=f"cfg3: {n_rays} random rays of a {H}x{W} frame, max_steps {args.max_steps}, occupancy={args.scene}, "
                          "march_rays_train -> head (see 'mlp') -> composite_rays_train_triplane -> MSE -> backward (weight gradients + grid "
                          "scatter-add) -> Adam; sample buffers sized by mean_count like the reference's steady state (no D2H copy in the step)",
+                sample_rows={"step": "step-major groups of 64 rays in locality order (lz_ray_sort_keys -> sort -> lz_march_rays_train_grouped, all inside the timed step)",
+                             "ray": "ray-major (the reference's)"}[layout],
                 rays=n_rays, samples_per_step=int(n_samples[0]), steps=k_steps, sample_buffer_overflow=overflow,
                 device_allocations_in_timed_region=dev_allocs, device_frees_in_timed_region=dev_frees,
                 ms_per_step_median=round(per_step[len(per_step) // 2], 3), ms_per_step_min=round(per_step[0], 3), ms_per_step_max=round(per_step[-1], 3),
                 ms_per_step=round(dt * 1e3, 3), samples_per_s=round(n_samples[0] / dt, 1), rays_per_s=round(n_rays / dt, 1),
                 loss=float(loss.detach()), dtype=train_dtype(args), mlp={"fused": "fused head forward + backward kernels, " + ("activations recomputed in the backward (csrc/lz_head.hip, lz_head_bwd.hip)" if args.train_recompute else ("the forward keeps only the enc_x halves (80 B per sample), the backward kernel recomputes the MLP from them (csrc/lz_head_fwd16_chain.h, lz_head_rec.hip RC)" if (args.train_forward == "f16" and args.train_backward == "f16" and not getattr(args, "train_keep_records", False)) else "forward records, backward starts from the record (csrc/lz_head_rec.hip" + (", lz_head_rec16.hip" if args.train_forward == "f16" else "") + "), " + ("f16" if "f16" in (args.train_forward, args.train_backward) else args.train_records) + " records")), "lz": "csrc/lz_linear.hip (MFMA f32)",
                      "torch": "torch/rocBLAS"}[args.train_mlp])
+
+
+def ray_order_perm(kind, H, W, device):
+    """pixel permutations for the ray-order experiment: 'tile<w>x<h>' (row-major tiles, row-major inside), 'morton', 'random'"""
+    y, x = np.divmod(np.arange(H * W), W)
+    if kind.startswith("tile"):
+        tw, th = (int(v) for v in kind[4:].split("x"))
+        key = ((y // th) * (W // tw) + x // tw) * (tw * th) + (y % th) * tw + x % tw
+    elif kind == "morton":
+        def spread(v):
+            v = v.astype(np.uint64)
+            out = np.zeros_like(v)
+            for b in range(16):
+                out |= ((v >> np.uint64(b)) & np.uint64(1)) << np.uint64(2 * b)
+            return out
+        key = spread(x) | (spread(y) << np.uint64(1))
+    elif kind == "random":
+        key = np.random.default_rng(0).permutation(H * W)
+    else:
+        raise ValueError(kind)
+    return torch.from_numpy(np.argsort(key, kind="stable")).to(device)
 
 
 class FrameJob:
@@ -342,6 +366,10 @@ class FrameJob:
 
     def step(self):
         rays_o, rays_d = self.sf.rays(self.pose, self.intr)          # ray generation is part of the step (north_star lists it on the path)
+        if os.environ.get("LZ_EXP_RAY_ORDER"):                       # experiment: the same rays handed over in another order (tools/exp_ray_order.sh)
+            if getattr(self, "_perm", None) is None:
+                self._perm = ray_order_perm(os.environ["LZ_EXP_RAY_ORDER"], self.H, self.W, rays_o.device)
+            rays_o, rays_d = rays_o[self._perm].contiguous(), rays_d[self._perm].contiguous()
         enc_a, ind, eye = self.cond
         out = self.r.render(rays_o, rays_d, enc_a, ind, eye, dt_gamma=1 / 256, max_steps=self.max_steps, T_thresh=1e-4,
                             rgb24=self.gather_fmt == "rgb24")

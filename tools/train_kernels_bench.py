@@ -29,9 +29,41 @@ ro, rd = ro[sel].contiguous(), rd[sel].contiguous()
 aabb = torch.tensor([-1, -0.5, -1, 1, 0.5, 1], dtype=torch.float32, device=dev)
 nears, fars = R.near_far_from_aabb(ro, rd, aabb, 0.05)
 ctr = torch.zeros(2, dtype=torch.int32, device=dev)
-xyz, d, _, _ = R.march_rays_train(ro, rd, 1.0, torch.from_numpy(ones_bitfield()).to(dev), 1, 128, nears, fars, ctr, -1, False, 128, True, 1 / 256, 192)
+xyz, d, _, rays = R.march_rays_train(ro, rd, 1.0, torch.from_numpy(ones_bitfield()).to(dev), 1, 128, nears, fars, ctr, -1, False, 128, True, 1 / 256, 192)
 xyz, d = xyz.detach().contiguous(), d.detach().contiguous()
 M = xyz.shape[0]
+
+
+def interleave_perm(rays, M, G):
+    """processing order that walks groups of G consecutive rays step by step (step k of every ray of the group, then step k + 1 ...):
+    perm[p] = buffer row of processing position p; rows past the last sample keep their place"""
+    rays = rays.long()
+    off, cnt = rays[:, 1], rays[:, 2]
+    N = rays.shape[0]
+    total = int((off + cnt).max())
+    ray_of = torch.repeat_interleave(torch.arange(N, device=dev), cnt)            # rows are ray-major in ray order
+    assert ray_of.numel() == total and bool((off[1:] == (off + cnt)[:-1]).all())
+    k = torch.arange(total, device=dev) - off[ray_of]
+    g0 = (ray_of // G) * G
+    gbase = off[g0]
+    pos = gbase.clone()
+    for j in range(G):
+        rj = torch.clamp(g0 + j, max=N - 1)
+        cj = torch.where(g0 + j < N, cnt[rj], torch.zeros_like(cnt[rj]))
+        pos += torch.minimum(cj, k) + ((cj > k) & (g0 + j < ray_of)).long()
+    perm = torch.arange(M, device=dev)
+    perm[pos] = torch.arange(total, device=dev)
+    assert bool((perm.sort().values == torch.arange(M, device=dev)).all())
+    return perm
+
+
+for a in list(sys.argv):
+    if a.startswith("--interleave="):
+        G = int(a.split("=")[1])
+        sys.argv.remove(a)
+        perm = interleave_perm(rays, M, G)
+        xyz, d = xyz[perm].contiguous(), d[perm].contiguous()
+        print("interleaved over groups of", G, "rays", flush=True)
 print("samples", M, flush=True)
 enc_a, ind, eye = [torch.from_numpy(golden[k]).to(dev) for k in ("net_enc_a", "net_ind", "net_eye")]
 
