@@ -921,7 +921,7 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
     __shared__ uint32_t mlut[LZ_MORTON_LUT];
     lz_morton_lut_stage(mlut);
     __syncthreads();
-    uint32_t n_list = n_alive_h, n_step = n_step_h, prefix = 0;
+    uint32_t n_list = n_alive_h, n_step = n_step_h, prefix = 0, n_alive_loop = 0;
     if (STATE) {
         const lz_loop_state S = *state;
         n_list = S.done ? 0u : (uint32_t)S.n_alive;                     // entries in the incoming list
@@ -951,6 +951,7 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
         }
         if (done_new) return;
         n_step = (uint32_t)n_step_new;
+        n_alive_loop = (uint32_t)n_alive_new;
         prefix = (uint32_t)pre;
     }
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -973,9 +974,14 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
         LzMarch m;
         m.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
         if (H <= LZ_MORTON_LUT) m.morton_lut = mlut;
-        float* px = xyzs + (size_t)row * n_step * 3;
-        float* pd = dirs + (size_t)row * n_step * 3;
-        float* pl = deltas + (size_t)row * n_step * 2;
+        // sample rows.  Operator entry (STATE = false): the reference's, a ray's n_step rows consecutive (raymarching.cu:866-868).  Device
+        // loop: STEP-MAJOR, sample s of list entry `row` at s * n_alive + row -- the rows between the loop's own launches are nobody
+        // else's business, and this way a wave of the head (and of the cfg2 level-major gather) holds 64 neighbouring rays at one step
+        // instead of 64 / n_step rays' runs, and the march's and the compositing's accesses are consecutive across lanes (round 5)
+        const size_t stride = STATE ? (size_t)n_alive_loop : 1u, first = STATE ? (size_t)row : (size_t)row * n_step;
+        float* px = xyzs + first * 3;
+        float* pd = dirs + first * 3;
+        float* pl = deltas + first * 2;
         float t = rays_t[index];
         const float far = fars[index];
         const float noise = noises ? noises[n] : 0.0f;
@@ -987,7 +993,7 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
                 pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
                 t += dt;
                 pl[0] = dt; pl[1] = t;
-                px += 3; pd += 3; pl += 2; step++;
+                px += 3 * stride; pd += 3 * stride; pl += 2 * stride; step++;
             }
         }
         if (STATE) {
@@ -995,7 +1001,7 @@ lz_k_march_rays(uint32_t n_alive_h, uint32_t n_step_h, lz_loop_state* __restrict
                 px[0] = 0; px[1] = 0; px[2] = 0;
                 pd[0] = 0; pd[1] = 0; pd[2] = 0;
                 pl[0] = 0; pl[1] = 0;
-                px += 3; pd += 3; pl += 2;
+                px += 3 * stride; pd += 3 * stride; pl += 2 * stride;
             }
             if (ray_counts) ray_counts[index] += (int)step;
         }
@@ -1406,7 +1412,7 @@ lz_k_composite_rays(uint32_t n_alive_h, uint32_t n_step_h, const lz_loop_state* 
         float a0 = NAMB > 0 ? amb0_sum[index] : 0.0f, a1 = NAMB > 1 ? amb1_sum[index] : 0.0f, u = UNC ? unc_sum[index] : 0.0f;
         uint32_t step = 0;
         while (step < n_step) {
-            const size_t i = (size_t)n * n_step + step;
+            const size_t i = STATE ? (size_t)step * n_alive + n : (size_t)n * n_step + step;      // device loop: step-major rows (lz_k_march_rays)
             const float2 dl = *reinterpret_cast<const float2*>(deltas + i * 2);
             if (dl.x == 0) break;
             const float alpha = 1.0f - lz_expf(-sigmas[i] * dl.x);
