@@ -941,9 +941,9 @@ __device__ __forceinline__ void lz_grid_level_scatter(const float* __restrict__ 
 
 // 64-bit FIXED-POINT accumulators in LDS.  Why not float: on gfx950 ds_add_f32 runs ~50x slower than the integer LDS atomics (measured:
 // 0.27 ms vs 1.02 ms per 2^22-sample plane with everything else equal); with float accumulators the atomics were the whole cost.  A workgroup first finds max|grad| over its (level, chunk), picks the power-of-two scale that leaves headroom for
-// 4 * chunk additions in 62 bits (>= 2^-42 of that maximum as resolution), accumulates round(w * g * scale) with ds_add_u64, and flushes
+// 4 * chunk additions in 51 bits (>= 2^-31 of that maximum as resolution; see to_fixed below), accumulates round(w * g * scale) with ds_add_u64, and flushes
 // float(acc) / scale with contiguous global float atomics.  Within a workgroup the sum is exact up to the per-term rounding
-// (<= 1.2e-13 of the chunk's largest gradient) and independent of the order -- tighter than f32 atomics for all but terms ~1e-9 of the
+// (<= 1.2e-10 of the chunk's largest gradient) and independent of the order -- tighter than f32 atomics for all but terms ~1e-6 of the
 // maximum.  Levels whose 8-byte table does not fit 128 KB take the global float-atomic path inside the same kernel.
 #define LZ_GRID_FX_LDS_BYTES 131072
 // |g| for the max pass, with NaN mapped to +inf: fmaxf drops NaN operands and __float2ll_rn(NaN) adds 0, so a NaN gradient would vanish
@@ -1031,9 +1031,18 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
     (void)frexpf(gm, &ex);                                    // gm < 2^ex
     int hb = 2;                                               // 4 corners... (2^D of them) per sample
     while ((1u << hb) < (b1 - b0) * (1u << D)) hb++;
-    int e = 62 - hb - ex;
+    // round(v * 2^e) as a 64-bit integer WITHOUT the f32 -> i64 conversion (a dozen vector instructions, four times per sample: half of
+    // this kernel's issue slots): in double, v * 2^e + 1.5 * 2^52 is rounded to an integer by the addition itself (round to nearest even,
+    // |v * 2^e| < 2^51) and the integer sits in the low mantissa bits -- one convert, one fma, one 32-bit subtract of the magic's high word.
+    // The scale leaves 51 bits instead of 62: >= 2^-31 of the chunk's largest gradient as resolution, far below an f32 ulp of the sum.
+    int e = 51 - hb - ex;
     e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    const float fx = ldexpf(1.0f, e), inv = ldexpf(1.0f, -e);
+    const float inv = ldexpf(1.0f, -e);
+    const double fxd = (double)ldexpf(1.0f, e);
+    auto to_fixed = [&](float v) -> unsigned long long {
+        const double t = __builtin_fma((double)v, fxd, 6755399441055744.0);
+        return (unsigned long long)(__double_as_longlong(t) - 0x4338000000000000ll);
+    };
     auto scatter_at = [&](const float (&x)[D], const float (&gcur)[C]) {
         bool oob = false;
 #pragma unroll
@@ -1064,8 +1073,7 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
                     const float w = wx[idx & 1u] * wy[idx >> 1];
 #pragma unroll
                     for (uint32_t ch = 0; ch < C; ch++) {
-                        const long long q = __float2ll_rn((w * gcur[ch]) * fx);
-                        __hip_atomic_fetch_add(lz_grid_acc64 + index + ch, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(lz_grid_acc64 + index + ch, to_fixed(w * gcur[ch]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
                 return;
@@ -1096,8 +1104,7 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
             }
 #pragma unroll
             for (uint32_t ch = 0; ch < C; ch++) {
-                const long long q = __float2ll_rn((w * gcur[ch]) * fx);
-                __hip_atomic_fetch_add(lz_grid_acc64 + index + ch, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(lz_grid_acc64 + index + ch, to_fixed(w * gcur[ch]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     };
