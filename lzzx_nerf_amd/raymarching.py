@@ -184,15 +184,23 @@ class _march_rays_train(Function):
         workspace = torch.empty(N + 2, dtype=torch.int32, device=dev)
         nears, fars = nears.contiguous(), fars.contiguous()   # two live names: a freed temporary's block could be handed to the next one
         ctx.layout = _LAYOUTS[layout]
+        auto_order = None
         if ctx.layout == 1:
             if order is None and N > 0:
                 order = ray_order(rays_o, rays_d, bound)
+                auto_order = order
             elif order is False:
                 order = None                                  # groups of 64 in ray-id order
             if order is not None:
+                given = order
                 order = _cuda(order).to(torch.int32).contiguous()
                 if order.numel() != N:
                     raise ValueError(f"march_rays_train: order has {order.numel()} entries for {N} rays")
+                if given is not auto_order and N > 0:
+                    # a caller's own order is read by the kernels as ray ids: anything but a permutation of 0..N-1 reads out of bounds or
+                    # writes two rays into one row range.  One sort + a host sync, paid only by callers who bring their own order.
+                    if not bool((torch.sort(order.long()).values == torch.arange(N, device=order.device)).all()):
+                        raise ValueError("march_rays_train: order must be a permutation of 0..N-1")
             call("lz_march_rays_train_grouped", ptr(rays_o), ptr(rays_d), ptr(density_bitfield), float(bound), float(dt_gamma), int(max_steps), N,
                  int(C), int(H), M, ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays),
                  ptr(step_counter), ptr(noises), ptr(order), ptr(workspace), stream())

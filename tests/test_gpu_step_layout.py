@@ -281,3 +281,21 @@ def test_training_step_is_layout_independent():
         scale = float(ga.abs().max())
         assert scale > 0 and torch.isfinite(gb).all(), k
         assert float((ga - gb).abs().max()) <= 2e-3 * scale, (k, float((ga - gb).abs().max()), scale)
+
+
+def test_a_callers_order_must_be_a_permutation():
+    dev = torch.device("cuda")
+    bits = _scene("ones", dev)
+    ro, rd = _rays(dev, 130)
+    bad = torch.arange(130, dtype=torch.int32, device=dev)
+    bad[7] = 8                                             # a duplicate (and 7 missing)
+    with pytest.raises(ValueError, match="permutation"):
+        _march(ro, rd, bits, "step", order=bad)
+    bad = torch.arange(130, dtype=torch.int32, device=dev)
+    bad[0] = 130                                           # out of range
+    with pytest.raises(ValueError, match="permutation"):
+        _march(ro, rd, bits, "step", order=bad)
+    with pytest.raises(ValueError, match="entries"):
+        _march(ro, rd, bits, "step", order=torch.arange(64, dtype=torch.int32, device=dev))
+    with pytest.raises(ValueError, match="layout"):
+        _march(ro, rd, bits, "steps")

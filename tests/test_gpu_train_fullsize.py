@@ -45,13 +45,13 @@ def _rays(device, n_rays=N_RAYS):
     return ro[sel].contiguous(), rd[sel].contiguous(), target
 
 
-def _march(ro, rd, bits, mean_count=-1, force_all=True):
+def _march(ro, rd, bits, mean_count=-1, force_all=True, layout="ray"):
     from lzzx_nerf_amd import raymarching as R
     aabb = torch.tensor([-1, -0.5, -1, 1, 0.5, 1], dtype=torch.float32, device=ro.device)
     nears, fars = R.near_far_from_aabb(ro, rd, aabb, 0.05)
     ctr = torch.zeros(2, dtype=torch.int32, device=ro.device)
     xyzs, dirs, deltas, rays = R.march_rays_train(ro, rd, 1.0, bits, 1, 128, nears, fars, ctr, mean_count, False, 128, force_all, 1 / 256,
-                                                  MAX_STEPS)
+                                                  MAX_STEPS, layout=layout)
     return xyzs, dirs, deltas, rays, ctr, nears, fars
 
 
@@ -177,3 +177,47 @@ def test_full_size_training_step_properties(params, golden, scene):
             got = grads[name][n]
             l2 = float((got - want).norm() / want.norm())
             assert l2 <= tol, (name, n, l2)
+
+
+@pytest.mark.parametrize("scene", ["ones", "ellipsoid"])
+def test_full_size_step_major_rows_give_the_same_step(params, golden, scene):
+    """the bench's `-O` step on STEP-MAJOR sample rows (march_rays_train(layout="step"), tests/test_gpu_step_layout.py for the operators) at
+    full size: same counts per ray, the image and the loss are the ray-major step's bits, the table scatter is still a partition of unity
+    per plane and level (the lane-major row walk of lz_k_grid_backward_lds_fx), weight gradients agree in the relative l2 norm"""
+    from lzzx_nerf_amd import raymarching as R
+    from lzzx_nerf_amd.head_train import FusedTriplaneTrainHead
+    dev = torch.device("cuda")
+    bits = _scene(scene, dev)
+    ro, rd, target = _rays(dev)
+    cond = tuple(torch.from_numpy(np.ascontiguousarray(golden[k])).to(dev) for k in ("net_enc_a", "net_ind", "net_eye"))
+    res = {}
+    for layout in ("ray", "step"):
+        xyzs, dirs, deltas, rays, ctr, _, _ = _march(ro, rd, bits, layout=layout)
+        assert rays.lz_layout == layout
+        net = FusedTriplaneTrainHead(dict(params), bound=1.0, forward_dtype="f16", backward_dtype="f16").to(dev)
+        net.keep_denc = True
+        enc_a, ind, eye = cond
+        sigma, rgb, a0, a1, unc = net(xyzs, dirs, enc_a, ind, eye)
+        ws, a0s, a1s, us, dep, img = R.composite_rays_train_triplane(sigma, rgb, a0.squeeze(-1), a1.squeeze(-1), unc.squeeze(-1), deltas, rays)
+        loss = ((img + (1 - ws).unsqueeze(-1) - target) ** 2).mean() + 1e-4 * a0s.mean() + 1e-4 * a1s.mean() + 1e-3 * us.mean()
+        (loss * 65536.0).backward()
+        per_ray = torch.zeros(N_RAYS, dtype=torch.long, device=dev)
+        per_ray[rays[:, 0].long()] = rays[:, 2].long()
+        denc = net.last_denc.double() / 65536.0
+        off = net.offsets.cpu().numpy().astype(np.int64)
+        for p, enc in enumerate((net.encoder_xy, net.encoder_yz, net.encoder_xz)):
+            ge = enc.embeddings.grad.double()[:, 0] / 65536.0
+            assert bool(torch.isfinite(ge).all()) and float(ge.abs().max()) > 0
+            for l in range(12):
+                want, got, ref = float(denc[p, l].sum()), float(ge[off[l]:off[l + 1]].sum()), float(denc[p, l].abs().sum())
+                assert abs(got - want) <= 2e-3 * ref + 1e-12, (layout, p, l, got, want, ref)
+        res[layout] = (int(ctr[0].item()), per_ray, loss.detach(), img.detach(), ws.detach(),
+                       {n: (q.grad / 65536.0).double().cpu() for n, q in net.named_parameters()})
+        del net, sigma, rgb, a0, a1, unc, xyzs, dirs, deltas
+        torch.cuda.empty_cache()
+    a, b = res["ray"], res["step"]
+    assert a[0] == b[0] and torch.equal(a[1], b[1])
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    for n, want in a[5].items():
+        l2 = float((b[5][n] - want).norm() / want.norm())
+        assert l2 <= 1e-3, (n, l2)
