@@ -195,7 +195,8 @@ int lz_composite_train_forward_v(const float* sigmas, const float* rgbs, const f
                                     float T_thresh, int n_amb, int amb_weighted, int has_unc, int layout, float* weights_sum,
                                     float* amb0_sum, float* amb1_sum, float* unc_sum, float* depth, float* image,
                                     lz_stream_t stream);
-/* grad_* outputs pre-zeroed by the caller (raymarching.py:332-334, 649-653) */
+/* grad_* outputs pre-zeroed by the caller (raymarching.py:332-334, 649-653) for layout 0; with layout 1 the call writes EVERY row of them
+ * (zeros behind a ray's early termination and on rows no ray owns) and the caller may pass uninitialised memory */
 int lz_composite_train_backward_v(const float* grad_weights_sum, const float* grad_amb0_sum, const float* grad_amb1_sum,
                                      const float* grad_unc_sum, const float* grad_image, const float* sigmas,
                                      const float* rgbs, const float* amb0, const float* amb1, const float* unc,

@@ -1315,11 +1315,33 @@ lz_k_composite_train_bwd_g(const float* __restrict__ grad_weights_sum, const flo
                            float* __restrict__ grad_amb1, float* __restrict__ grad_unc) {
     const uint32_t lane = threadIdx.x, n = blockIdx.x * 64 + lane;
     uint32_t index = 0, offset = 0, ns = 0;
+    // EVERY row of the gradient buffers is written here (the reference's wrapper pre-fills them with zeros, raymarching.py:649-653 -- five
+    // fill launches and 170 MB per cfg3 step): a ray's rows behind its early termination get zeros in the loop below, and the rows no ray
+    // owns -- in front of the first ray's, behind the last kept ray's (alignment padding, rays dropped for lack of room) -- right here.
+    uint32_t zb = 0, ze = 0;
     if (n < N) {
         index = (uint32_t)rays[(size_t)n * 3];
         offset = (uint32_t)rays[(size_t)n * 3 + 1];
         ns = (uint32_t)rays[(size_t)n * 3 + 2];
-        if (ns == 0 || offset + ns > M) ns = 0;   // dropped ray: its gradients stay as the caller initialised them
+        const bool dropped = offset + ns > M;
+        if (n == 0 && offset > 0) { zb = 0; ze = offset < M ? offset : M; }
+        if (dropped) {              // the dropped rays are a suffix: the first of them clears everything from its offset on
+            const bool prev_kept = n == 0 || (uint32_t)rays[(size_t)(n - 1) * 3 + 1] + (uint32_t)rays[(size_t)(n - 1) * 3 + 2] <= M;
+            if (n == 0) { zb = 0; ze = M; }
+            else if (prev_kept && offset < M) { zb = offset; ze = M; }
+        } else if (n == N - 1 && offset + ns < M) { zb = offset + ns; ze = M; }
+        if (ns == 0 || dropped) ns = 0;
+    }
+    for (unsigned long long todo = __ballot(zb < ze); todo; todo &= todo - 1ull) {
+        const int src = __builtin_ctzll(todo);
+        const uint32_t r0 = (uint32_t)__shfl((int)zb, src, 64), r1 = (uint32_t)__shfl((int)ze, src, 64);
+        for (size_t i = (size_t)r0 + lane; i < r1; i += 64) {
+            grad_sigmas[i] = 0.0f;
+            grad_rgbs[i * 3] = 0.0f; grad_rgbs[i * 3 + 1] = 0.0f; grad_rgbs[i * 3 + 2] = 0.0f;
+            if (NAMB > 0) grad_amb0[i] = 0.0f;
+            if (NAMB > 1) grad_amb1[i] = 0.0f;
+            if (UNC) grad_unc[i] = 0.0f;
+        }
     }
     const uint32_t gb = lz_tg_base(offset, lane);
     const unsigned long long gm = lz_tg_mask(lane), below = ((1ull << lane) - 1ull) & gm;
@@ -1339,7 +1361,7 @@ lz_k_composite_train_bwd_g(const float* __restrict__ grad_weights_sum, const flo
     float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, amb = 0, u = 0;
     bool live = ns > 0;
     uint32_t S = 0;
-    for (uint32_t base = 0; __any(live && base < ns); base += LZ_CT_CHUNK) {
+    for (uint32_t base = 0; __any(base < ns); base += LZ_CT_CHUNK) {        // to the end of the longest ray: the rows behind a termination are zeroed
         float v[LZ_CT_CHUNK][LZ_CT_BWD_NF];
         uint32_t row[LZ_CT_CHUNK];
 #pragma unroll
@@ -1385,6 +1407,13 @@ lz_k_composite_train_bwd_g(const float* __restrict__ grad_weights_sum, const flo
                 s = lz_fmaf(gws, 1 - ws_final, s);
                 grad_sigmas[i] = dl0 * s;
                 if (T < T_thresh) live = false;
+            } else if (base + k < ns) {
+                const size_t i = row[k];
+                grad_sigmas[i] = 0.0f;
+                grad_rgbs[i * 3] = 0.0f; grad_rgbs[i * 3 + 1] = 0.0f; grad_rgbs[i * 3 + 2] = 0.0f;
+                if (NAMB > 0) grad_amb0[i] = 0.0f;
+                if (NAMB > 1) grad_amb1[i] = 0.0f;
+                if (UNC) grad_unc[i] = 0.0f;
             }
         }
     }

@@ -260,10 +260,12 @@ def _composite_train_bwd(variant, g_ws, g_a0, g_a1, g_u, g_img, sigmas, rgbs, am
                          image, T_thresh, layout=0):
     na, aw, hu = variant
     M, N = sigmas.shape[0], rays.shape[0]
-    grad_sigmas, grad_rgbs = torch.zeros_like(sigmas), torch.zeros_like(rgbs)
-    ga0 = torch.zeros_like(amb0) if na > 0 else None
-    ga1 = torch.zeros_like(amb1) if na > 1 else None
-    gu = torch.zeros_like(unc) if hu else None
+    # ray-major rows: pre-zeroed like the reference's wrapper (raymarching.py:332-334, 649-653); the step-major kernel writes every row itself
+    fresh = torch.empty_like if (layout == 1 and N > 0) else torch.zeros_like
+    grad_sigmas, grad_rgbs = fresh(sigmas), fresh(rgbs)
+    ga0 = fresh(amb0) if na > 0 else None
+    ga1 = fresh(amb1) if na > 1 else None
+    gu = fresh(unc) if hu else None
     call("lz_composite_train_backward_v", ptr(g_ws), ptr(g_a0), ptr(g_a1), ptr(g_u), ptr(g_img), ptr(sigmas), ptr(rgbs), ptr(amb0),
          ptr(amb1), ptr(unc), ptr(deltas), ptr(rays), ptr(weights_sum), ptr(a0s), ptr(us), ptr(image), M, N, float(T_thresh), na, aw, hu,
          int(layout), ptr(grad_sigmas), ptr(grad_rgbs), ptr(ga0), ptr(ga1), ptr(gu), stream())
