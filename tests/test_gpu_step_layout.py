@@ -303,3 +303,49 @@ def test_a_callers_order_must_be_a_permutation():
         _march(ro, rd, bits, "step", order=torch.arange(64, dtype=torch.int32, device=dev))
     with pytest.raises(ValueError, match="layout"):
         _march(ro, rd, bits, "steps")
+
+
+@pytest.mark.parametrize("n_rays", [1, 63, 64, 65, 129, 1000])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_ragged_groups_empty_rays_and_perturbed_starts(n_rays, perturb):
+    """group edges and rays without a sample: fewer rays than a group, one ray more than a group, rays that miss the occupied cells
+    (count 0 inside a group), perturbed start times (the same noise under both layouts: the generator is re-seeded) -- march rows and
+    the triplane compositing forward / backward against the ray-major operators"""
+    from lzzx_nerf_amd import raymarching as R
+    dev = torch.device("cuda")
+    bits = _scene("ellipsoid", dev)
+    ro, rd = _rays(dev, n_rays, size=64, seed=n_rays)
+    torch.manual_seed(1234)
+    a = _march(ro, rd, bits, "ray", perturb=perturb)
+    torch.manual_seed(1234)
+    b = _march(ro, rd, bits, "step", perturb=perturb)
+    counts = a[3][:, 2].cpu().numpy()
+    if n_rays >= 63:
+        assert (counts == 0).any() and (counts > 0).any()          # the 64 x 64 frame of the ellipsoid scene has rays of both kinds
+    _check_march(a, b, a[0].shape[0], None)
+    M, N = a[0].shape[0], n_rays
+    if M == 0:
+        return
+    g = torch.Generator(device=dev).manual_seed(7)
+    rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
+    sig, rgb, a0, a1, un = rnd(M) * 30, rnd(M, 3), rnd(M), rnd(M), rnd(M)
+    # the SAME per-sample values under both layouts: ray-major values -> step-major rows through the two rays tables
+    ra, rb = a[3].cpu().numpy(), b[3].cpu().numpy()
+    src_b, dst_b = step_rows(rb, M)                                   # processing-order ray-major row -> step row
+    srt = np.argsort(src_b, kind="stable")
+    ids = np.repeat(rb[:, 0], rb[:, 2])
+    kk = src_b[srt] - np.repeat(rb[:, 1], rb[:, 2])
+    rm = torch.from_numpy(ra[ids, 1] + kk).to(dev)                    # the sample's row in the ray-major buffers
+    st = torch.from_numpy(dst_b[srt]).to(dev)
+    perm = lambda x: torch.zeros_like(x).index_copy_(0, st, x[rm])
+    f_r = R._composite_train_fwd((2, 0, 1), sig, rgb, a0, a1, un, a[2].contiguous(), a[3], 1e-4, 0)
+    f_s = R._composite_train_fwd((2, 0, 1), perm(sig), perm(rgb), perm(a0), perm(a1), perm(un), b[2].contiguous(), b[3], 1e-4, 1)
+    for x, y in zip(f_r, f_s):
+        assert torch.equal(x, y)
+    gws, ga0, ga1, gu, gim = rnd(N), rnd(N), rnd(N), rnd(N), rnd(N, 3)
+    ws, a0s, a1s, us, dep, img = f_r
+    b_r = R._composite_train_bwd((2, 0, 1), gws, ga0, ga1, gu, gim, sig, rgb, a0, a1, un, a[2].contiguous(), a[3], ws, a0s, us, img, 1e-4, 0)
+    b_s = R._composite_train_bwd((2, 0, 1), gws, ga0, ga1, gu, gim, perm(sig), perm(rgb), perm(a0), perm(a1), perm(un), b[2].contiguous(), b[3], ws,
+                                 a0s, us, img, 1e-4, 1)
+    for x, y in zip(b_r, b_s):
+        assert torch.equal(perm(x), y)
