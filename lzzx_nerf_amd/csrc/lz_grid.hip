@@ -487,6 +487,35 @@ lz_k_grid_input_backward(const T* __restrict__ grad, const T* __restrict__ dy_dx
 // A level that does not fit LDS falls back to global gathers inside the same kernel (wave-uniform branch).
 #define LZ_GRID_LDS_BYTES 65536
 
+// Index terms per dimension for the dense (mode 0) and power-of-two hashed (mode 1) levels: term[d][0] belongs to the lower cell
+// coordinate pg[d], term[d][1] to pg[d] + 1 -- the lower one plus a constant modulo 2^32, exactly the reference's uint32 arithmetic
+// (gridencoder.cu:60-98: index += pos * stride / result ^= pos * prime).  A corner's index is then the sum (dense) or the xor (hashed)
+// of D terms: one 32-bit multiply per dimension and sample, spelled out (the compiler found the same common subexpressions in the
+// per-corner form: measured, no change in the triplane plane or the cfg2 gather -- neither is bound by the index arithmetic).
+template <uint32_t D>
+__device__ __forceinline__ void lz_grid_terms(const uint32_t (&pg)[D], uint32_t mode, uint32_t resolution, bool align_corners, uint32_t (&term)[D][2]) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t stride = 1;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const uint32_t k = mode == 1u ? primes[d] : stride;
+        term[d][0] = d == 0 ? pg[d] : pg[d] * k;      // primes[0] == 1 and the first stride is 1
+        term[d][1] = term[d][0] + k;
+        stride *= align_corners ? resolution : (resolution + 1);
+    }
+}
+template <uint32_t D>
+__device__ __forceinline__ uint32_t lz_grid_corner(const uint32_t (&term)[D][2], uint32_t idx, uint32_t mode, uint32_t hs) {
+    uint32_t lin = 0, h = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const uint32_t t = term[d][(idx >> d) & 1u];
+        lin += t;
+        h ^= t;
+    }
+    return mode == 1u ? (h & (hs - 1u)) : lin;
+}
+
 template <typename T, uint32_t D, uint32_t C, bool IN_LDS>
 __device__ __forceinline__ void lz_grid_level_stream(const float* __restrict__ inputs, const T* __restrict__ tab, T* __restrict__ outputs,
                                                      uint32_t b0, uint32_t b1, uint32_t L, uint32_t level, float scale,
@@ -512,6 +541,9 @@ __device__ __forceinline__ void lz_grid_level_stream(const float* __restrict__ i
         float res[C];
 #pragma unroll
         for (uint32_t ch = 0; ch < C; ch++) res[ch] = 0.0f;
+        // per-dimension index terms (lz_grid_terms)
+        uint32_t term[D][2];
+        if (mode != 2u) lz_grid_terms<D>(pg, mode, resolution, align_corners, term);
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << D); idx++) {
             float w = 1.0f;
@@ -522,19 +554,8 @@ __device__ __forceinline__ void lz_grid_level_stream(const float* __restrict__ i
                 else { w *= pos[d]; pl[d] = pg[d] + 1; }
             }
             uint32_t index;
-            if (mode == 2u) {  // workgroup-uniform: true modulo / wrapped strides
-                index = lz_grid_index<D>(C, gridtype, align_corners, hashmap_size, resolution, pl);
-            } else {
-                constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-                uint32_t lin = 0, h = 0, stride = 1;
-#pragma unroll
-                for (uint32_t d = 0; d < D; d++) {
-                    lin += pl[d] * stride;
-                    stride *= align_corners ? resolution : (resolution + 1);
-                    h ^= pl[d] * primes[d];
-                }
-                index = (mode == 1u ? (h & (hashmap_size - 1u)) : lin) * C;
-            }
+            if (mode == 2u) index = lz_grid_index<D>(C, gridtype, align_corners, hashmap_size, resolution, pl);   // workgroup-uniform: true modulo / wrapped strides
+            else index = lz_grid_corner<D>(term, idx, mode, hashmap_size) * C;
 #pragma unroll
             for (uint32_t ch = 0; ch < C; ch++) res[ch] = LzElem<T>::acc(res[ch], w, LzElem<T>::ld(tab + index + ch));
         }
@@ -548,8 +569,14 @@ __device__ __forceinline__ void lz_grid_level_stream(const float* __restrict__ i
     }
 }
 
+#ifndef LZ_GRID_LDS_WG
+#define LZ_GRID_LDS_WG 512
+#endif
+#ifndef LZ_GRID_LDS_CHUNK
+#define LZ_GRID_LDS_CHUNK 32768
+#endif
 template <typename T, uint32_t D, uint32_t C>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(LZ_GRID_LDS_WG)
 lz_k_grid_forward_lds(const float* __restrict__ inputs, const T* __restrict__ grid, const int* __restrict__ offsets,
                       T* __restrict__ outputs, uint32_t B, uint32_t L, LzGridLevels lv, uint32_t gridtype, bool align_corners,
                       uint32_t chunk, uint32_t n_chunks) {
@@ -597,11 +624,11 @@ template <typename T, uint32_t D, uint32_t C>
 static void lz_grid_lds_launch(const float* inputs, const T* emb, const int* offsets, T* out, uint32_t B, uint32_t L,
                                const LzGridLevels& lv, uint32_t gridtype, bool ac, hipStream_t st) {
     // chunk: large enough to amortise the table copy (<= 64 KB per chunk per level), small enough for >= ~2 waves of CUs
-    uint32_t chunk = 32768;
+    uint32_t chunk = LZ_GRID_LDS_CHUNK;
     while (chunk > 2048 && (uint64_t)lz_div_up(B, chunk) * L < 1024) chunk >>= 1;
     const uint32_t n_chunks = lz_div_up(B, chunk);
     const uint32_t groups = lz_div_up(n_chunks, 8);
-    hipLaunchKernelGGL((lz_k_grid_forward_lds<T, D, C>), dim3(8u * groups * L), dim3(512), LZ_GRID_LDS_BYTES, st, inputs, emb, offsets, out, B, L,
+    hipLaunchKernelGGL((lz_k_grid_forward_lds<T, D, C>), dim3(8u * groups * L), dim3(LZ_GRID_LDS_WG), LZ_GRID_LDS_BYTES, st, inputs, emb, offsets, out, B, L,
                        lv, gridtype, ac, chunk, n_chunks);
 }
 
@@ -666,6 +693,8 @@ lz_k_grid_forward_lm(const float* __restrict__ inputs, const T* __restrict__ gri
     }
     uint32_t index[1u << D];
     float w[1u << D];
+    uint32_t term[D][2];
+    if (mode != 2u) lz_grid_terms<D>(pg, mode, resolution, align_corners, term);
 #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
         float wc = 1.0f;
@@ -676,19 +705,8 @@ lz_k_grid_forward_lm(const float* __restrict__ inputs, const T* __restrict__ gri
             else { wc *= pos[d]; pl[d] = pg[d] + 1; }
         }
         w[idx] = wc;
-        if (mode == 2u) {  // workgroup-uniform
-            index[idx] = lz_grid_index<D>(C, gridtype, align_corners, hs, resolution, pl);
-        } else {
-            constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-            uint32_t lin = 0, h = 0, stride = 1;
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) {
-                lin += pl[d] * stride;
-                stride *= align_corners ? resolution : (resolution + 1);
-                h ^= pl[d] * primes[d];
-            }
-            index[idx] = (mode == 1u ? (h & (hs - 1u)) : lin) * C;
-        }
+        if (mode == 2u) index[idx] = lz_grid_index<D>(C, gridtype, align_corners, hs, resolution, pl);   // workgroup-uniform
+        else index[idx] = lz_grid_corner<D>(term, idx, mode, hs) * C;
     }
     // all 2^D corner reads in flight before the first use; (index * sizeof(T)) is a multiple of the vector size
     LzVec<T, C> cv[1u << D];
@@ -752,6 +770,8 @@ lz_k_grid_forward_lmp(const float* __restrict__ inputs, const T* __restrict__ gr
         pos[d] -= (float)pg[d];
     }
     uint32_t own[NC][WORDS], oth[NC][WORDS];
+    uint32_t term[D][2];
+    if (mode != 2u) lz_grid_terms<D>(pg, mode, resolution, align_corners, term);
 #pragma unroll
     for (uint32_t h = 0; h < NC; h++) {
         const uint32_t idx = (h << 1) | xb;
@@ -759,19 +779,8 @@ lz_k_grid_forward_lmp(const float* __restrict__ inputs, const T* __restrict__ gr
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1u);
         uint32_t index;
-        if (mode == 2u) {
-            index = lz_grid_index<D>(C, gridtype, align_corners, hs, resolution, pl);
-        } else {
-            constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-            uint32_t lin = 0, hh = 0, stride = 1;
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) {
-                lin += pl[d] * stride;
-                stride *= align_corners ? resolution : (resolution + 1);
-                hh ^= pl[d] * primes[d];
-            }
-            index = (mode == 1u ? (hh & (hs - 1u)) : lin) * C;
-        }
+        if (mode == 2u) index = lz_grid_index<D>(C, gridtype, align_corners, hs, resolution, pl);
+        else index = lz_grid_corner<D>(term, idx, mode, hs) * C;
         __builtin_memcpy(own[h], __builtin_assume_aligned(g + index, sizeof(T) * C), sizeof(T) * C);
     }
 #pragma unroll
@@ -907,6 +916,8 @@ __device__ __forceinline__ void lz_grid_level_scatter(const float* __restrict__ 
             pg[d] = (uint32_t)floorf(pos[d]);
             pos[d] -= (float)pg[d];
         }
+        uint32_t term[D][2];
+        if (mode != 2u) lz_grid_terms<D>(pg, mode, resolution, align_corners, term);
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << D); idx++) {
             float w = 1.0f;
@@ -917,19 +928,8 @@ __device__ __forceinline__ void lz_grid_level_scatter(const float* __restrict__ 
                 else { w *= pos[d]; pl[d] = pg[d] + 1; }
             }
             uint32_t index;
-            if (mode == 2u) {
-                index = lz_grid_index<D>(C, gridtype, align_corners, hs, resolution, pl);
-            } else {
-                constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-                uint32_t lin = 0, h = 0, stride = 1;
-#pragma unroll
-                for (uint32_t d = 0; d < D; d++) {
-                    lin += pl[d] * stride;
-                    stride *= align_corners ? resolution : (resolution + 1);
-                    h ^= pl[d] * primes[d];
-                }
-                index = (mode == 1u ? (h & (hs - 1u)) : lin) * C;
-            }
+            if (mode == 2u) index = lz_grid_index<D>(C, gridtype, align_corners, hs, resolution, pl);
+            else index = lz_grid_corner<D>(term, idx, mode, hs) * C;
 #pragma unroll
             for (uint32_t ch = 0; ch < C; ch++) {
                 if constexpr (IN_LDS) __hip_atomic_fetch_add(dst + index + ch, w * gcur[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1079,6 +1079,8 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
                 return;
             }
         }
+        uint32_t gterm[D][2];
+        if (mode != 2u) lz_grid_terms<D>(pg, mode, res, align_corners, gterm);
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << D); idx++) {
             float w = 1.0f;
@@ -1089,19 +1091,8 @@ lz_k_grid_backward_lds_fx(const float* __restrict__ grad, const float* __restric
                 else { w *= pos[d]; pl[d] = pg[d] + 1; }
             }
             uint32_t index;
-            if (mode == 2u) {
-                index = lz_grid_index<D>(C, gridtype, align_corners, hs, res, pl);
-            } else {
-                constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-                uint32_t lin = 0, h = 0, stride = 1;
-#pragma unroll
-                for (uint32_t d = 0; d < D; d++) {
-                    lin += pl[d] * stride;
-                    stride *= align_corners ? res : (res + 1);
-                    h ^= pl[d] * primes[d];
-                }
-                index = (mode == 1u ? (h & (hs - 1u)) : lin) * C;
-            }
+            if (mode == 2u) index = lz_grid_index<D>(C, gridtype, align_corners, hs, res, pl);
+            else index = lz_grid_corner<D>(gterm, idx, mode, hs) * C;
 #pragma unroll
             for (uint32_t ch = 0; ch < C; ch++) {
                 __hip_atomic_fetch_add(lz_grid_acc64 + index + ch, to_fixed(w * gcur[ch]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
