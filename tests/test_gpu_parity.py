@@ -1103,9 +1103,10 @@ def test_composite_reference_named_entry_points():
 
 
 def test_grid_backward_level_resident_on_runs_of_equal_cells():
-    """march-ordered samples of rays normal to a plane fall into the SAME cell in long runs; lz_k_grid_backward_lds_fx then deals the lanes of
-    a wave samples that lie 64 apart (its workgroups vote on their first 1024 samples) so that the LDS atomics do not all hit one address.
-    The fixed-point sums are exact integers, so the result must not depend on the map: runs of 1 .. 200 equal positions (plus jitter far
+    """march-ordered samples of rays normal to a plane fall into the SAME cell in long runs; lz_k_grid_backward_lds_fx deals the lanes of a
+    wave-instruction rows that lie a whole segment of the chunk apart (lane-major segments; rounds 3-4: a per-workgroup vote and a 4-row
+    spread) so that the LDS atomics do not all hit one address.  The fixed-point sums are exact integers, so the result must not depend on
+    the order: runs of 1 .. 200 equal positions (plus jitter far
     below a cell of the coarse levels) against the checker and against the same call on a shuffled copy of the samples."""
     from lzzx_nerf_amd.gridencoder import GridEncoder
     from lzzx_nerf_amd._util import call, ptr, stream

@@ -1,7 +1,7 @@
 """BASELINE cfg3 at FULL size under -m gpu (Missing 4): 65 536 random rays of the 512x512 frame, max_steps 192, both scenes,
 through march_rays_train -> FusedTriplaneTrainHead -> composite_rays_train_triplane -> loss -> backward, i.e. the step bench.py times
 (reference: renderer.py:279-304, raymarching.py:186-280, raymarching.cu:1999-2122, gridencoder.cu:226-313).  The gradient tests of
-test_gpu_train_step.py run 24^2 / 48^2 rays against a float64 model; nothing there reaches the vote-selected scatter map, the
+test_gpu_train_step.py run 24^2 / 48^2 rays against a float64 model; nothing there reaches the lane-major row walk of the table scatter (full 73 728-row chunks), the
 register-keep path of the LDS grid backward or the mean_count-sized buffers.  A float64 model of 6 M samples is out of reach, so the step
 is held to size-independent properties:
 
