@@ -286,6 +286,9 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
     import gc
     gc.collect()
     gc.disable()       # as timeit does: a generation-2 collection in the middle of a step is a host stall of tens of milliseconds
+    for _ in range(4):      # the synchronize / .item() / gc.collect() above let the GPU idle and its clock drop: the first steps behind them
+        step()              # ran 5.35, 4.57, 4.47, 4.39 ms against 4.25 steady (LZ_TRAIN_STEP_TRACE=1); these four are not timed
+    torch.cuda.synchronize()   # (a bare wait: the queue is full again microseconds later)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(k_steps):
@@ -294,7 +297,10 @@ def train_bench(args, device, P, golden, bits, rank=0, world=1, n_rays=None):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / k_steps
     gc.enable()
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(k_steps))
+    per_step_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(k_steps)]
+    if os.environ.get("LZ_TRAIN_STEP_TRACE"):
+        log("train steps ms: " + " ".join(f"{t:.2f}" for t in per_step_order))
+    per_step = sorted(per_step_order)
     ms1 = torch.cuda.memory_stats(device)
     # hipMalloc / hipFree calls of torch's caching allocator inside the timed region (each is a device-wide stall of milliseconds at these
     # buffer sizes): must be 0 for the number to mean anything
