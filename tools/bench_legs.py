@@ -389,14 +389,14 @@ def timed(job, steps, warmup, world, device, timing=True):
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+    import gc
+    gc.collect()       # before the warm-up steps: a collection between them and the timed region is milliseconds of idle GPU (clock ramp)
+    gc.disable()       # as timeit does
     for _ in range(warmup):
         job.step()
     barrier()
     if timing:
         job.r.timing_start(steps * job.max_steps + 16)   # HIP event pair around every head launch, on the launch stream
-    import gc
-    gc.collect()
-    gc.disable()       # as timeit does
     t0 = time.perf_counter()
     for _ in range(steps):
         out, tiles = job.step()
