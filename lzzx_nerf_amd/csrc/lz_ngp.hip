@@ -47,8 +47,14 @@ struct LzNgpK {
 };
 
 // FEAT: 0 = row-major f32 [rows, 32]; 1 = tiled f32 (lz_grid_encode_forward_tiled); 2 = tiled f16
+#ifndef LZN_WG
+#define LZN_WG 512     /* threads per workgroup: the 24 KB weight image is copied once per workgroup (256 -> 512 and 4 -> 8 passes per wave: cfg2 frame 2.07 -> 2.03 ms) */
+#endif
+#ifndef LZN_PASSES
+#define LZN_PASSES 8   /* passes per wave the grid is sized for when there are rows enough for two workgroups per CU; halved until there are */
+#endif
 template <int FEAT>
-__global__ void __launch_bounds__(256) lz_k_ngp_head(LzNgpK P) {
+__global__ void __launch_bounds__(LZN_WG) lz_k_ngp_head(LzNgpK P) {
     __shared__ __align__(16) float wl[LZ_NGP_FRAGS * 64];
     {
         const float4* src = reinterpret_cast<const float4*>(P.packed);
@@ -93,8 +99,8 @@ __global__ void __launch_bounds__(256) lz_k_ngp_head(LzNgpK P) {
             I.dx[u] = P.dirs[(size_t)r * 3]; I.dy[u] = P.dirs[(size_t)r * 3 + 1]; I.dz[u] = P.dirs[(size_t)r * 3 + 2];
         }
     };
-    const uint32_t stride = gridDim.x * 4u * T;
-    uint32_t slice0 = (blockIdx.x * 4u + (uint32_t)wave) * T;
+    const uint32_t stride = gridDim.x * (LZN_WG / 64u) * T;
+    uint32_t slice0 = (blockIdx.x * (LZN_WG / 64u) + (uint32_t)wave) * T;
     if (rows == 0 || slice0 >= n_slices) return;
     In nxt;
     load(slice0, nxt);
@@ -196,15 +202,17 @@ extern "C" int lz_ngp_head_forward(const float* packed, const void* feats, int f
     LZ_REQUIRE(packed && feats && dirs && sigmas && rgbs, LZ_ERR_BAD_ARGUMENT, "ngp_head_forward: null tensor");
     LZ_REQUIRE(feat_layout >= 0 && feat_layout <= 2, LZ_ERR_BAD_ARGUMENT, "ngp_head_forward: feat_layout 0 (row-major f32), 1 (tiled f32) or 2 (tiled f16)");
     LzNgpK K{packed, feats, dirs, count, sigmas, rgbs, rows};
-    uint32_t grid = lz_div_up(rows, 16 * 4 * 4 * LZN_T);      // ~4 passes per wave
+    uint32_t passes = LZN_PASSES;      // the reference schedule's iterations hold one sample per ray: few rows, keep every CU busy
+    while (passes > 1 && lz_div_up(rows, 16 * (LZN_WG / 64) * passes * LZN_T) < 512) passes >>= 1;
+    uint32_t grid = lz_div_up(rows, 16 * (LZN_WG / 64) * passes * LZN_T);
     // every workgroup stages the 24 KB of weights once: as many workgroups as the chip holds at a time (3 waves per SIMD = 3 of these 4-wave
     // workgroups per CU), each looping over its share of the slices, not one per 16 slices
     const uint32_t cap = (uint32_t)lz_cu_count() * LZN_WG_PER_CU;
     grid = grid < 1 ? 1 : (grid > cap ? cap : grid);
     hipStream_t st = lz_st(stream);
-    if (feat_layout == 0) hipLaunchKernelGGL((lz_k_ngp_head<0>), dim3(grid), dim3(256), 0, st, K);
-    else if (feat_layout == 1) hipLaunchKernelGGL((lz_k_ngp_head<1>), dim3(grid), dim3(256), 0, st, K);
-    else hipLaunchKernelGGL((lz_k_ngp_head<2>), dim3(grid), dim3(256), 0, st, K);
+    if (feat_layout == 0) hipLaunchKernelGGL((lz_k_ngp_head<0>), dim3(grid), dim3(LZN_WG), 0, st, K);
+    else if (feat_layout == 1) hipLaunchKernelGGL((lz_k_ngp_head<1>), dim3(grid), dim3(LZN_WG), 0, st, K);
+    else hipLaunchKernelGGL((lz_k_ngp_head<2>), dim3(grid), dim3(LZN_WG), 0, st, K);
     LZ_CHECK_LAUNCH("ngp_head_forward");
     return LZ_OK;
 }
