@@ -73,7 +73,7 @@ def _rays(device, n_rays, size=96, seed=0):
 def _march(ro, rd, bits, layout, order=None, mean_count=-1, force_all=True, ctr0=(0, 0), perturb=False):
     from lzzx_nerf_amd import raymarching as R
     aabb = torch.tensor([-1, -0.5, -1, 1, 0.5, 1], dtype=torch.float32, device=ro.device)
-    nears, fars = R.near_far_from_aabb(ro, rd, aabb, 0.05)
+    nears, fars = R.near_far_from_aabb(ro.detach(), rd.detach(), aabb, 0.05)     # (no backward, like the reference's: raymarching.py:18-60)
     ctr = torch.tensor(ctr0, dtype=torch.int32, device=ro.device)
     out = R.march_rays_train(ro, rd, 1.0, bits, 1, 128, nears, fars, ctr, mean_count, perturb, 128, force_all, 1 / 256, MAX_STEPS,
                              layout=layout, order=order)
@@ -349,3 +349,32 @@ def test_ragged_groups_empty_rays_and_perturbed_starts(n_rays, perturb):
                                  a0s, us, img, 1e-4, 1)
     for x, y in zip(b_r, b_s):
         assert torch.equal(perm(x), y)
+
+
+def test_camera_gradients_through_the_step_major_march():
+    """opt.train_camera (renderer.py:225-230): rays that require gradients get them through march_rays_train's backward under either layout
+    -- the same sums over a ray's samples, in step order along the ray, so the same bits"""
+    dev = torch.device("cuda")
+    bits = _scene("ellipsoid", dev)
+    ro, rd = _rays(dev, 300)
+    out = {}
+    for layout in ("ray", "step"):
+        o, d = ro.clone().requires_grad_(True), rd.clone().requires_grad_(True)
+        xyzs, dirs, deltas, rays, _ = _march(o, d, bits, layout)
+        w = torch.linspace(0.5, 1.5, 3, device=dev)
+        # a per-ray-separable loss (every sample of ray n weighted by a function of n): independent of which rows the samples sit in
+        ids = torch.zeros(xyzs.shape[0], dtype=torch.long, device=dev)
+        from lzzx_nerf_amd import raymarching as R
+        if layout == "ray":
+            r = rays.long()
+            ids[:int(r[:, 2].sum())] = torch.repeat_interleave(r[:, 0], r[:, 2])
+        else:
+            src, dst = step_rows(rays.cpu().numpy(), xyzs.shape[0])
+            rs = rays.cpu().numpy()
+            srt = np.argsort(src, kind="stable")
+            ids[torch.from_numpy(dst[srt]).to(dev)] = torch.from_numpy(np.repeat(rs[:, 0], rs[:, 2])).to(dev).long()
+        scale = (1.0 + 0.01 * ids.float()).unsqueeze(1)
+        ((xyzs * w * scale).sum() + (dirs * scale).sum() * 0.25).backward()
+        out[layout] = (o.grad.clone(), d.grad.clone())
+    assert torch.equal(out["ray"][0], out["step"][0]) and torch.equal(out["ray"][1], out["step"][1])
+    assert float(out["ray"][0].abs().max()) > 0 and float(out["ray"][1].abs().max()) > 0
