@@ -81,6 +81,7 @@ def compact(result, detail="bench_detail.json"):
                        ("cfg5_f16_ms", ("cfg5_1024_ellipsoid_f16", "ms_per_step")),
                        ("reference_schedule_loop_ms", ("reference_schedule", "ms_per_step")),
                        ("deployed_max_steps_16_ms", ("deployed_max_steps_16", "ms_per_step")),
+                       ("deployed_max_steps_16_f16_ms", ("deployed_max_steps_16", "f16_ms_per_step")),
                        ("talking_head_frame_f16_ms", ("talking_head_frame", "f16", "ms_per_frame"))):
         v = _pick(result, *path)
         if v is not None:

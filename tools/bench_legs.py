@@ -628,12 +628,14 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             ebits16 = ellipsoid_bitfield_device(device)[0]
             keep_ms = args.max_steps
             args.max_steps = 16
+            h16 = head if args.precision == "f16" else FusedTriplaneHead(sd, bound=1.0, device=device, precision="f16")
             try:
                 jf = make_job("frame", args.tiles, 1, 8, head, mode="fused")
                 jl = make_job("frame", args.tiles, 1, 8, head, mode="loop")
+                j16 = make_job("frame", args.tiles, 1, 8, h16, mode="fused")      # the deployed ARITHMETIC too: opt.fp16 (HubertInferenceMQ.py:53)
             finally:
                 args.max_steps = keep_ms
-            jf.r.bitfield = jl.r.bitfield = ebits16
+            jf.r.bitfield = jl.r.bitfield = j16.r.bitfield = ebits16
             k16 = args.steps
             df, _, of_, _ = timed(jf, k16, 2, 1, device)
             img_f, st_f = of_["image"].clone(), of_["state"].cpu().numpy()
@@ -641,14 +643,16 @@ def side_legs(args, result, device, P, golden, sd, head, bits, bits_dev, job, im
             st_l = ol_["state"].cpu().numpy()
             cf = jf.r.render(*jf.sf.rays(jf.pose, jf.intr), *jf.cond, max_steps=16, count_samples=True)["ray_counts"].clone()
             cl = jl.r.render(*jl.sf.rays(jl.pose, jl.intr), *jl.cond, max_steps=16, count_samples=True)["ray_counts"]
+            d16, _, o16_, _ = timed(j16, k16, 2, 1, device)
             result["deployed_max_steps_16"] = dict(
+                f16_ms_per_step=round(d16 / k16 * 1e3, 4), f16_max_abs_diff_vs_f32_image=float((o16_["image"] - img_f).abs().max()),
                 workload=f"{H}x{W} frame, ellipsoid occupancy, max_steps 16 (the reference's deployed value), cap = {args.cap}",
                 ms_per_step=round(df / k16 * 1e3, 4), composited_samples_per_frame=int(st_f[5]), value=round(int(st_f[5]) * k16 / df, 1), unit="samples/s",
                 c_eff=int(st_f[10]), reference_loop_iterations=int(st_f[11]), rays_continued_past_max_steps=int(st_f[9]),
                 loop_mode_reference_schedule_ms_per_step=round(dl / k16 * 1e3, 4), loop_mode_iterations=int(st_l[6]),
                 image_equal_to_reference_schedule=bool(torch.equal(img_f, ol_["image"])),
                 ray_counts_equal_to_reference_schedule=bool(torch.equal(cf, cl)), max_ray_count=int(cf.max()))
-            del jf, jl
+            del jf, jl, j16
         except Exception as exc:
             err("deployed_max_steps_16", exc)
     if args.precision == "f32" and args.mode == "fused" and not args.no_fat_schedule:
